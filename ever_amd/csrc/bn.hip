@@ -1,0 +1,332 @@
+// BatchNorm2d (+ residual add, + ReLU) forward / backward on NHWC fp32 for gfx950.
+// Replaces aten::batch_norm / native_batch_norm_backward, aten::add_, aten::relu_ at reference
+// ever/module/_resnets.py:95-112 (bn1..bn3, `out += identity`, relu), fs_relation.py:39-53,
+// fpn.py:163-167.  HBM-bound: every kernel streams [rows][C] with 16-byte accesses, a workgroup's
+// row range is one contiguous span.  Statistics are reduced in two stages (fp32 partials per
+// workgroup, fp64 finalisation) so results do not depend on the launch grid.
+#include "common.hpp"
+
+namespace evk {
+
+constexpr int kMaxStatBlocks = 1024;
+
+struct BnPlan {
+  int nblk;
+  int64_t rows_per_blk;
+  int tpc, rl;
+};
+static BnPlan bn_plan(int64_t rows, int C) {
+  BnPlan p;
+  const int c4 = C / 4;
+  p.tpc = c4 < 256 ? c4 : 256;
+  p.rl = 256 / p.tpc;
+  int64_t nb = (rows * (int64_t)C + 65535) / 65536;  // ~64K elements per workgroup
+  if (nb > kMaxStatBlocks) nb = kMaxStatBlocks;
+  if (nb < 1) nb = 1;
+  int64_t rpb = (rows + nb - 1) / nb;
+  rpb = ((rpb + p.rl - 1) / p.rl) * p.rl;
+  p.rows_per_blk = rpb;
+  p.nblk = (int)((rows + rpb - 1) / rpb);
+  return p;
+}
+
+// partial[blk][0][C] = sum x, partial[blk][1][C] = sum x^2
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                               int64_t rows, int C, int64_t rows_per_blk, int tpc,
+                                                               int rl) {
+  __shared__ f32x4 red[2][256];
+  const int c4 = C >> 2;
+  const int tc = threadIdx.x % tpc, tr = threadIdx.x / tpc;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+  const int64_t r1 = min(rows, r0 + rows_per_blk);
+  for (int cb = tc; cb < c4; cb += tpc) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    if (tr < rl)
+      for (int64_t r = r0 + tr; r < r1; r += rl) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * C + cb * 4);
+        s += v;
+        q += v * v;
+      }
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = q;
+    __syncthreads();
+    if (tr == 0) {
+      for (int k = 1; k < rl; ++k) {
+        s += red[0][k * tpc + tc];
+        q += red[1][k * tpc + tc];
+      }
+      float* o = partial + (size_t)blockIdx.x * 2 * C;
+      *reinterpret_cast<f32x4*>(o + cb * 4) = s;
+      *reinterpret_cast<f32x4*>(o + C + cb * 4) = q;
+    }
+    __syncthreads();
+  }
+}
+
+// mean / biased var -> save_mean, save_invstd, scale/shift for the apply pass; running stats update
+// follows torch: running = (1-m)*running + m*stat, with the UNBIASED variance (n/(n-1)).
+__global__ void bn_stats_final_kernel(const float* __restrict__ partial, int nblk, int C, double inv_rows,
+                                      double unbias, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      float* __restrict__ running_mean, float* __restrict__ running_var,
+                                      float momentum, float eps, float* __restrict__ save_mean,
+                                      float* __restrict__ save_invstd, float* __restrict__ scale_shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s += (double)partial[(size_t)b * 2 * C + c];
+    q += (double)partial[(size_t)b * 2 * C + C + c];
+  }
+  const double mean = s * inv_rows;
+  double var = q * inv_rows - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float meanf = (float)mean;
+  save_mean[c] = meanf;
+  save_invstd[c] = invstd;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * unbias);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float sc = g * invstd;
+  scale_shift[c] = sc;
+  scale_shift[C + c] = b - meanf * sc;
+}
+
+__global__ void bn_eval_coef_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ rm, const float* __restrict__ rv, float eps, int C,
+                                    float* __restrict__ scale_shift, float* __restrict__ save_mean,
+                                    float* __restrict__ save_invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = (float)(1.0 / sqrt((double)rv[c] + (double)eps));
+  if (save_mean) save_mean[c] = rm[c];
+  if (save_invstd) save_invstd[c] = invstd;
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float sc = g * invstd;
+  scale_shift[c] = sc;
+  scale_shift[C + c] = b - rm[c] * sc;
+}
+
+// y = act(x*scale + shift [+ residual]);  scale/shift staged in LDS
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ residual,
+                                                       const float* __restrict__ scale_shift, float* __restrict__ y,
+                                                       size_t n4, int C, int relu) {
+  extern __shared__ __attribute__((aligned(16))) float ss[];  // [2][C]
+  for (int i = threadIdx.x; i < 2 * C; i += 256) ss[i] = scale_shift[i];
+  __syncthreads();
+  const int c4 = C >> 2;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  const f32x4* r4 = reinterpret_cast<const f32x4*>(residual);
+  f32x4* y4 = reinterpret_cast<f32x4*>(y);
+  const f32x4* sc4 = reinterpret_cast<const f32x4*>(ss);
+  const f32x4* sh4 = reinterpret_cast<const f32x4*>(ss + C);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const int cb = (int)(i % c4);
+    f32x4 v = x4[i] * sc4[cb] + sh4[cb];
+    if (residual) v += r4[i];
+    if (relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    y4[i] = v;
+  }
+}
+
+// Backward stage 1: g = dy * (y > 0) ; partial[blk][0][C] = sum g, [1][C] = sum g * xhat.
+// Optionally writes g to d_residual.
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ y,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             float* __restrict__ d_residual,
+                                                             float* __restrict__ partial, int64_t rows, int C,
+                                                             int64_t rows_per_blk, int tpc, int rl, int relu) {
+  __shared__ f32x4 red[2][256];
+  const int c4 = C >> 2;
+  const int tc = threadIdx.x % tpc, tr = threadIdx.x / tpc;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+  const int64_t r1 = min(rows, r0 + rows_per_blk);
+  for (int cb = tc; cb < c4; cb += tpc) {
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + cb * 4);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + cb * 4);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    if (tr < rl)
+      for (int64_t r = r0 + tr; r < r1; r += rl) {
+        const size_t off = (size_t)r * C + cb * 4;
+        f32x4 g = *reinterpret_cast<const f32x4*>(dy + off);
+        if (relu) {
+          const f32x4 yy = *reinterpret_cast<const f32x4*>(y + off);
+          g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+          g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+        }
+        if (d_residual) *reinterpret_cast<f32x4*>(d_residual + off) = g;
+        const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + off) - mu) * is;
+        s += g;
+        q += g * xh;
+      }
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = q;
+    __syncthreads();
+    if (tr == 0) {
+      for (int k = 1; k < rl; ++k) {
+        s += red[0][k * tpc + tc];
+        q += red[1][k * tpc + tc];
+      }
+      float* o = partial + (size_t)blockIdx.x * 2 * C;
+      *reinterpret_cast<f32x4*>(o + cb * 4) = s;
+      *reinterpret_cast<f32x4*>(o + C + cb * 4) = q;
+    }
+    __syncthreads();
+  }
+}
+
+// coef[0][C] = gamma*invstd ; coef[1][C] = mean(g) ; coef[2][C] = mean(g*xhat)  (0 when !train)
+__global__ void bn_bwd_final_kernel(const float* __restrict__ partial, int nblk, int C, double inv_rows,
+                                    const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef,
+                                    int train) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s += (double)partial[(size_t)b * 2 * C + c];
+    q += (double)partial[(size_t)b * 2 * C + C + c];
+  }
+  if (dbeta) dbeta[c] = (float)s;
+  if (dgamma) dgamma[c] = (float)q;
+  const float g = gamma ? gamma[c] : 1.f;
+  coef[c] = g * invstd[c];
+  coef[C + c] = train ? (float)(s * inv_rows) : 0.f;
+  coef[2 * C + c] = train ? (float)(q * inv_rows) : 0.f;
+}
+
+// dx = coef0 * (g - coef1 - xhat*coef2)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ y, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ coef, float* __restrict__ dx,
+                                                           size_t n4, int C, int relu) {
+  extern __shared__ __attribute__((aligned(16))) float ss[];  // [5][C]: coef0..2, mean, invstd
+  for (int i = threadIdx.x; i < 3 * C; i += 256) ss[i] = coef[i];
+  for (int i = threadIdx.x; i < C; i += 256) {
+    ss[3 * C + i] = mean[i];
+    ss[4 * C + i] = invstd[i];
+  }
+  __syncthreads();
+  const int c4 = C >> 2;
+  const f32x4* k0 = reinterpret_cast<const f32x4*>(ss);
+  const f32x4* k1 = reinterpret_cast<const f32x4*>(ss + C);
+  const f32x4* k2 = reinterpret_cast<const f32x4*>(ss + 2 * C);
+  const f32x4* mu = reinterpret_cast<const f32x4*>(ss + 3 * C);
+  const f32x4* is = reinterpret_cast<const f32x4*>(ss + 4 * C);
+  const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
+  f32x4* dx4 = reinterpret_cast<f32x4*>(dx);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const int cb = (int)(i % c4);
+    f32x4 g = dy4[i];
+    if (relu) {
+      const f32x4 yy = y4[i];
+      g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+      g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+    }
+    const f32x4 xh = (x4[i] - mu[cb]) * is[cb];
+    dx4[i] = k0[cb] * (g - k1[cb] - xh * k2[cb]);
+  }
+}
+
+static int stream_grid(size_t n4) {
+  size_t b = (n4 + 255) / 256;
+  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+}  // namespace evk
+
+using namespace evk;
+
+extern "C" size_t evk_bn_workspace_bytes(int64_t rows, int32_t C) {
+  if (rows <= 0 || C <= 0) return 0;
+  return ((size_t)kMaxStatBlocks * 2 * C + 8 * (size_t)C) * sizeof(float);
+}
+
+extern "C" int evk_bn_fwd_train(const float* x, const float* residual, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps, float* y,
+                                float* save_mean, float* save_invstd, int64_t rows, int32_t C, uint32_t flags,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  EVK_REQUIRE(x && y && save_mean && save_invstd, EVK_E_INVALID, "bn_fwd_train: null pointer");
+  EVK_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 2048, EVK_E_UNSUPPORTED, "bn_fwd_train: rows=%lld C=%d",
+              (long long)rows, C);
+  EVK_REQUIRE(workspace && workspace_bytes >= evk_bn_workspace_bytes(rows, C), EVK_E_WORKSPACE,
+              "bn_fwd_train: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const BnPlan pl = bn_plan(rows, C);
+  float* partial = (float*)workspace;
+  float* scale_shift = partial + (size_t)kMaxStatBlocks * 2 * C;
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(pl.nblk), dim3(256), 0, st, x, partial, rows, C, pl.rows_per_blk,
+                     pl.tpc, pl.rl);
+  int rc = check_launch("bn_stats_partial");
+  if (rc) return rc;
+  const double unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, pl.nblk, C,
+                     1.0 / (double)rows, unbias, gamma, beta, running_mean, running_var, momentum, eps, save_mean,
+                     save_invstd, scale_shift);
+  rc = check_launch("bn_stats_final");
+  if (rc) return rc;
+  const size_t n4 = (size_t)rows * C / 4;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(n4)), dim3(256), 2 * C * sizeof(float), st, x, residual,
+                     scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0);
+  return check_launch("bn_apply");
+}
+
+extern "C" int evk_bn_fwd_eval(const float* x, const float* residual, const float* gamma, const float* beta,
+                               const float* running_mean, const float* running_var, float eps, float* y,
+                               float* save_mean, float* save_invstd, int64_t rows, int32_t C, uint32_t flags,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  EVK_REQUIRE(x && y && running_mean && running_var, EVK_E_INVALID, "bn_fwd_eval: null pointer");
+  EVK_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 2048, EVK_E_UNSUPPORTED, "bn_fwd_eval: rows=%lld C=%d",
+              (long long)rows, C);
+  EVK_REQUIRE(workspace && workspace_bytes >= 2 * (size_t)C * sizeof(float), EVK_E_WORKSPACE,
+              "bn_fwd_eval: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* scale_shift = (float*)workspace;
+  hipLaunchKernelGGL(bn_eval_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, st, gamma, beta, running_mean,
+                     running_var, eps, C, scale_shift, save_mean, save_invstd);
+  int rc = check_launch("bn_eval_coef");
+  if (rc) return rc;
+  const size_t n4 = (size_t)rows * C / 4;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(n4)), dim3(256), 2 * C * sizeof(float), st, x, residual,
+                     scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0);
+  return check_launch("bn_apply");
+}
+
+extern "C" int evk_bn_bwd(const float* dy, const float* x, const float* y, const float* gamma,
+                          const float* save_mean, const float* save_invstd, float* dx, float* d_residual,
+                          float* dgamma, float* dbeta, int64_t rows, int32_t C, uint32_t flags, int32_t train,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+  EVK_REQUIRE(dy && x && save_mean && save_invstd && dx, EVK_E_INVALID, "bn_bwd: null pointer");
+  const int relu = (flags & EVK_BN_RELU) ? 1 : 0;
+  EVK_REQUIRE(!relu || y, EVK_E_INVALID, "bn_bwd: ReLU mask needs the forward output y");
+  EVK_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 2048, EVK_E_UNSUPPORTED, "bn_bwd: rows=%lld C=%d",
+              (long long)rows, C);
+  EVK_REQUIRE(workspace && workspace_bytes >= evk_bn_workspace_bytes(rows, C), EVK_E_WORKSPACE,
+              "bn_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const BnPlan pl = bn_plan(rows, C);
+  float* partial = (float*)workspace;
+  float* coef = partial + (size_t)kMaxStatBlocks * 2 * C;
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(pl.nblk), dim3(256), 0, st, dy, x, y, save_mean, save_invstd,
+                     d_residual, partial, rows, C, pl.rows_per_blk, pl.tpc, pl.rl, relu);
+  int rc = check_launch("bn_bwd_partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, pl.nblk, C,
+                     1.0 / (double)rows, gamma, save_invstd, dgamma, dbeta, coef, train ? 1 : 0);
+  rc = check_launch("bn_bwd_final");
+  if (rc) return rc;
+  const size_t n4 = (size_t)rows * C / 4;
+  // when d_residual holds g already, stage 3 can read it instead of re-masking dy
+  const float* gsrc = d_residual ? d_residual : dy;
+  const int relu3 = d_residual ? 0 : relu;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(256), 5 * C * sizeof(float), st, gsrc, x, y,
+                     save_mean, save_invstd, coef, dx, n4, C, relu3);
+  return check_launch("bn_bwd_apply");
+}

@@ -1,0 +1,306 @@
+// Convolution weight gradient for gfx950 on v_mfma_f32_32x32x2_f32.
+//
+//   dw[co][k] = sum_m dy[m][co] * im2col(x)[m][k]        m = (n, oy, ox),  k = (ky, kx, ci)
+//
+// Replaces aten::convolution_backward(weight, bias) of the nn.Conv2d sites listed in
+// conv_igemm.hip (reference ever/module/_resnets.py:21-29,149 ; fpn.py ; fs_relation.py).
+//
+// GEMM view: rows = Cout, cols = kh*kw*Cin, reduction = pixels.  Both operands are stored
+// pixel-major in HBM ([pixel][channel]), which is exactly the k-major LDS image the f32 MFMA
+// fragments want (lane l reads row k=l>>5, column i=l&31: 32 consecutive words, conflict free),
+// so tiles are staged [32 pixels][BM or BN channels] without any transpose.  The pixel range is
+// split across workgroups (grid.z); partial tiles go to the caller's workspace and are summed in a
+// fixed order by a second kernel => bitwise reproducible, no atomics.
+#include "common.hpp"
+
+namespace evk {
+
+struct WGradArgs {
+  const float* x;
+  const float* dy;
+  float* out;  // dw (splitk==1) or workspace [splitk][Cout][Ktot]
+  int N, H, W, Cin, Ho, Wo, Cout;
+  int kh, kw, cpt;
+  int sh, sw, ph, pw, dh, dw;
+  int M, Ktot;
+  int chunk;  // pixels per split (multiple of 32)
+  int tiles_co, tiles_k, splitk;
+  FastDiv fd_hw, fd_w;
+};
+
+constexpr int BKP = 32;  // pixels per step
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGradArgs p) {
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int MB = WM / 32, NB = WN / 32;
+  constexpr int ACH = BM / 4, BCH = BN / 4;          // 16-byte chunks per staged row
+  constexpr int APASS = BKP * ACH / 256, BPASS = BKP * BCH / 256;
+  constexpr int AROWS = 256 / ACH, BROWS = 256 / BCH;  // rows covered per pass
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                   // [2][32][BM]
+  float* Bs = smem + 2 * BKP * BM;    // [2][32][BN]
+
+  const int tile_k = blockIdx.x % p.tiles_k;
+  const int tile_co = blockIdx.x / p.tiles_k;
+  const int z = blockIdx.y;
+  const int co0 = tile_co * BM, k0 = tile_k * BN;
+  const int pbeg = z * p.chunk;
+  const int pend = min(p.M, pbeg + p.chunk);
+
+  const int tid = threadIdx.x;
+  // A staging: dy rows
+  const int a_c = tid % ACH, a_r = tid / ACH;
+  const bool a_cvalid = (co0 + a_c * 4) < p.Cout;
+  // B staging: im2col rows; this thread's K chunk is fixed for the whole reduction
+  const int b_c = tid % BCH, b_r = tid / BCH;
+  const int q = (k0 >> 2) + b_c;
+  const bool b_cvalid = q * 4 < p.Ktot;
+  int b_dy = 0, b_dx = 0, b_cc = 0;
+  if (b_cvalid) {
+    const int tap = q / p.cpt;
+    b_cc = (q - tap * p.cpt) * 4;
+    const int ky = tap / p.kw, kx = tap - ky * p.kw;
+    b_dy = ky * p.dh - p.ph;
+    b_dx = kx * p.dw - p.pw;
+  }
+
+  f32x4 ra[APASS], rb[BPASS];
+
+  auto load_tiles = [&](int pix0) {
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) {
+      const int m = pix0 + a_r + j * AROWS;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (a_cvalid && m < pend) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.Cout + co0 + a_c * 4);
+      ra[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) {
+      const int m = pix0 + b_r + j * BROWS;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (b_cvalid && m < pend) {
+        const uint32_t n = fdiv((uint32_t)m, p.fd_hw);
+        const uint32_t rem = (uint32_t)m - n * p.fd_hw.div;
+        const uint32_t oy = fdiv(rem, p.fd_w);
+        const uint32_t ox = rem - oy * p.fd_w.div;
+        const int sy = (int)oy * p.sh + b_dy;
+        const int sx = (int)ox * p.sw + b_dx;
+        if ((unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W) {
+          const size_t off = (((size_t)n * p.H + sy) * p.W + sx) * p.Cin + b_cc;
+          v = *reinterpret_cast<const f32x4*>(p.x + off);
+        }
+      }
+      rb[j] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float* Ab = As + buf * BKP * BM;
+    float* Bb = Bs + buf * BKP * BN;
+#pragma unroll
+    for (int j = 0; j < APASS; ++j)
+      *reinterpret_cast<f32x4*>(Ab + (a_r + j * AROWS) * BM + a_c * 4) = ra[j];
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j)
+      *reinterpret_cast<f32x4*>(Bb + (b_r + j * BROWS) * BN + b_c * 4) = rb[j];
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int li = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nk = (pend - pbeg + BKP - 1) / BKP;
+  if (nk > 0) {
+    load_tiles(pbeg);
+    store_tiles(0);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tiles(pbeg + (kt + 1) * BKP);
+    const float* Ab = As + buf * BKP * BM + wm * WM + li;
+    const float* Bb = Bs + buf * BKP * BN + wn * WN + li;
+#pragma unroll
+    for (int s = 0; s < BKP / 2; ++s) {
+      float fa[MB], fb[NB];
+#pragma unroll
+      for (int a = 0; a < MB; ++a) fa[a] = Ab[(2 * s + lh) * BM + a * 32];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) fb[b] = Bb[(2 * s + lh) * BN + b * 32];
+#pragma unroll
+      for (int a = 0; a < MB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* out = p.out + (size_t)z * p.Cout * p.Ktot;
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = co0 + wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row >= p.Cout) continue;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int col = k0 + wn * WN + b * 32 + li;
+        if (col < p.Ktot) out[(size_t)row * p.Ktot + col] = acc[a][b][r];
+      }
+    }
+}
+
+// out[i] = sum_z ws[z][i]  (fixed order)
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, size_t n4, int splitk,
+                                     size_t stride4) {
+  const f32x4* w4 = reinterpret_cast<const f32x4*>(ws);
+  f32x4* o4 = reinterpret_cast<f32x4*>(out);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 s = w4[i];
+    for (int z = 1; z < splitk; ++z) s += w4[(size_t)z * stride4 + i];
+    o4[i] = s;
+  }
+}
+
+// Column sums of a [rows][C] matrix: stage 1 -> partial[blk][C], stage 2 -> out[C].  C % 4 == 0.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ src, float* __restrict__ partial,
+                                                             int64_t rows, int C, int64_t rows_per_blk) {
+  __shared__ f32x4 red[256];
+  const int c4 = C >> 2;
+  const int tpc = min(c4, 256);       // threads across channels
+  const int rl = 256 / tpc;           // row lanes
+  const int tc = threadIdx.x % tpc, tr = threadIdx.x / tpc;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+  const int64_t r1 = min(rows, r0 + rows_per_blk);
+  for (int cb = tc; cb < c4; cb += tpc) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (tr < rl)
+      for (int64_t r = r0 + tr; r < r1; r += rl) s += *reinterpret_cast<const f32x4*>(src + r * C + cb * 4);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (tr == 0) {
+      for (int k = 1; k < rl; ++k) s += red[k * tpc + tc];
+      *reinterpret_cast<f32x4*>(partial + (size_t)blockIdx.x * C + cb * 4) = s;
+    }
+    __syncthreads();
+  }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * C + c];
+  out[c] = (float)s;
+}
+
+struct WGradPlan {
+  int bm, bn, tiles_co, tiles_k, splitk, chunk;
+};
+static WGradPlan plan_wgrad(const evk_conv_desc* d) {
+  WGradPlan pl;
+  const int Ktot = d->kh * d->kw * d->Cin;
+  const int M = d->N * d->Ho * d->Wo;
+  pl.bm = d->Cout <= 64 ? 64 : 128;
+  pl.bn = Ktot <= 64 ? 64 : 128;
+  pl.tiles_co = ceil_div(d->Cout, pl.bm);
+  pl.tiles_k = ceil_div(Ktot, pl.bn);
+  const int tiles = pl.tiles_co * pl.tiles_k;
+  int want = ceil_div(1024, tiles);
+  int maxsplit = ceil_div(M, 128);  // at least 128 pixels per split
+  int sk = want < 1 ? 1 : want;
+  if (sk > maxsplit) sk = maxsplit;
+  if (sk < 1) sk = 1;
+  int chunk = ceil_div(M, sk);
+  chunk = ((chunk + BKP - 1) / BKP) * BKP;
+  pl.chunk = chunk;
+  pl.splitk = ceil_div(M, chunk);
+  return pl;
+}
+static int colsum_blocks(int64_t rows) {
+  int64_t b = (rows + 255) / 256;
+  return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch_wgrad(const WGradArgs& a, hipStream_t stream) {
+  const size_t lds = (size_t)2 * BKP * (BM + BN) * sizeof(float);
+  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WAVES_M, WAVES_N>), dim3(a.tiles_co * a.tiles_k, a.splitk),
+                     dim3(256), lds, stream, a);
+  return check_launch("conv_wgrad");
+}
+
+}  // namespace evk
+
+using namespace evk;
+
+extern "C" size_t evk_conv2d_wgrad_workspace_bytes(const evk_conv_desc* d) {
+  if (!d) return 0;
+  const WGradPlan pl = plan_wgrad(d);
+  const size_t Ktot = (size_t)d->kh * d->kw * d->Cin;
+  size_t a = pl.splitk > 1 ? (size_t)pl.splitk * d->Cout * Ktot * sizeof(float) : 0;
+  size_t b = (size_t)colsum_blocks((int64_t)d->N * d->Ho * d->Wo) * d->Cout * sizeof(float);
+  return (a > b ? a : b) + 256;
+}
+
+extern "C" int evk_conv2d_wgrad(const evk_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  EVK_REQUIRE(d && x && dy && dw, EVK_E_INVALID, "conv2d_wgrad: null pointer");
+  EVK_REQUIRE(d->Cin % 4 == 0 && d->Cout % 4 == 0, EVK_E_UNSUPPORTED,
+              "conv2d_wgrad: Cin=%d and Cout=%d must be multiples of 4", d->Cin, d->Cout);
+  EVK_REQUIRE(workspace_bytes >= evk_conv2d_wgrad_workspace_bytes(d) && (workspace || workspace_bytes == 0),
+              EVK_E_WORKSPACE, "conv2d_wgrad: workspace %zu < %zu", workspace_bytes,
+              evk_conv2d_wgrad_workspace_bytes(d));
+  hipStream_t st = (hipStream_t)stream;
+  const WGradPlan pl = plan_wgrad(d);
+  WGradArgs a{};
+  a.x = x; a.dy = dy;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+  a.kh = d->kh; a.kw = d->kw; a.cpt = d->Cin / 4;
+  a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
+  a.M = d->N * d->Ho * d->Wo;
+  a.Ktot = d->kh * d->kw * d->Cin;
+  a.chunk = pl.chunk; a.tiles_co = pl.tiles_co; a.tiles_k = pl.tiles_k; a.splitk = pl.splitk;
+  a.fd_hw = make_fastdiv((uint32_t)(d->Ho * d->Wo));
+  a.fd_w = make_fastdiv((uint32_t)d->Wo);
+  a.out = pl.splitk > 1 ? (float*)workspace : dw;
+  int rc;
+  if (pl.bm == 128 && pl.bn == 128) rc = launch_wgrad<128, 128, 2, 2>(a, st);
+  else if (pl.bm == 64 && pl.bn == 128) rc = launch_wgrad<64, 128, 2, 2>(a, st);
+  else if (pl.bm == 128 && pl.bn == 64) rc = launch_wgrad<128, 64, 2, 2>(a, st);
+  else rc = launch_wgrad<64, 64, 2, 2>(a, st);
+  if (rc) return rc;
+  if (pl.splitk > 1) {
+    const size_t n = (size_t)d->Cout * a.Ktot;  // multiple of 4 since Cin % 4 == 0
+    const size_t n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, n4,
+                       pl.splitk, n4);
+    rc = check_launch("splitk_reduce");
+    if (rc) return rc;
+  }
+  if (dbias) {
+    const int64_t rows = a.M;
+    const int nblk = colsum_blocks(rows);
+    const int64_t rpb = (rows + nblk - 1) / nblk;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, st, dy, (float*)workspace, rows, d->Cout, rpb);
+    rc = check_launch("colsum_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((d->Cout + 255) / 256), dim3(256), 0, st, (const float*)workspace,
+                       dbias, nblk, d->Cout);
+    rc = check_launch("colsum_final");
+  }
+  return rc;
+}

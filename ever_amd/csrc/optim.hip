@@ -1,0 +1,95 @@
+// Multi-tensor SGD step and global gradient-norm clipping (gfx950), one launch over a device-side
+// table of tensors.  Replaces the per-tensor loops of torch.optim.SGD (reference
+// ever/opt/optimizer.py:7) and clip_grad_norm_ (ever/interface/module.py:96-108).  HBM-bound.
+#include "common.hpp"
+
+namespace evk {
+
+constexpr int kOptBlocksPerTensor = 32;
+
+__global__ __launch_bounds__(256) void sqnorm_multi_kernel(const float* const* __restrict__ grads,
+                                                           const int64_t* __restrict__ sizes,
+                                                           double* __restrict__ partial) {
+  __shared__ double red[4];
+  const int t = blockIdx.y;
+  const float* g = grads[t];
+  const int64_t n = sizes[t];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = g[i];
+    s += (double)v * (double)v;
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(size_t)t * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// total_norm = sqrt(sum partial); coef = min(1, max_norm / (total_norm + 1e-6))   (torch semantics)
+__global__ void clip_coef_kernel(const double* __restrict__ partial, int n, float max_norm, float* total_norm,
+                                 float* coef) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float tn = (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
+    *total_norm = tn;
+    const float c = max_norm / (tn + 1e-6f);
+    *coef = c < 1.f ? c : 1.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void sgd_multi_kernel(float* const* __restrict__ params,
+                                                        const float* const* __restrict__ grads,
+                                                        float* const* __restrict__ bufs,
+                                                        const int64_t* __restrict__ sizes, float lr, float momentum,
+                                                        float dampening, float wd, int nesterov, int first_step,
+                                                        const float* __restrict__ clip_coef) {
+  const int t = blockIdx.y;
+  float* p = params[t];
+  const float* g = grads[t];
+  float* b = bufs ? bufs[t] : nullptr;
+  const int64_t n = sizes[t];
+  const float cc = clip_coef ? *clip_coef : 1.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float d = g[i] * cc;
+    const float w = p[i];
+    if (wd != 0.f) d += wd * w;
+    if (momentum != 0.f) {
+      float m = first_step ? d : momentum * b[i] + (1.f - dampening) * d;
+      b[i] = m;
+      d = nesterov ? d + momentum * m : m;
+    }
+    p[i] = w - lr * d;
+  }
+}
+
+}  // namespace evk
+using namespace evk;
+
+extern "C" int32_t evk_opt_blocks_per_tensor(void) { return kOptBlocksPerTensor; }
+
+extern "C" int evk_sqnorm_multi(const float* const* grads, const int64_t* sizes, int32_t ntensors, double* partial,
+                                float max_norm, float* total_norm, float* clip_coef, void* stream) {
+  EVK_REQUIRE(grads && sizes && partial && total_norm && clip_coef && ntensors > 0, EVK_E_INVALID,
+              "sqnorm_multi: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sqnorm_multi_kernel, dim3(kOptBlocksPerTensor, ntensors), dim3(256), 0, st, grads, sizes, partial);
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, st, (const double*)partial,
+                     kOptBlocksPerTensor * ntensors, max_norm, total_norm, clip_coef);
+  return check_launch("sqnorm_multi");
+}
+
+extern "C" int evk_sgd_multi(float* const* params, const float* const* grads, float* const* momentum_bufs,
+                             const int64_t* sizes, int32_t ntensors, float lr, float momentum, float dampening,
+                             float weight_decay, int32_t nesterov, int32_t first_step, const float* clip_coef,
+                             void* stream) {
+  EVK_REQUIRE(params && grads && sizes && ntensors > 0, EVK_E_INVALID, "sgd_multi: bad argument");
+  EVK_REQUIRE(momentum == 0.f || momentum_bufs, EVK_E_INVALID, "sgd_multi: momentum needs buffers");
+  hipLaunchKernelGGL(sgd_multi_kernel, dim3(kOptBlocksPerTensor, ntensors), dim3(256), 0, (hipStream_t)stream, params,
+                     grads, momentum_bufs, sizes, lr, momentum, dampening, weight_decay, nesterov, first_step,
+                     clip_coef);
+  return check_launch("sgd_multi");
+}

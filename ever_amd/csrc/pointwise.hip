@@ -1,0 +1,608 @@
+// HBM-bound wavefront kernels of the EVer hot path on NHWC fp32 (gfx950): ReLU / add / scale,
+// channel padding and NCHW<->NHWC at the model boundary, MaxPool 3x3 s2, nearest x2 + lateral add,
+// bilinear align_corners=True resampling and its adjoint, global average pool, FS-Relation, 4-way mean.
+// Reference call sites are cited per entry point in include/ever_hip.h.
+// All kernels use 16-byte accesses along the channel axis (C % 4 == 0) with a scalar fallback where
+// the path has C == 1 (classifier logits).
+#include "common.hpp"
+
+namespace evk {
+
+static inline int grid_for(size_t n, int per_block = 256, int cap = 4096) {
+  size_t b = (n + per_block - 1) / per_block;
+  return (int)(b > (size_t)cap ? cap : (b < 1 ? 1 : b));
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int OP>  // 0 relu, 1 relu_bwd, 2 add, 3 scale
+__global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                 float* __restrict__ o, size_t n, float alpha) {
+  const size_t n4 = n >> 2;
+  const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
+  const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
+  f32x4* o4 = reinterpret_cast<f32x4*>(o);
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    f32x4 v = a4[i];
+    if (OP == 0) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    } else if (OP == 1) {  // a = dy, b = y
+      const f32x4 y = b4[i];
+      v.x = y.x > 0.f ? v.x : 0.f; v.y = y.y > 0.f ? v.y : 0.f;
+      v.z = y.z > 0.f ? v.z : 0.f; v.w = y.w > 0.f ? v.w : 0.f;
+    } else if (OP == 2) {
+      v += b4[i];
+    } else {
+      v *= alpha;
+    }
+    o4[i] = v;
+  }
+  // tail
+  for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    float v = a[i];
+    if (OP == 0) v = fmaxf(v, 0.f);
+    else if (OP == 1) v = b[i] > 0.f ? v : 0.f;
+    else if (OP == 2) v += b[i];
+    else v *= alpha;
+    o[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void mean4_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                    const float* __restrict__ c, const float* __restrict__ d,
+                                                    float* __restrict__ o, size_t n4) {
+  const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
+  const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
+  const f32x4* c4 = reinterpret_cast<const f32x4*>(c);
+  const f32x4* d4 = reinterpret_cast<const f32x4*>(d);
+  f32x4* o4 = reinterpret_cast<f32x4*>(o);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+    o4[i] = (((a4[i] + b4[i]) + c4[i]) + d4[i]) * 0.25f;  // same association as python sum(list)/4
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void pad_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t rows, int C,
+                                    int Cp) {
+  const size_t total = rows * (size_t)Cp;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / Cp;
+    const int c = (int)(i - r * Cp);
+    dst[i] = c < C ? src[r * C + c] : 0.f;
+  }
+}
+__global__ void unpad_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t rows, int Cp,
+                                      int C) {
+  const size_t total = rows * (size_t)C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / C;
+    const int c = (int)(i - r * C);
+    dst[i] = src[r * Cp + c];
+  }
+}
+// one thread per pixel: plane reads are coalesced across lanes, the Cp-wide pixel is written whole
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, size_t HW,
+                                    int Cp) {
+  const size_t total = (size_t)N * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i / HW, p = i - n * HW;
+    const float* s = src + n * C * HW + p;
+    float* d = dst + i * Cp;
+    for (int c = 0; c < Cp; ++c) d[c] = c < C ? s[(size_t)c * HW] : 0.f;
+  }
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, size_t HW,
+                                    int Cp) {
+  const size_t total = (size_t)N * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i / HW, p = i - n * HW;
+    const float* s = src + i * Cp;
+    float* d = dst + n * C * HW + p;
+    for (int c = 0; c < C; ++c) d[(size_t)c * HW] = s[c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MaxPool2d(3, 2, 1).  code[..] = winning tap ky*3+kx (first maximum in scan order, NaN propagates,
+// matching aten's max_pool2d_with_indices).
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          uint8_t* __restrict__ code, int N, int H, int W, int C,
+                                                          int Ho, int Wo) {
+  const int c4 = C >> 2;
+  const size_t total = (size_t)N * Ho * Wo * c4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cb = (int)(i % c4);
+    size_t pix = i / c4;
+    const int ox = (int)(pix % Wo);
+    pix /= Wo;
+    const int oy = (int)(pix % Ho);
+    const int n = (int)(pix / Ho);
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bx = 0, by = 0, bz = 0, bw = 0;
+    bool first = true;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 - 1 + kx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)n * H + iy) * W + ix) * C + cb * 4);
+        const int t = ky * 3 + kx;
+        if (first) {
+          best = v; bx = by = bz = bw = t; first = false;
+        } else {
+          if (v.x > best.x || v.x != v.x) { best.x = v.x; bx = t; }
+          if (v.y > best.y || v.y != v.y) { best.y = v.y; by = t; }
+          if (v.z > best.z || v.z != v.z) { best.z = v.z; bz = t; }
+          if (v.w > best.w || v.w != v.w) { best.w = v.w; bw = t; }
+        }
+      }
+    }
+    const size_t o = (((size_t)n * Ho + oy) * Wo + ox) * C + cb * 4;
+    *reinterpret_cast<f32x4*>(y + o) = best;
+    *reinterpret_cast<uint32_t*>(code + o) = (uint32_t)bx | ((uint32_t)by << 8) | ((uint32_t)bz << 16) | ((uint32_t)bw << 24);
+  }
+}
+// gather-form adjoint: input pixel (iy,ix) is tap (iy-2oy+1, ix-2ox+1) of at most 2x2 windows
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy,
+                                                          const uint8_t* __restrict__ code, float* __restrict__ dx,
+                                                          int N, int H, int W, int C, int Ho, int Wo) {
+  const int c4 = C >> 2;
+  const size_t total = (size_t)N * H * W * c4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cb = (int)(i % c4);
+    size_t pix = i / c4;
+    const int ix = (int)(pix % W);
+    pix /= W;
+    const int iy = (int)(pix % H);
+    const int n = (int)(pix / H);
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    const int oy_lo = max(0, iy >> 1), oy_hi = min(Ho - 1, (iy + 1) >> 1);
+    const int ox_lo = max(0, ix >> 1), ox_hi = min(Wo - 1, (ix + 1) >> 1);
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      const int ky = iy - 2 * oy + 1;
+      if ((unsigned)ky > 2u) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        const int kx = ix - 2 * ox + 1;
+        if ((unsigned)kx > 2u) continue;
+        const uint32_t t = (uint32_t)(ky * 3 + kx);
+        const size_t o = (((size_t)n * Ho + oy) * Wo + ox) * C + cb * 4;
+        const uint32_t cd = *reinterpret_cast<const uint32_t*>(code + o);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + o);
+        if ((cd & 0xff) == t) g.x += d.x;
+        if (((cd >> 8) & 0xff) == t) g.y += d.y;
+        if (((cd >> 16) & 0xff) == t) g.z += d.z;
+        if ((cd >> 24) == t) g.w += d.w;
+      }
+    }
+    *reinterpret_cast<f32x4*>(dx + i * 4) = g;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nearest2x_add_kernel(const float* __restrict__ top,
+                                                            const float* __restrict__ lateral,
+                                                            float* __restrict__ out, int N, int H, int W, int C) {
+  const int c4 = C >> 2;
+  const int Ht = H >> 1, Wt = W >> 1;
+  const size_t total = (size_t)N * H * W * c4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cb = (int)(i % c4);
+    size_t pix = i / c4;
+    const int x = (int)(pix % W);
+    pix /= W;
+    const int y = (int)(pix % H);
+    const int n = (int)(pix / H);
+    const f32x4 t = *reinterpret_cast<const f32x4*>(top + (((size_t)n * Ht + (y >> 1)) * Wt + (x >> 1)) * C + cb * 4);
+    const f32x4 l = *reinterpret_cast<const f32x4*>(lateral + i * 4);
+    *reinterpret_cast<f32x4*>(out + i * 4) = l + t;
+  }
+}
+__global__ __launch_bounds__(256) void nearest2x_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dtop,
+                                                            int N, int H, int W, int C) {
+  // H, W are the fine (dout) dims
+  const int c4 = C >> 2;
+  const int Ht = H >> 1, Wt = W >> 1;
+  const size_t total = (size_t)N * Ht * Wt * c4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cb = (int)(i % c4);
+    size_t pix = i / c4;
+    const int x = (int)(pix % Wt);
+    pix /= Wt;
+    const int y = (int)(pix % Ht);
+    const int n = (int)(pix / Ht);
+    const float* b = dout + (((size_t)n * H + 2 * y) * W + 2 * x) * C + cb * 4;
+    const f32x4 s = (*reinterpret_cast<const f32x4*>(b) + *reinterpret_cast<const f32x4*>(b + C)) +
+                    (*reinterpret_cast<const f32x4*>(b + (size_t)W * C) +
+                     *reinterpret_cast<const f32x4*>(b + (size_t)W * C + C));
+    *reinterpret_cast<f32x4*>(dtop + i * 4) = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bilinear, align_corners=True (nn.UpsamplingBilinear2d).  Index math follows aten's
+// upsample_bilinear2d: scale = (in-1)/(out-1) in float, src = scale*dst, i0 = (int)src,
+// i1 = i0 + (i0 < in-1), l1 = src - i0, l0 = 1 - l1.
+__device__ __forceinline__ void bl_coord(int o, float scale, int in, int& i0, int& i1, float& l0, float& l1) {
+  const float s = scale * (float)o;
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+  l0 = 1.f - l1;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N,
+                                                           int Hi, int Wi, int Ho, int Wo, int C, float sy, float sx) {
+  const int cv = C / VEC;
+  const size_t total = (size_t)N * Ho * Wo * cv;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cb = (int)(i % cv);
+    size_t pix = i / cv;
+    const int ox = (int)(pix % Wo);
+    pix /= Wo;
+    const int oy = (int)(pix % Ho);
+    const int n = (int)(pix / Ho);
+    int y0, y1, x0, x1;
+    float hy0, hy1, wx0, wx1;
+    bl_coord(oy, sy, Hi, y0, y1, hy0, hy1);
+    bl_coord(ox, sx, Wi, x0, x1, wx0, wx1);
+    const float* b = x + (size_t)n * Hi * Wi * C + cb * VEC;
+    const size_t o00 = ((size_t)y0 * Wi + x0) * C, o01 = ((size_t)y0 * Wi + x1) * C;
+    const size_t o10 = ((size_t)y1 * Wi + x0) * C, o11 = ((size_t)y1 * Wi + x1) * C;
+    if (VEC == 4) {
+      const f32x4 v00 = *reinterpret_cast<const f32x4*>(b + o00), v01 = *reinterpret_cast<const f32x4*>(b + o01);
+      const f32x4 v10 = *reinterpret_cast<const f32x4*>(b + o10), v11 = *reinterpret_cast<const f32x4*>(b + o11);
+      *reinterpret_cast<f32x4*>(y + i * 4) = hy0 * (wx0 * v00 + wx1 * v01) + hy1 * (wx0 * v10 + wx1 * v11);
+    } else {
+      y[i] = hy0 * (wx0 * b[o00] + wx1 * b[o01]) + hy1 * (wx0 * b[o10] + wx1 * b[o11]);
+    }
+  }
+}
+
+// adjoint in gather form: every input pixel sums the (few) output pixels whose 2x2 footprint
+// contains it, with exactly the forward's weights.  Candidate range per axis:
+// src in (i-1, i+1)  <=>  o in ((i-1)/scale, (i+1)/scale), widened by one for float rounding.
+constexpr int kMaxCand = 12;
+template <int VEC>
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N,
+                                                           int Hi, int Wi, int Ho, int Wo, int C, float sy, float sx,
+                                                           float isy, float isx) {
+  const int cv = C / VEC;
+  const size_t total = (size_t)N * Hi * Wi * cv;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cb = (int)(i % cv);
+    size_t pix = i / cv;
+    const int ix = (int)(pix % Wi);
+    pix /= Wi;
+    const int iy = (int)(pix % Hi);
+    const int n = (int)(pix / Hi);
+    int oy_lo = (int)floorf((float)(iy - 1) * isy) - 1, oy_hi = (int)ceilf((float)(iy + 1) * isy) + 1;
+    int ox_lo = (int)floorf((float)(ix - 1) * isx) - 1, ox_hi = (int)ceilf((float)(ix + 1) * isx) + 1;
+    oy_lo = max(oy_lo, 0); oy_hi = min(oy_hi, Ho - 1);
+    ox_lo = max(ox_lo, 0); ox_hi = min(ox_hi, Wo - 1);
+    f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+    float acc1 = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1;
+      float hy0, hy1;
+      bl_coord(oy, sy, Hi, y0, y1, hy0, hy1);
+      float wy = 0.f;
+      if (y0 == iy) wy += hy0;
+      if (y1 == iy) wy += hy1;
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1;
+        float wx0, wx1;
+        bl_coord(ox, sx, Wi, x0, x1, wx0, wx1);
+        float wx = 0.f;
+        if (x0 == ix) wx += wx0;
+        if (x1 == ix) wx += wx1;
+        if (wx == 0.f) continue;
+        const size_t o = (((size_t)n * Ho + oy) * Wo + ox) * C + cb * VEC;
+        if (VEC == 4) acc4 += (wy * wx) * *reinterpret_cast<const f32x4*>(dy + o);
+        else acc1 += (wy * wx) * dy[o];
+      }
+    }
+    if (VEC == 4) *reinterpret_cast<f32x4*>(dx + i * 4) = acc4;
+    else dx[i] = acc1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Global average pool: x [N][HW][C] -> y [N][C].  grid (ceil(c4/tpc), N)
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int HW, int C,
+                                                      int tpc, int rl, float inv) {
+  __shared__ f32x4 red[256];
+  const int c4 = C >> 2;
+  const int tc = threadIdx.x % tpc, tr = threadIdx.x / tpc;
+  const int cb = blockIdx.x * tpc + tc;
+  const int n = blockIdx.y;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (cb < c4 && tr < rl)
+    for (int p = tr; p < HW; p += rl) s += *reinterpret_cast<const f32x4*>(x + ((size_t)n * HW + p) * C + cb * 4);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (tr == 0 && cb < c4) {
+    for (int k = 1; k < rl; ++k) s += red[k * tpc + tc];
+    *reinterpret_cast<f32x4*>(y + (size_t)n * C + cb * 4) = s * inv;
+  }
+}
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N,
+                                                      int HW, int C, float inv) {
+  const int c4 = C >> 2;
+  const size_t total = (size_t)N * HW * c4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cb = (int)(i % c4);
+    const size_t n = i / ((size_t)HW * c4);
+    *reinterpret_cast<f32x4*>(dx + i * 4) = *reinterpret_cast<const f32x4*>(dy + n * C + cb * 4) * inv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FS-Relation: one wave per pixel; lanes stride the channel axis in 16-byte chunks.
+__global__ __launch_bounds__(256) void relation_fwd_kernel(const float* __restrict__ scene,
+                                                           const float* __restrict__ content,
+                                                           const float* __restrict__ feat, float* __restrict__ out,
+                                                           float* __restrict__ r, int N, int HW, int C) {
+  const int c4 = C >> 2;
+  const int lane = threadIdx.x & 63;
+  const size_t npix = (size_t)N * HW;
+  const size_t wstride = (size_t)gridDim.x * 4;
+  for (size_t pix = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); pix < npix; pix += wstride) {
+    const size_t n = pix / HW;
+    const float* sc = scene + n * C;
+    const float* ct = content + pix * C;
+    float dot = 0.f;
+    for (int cb = lane; cb < c4; cb += 64) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(sc + cb * 4);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(ct + cb * 4);
+      dot += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+    dot = wave_sum(dot);
+    const float rv = 1.f / (1.f + expf(-dot));
+    if (lane == 0) r[pix] = rv;
+    const float* ft = feat + pix * C;
+    float* o = out + pix * C;
+    for (int cb = lane; cb < c4; cb += 64)
+      *reinterpret_cast<f32x4*>(o + cb * 4) = *reinterpret_cast<const f32x4*>(ft + cb * 4) * rv;
+  }
+}
+// backward: dfeat = r*dout ; dz = (sum_c dout*feat) * r*(1-r) ; dcontent = dz*scene ;
+// partial dscene[blk][n?]: each workgroup owns a pixel range inside ONE image n and accumulates
+// sum_p dz*content into partial[n][blk][C].
+__global__ __launch_bounds__(256) void relation_bwd_kernel(const float* __restrict__ dout,
+                                                           const float* __restrict__ scene,
+                                                           const float* __restrict__ content,
+                                                           const float* __restrict__ feat, const float* __restrict__ r,
+                                                           float* __restrict__ dcontent, float* __restrict__ dfeat,
+                                                           float* __restrict__ partial, int HW, int C, int pix_per_blk,
+                                                           int nblk) {
+  extern __shared__ __attribute__((aligned(16))) float sacc[];  // [4 waves][C]
+  const int c4 = C >> 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.y;
+  const int p0 = blockIdx.x * pix_per_blk, p1 = min(HW, p0 + pix_per_blk);
+  const float* sc = scene + (size_t)n * C;
+  float* myacc = sacc + wave * C;
+  for (int c = lane; c < C; c += 64) myacc[c] = 0.f;
+  for (int p = p0 + wave; p < p1; p += 4) {
+    const size_t pix = (size_t)n * HW + p;
+    const float rv = r[pix];
+    const float* d_o = dout + pix * C;
+    const float* ft = feat + pix * C;
+    const float* ct = content + pix * C;
+    float dot = 0.f;
+    for (int cb = lane; cb < c4; cb += 64) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(d_o + cb * 4);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(ft + cb * 4);
+      dot += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+      *reinterpret_cast<f32x4*>(dfeat + pix * C + cb * 4) = a * rv;
+    }
+    dot = wave_sum(dot);
+    const float dz = dot * rv * (1.f - rv);
+    for (int cb = lane; cb < c4; cb += 64) {
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(sc + cb * 4);
+      const f32x4 c4v = *reinterpret_cast<const f32x4*>(ct + cb * 4);
+      *reinterpret_cast<f32x4*>(dcontent + pix * C + cb * 4) = s4 * dz;
+      f32x4* a = reinterpret_cast<f32x4*>(myacc + cb * 4);
+      *a = *a + c4v * dz;
+    }
+  }
+  __syncthreads();
+  float* o = partial + ((size_t)n * nblk + blockIdx.x) * C;
+  for (int c = threadIdx.x; c < C; c += 256) o[c] = (sacc[c] + sacc[C + c]) + (sacc[2 * C + c] + sacc[3 * C + c]);
+}
+__global__ void relation_dscene_final_kernel(const float* __restrict__ partial, float* __restrict__ dscene, int nblk,
+                                             int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = blockIdx.y;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)partial[((size_t)n * nblk + b) * C + c];
+  dscene[(size_t)n * C + c] = (float)s;
+}
+
+static int relation_blocks(int HW) {
+  int b = (HW + 63) / 64;
+  return b > 256 ? 256 : (b < 1 ? 1 : b);
+}
+
+}  // namespace evk
+
+using namespace evk;
+
+#define EW_LAUNCH(OP, a, b, o, n, alpha, name)                                                                  \
+  do {                                                                                                          \
+    EVK_REQUIRE((a) && (o) && (n) >= 0, EVK_E_INVALID, name ": bad argument");                                  \
+    if ((n) == 0) return EVK_OK;                                                                                \
+    hipLaunchKernelGGL(ew_kernel<OP>, dim3(grid_for(((size_t)(n) + 3) / 4)), dim3(256), 0, (hipStream_t)stream, \
+                       a, b, o, (size_t)(n), alpha);                                                            \
+    return check_launch(name);                                                                                  \
+  } while (0)
+
+extern "C" int evk_relu_fwd(const float* x, float* y, int64_t n, void* stream) {
+  EW_LAUNCH(0, x, (const float*)nullptr, y, n, 0.f, "relu_fwd");
+}
+extern "C" int evk_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream) {
+  EVK_REQUIRE(y, EVK_E_INVALID, "relu_bwd: null y");
+  EW_LAUNCH(1, dy, y, dx, n, 0.f, "relu_bwd");
+}
+extern "C" int evk_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
+  EVK_REQUIRE(b, EVK_E_INVALID, "add: null b");
+  EW_LAUNCH(2, a, b, out, n, 0.f, "add");
+}
+extern "C" int evk_scale(const float* a, float alpha, float* out, int64_t n, void* stream) {
+  EW_LAUNCH(3, a, (const float*)nullptr, out, n, alpha, "scale");
+}
+extern "C" int evk_mean4_fwd(const float* a, const float* b, const float* c, const float* d, float* out, int64_t n,
+                             void* stream) {
+  EVK_REQUIRE(a && b && c && d && out && n > 0 && n % 4 == 0, EVK_E_INVALID, "mean4: bad argument");
+  hipLaunchKernelGGL(mean4_kernel, dim3(grid_for((size_t)n / 4)), dim3(256), 0, (hipStream_t)stream, a, b, c, d, out,
+                     (size_t)n / 4);
+  return check_launch("mean4");
+}
+
+extern "C" int evk_pad_channels(const float* src, float* dst, int64_t rows, int32_t C, int32_t Cp, void* stream) {
+  EVK_REQUIRE(src && dst && rows > 0 && C > 0 && Cp >= C, EVK_E_INVALID, "pad_channels: bad argument");
+  hipLaunchKernelGGL(pad_channels_kernel, dim3(grid_for((size_t)rows * Cp)), dim3(256), 0, (hipStream_t)stream, src,
+                     dst, (size_t)rows, C, Cp);
+  return check_launch("pad_channels");
+}
+extern "C" int evk_unpad_channels(const float* src, float* dst, int64_t rows, int32_t Cp, int32_t C, void* stream) {
+  EVK_REQUIRE(src && dst && rows > 0 && C > 0 && Cp >= C, EVK_E_INVALID, "unpad_channels: bad argument");
+  hipLaunchKernelGGL(unpad_channels_kernel, dim3(grid_for((size_t)rows * C)), dim3(256), 0, (hipStream_t)stream, src,
+                     dst, (size_t)rows, Cp, C);
+  return check_launch("unpad_channels");
+}
+extern "C" int evk_nchw_to_nhwc(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cp,
+                                void* stream) {
+  EVK_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && Cp >= C, EVK_E_INVALID, "nchw_to_nhwc: bad argument");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((size_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, src,
+                     dst, N, C, (size_t)H * W, Cp);
+  return check_launch("nchw_to_nhwc");
+}
+extern "C" int evk_nhwc_to_nchw(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cp,
+                                void* stream) {
+  EVK_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && Cp >= C, EVK_E_INVALID, "nhwc_to_nchw: bad argument");
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((size_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, src,
+                     dst, N, C, (size_t)H * W, Cp);
+  return check_launch("nhwc_to_nchw");
+}
+
+extern "C" int evk_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* code, int32_t N, int32_t H, int32_t W, int32_t C,
+                                    void* stream) {
+  EVK_REQUIRE(x && y && code && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, EVK_E_INVALID,
+              "maxpool_fwd: bad argument");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((size_t)N * Ho * Wo * (C / 4))), dim3(256), 0,
+                     (hipStream_t)stream, x, y, code, N, H, W, C, Ho, Wo);
+  return check_launch("maxpool_fwd");
+}
+extern "C" int evk_maxpool3x3s2_bwd(const float* dy, const uint8_t* code, float* dx, int32_t N, int32_t H, int32_t W,
+                                    int32_t C, void* stream) {
+  EVK_REQUIRE(dy && dx && code && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, EVK_E_INVALID,
+              "maxpool_bwd: bad argument");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((size_t)N * H * W * (C / 4))), dim3(256), 0,
+                     (hipStream_t)stream, dy, code, dx, N, H, W, C, Ho, Wo);
+  return check_launch("maxpool_bwd");
+}
+
+extern "C" int evk_upsample_nearest2x_add_fwd(const float* top, const float* lateral, float* out, int32_t N, int32_t H,
+                                              int32_t W, int32_t C, void* stream) {
+  EVK_REQUIRE(top && lateral && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && H % 2 == 0 && W % 2 == 0,
+              EVK_E_INVALID, "nearest2x_add: bad argument (H,W must be even, C %% 4 == 0)");
+  hipLaunchKernelGGL(nearest2x_add_kernel, dim3(grid_for((size_t)N * H * W * (C / 4))), dim3(256), 0,
+                     (hipStream_t)stream, top, lateral, out, N, H, W, C);
+  return check_launch("nearest2x_add");
+}
+extern "C" int evk_upsample_nearest2x_bwd(const float* dout, float* dtop, int32_t N, int32_t H, int32_t W, int32_t C,
+                                          void* stream) {
+  EVK_REQUIRE(dout && dtop && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && H % 2 == 0 && W % 2 == 0,
+              EVK_E_INVALID, "nearest2x_bwd: bad argument");
+  hipLaunchKernelGGL(nearest2x_bwd_kernel, dim3(grid_for((size_t)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0,
+                     (hipStream_t)stream, dout, dtop, N, H, W, C);
+  return check_launch("nearest2x_bwd");
+}
+
+static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+extern "C" int evk_upsample_bilinear_fwd(const float* x, float* y, int32_t N, int32_t Hi, int32_t Wi, int32_t Ho,
+                                         int32_t Wo, int32_t C, void* stream) {
+  EVK_REQUIRE(x && y && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, EVK_E_INVALID,
+              "bilinear_fwd: bad argument");
+  const float sy = ac_scale(Hi, Ho), sx = ac_scale(Wi, Wo);
+  if (C % 4 == 0)
+    hipLaunchKernelGGL(bilinear_fwd_kernel<4>, dim3(grid_for((size_t)N * Ho * Wo * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, x, y, N, Hi, Wi, Ho, Wo, C, sy, sx);
+  else
+    hipLaunchKernelGGL(bilinear_fwd_kernel<1>, dim3(grid_for((size_t)N * Ho * Wo * C)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, N, Hi, Wi, Ho, Wo, C, sy, sx);
+  return check_launch("bilinear_fwd");
+}
+extern "C" int evk_upsample_bilinear_bwd(const float* dy, float* dx, int32_t N, int32_t Hi, int32_t Wi, int32_t Ho,
+                                         int32_t Wo, int32_t C, void* stream) {
+  EVK_REQUIRE(dy && dx && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, EVK_E_INVALID,
+              "bilinear_bwd: bad argument");
+  const float sy = ac_scale(Hi, Ho), sx = ac_scale(Wi, Wo);
+  // inverse scales for the candidate range; in == 1 => every output maps to input 0
+  const float isy = sy > 0.f ? 1.f / sy : (float)Ho, isx = sx > 0.f ? 1.f / sx : (float)Wo;
+  if (C % 4 == 0)
+    hipLaunchKernelGGL(bilinear_bwd_kernel<4>, dim3(grid_for((size_t)N * Hi * Wi * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, dy, dx, N, Hi, Wi, Ho, Wo, C, sy, sx, isy, isx);
+  else
+    hipLaunchKernelGGL(bilinear_bwd_kernel<1>, dim3(grid_for((size_t)N * Hi * Wi * C)), dim3(256), 0,
+                       (hipStream_t)stream, dy, dx, N, Hi, Wi, Ho, Wo, C, sy, sx, isy, isx);
+  return check_launch("bilinear_bwd");
+}
+
+extern "C" int evk_gap_fwd(const float* x, float* y, int32_t N, int32_t HW, int32_t C, void* stream) {
+  EVK_REQUIRE(x && y && N > 0 && HW > 0 && C > 0 && C % 4 == 0, EVK_E_INVALID, "gap_fwd: bad argument");
+  const int c4 = C / 4;
+  const int tpc = c4 < 64 ? c4 : 64;
+  const int rl = 256 / tpc;
+  hipLaunchKernelGGL(gap_fwd_kernel, dim3((c4 + tpc - 1) / tpc, N), dim3(256), 0, (hipStream_t)stream, x, y, HW, C,
+                     tpc, rl, 1.f / (float)HW);
+  return check_launch("gap_fwd");
+}
+extern "C" int evk_gap_bwd(const float* dy, float* dx, int32_t N, int32_t HW, int32_t C, void* stream) {
+  EVK_REQUIRE(dy && dx && N > 0 && HW > 0 && C > 0 && C % 4 == 0, EVK_E_INVALID, "gap_bwd: bad argument");
+  hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_for((size_t)N * HW * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy,
+                     dx, N, HW, C, 1.f / (float)HW);
+  return check_launch("gap_bwd");
+}
+
+extern "C" int evk_relation_fwd(const float* scene, const float* content, const float* feat, float* out, float* r,
+                                int32_t N, int32_t HW, int32_t C, void* stream) {
+  EVK_REQUIRE(scene && content && feat && out && r && N > 0 && HW > 0 && C > 0 && C % 4 == 0, EVK_E_INVALID,
+              "relation_fwd: bad argument");
+  hipLaunchKernelGGL(relation_fwd_kernel, dim3(grid_for((size_t)N * HW, 4, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     scene, content, feat, out, r, N, HW, C);
+  return check_launch("relation_fwd");
+}
+extern "C" size_t evk_relation_workspace_bytes(int32_t N, int32_t HW, int32_t C) {
+  if (N <= 0 || HW <= 0 || C <= 0) return 0;
+  return (size_t)N * relation_blocks(HW) * C * sizeof(float);
+}
+extern "C" int evk_relation_bwd(const float* dout, const float* scene, const float* content, const float* feat,
+                                const float* r, float* dscene, float* dcontent, float* dfeat, int32_t N, int32_t HW,
+                                int32_t C, void* workspace, size_t workspace_bytes, void* stream) {
+  EVK_REQUIRE(dout && scene && content && feat && r && dscene && dcontent && dfeat, EVK_E_INVALID,
+              "relation_bwd: null pointer");
+  EVK_REQUIRE(N > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 4096, EVK_E_UNSUPPORTED, "relation_bwd: C=%d", C);
+  EVK_REQUIRE(workspace && workspace_bytes >= evk_relation_workspace_bytes(N, HW, C), EVK_E_WORKSPACE,
+              "relation_bwd: workspace too small");
+  const int nblk = relation_blocks(HW);
+  const int ppb = (HW + nblk - 1) / nblk;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(relation_bwd_kernel, dim3(nblk, N), dim3(256), 4 * C * sizeof(float), st, dout, scene, content,
+                     feat, r, dcontent, dfeat, (float*)workspace, HW, C, ppb, nblk);
+  int rc = check_launch("relation_bwd");
+  if (rc) return rc;
+  hipLaunchKernelGGL(relation_dscene_final_kernel, dim3((C + 255) / 256, N), dim3(256), 0, st,
+                     (const float*)workspace, dscene, nblk, C);
+  return check_launch("relation_dscene_final");
+}

@@ -1,0 +1,672 @@
+"""Autograd-aware host wrappers over the C-ABI kernels (include/ever_hip.h).
+
+Every function here takes / returns torch CUDA tensors whose *logical* shape is the reference's
+NCHW and whose *memory* is dense NHWC (channels_last); convolution weights are logical OIHW with
+OHWI memory.  There is no CPU implementation: a CPU tensor raises `HipPathError`.
+
+Reference call sites replaced (ever/module/...): see the per-function docstrings.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _C
+from .workspace import workspace
+
+__all__ = [
+    'HipPathError', 'empty_nhwc', 'as_nhwc', 'is_nhwc', 'image_to_nhwc', 'conv2d', 'batch_norm_act', 'relu',
+    'max_pool3x3s2', 'upsample_nearest2x_add', 'upsample_bilinear', 'global_avg_pool', 'fs_relation',
+    'mean4', 'add', 'bce_with_logits', 'dice_loss_with_logits', 'cross_entropy',
+]
+
+
+class HipPathError(RuntimeError):
+    """Raised when the HIP path is asked to run on something it cannot (CPU tensor, wrong dtype)."""
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        raise HipPathError(
+            f'{what}: ever_amd kernels run on MI355X only (got a {t.device} tensor). '
+            f'There is no CPU fallback; move the model and data to cuda.')
+    if t.dtype != torch.float32:
+        raise HipPathError(f'{what}: fp32 tensors required, got {t.dtype}')
+
+
+def empty_nhwc(n, c, h, w, device, dtype=torch.float32):
+    """Logical [n,c,h,w] tensor over dense NHWC memory."""
+    return torch.empty((n, h, w, c), device=device, dtype=dtype).permute(0, 3, 1, 2)
+
+
+def is_nhwc(t):
+    return t.dim() == 4 and t.permute(0, 2, 3, 1).is_contiguous()
+
+
+def as_nhwc(t, what='tensor'):
+    """Return `t` if its memory is already dense NHWC, else transpose it with the HIP kernel."""
+    _require_cuda(t, what)
+    if is_nhwc(t):
+        return t
+    return _ToNHWC.apply(t)
+
+
+class _ToNHWC(Function):
+    @staticmethod
+    def forward(ctx, x):
+        n, c, h, w = x.shape
+        xc = x.contiguous()  # dense NCHW source
+        out = empty_nhwc(n, c, h, w, x.device)
+        _C.call('evk_nchw_to_nhwc', xc.data_ptr(), out.data_ptr(), n, c, h, w, c, _stream())
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        return g
+
+
+def image_to_nhwc(x, cpad):
+    """Model-boundary transpose: NCHW image -> NHWC with channels zero-padded to `cpad` (no grad)."""
+    _require_cuda(x, 'image_to_nhwc')
+    n, c, h, w = x.shape
+    out = empty_nhwc(n, cpad, h, w, x.device)
+    if is_nhwc(x):
+        _C.call('evk_pad_channels', x.data_ptr(), out.data_ptr(), n * h * w, c, cpad, _stream())
+    else:
+        xc = x.contiguous()
+        _C.call('evk_nchw_to_nhwc', xc.data_ptr(), out.data_ptr(), n, c, h, w, cpad, _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------ convolution
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+def _conv_desc(n, h, w, cin, cout, kh, kw, stride, padding, dilation):
+    sh, sw = stride
+    ph, pw = padding
+    dh, dw = dilation
+    ho = (h + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+    wo = (w + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    return _C.ConvDesc(n, h, w, cin, ho, wo, cout, kh, kw, sh, sw, ph, pw, dh, dw)
+
+
+def _pad4(c):
+    return (c + 3) // 4 * 4
+
+
+def _pad_last(t2d_ptr, rows, c, cp, device):
+    out = torch.empty((rows, cp), device=device, dtype=torch.float32)
+    _C.call('evk_pad_channels', t2d_ptr, out.data_ptr(), rows, c, cp, _stream())
+    return out
+
+
+def _weight_ohwi(weight):
+    """Weight memory as dense [O][kh][kw][I]; transposes with the HIP kernel if it is OIHW-dense."""
+    if is_nhwc(weight):
+        return weight
+    o, i, kh, kw = weight.shape
+    wc = weight.contiguous()
+    out = empty_nhwc(o, i, kh, kw, weight.device)
+    _C.call('evk_nchw_to_nhwc', wc.data_ptr(), out.data_ptr(), o, i, kh, kw, i, _stream())
+    return out
+
+
+class _Conv2dFn(Function):
+    """nn.Conv2d forward/backward on the MFMA implicit-GEMM kernels.
+
+    Replaces aten::convolution(+_backward) at reference ever/module/_resnets.py:21-29,149,
+    fpn.py:23-37,72-73,165,179 and fs_relation.py:23-53.
+    """
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, dilation, relu):
+        n, cin, h, w = x.shape
+        cout, cin_w, kh, kw = weight.shape
+        if cin_w != cin:
+            raise ValueError(f'conv2d: input has {cin} channels but weight expects {cin_w} (groups != 1 unsupported)')
+        dev = x.device
+        st = _stream()
+        w_ohwi = _weight_ohwi(weight.detach())
+        cin_p = _pad4(cin)
+        if cin_p != cin:
+            xk = _pad_last(x.data_ptr(), n * h * w, cin, cin_p, dev)
+            wk = _pad_last(w_ohwi.data_ptr(), cout * kh * kw, cin, cin_p, dev)
+            x_ptr, w_ptr = xk.data_ptr(), wk.data_ptr()
+        else:
+            xk = x
+            x_ptr, w_ptr = x.data_ptr(), w_ohwi.data_ptr()
+        d = _conv_desc(n, h, w, cin_p, cout, kh, kw, stride, padding, dilation)
+        y = empty_nhwc(n, cout, d.Ho, d.Wo, dev)
+        _C.call('evk_conv2d_fwd', ctypes.byref(d), x_ptr, w_ptr, _ptr(bias), y.data_ptr(), 1 if relu else 0, st)
+        ctx.desc = d
+        ctx.relu = relu
+        ctx.cin = cin
+        ctx.has_bias = bias is not None
+        # xk (channel-padded copy when Cin % 4 != 0) is what wgrad reads
+        ctx.save_for_backward(xk, w_ohwi, y if relu else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        xk, w_ohwi, y = ctx.saved_tensors
+        d = ctx.desc
+        dev = dy.device
+        st = _stream()
+        n, cin_p, cout, kh, kw = d.N, d.Cin, d.Cout, d.kh, d.kw
+        cin = ctx.cin
+        dy = as_nhwc(dy, 'conv2d.backward')
+        if ctx.relu:
+            g = torch.empty_like(dy)
+            _C.call('evk_relu_bwd', dy.data_ptr(), y.data_ptr(), g.data_ptr(), dy.numel(), st)
+            dy = g
+        rows_o = n * d.Ho * d.Wo
+        cout_p = _pad4(cout)
+        if cout_p != cout:
+            # narrow heads (classifier Cout=1): pad dy / weight rows to 4 output channels
+            dyk = _pad_last(dy.data_ptr(), rows_o, cout, cout_p, dev)
+            dy_ptr = dyk.data_ptr()
+        else:
+            dyk = dy
+            dy_ptr = dy.data_ptr()
+        dk = _C.ConvDesc(d.N, d.H, d.W, cin_p, d.Ho, d.Wo, cout_p, kh, kw, d.stride_h, d.stride_w, d.pad_h, d.pad_w,
+                         d.dil_h, d.dil_w)
+        dx = dw = db = None
+        need_dx, need_dw, need_db = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        taps = kh * kw
+        if need_dx:
+            # weights as [cout_p][taps][cin_p]
+            if cin_p != cin or cout_p != cout:
+                wfull = torch.zeros((cout_p, taps, cin_p), device=dev, dtype=torch.float32)
+                tmp = (_pad_last(w_ohwi.data_ptr(), cout * taps, cin, cin_p, dev) if cin_p != cin
+                       else w_ohwi.permute(0, 2, 3, 1))  # OHWI memory order
+                wfull[:cout].copy_(tmp.reshape(cout, taps, cin_p))
+                w_src = wfull
+            else:
+                w_src = w_ohwi
+            wt = torch.empty((cin_p, taps, cout_p), device=dev, dtype=torch.float32)
+            _C.call('evk_conv2d_pack_dgrad_weight', ctypes.byref(dk), w_src.data_ptr(), wt.data_ptr(), st)
+            dxk = empty_nhwc(n, cin_p, d.H, d.W, dev)
+            _C.call('evk_conv2d_dgrad', ctypes.byref(dk), dy_ptr, wt.data_ptr(), dxk.data_ptr(), st)
+            if cin_p != cin:
+                dx = empty_nhwc(n, cin, d.H, d.W, dev)
+                _C.call('evk_unpad_channels', dxk.data_ptr(), dx.data_ptr(), n * d.H * d.W, cin_p, cin, st)
+            else:
+                dx = dxk
+        if need_dw or need_db:
+            lib = _C.load()
+            ws_bytes = lib.evk_conv2d_wgrad_workspace_bytes(ctypes.byref(dk))
+            ws = workspace(dev, ws_bytes)
+            dwk = torch.empty((cout_p, taps, cin_p), device=dev, dtype=torch.float32)
+            dbk = torch.empty((cout_p,), device=dev, dtype=torch.float32) if need_db else None
+            _C.call('evk_conv2d_wgrad', ctypes.byref(dk), xk.data_ptr(), dy_ptr, dwk.data_ptr(), _ptr(dbk),
+                    ws.data_ptr(), ws_bytes, st)
+            if need_dw:
+                if cin_p != cin:
+                    dw2 = torch.empty((cout_p * taps, cin), device=dev, dtype=torch.float32)
+                    _C.call('evk_unpad_channels', dwk.data_ptr(), dw2.data_ptr(), cout_p * taps, cin_p, cin, st)
+                    dwk = dw2.reshape(cout_p, taps, cin)
+                # logical OIHW view over OHWI memory (matches a channels_last parameter)
+                dw = dwk[:cout].reshape(cout, kh, kw, cin).permute(0, 3, 1, 2)
+            if need_db:
+                db = dbk[:cout]
+        return dx, dw, db, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False):
+    _require_cuda(x, 'conv2d')
+    x = as_nhwc(x, 'conv2d')
+    return _Conv2dFn.apply(x, weight, bias, _pair(stride), _pair(padding), _pair(dilation), bool(relu))
+
+
+# ------------------------------------------------------------------------------------ batch norm
+class _BatchNormActFn(Function):
+    """BatchNorm2d (+ residual add) (+ ReLU) in one pass.
+
+    Replaces aten::batch_norm, `out += identity`, relu_ at reference ever/module/_resnets.py:95-112,
+    fs_relation.py:39-53, fpn.py:163-167.
+    """
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+        n, c, h, w = x.shape
+        rows = n * h * w
+        dev = x.device
+        st = _stream()
+        lib = _C.load()
+        ws_bytes = lib.evk_bn_workspace_bytes(rows, c)
+        ws = workspace(dev, ws_bytes)
+        y = empty_nhwc(n, c, h, w, dev)
+        save_mean = torch.empty((c,), device=dev, dtype=torch.float32)
+        save_invstd = torch.empty((c,), device=dev, dtype=torch.float32)
+        flags = 1 if relu else 0
+        if training:
+            _C.call('evk_bn_fwd_train', x.data_ptr(), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(running_mean),
+                    _ptr(running_var), float(momentum), float(eps), y.data_ptr(), save_mean.data_ptr(),
+                    save_invstd.data_ptr(), rows, c, flags, ws.data_ptr(), ws_bytes, st)
+        else:
+            _C.call('evk_bn_fwd_eval', x.data_ptr(), _ptr(residual), _ptr(weight), _ptr(bias), running_mean.data_ptr(),
+                    running_var.data_ptr(), float(eps), y.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(),
+                    rows, c, flags, ws.data_ptr(), ws_bytes, st)
+        ctx.training = training
+        ctx.relu = relu
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, y if relu else None, weight, save_mean, save_invstd)
+        ctx.mark_non_differentiable(*[t for t in (running_mean, running_var) if t is not None])
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, y, weight, save_mean, save_invstd = ctx.saved_tensors
+        n, c, h, w = x.shape
+        rows = n * h * w
+        dev = x.device
+        st = _stream()
+        dy = as_nhwc(dy, 'batch_norm.backward')
+        lib = _C.load()
+        ws_bytes = lib.evk_bn_workspace_bytes(rows, c)
+        ws = workspace(dev, ws_bytes)
+        dx = torch.empty_like(x)
+        need_res = ctx.has_res and ctx.needs_input_grad[1]
+        dres = torch.empty_like(x) if need_res else None
+        has_affine = weight is not None
+        dgamma = torch.empty((c,), device=dev, dtype=torch.float32) if has_affine else None
+        dbeta = torch.empty((c,), device=dev, dtype=torch.float32) if has_affine else None
+        _C.call('evk_bn_bwd', dy.data_ptr(), x.data_ptr(), _ptr(y), _ptr(weight), save_mean.data_ptr(),
+                save_invstd.data_ptr(), dx.data_ptr(), _ptr(dres), _ptr(dgamma), _ptr(dbeta), rows, c,
+                1 if ctx.relu else 0, 1 if ctx.training else 0, ws.data_ptr(), ws_bytes, st)
+        if ctx.has_res and not need_res:
+            dres = None
+        return (dx, dres, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None,
+                None, None, None, None, None, None)
+
+
+def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentum, eps, residual=None, relu=False):
+    _require_cuda(x, 'batch_norm')
+    x = as_nhwc(x, 'batch_norm')
+    if x.shape[1] % 4 != 0:
+        raise HipPathError(f'batch_norm: channel count {x.shape[1]} must be a multiple of 4')
+    if residual is not None:
+        residual = as_nhwc(residual, 'batch_norm.residual')
+    use_batch_stats = training or running_mean is None
+    return _BatchNormActFn.apply(x, residual, weight, bias, running_mean, running_var, bool(use_batch_stats),
+                                 0.0 if momentum is None else momentum, eps, bool(relu))
+
+
+# ------------------------------------------------------------------------------------ pointwise
+class _ReluFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.empty_like(x)
+        _C.call('evk_relu_fwd', x.data_ptr(), y.data_ptr(), x.numel(), _stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = as_nhwc(dy, 'relu.backward') if dy.dim() == 4 else dy.contiguous()
+        dx = torch.empty_like(y)
+        _C.call('evk_relu_bwd', dy.data_ptr(), y.data_ptr(), dx.data_ptr(), y.numel(), _stream())
+        return dx
+
+
+def relu(x):
+    """nn.ReLU (reference fs_relation.py:25)."""
+    _require_cuda(x, 'relu')
+    if x.dim() == 4:
+        x = as_nhwc(x, 'relu')
+    return _ReluFn.apply(x)
+
+
+class _AddFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        out = torch.empty_like(a)
+        _C.call('evk_add', a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream())
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    _require_cuda(a, 'add')
+    a, b = as_nhwc(a, 'add'), as_nhwc(b, 'add')
+    if a.shape != b.shape:
+        raise ValueError(f'add: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}')
+    return _AddFn.apply(a, b)
+
+
+class _MaxPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        n, c, h, w = x.shape
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = empty_nhwc(n, c, ho, wo, x.device)
+        code = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.uint8)
+        _C.call('evk_maxpool3x3s2_fwd', x.data_ptr(), y.data_ptr(), code.data_ptr(), n, h, w, c, _stream())
+        ctx.save_for_backward(code)
+        ctx.shape = (n, c, h, w)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (code,) = ctx.saved_tensors
+        n, c, h, w = ctx.shape
+        dy = as_nhwc(dy, 'max_pool.backward')
+        dx = empty_nhwc(n, c, h, w, dy.device)
+        _C.call('evk_maxpool3x3s2_bwd', dy.data_ptr(), code.data_ptr(), dx.data_ptr(), n, h, w, c, _stream())
+        return dx
+
+
+def max_pool3x3s2(x):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (reference _resnets.py:153)."""
+    _require_cuda(x, 'max_pool')
+    x = as_nhwc(x, 'max_pool')
+    if x.shape[1] % 4:
+        raise HipPathError('max_pool: channels must be a multiple of 4')
+    return _MaxPoolFn.apply(x)
+
+
+class _Nearest2xAddFn(Function):
+    @staticmethod
+    def forward(ctx, top, lateral):
+        n, c, h, w = lateral.shape
+        out = empty_nhwc(n, c, h, w, lateral.device)
+        _C.call('evk_upsample_nearest2x_add_fwd', top.data_ptr(), lateral.data_ptr(), out.data_ptr(), n, h, w, c,
+                _stream())
+        ctx.shape = (n, c, h, w)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        n, c, h, w = ctx.shape
+        g = as_nhwc(g, 'nearest2x.backward')
+        dtop = None
+        if ctx.needs_input_grad[0]:
+            dtop = empty_nhwc(n, c, h // 2, w // 2, g.device)
+            _C.call('evk_upsample_nearest2x_bwd', g.data_ptr(), dtop.data_ptr(), n, h, w, c, _stream())
+        return dtop, (g if ctx.needs_input_grad[1] else None)
+
+
+def upsample_nearest2x_add(top, lateral):
+    """`inner_lateral + F.interpolate(last_inner, scale_factor=2, mode="nearest")` (reference fpn.py:100-105)."""
+    _require_cuda(top, 'upsample_nearest2x_add')
+    top, lateral = as_nhwc(top, 'fpn.top'), as_nhwc(lateral, 'fpn.lateral')
+    n, c, h, w = lateral.shape
+    if top.shape != (n, c, h // 2, w // 2) or h % 2 or w % 2:
+        # same failure mode as the reference's `inner_lateral + inner_top_down` (fpn.py:105)
+        raise RuntimeError(f'The size of tensor a ({tuple(lateral.shape)}) must match the size of tensor b '
+                           f'(nearest x2 of {tuple(top.shape)})')
+    return _Nearest2xAddFn.apply(top, lateral)
+
+
+class _BilinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, ho, wo):
+        n, c, h, w = x.shape
+        y = empty_nhwc(n, c, ho, wo, x.device)
+        _C.call('evk_upsample_bilinear_fwd', x.data_ptr(), y.data_ptr(), n, h, w, ho, wo, c, _stream())
+        ctx.dims = (n, c, h, w, ho, wo)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        n, c, h, w, ho, wo = ctx.dims
+        dy = as_nhwc(dy, 'bilinear.backward')
+        dx = empty_nhwc(n, c, h, w, dy.device)
+        _C.call('evk_upsample_bilinear_bwd', dy.data_ptr(), dx.data_ptr(), n, h, w, ho, wo, c, _stream())
+        return dx, None, None
+
+
+def upsample_bilinear(x, scale_factor):
+    """nn.UpsamplingBilinear2d(scale_factor) == bilinear with align_corners=True (reference fpn.py:168,180)."""
+    _require_cuda(x, 'upsample_bilinear')
+    x = as_nhwc(x, 'upsample_bilinear')
+    sh, sw = (scale_factor, scale_factor) if not isinstance(scale_factor, (tuple, list)) else scale_factor
+    ho, wo = int(x.shape[2] * sh), int(x.shape[3] * sw)  # floor(in * scale), as aten
+    return _BilinearFn.apply(x, ho, wo)
+
+
+class _GapFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        n, c, h, w = x.shape
+        y = empty_nhwc(n, c, 1, 1, x.device)
+        _C.call('evk_gap_fwd', x.data_ptr(), y.data_ptr(), n, h * w, c, _stream())
+        ctx.shape = (n, c, h, w)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        n, c, h, w = ctx.shape
+        dy = dy.reshape(n, c).contiguous()
+        dx = empty_nhwc(n, c, h, w, dy.device)
+        _C.call('evk_gap_bwd', dy.data_ptr(), dx.data_ptr(), n, h * w, c, _stream())
+        return dx
+
+
+def global_avg_pool(x):
+    """F.adaptive_avg_pool2d(x, 1) (reference fs_relation.py:177)."""
+    _require_cuda(x, 'global_avg_pool')
+    x = as_nhwc(x, 'global_avg_pool')
+    return _GapFn.apply(x)
+
+
+class _RelationFn(Function):
+    @staticmethod
+    def forward(ctx, scene, content, feat):
+        n, c, h, w = content.shape
+        out = empty_nhwc(n, c, h, w, content.device)
+        r = torch.empty((n, h * w), device=content.device, dtype=torch.float32)
+        _C.call('evk_relation_fwd', scene.data_ptr(), content.data_ptr(), feat.data_ptr(), out.data_ptr(),
+                r.data_ptr(), n, h * w, c, _stream())
+        ctx.save_for_backward(scene, content, feat, r)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        scene, content, feat, r = ctx.saved_tensors
+        n, c, h, w = content.shape
+        dev = content.device
+        dout = as_nhwc(dout, 'fs_relation.backward')
+        lib = _C.load()
+        ws_bytes = lib.evk_relation_workspace_bytes(n, h * w, c)
+        ws = workspace(dev, ws_bytes)
+        dscene = empty_nhwc(n, c, 1, 1, dev)
+        dcontent = torch.empty_like(content)
+        dfeat = torch.empty_like(feat)
+        _C.call('evk_relation_bwd', dout.data_ptr(), scene.data_ptr(), content.data_ptr(), feat.data_ptr(),
+                r.data_ptr(), dscene.data_ptr(), dcontent.data_ptr(), dfeat.data_ptr(), n, h * w, c, ws.data_ptr(),
+                ws_bytes, _stream())
+        return dscene, dcontent, dfeat
+
+
+def fs_relation(scene, content, feat):
+    """`sigmoid((scene * content).sum(dim=1, keepdim=True)) * feat` (reference fs_relation.py:61-71)."""
+    _require_cuda(content, 'fs_relation')
+    content, feat = as_nhwc(content, 'fs_relation.content'), as_nhwc(feat, 'fs_relation.feat')
+    n, c, h, w = content.shape
+    scene = as_nhwc(scene.reshape(n, c, 1, 1), 'fs_relation.scene')
+    return _RelationFn.apply(scene, content, feat)
+
+
+class _Mean4Fn(Function):
+    @staticmethod
+    def forward(ctx, a, b, c, d):
+        out = torch.empty_like(a)
+        _C.call('evk_mean4_fwd', a.data_ptr(), b.data_ptr(), c.data_ptr(), d.data_ptr(), out.data_ptr(), a.numel(),
+                _stream())
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g = as_nhwc(g, 'mean4.backward')
+        q = torch.empty_like(g)
+        _C.call('evk_scale', g.data_ptr(), 0.25, q.data_ptr(), g.numel(), _stream())
+        return q, q, q, q
+
+
+def mean4(a, b, c, d):
+    """`sum(inner_feat_list) / len(inner_feat_list)` for the 4 decoder branches (reference fpn.py:189)."""
+    ts = [as_nhwc(t, 'mean4') for t in (a, b, c, d)]
+    for t in ts[1:]:
+        if t.shape != ts[0].shape:
+            raise ValueError('mean4: shape mismatch')
+    return _Mean4Fn.apply(*ts)
+
+
+# ------------------------------------------------------------------------------------ losses
+def _stats_buf(k, device):
+    n = _C.load().evk_loss_stats_doubles(k)
+    return torch.empty((n,), device=device, dtype=torch.float64)
+
+
+def _labels(y_true, npix, what):
+    if y_true.dtype != torch.int64:
+        y_true = y_true.long()
+    y_true = y_true.contiguous()
+    if y_true.numel() != npix:
+        raise ValueError(f'{what}: labels have {y_true.numel()} elements, logits have {npix} pixels')
+    return y_true
+
+
+class _BceFn(Function):
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        npix = logits.numel()
+        stats = _stats_buf(2, logits.device)
+        loss = torch.empty((), device=logits.device, dtype=torch.float32)
+        _C.call('evk_bce_fwd', logits.data_ptr(), labels.data_ptr(), npix, ignore_index, loss.data_ptr(),
+                stats.data_ptr(), _stream())
+        ctx.save_for_backward(logits, labels, stats)
+        ctx.ignore_index = ignore_index
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        logits, labels, stats = ctx.saved_tensors
+        g = g.contiguous().float()
+        d = torch.empty_like(logits)
+        _C.call('evk_bce_bwd', logits.data_ptr(), labels.data_ptr(), logits.numel(), ctx.ignore_index,
+                stats.data_ptr(), g.data_ptr(), d.data_ptr(), 0, _stream())
+        return d, None, None
+
+
+def bce_with_logits(y_pred, y_true, ignore_index=255):
+    """reference ever/module/loss.py:229-235 (reduction='mean', pos_weight=None)."""
+    _require_cuda(y_pred, 'binary_cross_entropy_with_logits')
+    if y_pred.dim() == 4:
+        if y_pred.shape[1] != 1:
+            raise ValueError('binary_cross_entropy_with_logits: logits must have one channel')
+        y_pred = as_nhwc(y_pred, 'bce')
+    else:
+        y_pred = y_pred.contiguous()
+    labels = _labels(y_true, y_pred.numel(), 'bce')
+    return _BceFn.apply(y_pred, labels, int(ignore_index))
+
+
+class _DiceFn(Function):
+    @staticmethod
+    def forward(ctx, logits, labels, smooth, ignore_index, ignore_channel, sync):
+        n, c, h, w = logits.shape
+        npix = n * h * w
+        stats = _stats_buf(2 * c, logits.device)
+        st = _stream()
+        _C.call('evk_dice_stats', logits.data_ptr(), labels.data_ptr(), npix, c, ignore_index, stats.data_ptr(), st)
+        world = 1
+        if sync:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                world = dist.get_world_size()
+                dist.all_reduce(stats[:2 * c])  # loss.py:46-48: inter / z summed over ranks before the ratio
+        loss = torch.empty((), device=logits.device, dtype=torch.float32)
+        _C.call('evk_dice_finish', stats.data_ptr(), c, float(smooth), ignore_channel, loss.data_ptr(), st)
+        ctx.save_for_backward(logits, labels, stats)
+        ctx.cfg = (float(smooth), ignore_index, ignore_channel, world)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        logits, labels, stats = ctx.saved_tensors
+        smooth, ignore_index, ignore_channel, world = ctx.cfg
+        n, c, h, w = logits.shape
+        g = g.contiguous().float()
+        if world > 1:
+            # backward of torch.distributed.nn.all_reduce(SUM) is an all_reduce(SUM) of the upstream grads
+            import torch.distributed as dist
+            g = g.clone()
+            dist.all_reduce(g)
+        d = torch.empty_like(logits)
+        _C.call('evk_dice_bwd', logits.data_ptr(), labels.data_ptr(), n * h * w, c, ignore_index, stats.data_ptr(),
+                smooth, ignore_channel, g.data_ptr(), d.data_ptr(), 0, _stream())
+        return d, None, None, None, None, None
+
+
+def dice_loss_with_logits(y_pred, y_true, smooth_value=1.0, ignore_index=255, ignore_channel=-1,
+                          sync_statistics=True):
+    """reference ever/module/loss.py:40-75."""
+    _require_cuda(y_pred, 'dice_loss_with_logits')
+    if y_pred.dim() != 4 or y_true.dim() != 3:
+        raise AssertionError('dice_loss_with_logits expects y_pred [N,C,H,W] and y_true [N,H,W]')
+    y_pred = as_nhwc(y_pred, 'dice')
+    labels = _labels(y_true, y_pred.numel() // y_pred.shape[1], 'dice')
+    return _DiceFn.apply(y_pred, labels, smooth_value, int(ignore_index), int(ignore_channel), bool(sync_statistics))
+
+
+class _CeFn(Function):
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index, eps):
+        n, c, h, w = logits.shape
+        stats = _stats_buf(3, logits.device)
+        loss = torch.empty((), device=logits.device, dtype=torch.float32)
+        _C.call('evk_ce_fwd', logits.data_ptr(), labels.data_ptr(), n * h * w, c, ignore_index, eps, loss.data_ptr(),
+                stats.data_ptr(), _stream())
+        ctx.save_for_backward(logits, labels, stats)
+        ctx.cfg = (ignore_index, eps)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        logits, labels, stats = ctx.saved_tensors
+        ignore_index, eps = ctx.cfg
+        n, c, h, w = logits.shape
+        g = g.contiguous().float()
+        d = torch.empty_like(logits)
+        _C.call('evk_ce_bwd', logits.data_ptr(), labels.data_ptr(), n * h * w, c, ignore_index, eps, stats.data_ptr(),
+                g.data_ptr(), d.data_ptr(), 0, _stream())
+        return d, None, None, None
+
+
+def cross_entropy(y_pred, y_true, ignore_index=255, label_smoothing=0.0):
+    """F.cross_entropy(ignore_index=...) / label_smoothing_cross_entropy (reference loss.py:207-219)."""
+    _require_cuda(y_pred, 'cross_entropy')
+    y_pred = as_nhwc(y_pred, 'cross_entropy')
+    labels = _labels(y_true, y_pred.numel() // y_pred.shape[1], 'cross_entropy')
+    return _CeFn.apply(y_pred, labels, int(ignore_index), float(label_smoothing))

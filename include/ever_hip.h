@@ -1,0 +1,216 @@
+/*
+ * ever_hip.h — C-ABI of libever_hip.so: the MI355X (gfx950 / CDNA4) kernels behind the
+ * EVer hot path  ResNet encoder -> FPN / FS-Relation / decoder -> per-pixel head -> pixel loss,
+ * forward + backward.
+ *
+ * The reference (Z-Zheng/ever 0.5.6) has no FFI: its device boundary is the set of ATen ops its
+ * torch.nn modules issue.  Every entry point below cites the reference
+ * call site (file:line under the reference tree) whose ATen op it replaces.
+ *
+ * Conventions
+ *   - All activations are dense fp32 **NHWC** (pixel-major, channel-minor) in HBM.  A logical
+ *     [N,C,H,W] torch tensor with channels_last strides is exactly this layout.
+ *   - Convolution weights are dense fp32 **OHWI** ([Cout][kh][kw][Cin]; an OIHW torch tensor with
+ *     channels_last strides).  Gradients are produced in the same layout.
+ *   - Pointers are raw device pointers (hipMalloc / torch caching allocator).  The library
+ *     allocates nothing: scratch is caller-provided, sizes come from the *_workspace_bytes query.
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on that stream,
+ *     is re-entrant across streams and never synchronises.
+ *   - Return value: 0 = ok, <0 = error (EVK_E_*); evk_last_error() returns a thread-local text.
+ *     No C++ exception crosses this boundary.
+ */
+#ifndef EVER_HIP_H_
+#define EVER_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVK_OK 0
+#define EVK_E_INVALID (-1)     /* bad argument (null pointer, non-positive dim, misaligned channels) */
+#define EVK_E_UNSUPPORTED (-2) /* shape outside what the kernels implement */
+#define EVK_E_LAUNCH (-3)      /* hipLaunch / runtime failure; see evk_last_error() */
+#define EVK_E_WORKSPACE (-4)   /* caller workspace too small */
+
+const char* evk_last_error(void);
+/* library ABI version (bumped on any signature change) and the gfx arch it was built for */
+int evk_abi_version(void);
+const char* evk_build_arch(void);
+
+/* ------------------------------------------------------------------ convolution ------------ */
+/* Geometry of one 2-D convolution, square kernel/stride/dilation not assumed.
+ * Replaces nn.Conv2d at: _resnets.py:21-29 (3x3 / 1x1), _resnets.py:149 (7x7 stem),
+ * fpn.py:23-37,72-73 (FPN lateral / output), fs_relation.py:23-53 (scene MLP, content /
+ * re-encode 1x1 + bias), fpn.py:165 (decoder 3x3), fpn.py:179 (classifier + bias). */
+typedef struct evk_conv_desc {
+  int32_t N, H, W, Cin;   /* input  x: [N,H,W,Cin]   (Cin % 4 == 0; pad channels with evk_pad_channels) */
+  int32_t Ho, Wo, Cout;   /* output y: [N,Ho,Wo,Cout] */
+  int32_t kh, kw;
+  int32_t stride_h, stride_w;
+  int32_t pad_h, pad_w;
+  int32_t dil_h, dil_w;
+} evk_conv_desc;
+
+/* flags for evk_conv2d_fwd */
+#define EVK_CONV_RELU 1u /* y = max(y, 0) in the epilogue */
+
+/* y = conv(x, w) (+ bias).  w: [Cout][kh][kw][Cin].  bias may be NULL.
+ * Implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32), im2col rows gathered to LDS. */
+int evk_conv2d_fwd(const evk_conv_desc* d, const float* x, const float* w, const float* bias,
+                   float* y, uint32_t flags, void* stream);
+
+/* dx = conv_transpose(dy, w)  (autograd of nn.Conv2d wrt input; aten::convolution_backward).
+ * wt is the weight re-packed by evk_conv2d_pack_dgrad_weight: [Cin][kh][kw][Cout] (K = taps x Cout
+ * contiguous per input channel).
+ * dx is fully overwritten. */
+int evk_conv2d_dgrad(const evk_conv_desc* d, const float* dy, const float* wt, float* dx,
+                     void* stream);
+int evk_conv2d_pack_dgrad_weight(const evk_conv_desc* d, const float* w, float* wt, void* stream);
+
+/* dw[Cout][kh][kw][Cin] = sum_pixels dy (x) im2col(x); dbias[Cout] = sum_pixels dy (dbias may be
+ * NULL).  Split over pixel ranges; partials go to `workspace` and are reduced deterministically. */
+size_t evk_conv2d_wgrad_workspace_bytes(const evk_conv_desc* d);
+int evk_conv2d_wgrad(const evk_conv_desc* d, const float* x, const float* dy, float* dw,
+                     float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+
+/* [N,H,W,C] -> [N,H,W,Cp] zero padded (forward) and the adjoint / slice (backward). Also used for
+ * OHWI weights with rows = Cout*kh*kw.  C, Cp arbitrary. */
+int evk_pad_channels(const float* src, float* dst, int64_t rows, int32_t C, int32_t Cp, void* stream);
+int evk_unpad_channels(const float* src, float* dst, int64_t rows, int32_t Cp, int32_t C, void* stream);
+/* NCHW <-> NHWC(+pad) transposes at the model boundary (image in, logits out). */
+int evk_nchw_to_nhwc(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W,
+                     int32_t Cp, void* stream);
+int evk_nhwc_to_nchw(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W,
+                     int32_t Cp, void* stream);
+
+/* ------------------------------------------------------------------ batch norm ------------- */
+/* nn.BatchNorm2d (+ReLU, + residual add) — _resnets.py:95-112 (bn1/bn2/bn3, `out += identity`,
+ * relu), fs_relation.py:39-53, fpn.py:163-167.  rows = N*H*W, C % 4 == 0, C <= 2048.
+ * Training forward: batch statistics (biased var for normalisation, unbiased for running_var,
+ * momentum update, as torch), y = act(gamma * (x-mean)*invstd + beta [+ residual]).
+ * save_mean / save_invstd: [C] outputs kept for backward. */
+#define EVK_BN_RELU 1u
+size_t evk_bn_workspace_bytes(int64_t rows, int32_t C);
+int evk_bn_fwd_train(const float* x, const float* residual, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps,
+                     float* y, float* save_mean, float* save_invstd, int64_t rows, int32_t C,
+                     uint32_t flags, void* workspace, size_t workspace_bytes, void* stream);
+/* Eval forward (running statistics): y = act((x-rm)/sqrt(rv+eps)*gamma+beta [+ residual]). */
+int evk_bn_fwd_eval(const float* x, const float* residual, const float* gamma, const float* beta,
+                    const float* running_mean, const float* running_var, float eps, float* y,
+                    float* save_mean /* may be NULL */, float* save_invstd /* may be NULL */,
+                    int64_t rows, int32_t C, uint32_t flags, void* workspace, size_t workspace_bytes,
+                    void* stream);
+/* Backward of the training forward.  y is the forward output (ReLU mask; may be NULL when
+ * !EVK_BN_RELU).  d_residual (may be NULL) receives the masked upstream gradient.
+ * `train`=0 differentiates the eval forward (statistics are constants). */
+int evk_bn_bwd(const float* dy, const float* x, const float* y, const float* gamma,
+               const float* save_mean, const float* save_invstd, float* dx, float* d_residual,
+               float* dgamma, float* dbeta, int64_t rows, int32_t C, uint32_t flags, int32_t train,
+               void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ pointwise / resampling - */
+/* nn.ReLU (fs_relation.py:25) and its backward; elementwise add (fpn.py:105). */
+int evk_relu_fwd(const float* x, float* y, int64_t n, void* stream);
+int evk_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+int evk_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+int evk_scale(const float* a, float alpha, float* out, int64_t n, void* stream);
+
+/* nn.MaxPool2d(3, 2, 1) — _resnets.py:153.  code: one byte per output element = winning tap
+ * ky*3+kx (first maximum in scan order).  x: [N,H,W,C] -> y: [N,Ho,Wo,C], Ho = (H-1)/2+1. */
+int evk_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* code, int32_t N, int32_t H, int32_t W,
+                         int32_t C, void* stream);
+int evk_maxpool3x3s2_bwd(const float* dy, const uint8_t* code, float* dx, int32_t N, int32_t H,
+                         int32_t W, int32_t C, void* stream);
+
+/* F.interpolate(scale_factor=2, mode="nearest") + lateral add — fpn.py:100-105.
+ * out[n,y,x,:] = lateral[n,y,x,:] + top[n,y/2,x/2,:];  top is [N,H/2,W/2,C]. */
+int evk_upsample_nearest2x_add_fwd(const float* top, const float* lateral, float* out, int32_t N,
+                                   int32_t H, int32_t W, int32_t C, void* stream);
+/* adjoint wrt `top`: dtop[n,y,x,:] = sum of the 2x2 block of dout. (d lateral = dout.) */
+int evk_upsample_nearest2x_bwd(const float* dout, float* dtop, int32_t N, int32_t H, int32_t W,
+                               int32_t C, void* stream);
+
+/* nn.UpsamplingBilinear2d(scale_factor=s) == bilinear, align_corners=True — fpn.py:168,180.
+ * x: [N,Hi,Wi,C] -> y: [N,Ho,Wo,C]; src = dst*(in-1)/(out-1). Backward is the gather-form adjoint. */
+int evk_upsample_bilinear_fwd(const float* x, float* y, int32_t N, int32_t Hi, int32_t Wi,
+                              int32_t Ho, int32_t Wo, int32_t C, void* stream);
+int evk_upsample_bilinear_bwd(const float* dy, float* dx, int32_t N, int32_t Hi, int32_t Wi,
+                              int32_t Ho, int32_t Wo, int32_t C, void* stream);
+
+/* F.adaptive_avg_pool2d(x, 1) — fs_relation.py:177. x: [N,HW,C] -> y: [N,C]. */
+int evk_gap_fwd(const float* x, float* y, int32_t N, int32_t HW, int32_t C, void* stream);
+int evk_gap_bwd(const float* dy, float* dx, int32_t N, int32_t HW, int32_t C, void* stream);
+
+/* FS-Relation — fs_relation.py:61-71: r = sigmoid(sum_c scene[n,c]*content[n,p,c]); out = r*feat.
+ * scene: [N,C], content/feat/out: [N,HW,C], r: [N,HW] (saved for backward). */
+int evk_relation_fwd(const float* scene, const float* content, const float* feat, float* out,
+                     float* r, int32_t N, int32_t HW, int32_t C, void* stream);
+/* dscene must be zero-initialised by the caller? No: fully written (two-stage reduction inside,
+ * workspace from evk_relation_workspace_bytes). */
+size_t evk_relation_workspace_bytes(int32_t N, int32_t HW, int32_t C);
+int evk_relation_bwd(const float* dout, const float* scene, const float* content, const float* feat,
+                     const float* r, float* dscene, float* dcontent, float* dfeat, int32_t N,
+                     int32_t HW, int32_t C, void* workspace, size_t workspace_bytes, void* stream);
+
+/* `sum(list)/len(list)` over 4 decoder branches — fpn.py:189. */
+int evk_mean4_fwd(const float* a, const float* b, const float* c, const float* d, float* out,
+                  int64_t n, void* stream);
+
+/* ------------------------------------------------------------------ pixel losses ----------- */
+/* Labels are int64 [N*H*W]; ignore_index pixels are dropped from every sum (the reference
+ * compacts with masked_select, loss.py:10-17,26-37).  logits: [N*H*W, C] (NHWC).
+ * Each forward writes `stats` (doubles) that the matching backward consumes; loss is a device
+ * float scalar.  grad_scale is the upstream dL/dloss (device float pointer, may be NULL = 1).
+ * `stats` must hold evk_loss_stats_doubles(K) doubles (K finals followed by per-workgroup
+ * partials); K = 2 (BCE), 2*C (dice), 3 (CE).  Only the first K are meaningful to the caller. */
+int64_t evk_loss_stats_doubles(int32_t K);
+
+/* binary_cross_entropy_with_logits(ignore) — loss.py:229-235. C == 1. stats: double[2]={sum,count} */
+int evk_bce_fwd(const float* logits, const int64_t* labels, int64_t npix, int64_t ignore_index,
+                float* loss, double* stats, void* stream);
+int evk_bce_bwd(const float* logits, const int64_t* labels, int64_t npix, int64_t ignore_index,
+                const double* stats, const float* grad_scale, float* dlogits, int32_t accumulate,
+                void* stream);
+
+/* dice_loss_with_logits — loss.py:40-75.  C==1: p=sigmoid; C>1: p=softmax, one-hot target.
+ * stats: double[2*C] = {inter[c], z[c]} (z = sum p + sum y, before smoothing).  In distributed
+ * training the caller all-reduces `stats` between evk_dice_stats and evk_dice_finish
+ * (loss.py:20-23,46-48). */
+int evk_dice_stats(const float* logits, const int64_t* labels, int64_t npix, int32_t C,
+                   int64_t ignore_index, double* stats, void* stream);
+int evk_dice_finish(const double* stats, int32_t C, float smooth, int32_t ignore_channel,
+                    float* loss, void* stream);
+int evk_dice_bwd(const float* logits, const int64_t* labels, int64_t npix, int32_t C,
+                 int64_t ignore_index, const double* stats, float smooth, int32_t ignore_channel,
+                 const float* grad_scale, float* dlogits, int32_t accumulate, void* stream);
+
+/* F.cross_entropy(ignore_index) (user model code; label-smoothing variant loss.py:207-219).
+ * stats: double[3] = {sum nll, count, sum(-sum_c logp)} ; loss = (1-eps)*nll/count + eps/C*smooth/count */
+int evk_ce_fwd(const float* logits, const int64_t* labels, int64_t npix, int32_t C,
+               int64_t ignore_index, float label_smoothing, float* loss, double* stats, void* stream);
+int evk_ce_bwd(const float* logits, const int64_t* labels, int64_t npix, int32_t C,
+               int64_t ignore_index, float label_smoothing, const double* stats,
+               const float* grad_scale, float* dlogits, int32_t accumulate, void* stream);
+
+/* ------------------------------------------------------------------ optimizer -------------- */
+/* torch.optim.SGD step over a flat list of tensors (opt/optimizer.py:7) and
+ * clip_grad_norm_ (interface/module.py:96-108).  ptr tables live in device memory. */
+/* partial: double[evk_opt_blocks_per_tensor() * ntensors] scratch.  Writes the global L2 norm and
+ * clip_coef = min(1, max_norm / (norm + 1e-6)) to device scalars (no host sync). */
+int32_t evk_opt_blocks_per_tensor(void);
+int evk_sqnorm_multi(const float* const* grads, const int64_t* sizes, int32_t ntensors,
+                     double* partial, float max_norm, float* total_norm, float* clip_coef,
+                     void* stream);
+int evk_sgd_multi(float* const* params, const float* const* grads, float* const* momentum_bufs,
+                  const int64_t* sizes, int32_t ntensors, float lr, float momentum, float dampening,
+                  float weight_decay, int32_t nesterov, int32_t first_step,
+                  const float* clip_coef /* device scalar or NULL */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVER_HIP_H_ */

@@ -1,0 +1,316 @@
+"""Per-kernel parity of the HIP path (through the C-ABI) against stock PyTorch fp32 on CPU.
+
+Tolerances: conv / BN results are fp32 with a different summation order than oneDNN -> rtol 1e-4
+(the north-star contract is 1e-3 relative); index-producing ops (maxpool) are bit-exact.
+"""
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rtol=1e-4, atol=1e-5, what=''):
+    a = a.detach().cpu().contiguous().double()
+    b = b.detach().cpu().contiguous().double()
+    assert a.shape == b.shape, f'{what}: shape {a.shape} vs {b.shape}'
+    err = (a - b).abs().max().item()
+    scale = b.abs().max().item()
+    assert err <= atol + rtol * scale, f'{what}: max abs err {err:.3e} vs scale {scale:.3e}'
+
+
+CONV_CASES = [
+    # n, cin, h, w, cout, k, stride, pad, dil, bias
+    (2, 64, 16, 16, 64, 1, 1, 0, 1, False),
+    (2, 64, 16, 16, 256, 1, 1, 0, 1, True),
+    (2, 256, 16, 16, 128, 1, 2, 0, 1, False),   # downsample 1x1 s2 (scatter dgrad)
+    (2, 64, 20, 12, 64, 3, 1, 1, 1, False),     # ragged spatial size
+    (2, 128, 16, 16, 128, 3, 2, 1, 1, False),   # 3x3 s2
+    (1, 64, 16, 16, 96, 3, 1, 2, 2, False),     # dilation 2 (output_stride 16)
+    (2, 3, 32, 32, 64, 7, 2, 3, 1, False),      # stem, Cin=3 (channel padding path)
+    (2, 4, 32, 32, 64, 7, 2, 3, 1, False),      # 4-band stem
+    (2, 256, 8, 8, 1, 1, 1, 0, 1, True),        # classifier Cout=1
+    (2, 128, 8, 8, 16, 3, 1, 1, 1, True),       # FarSeg-paper classifier 3x3, 16 classes
+    (4, 2048, 1, 1, 256, 1, 1, 0, 1, True),     # scene MLP on 1x1 maps
+    (1, 512, 9, 7, 520, 3, 1, 1, 1, False),     # Cout not a multiple of the N tile
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv2d_fwd_bwd(cuda, case):
+    from ever_amd.hip import functional as F
+    n, cin, h, w, cout, k, s, p, d, bias = case
+    g = torch.Generator().manual_seed(1234 + cin + cout + k)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g) if bias else None
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = TF.conv2d(xr, wr, br, stride=s, padding=p, dilation=d)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+
+    xg = x.to(cuda).requires_grad_(True)
+    wg = wt.to(cuda).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bg = b.to(cuda).requires_grad_(True) if bias else None
+    yg = F.conv2d(xg, wg, bg, stride=s, padding=p, dilation=d)
+    yg.backward(gy.to(cuda))
+    torch.cuda.synchronize()
+    _close(yg, yr, what='y')
+    _close(xg.grad, xr.grad, what='dx')
+    _close(wg.grad, wr.grad, what='dw')
+    if bias:
+        _close(bg.grad, br.grad, what='db')
+
+
+def test_conv2d_relu_epilogue(cuda):
+    from ever_amd.hip import functional as F
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 64, 8, 8, generator=g)
+    w = torch.randn(32, 64, 1, 1, generator=g) / 8
+    b = torch.randn(32, generator=g)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = TF.relu(TF.conv2d(xr, wr, br))
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xg, wg, bg = x.to(cuda).requires_grad_(), w.to(cuda).requires_grad_(), b.to(cuda).requires_grad_()
+    yg = F.conv2d(xg, wg, bg, relu=True)
+    yg.backward(gy.to(cuda))
+    _close(yg, yr, what='y')
+    _close(xg.grad, xr.grad, what='dx')
+    _close(wg.grad, wr.grad, what='dw')
+    _close(bg.grad, br.grad, what='db')
+
+
+@pytest.mark.parametrize('c,h,w,res,relu,train', [
+    (64, 16, 16, False, True, True), (256, 8, 8, True, True, True), (2048, 4, 4, False, False, True),
+    (64, 9, 7, True, False, True), (128, 8, 8, True, True, False), (12, 5, 5, False, True, True),
+])
+def test_batch_norm_act(cuda, c, h, w, res, relu, train):
+    from ever_amd.hip import functional as F
+    g = torch.Generator().manual_seed(c + h)
+    n = 3
+    x = torch.randn(n, c, h, w, generator=g) * 2 + 0.5
+    r = torch.randn(n, c, h, w, generator=g) if res else None
+    gamma = torch.rand(c, generator=g) + 0.5
+    beta = torch.randn(c, generator=g)
+    rm, rv = torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5
+
+    xr = x.clone().requires_grad_()
+    rr = r.clone().requires_grad_() if res else None
+    gr, br = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    rm_r, rv_r = rm.clone(), rv.clone()
+    yr = TF.batch_norm(xr, rm_r, rv_r, gr, br, training=train, momentum=0.1, eps=1e-5)
+    if res:
+        yr = yr + rr
+    if relu:
+        yr = TF.relu(yr)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+
+    xg = x.to(cuda).requires_grad_()
+    rg = r.to(cuda).requires_grad_() if res else None
+    gg, bg = gamma.to(cuda).requires_grad_(), beta.to(cuda).requires_grad_()
+    rm_g, rv_g = rm.to(cuda), rv.to(cuda)
+    yg = F.batch_norm_act(xg, gg, bg, rm_g, rv_g, train, 0.1, 1e-5, residual=rg, relu=relu)
+    yg.backward(gy.to(cuda))
+    _close(yg, yr, what='y')
+    _close(xg.grad, xr.grad, what='dx', rtol=2e-4)
+    _close(gg.grad, gr.grad, what='dgamma', rtol=2e-4)
+    _close(bg.grad, br.grad, what='dbeta', rtol=2e-4)
+    if res:
+        _close(rg.grad, rr.grad, what='dres')
+    _close(rm_g, rm_r, what='running_mean')
+    _close(rv_g, rv_r, what='running_var')
+
+
+def test_maxpool(cuda):
+    from ever_amd.hip import functional as F
+    g = torch.Generator().manual_seed(3)
+    for (h, w) in [(16, 16), (15, 9)]:
+        x = torch.randn(2, 64, h, w, generator=g)
+        xr = x.clone().requires_grad_()
+        yr = TF.max_pool2d(xr, 3, 2, 1)
+        gy = torch.randn(yr.shape, generator=g)
+        yr.backward(gy)
+        xg = x.to(cuda).requires_grad_()
+        yg = F.max_pool3x3s2(xg)
+        yg.backward(gy.to(cuda))
+        assert torch.equal(yg.cpu().contiguous(), yr.detach()), 'maxpool fwd must be bit exact'
+        assert torch.equal(xg.grad.cpu().contiguous(), xr.grad), 'maxpool bwd must be bit exact'
+
+
+def test_nearest2x_add(cuda):
+    from ever_amd.hip import functional as F
+    g = torch.Generator().manual_seed(4)
+    top = torch.randn(2, 256, 4, 6, generator=g)
+    lat = torch.randn(2, 256, 8, 12, generator=g)
+    tr, lr = top.clone().requires_grad_(), lat.clone().requires_grad_()
+    yr = lr + TF.interpolate(tr, scale_factor=2, mode='nearest')
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    tg, lg = top.to(cuda).requires_grad_(), lat.to(cuda).requires_grad_()
+    yg = F.upsample_nearest2x_add(tg, lg)
+    yg.backward(gy.to(cuda))
+    assert torch.equal(yg.cpu().contiguous(), yr.detach())
+    _close(tg.grad, tr.grad, what='dtop', rtol=1e-6)
+    assert torch.equal(lg.grad.cpu().contiguous(), lr.grad)
+
+
+@pytest.mark.parametrize('c,h,w,s', [(256, 8, 8, 2), (1, 16, 16, 4), (16, 8, 12, 4), (128, 1, 1, 2), (64, 5, 3, 2)])
+def test_bilinear_align_corners(cuda, c, h, w, s):
+    from ever_amd.hip import functional as F
+    g = torch.Generator().manual_seed(5 + c)
+    x = torch.randn(2, c, h, w, generator=g)
+    xr = x.clone().requires_grad_()
+    yr = torch.nn.UpsamplingBilinear2d(scale_factor=s)(xr)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xg = x.to(cuda).requires_grad_()
+    yg = F.upsample_bilinear(xg, s)
+    yg.backward(gy.to(cuda))
+    _close(yg, yr, what='y', rtol=1e-6, atol=1e-6)
+    _close(xg.grad, xr.grad, what='dx', rtol=1e-5, atol=1e-5)
+
+
+def test_bilinear_kat(cuda):
+    """UpsamplingBilinear2d(2) of [[0,1],[2,3]] (captured from the reference import)."""
+    from ever_amd.hip import functional as F
+    x = torch.tensor([[0., 1.], [2., 3.]]).reshape(1, 1, 2, 2).to(cuda)
+    y = F.upsample_bilinear(x, 2).cpu().reshape(4, 4)
+    t = 1. / 3
+    exp = torch.tensor([[0, t, 2 * t, 1], [2 * t, 1, 1 + t, 1 + 2 * t], [1 + t, 1 + 2 * t, 2, 2 + t],
+                        [2, 2 + t, 2 + 2 * t, 3]])
+    _close(y, exp, rtol=1e-6, atol=1e-6)
+
+
+def test_gap_relation_mean4(cuda):
+    from ever_amd.hip import functional as F
+    g = torch.Generator().manual_seed(6)
+    n, c, h, w = 3, 256, 6, 5
+    x = torch.randn(n, 2048, 4, 4, generator=g)
+    xr = x.clone().requires_grad_()
+    yr = TF.adaptive_avg_pool2d(xr, 1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xg = x.to(cuda).requires_grad_()
+    yg = F.global_avg_pool(xg)
+    yg.backward(gy.to(cuda))
+    _close(yg, yr, what='gap', rtol=1e-5)
+    _close(xg.grad, xr.grad, what='gap dx', rtol=1e-6)
+
+    scene = torch.randn(n, c, 1, 1, generator=g) * 0.2
+    content = torch.randn(n, c, h, w, generator=g) * 0.3
+    feat = torch.randn(n, c, h, w, generator=g)
+    sr, cr, fr = scene.clone().requires_grad_(), content.clone().requires_grad_(), feat.clone().requires_grad_()
+    rel = torch.sigmoid((sr * cr).sum(dim=1, keepdim=True))
+    outr = rel * fr
+    go = torch.randn(outr.shape, generator=g)
+    outr.backward(go)
+    sg, cg, fg = scene.to(cuda).requires_grad_(), content.to(cuda).requires_grad_(), feat.to(cuda).requires_grad_()
+    outg = F.fs_relation(sg, cg, fg)
+    outg.backward(go.to(cuda))
+    _close(outg, outr, what='relation', rtol=1e-5)
+    _close(sg.grad, sr.grad, what='dscene', rtol=1e-4)
+    _close(cg.grad, cr.grad, what='dcontent', rtol=1e-4)
+    _close(fg.grad, fr.grad, what='dfeat', rtol=1e-5)
+
+    ts = [torch.randn(2, 64, 4, 4, generator=g) for _ in range(4)]
+    trs = [t.clone().requires_grad_() for t in ts]
+    mr = sum(trs) / len(trs)
+    gm = torch.randn(mr.shape, generator=g)
+    mr.backward(gm)
+    tgs = [t.to(cuda).requires_grad_() for t in ts]
+    mg = F.mean4(*tgs)
+    mg.backward(gm.to(cuda))
+    assert torch.equal(mg.cpu().contiguous(), mr.detach())
+    for a, b in zip(tgs, trs):
+        assert torch.equal(a.grad.cpu().contiguous(), b.grad)
+
+
+def _ref_bce(y_pred, y_true, ignore_index=255):
+    yp, yt = y_pred.reshape(-1), y_true.reshape(-1)
+    valid = yt != ignore_index
+    return TF.binary_cross_entropy_with_logits(yp[valid], yt[valid].float())
+
+
+def _ref_dice(y_pred, y_true, smooth=1.0, ignore_index=255, ignore_channel=-1):
+    c = y_pred.size(1)
+    yp = y_pred.permute(0, 2, 3, 1).reshape(-1, c)
+    yt = y_true.reshape(-1)
+    valid = yt != ignore_index
+    yp, yt = yp[valid], yt[valid]
+    w = torch.ones(c, dtype=torch.bool)
+    if c == 1:
+        prob, tgt = yp.sigmoid(), yt.reshape(-1, 1).float()
+    else:
+        prob, tgt = yp.log_softmax(dim=1).exp(), TF.one_hot(yt.long(), c).float()
+        if ignore_channel != -1:
+            w[ignore_channel] = False
+    prob, tgt = prob[:, w], tgt[:, w]
+    inter = (prob * tgt).sum(0)
+    z = prob.sum(0) + tgt.sum(0) + smooth
+    return 1. - ((2 * inter + smooth) / z).mean()
+
+
+@pytest.mark.parametrize('c', [1, 3, 16])
+def test_losses(cuda, c):
+    from ever_amd.hip import functional as F
+    g = torch.Generator().manual_seed(11 + c)
+    n, h, w = 2, 24, 20
+    logits = torch.randn(n, c, h, w, generator=g) * 2
+    labels = torch.randint(0, max(c, 2), (n, h, w), generator=g)
+    labels[:, :4, :4] = 255
+    if c == 1:
+        lr = logits.clone().requires_grad_()
+        ref = _ref_bce(lr, labels)
+        ref.backward()
+        lg = logits.to(cuda).requires_grad_()
+        out = F.bce_with_logits(lg, labels.to(cuda))
+        out.backward()
+        _close(out, ref, what='bce', rtol=1e-5)
+        _close(lg.grad, lr.grad, what='dbce', rtol=1e-4, atol=1e-9)
+    else:
+        lr = logits.clone().requires_grad_()
+        ref = TF.cross_entropy(lr, labels, ignore_index=255)
+        ref.backward()
+        lg = logits.to(cuda).requires_grad_()
+        out = F.cross_entropy(lg, labels.to(cuda), ignore_index=255)
+        out.backward()
+        _close(out, ref, what='ce', rtol=1e-5)
+        _close(lg.grad, lr.grad, what='dce', rtol=1e-4, atol=1e-9)
+    lr = logits.clone().requires_grad_()
+    ref = _ref_dice(lr, labels)
+    (ref * 0.5).backward()
+    lg = logits.to(cuda).requires_grad_()
+    out = F.dice_loss_with_logits(lg, labels.to(cuda))
+    (out * 0.5).backward()
+    _close(out, ref, what='dice', rtol=1e-5)
+    _close(lg.grad, lr.grad, what='ddice', rtol=1e-4, atol=1e-10)
+
+
+def test_loss_kats(cuda):
+    """Known answers captured from the imported reference."""
+    from ever_amd.hip import functional as F
+    logits = torch.tensor([[.5, -1.], [2., 0.]]).reshape(1, 1, 2, 2).to(cuda)
+    labels = torch.tensor([[1, 0], [1, 255]]).reshape(1, 2, 2).to(cuda)
+    assert abs(F.bce_with_logits(logits, labels).item() - 0.3047555983) < 1e-6
+    assert abs(F.dice_loss_with_logits(logits, labels).item() - 0.1604470611) < 1e-6
+    l3 = torch.tensor([[[1., 0.], [0., 2.]], [[0., 1.], [0., 0.]], [[-1., 0.], [3., 0.]]]).reshape(1, 3, 2, 2).to(cuda)
+    y3 = torch.tensor([[0, 1], [2, 255]]).reshape(1, 2, 2).to(cuda)
+    assert abs(F.dice_loss_with_logits(l3, y3).item() - 0.1912899017) < 1e-6
+    assert abs(F.cross_entropy(l3, y3).item() - 0.3513244689) < 1e-6
+    assert abs(F.cross_entropy(l3, y3, label_smoothing=0.1).item() - 0.4735466838) < 1e-6
+
+
+def test_all_ignored_is_nan(cuda):
+    from ever_amd.hip import functional as F
+    logits = torch.randn(1, 1, 4, 4).to(cuda)
+    labels = torch.full((1, 4, 4), 255).to(cuda)
+    assert torch.isnan(F.bce_with_logits(logits, labels)).item()  # mean of an empty selection (loss.py:10-17)
+
+
+def test_cpu_tensor_fails_loudly():
+    from ever_amd.hip import functional as F
+    with pytest.raises(F.HipPathError):
+        F.conv2d(torch.randn(1, 4, 4, 4), torch.randn(4, 4, 1, 1))
