@@ -1,0 +1,206 @@
+"""ResNet v1.5 bodies (reference ever/module/_resnets.py:32-227) on the HIP layers.
+
+Stride sits on the 3x3 conv of a bottleneck; conv init kaiming_normal(fan_out, relu); BN weight 1 /
+bias 0.  Attribute names (conv1, bn1, layer1.0.downsample.0 ...) equal torchvision's so pretrained
+and reference state dicts load.  Each residual block issues fused kernels:
+conv -> [BN+ReLU] -> conv -> [BN+ReLU] -> conv -> [BN + identity add + ReLU].
+"""
+import torch.nn as nn
+
+from .layers import AdaptiveAvgPool2d, BatchNorm2d, Conv2d, HipSequential, MaxPool2d, ReLU
+
+__all__ = ['ResNet', 'BasicBlock', 'Bottleneck', 'resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152',
+           'resnet50_v1c', 'resnet101_v1c']
+
+
+def conv3x3(cin, cout, stride=1, groups=1, dilation=1):
+    return Conv2d(cin, cout, kernel_size=3, stride=stride, padding=dilation, groups=groups, bias=False,
+                  dilation=dilation)
+
+
+def conv1x1(cin, cout, stride=1):
+    return Conv2d(cin, cout, kernel_size=1, stride=stride, bias=False)
+
+
+def _norm(norm_layer):
+    if norm_layer is None or norm_layer is nn.BatchNorm2d or norm_layer is BatchNorm2d:
+        return BatchNorm2d
+    raise NotImplementedError(f'ever_amd ResNet: norm_layer {norm_layer} has no HIP kernel (BatchNorm2d only)')
+
+
+def _shortcut(block, x):
+    return x if block.downsample is None else block.downsample[1](block.downsample[0](x))
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64, dilation=1,
+                 norm_layer=None):
+        super().__init__()
+        norm_layer = _norm(norm_layer)
+        if groups != 1 or base_width != 64:
+            raise ValueError('BasicBlock only supports groups=1 and base_width=64')
+        if dilation > 1:
+            raise NotImplementedError('Dilation > 1 not supported in BasicBlock')
+        self.conv1 = conv3x3(inplanes, planes, stride)
+        self.bn1 = norm_layer(planes)
+        self.relu = ReLU(inplace=True)
+        self.conv2 = conv3x3(planes, planes)
+        self.bn2 = norm_layer(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.bn1(self.conv1(x), relu=True)
+        return self.bn2(self.conv2(out), residual=_shortcut(self, x), relu=True)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64, dilation=1,
+                 norm_layer=None):
+        super().__init__()
+        norm_layer = _norm(norm_layer)
+        width = int(planes * (base_width / 64.)) * groups
+        self.conv1 = conv1x1(inplanes, width)
+        self.bn1 = norm_layer(width)
+        self.conv2 = conv3x3(width, width, stride, groups, dilation)
+        self.bn2 = norm_layer(width)
+        self.conv3 = conv1x1(width, planes * self.expansion)
+        self.bn3 = norm_layer(planes * self.expansion)
+        self.relu = ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
+        return self.bn3(self.conv3(out), residual=_shortcut(self, x), relu=True)
+
+
+class ResNet(nn.Module):
+    def __init__(self, block, layers, num_classes=1000, zero_init_residual=False, groups=1, width_per_group=64,
+                 replace_stride_with_dilation=None, norm_layer=None, deep_stem=False):
+        super().__init__()
+        norm_layer = _norm(norm_layer)
+        self._norm_layer = norm_layer
+        self.inplanes = 64
+        self.dilation = 1
+        if replace_stride_with_dilation is None:
+            replace_stride_with_dilation = [False, False, False]
+        if len(replace_stride_with_dilation) != 3:
+            raise ValueError('replace_stride_with_dilation should be None or a 3-element tuple, got {}'.format(
+                replace_stride_with_dilation))
+        self.groups = groups
+        self.base_width = width_per_group
+        self.deep_stem = deep_stem
+        if deep_stem:  # v1c: three 3x3 convs instead of the 7x7
+            half = self.inplanes // 2
+            self.stem = HipSequential(
+                Conv2d(3, half, 3, 2, 1, bias=False), BatchNorm2d(half), ReLU(inplace=True),
+                Conv2d(half, half, 3, 1, 1, bias=False), BatchNorm2d(half), ReLU(inplace=True),
+                Conv2d(half, self.inplanes, 3, 1, 1, bias=False), BatchNorm2d(self.inplanes), ReLU(inplace=True))
+        else:
+            self.conv1 = Conv2d(3, self.inplanes, kernel_size=7, stride=2, padding=3, bias=False)
+            self.bn1 = norm_layer(self.inplanes)
+            self.relu = ReLU(inplace=True)
+        self.maxpool = MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2, dilate=replace_stride_with_dilation[0])
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2, dilate=replace_stride_with_dilation[1])
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2, dilate=replace_stride_with_dilation[2])
+        self.avgpool = AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(512 * block.expansion, num_classes)
+
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        if zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, Bottleneck):
+                    nn.init.constant_(m.bn3.weight, 0)
+                elif isinstance(m, BasicBlock):
+                    nn.init.constant_(m.bn2.weight, 0)
+
+    def _make_layer(self, block, planes, blocks, stride=1, dilate=False):
+        norm_layer = self._norm_layer
+        previous_dilation = self.dilation
+        if dilate:
+            self.dilation *= stride
+            stride = 1
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(conv1x1(self.inplanes, planes * block.expansion, stride),
+                                       norm_layer(planes * block.expansion))
+        stack = [block(self.inplanes, planes, stride, downsample, self.groups, self.base_width, previous_dilation,
+                       norm_layer)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            stack.append(block(self.inplanes, planes, groups=self.groups, base_width=self.base_width,
+                               dilation=self.dilation, norm_layer=norm_layer))
+        return nn.Sequential(*stack)
+
+    def stem_forward(self, x):
+        if self.deep_stem:
+            return self.stem(x)
+        return self.bn1(self.conv1(x), relu=True)
+
+    def forward(self, x):
+        x = self.maxpool(self.stem_forward(x))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        x = self.avgpool(x)
+        return self.fc(x.reshape(x.size(0), -1))
+
+
+_URLS = {
+    'resnet18': 'https://download.pytorch.org/models/resnet18-5c106cde.pth',
+    'resnet34': 'https://download.pytorch.org/models/resnet34-333f7ec4.pth',
+    'resnet50': 'https://download.pytorch.org/models/resnet50-19c8e357.pth',
+    'resnet101': 'https://download.pytorch.org/models/resnet101-5d3b4d8f.pth',
+    'resnet152': 'https://download.pytorch.org/models/resnet152-b121ed2d.pth',
+    'resnet50_v1c': 'https://download.openmmlab.com/pretrain/third_party/resnet50_v1c-2cccc1ad.pth',
+    'resnet101_v1c': 'https://download.openmmlab.com/pretrain/third_party/resnet101_v1c-e67eebb6.pth',
+}
+
+
+def _build(arch, block, layers, pretrained, progress, **kwargs):
+    model = ResNet(block, layers, **kwargs)
+    if pretrained:
+        from torch.utils.model_zoo import load_url
+        state = load_url(_URLS[arch], progress=progress)
+        state = state.get('state_dict', state)
+        model.load_state_dict(state, strict=False)
+    return model
+
+
+def resnet18(pretrained=False, progress=True, **kw):
+    return _build('resnet18', BasicBlock, [2, 2, 2, 2], pretrained, progress, **kw)
+
+
+def resnet34(pretrained=False, progress=True, **kw):
+    return _build('resnet34', BasicBlock, [3, 4, 6, 3], pretrained, progress, **kw)
+
+
+def resnet50(pretrained=False, progress=True, **kw):
+    return _build('resnet50', Bottleneck, [3, 4, 6, 3], pretrained, progress, **kw)
+
+
+def resnet101(pretrained=False, progress=True, **kw):
+    return _build('resnet101', Bottleneck, [3, 4, 23, 3], pretrained, progress, **kw)
+
+
+def resnet152(pretrained=False, progress=True, **kw):
+    return _build('resnet152', Bottleneck, [3, 8, 36, 3], pretrained, progress, **kw)
+
+
+def resnet50_v1c(pretrained=False, progress=True, **kw):
+    return _build('resnet50_v1c', Bottleneck, [3, 4, 6, 3], pretrained, progress, deep_stem=True, **kw)
+
+
+def resnet101_v1c(pretrained=False, progress=True, **kw):
+    return _build('resnet101_v1c', Bottleneck, [3, 4, 23, 3], pretrained, progress, deep_stem=True, **kw)

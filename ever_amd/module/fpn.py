@@ -1,0 +1,132 @@
+"""FPN and the asymmetric decoder of FarSeg (API of reference ever/module/fpn.py:40-115,144-193).
+
+FPN convs carry NO bias / BN / ReLU (kaiming_uniform a=1); the top-down path is nearest x2 fused with
+the lateral add; decoder branches are [conv3x3 -> BN -> ReLU -> bilinear x2(align_corners)] x n, the
+four branches are averaged, the classifier conv has a bias and is followed by bilinear x scale.
+Module names / Sequential indices equal the reference's, so state-dict keys are identical
+(`fpn_inner1.0.weight`, `blocks.3.2.0.weight`, `classifier.0.bias`, ...).
+"""
+import math
+
+import torch.nn as nn
+
+from ..hip import functional as HF
+from .layers import BatchNorm2d, Conv2d, HipSequential, ReLU, UpsamplingBilinear2d
+from .ops import Bf16compatible, ConvBlock
+
+__all__ = ['FPN', 'AssymetricDecoder', 'conv_with_kaiming_uniform', 'default_conv_block', 'conv_bn_block',
+           'conv_bn_relu_block']
+
+
+def init_conv(m):
+    if isinstance(m, nn.Conv2d):
+        nn.init.kaiming_uniform_(m.weight, a=1)
+
+
+def conv_with_kaiming_uniform(use_bn=False, use_relu=False):
+    def make_conv(in_channels, out_channels, kernel_size, stride=1, dilation=1):
+        return ConvBlock(in_channels, out_channels, kernel_size, stride,
+                         padding=ConvBlock.same_padding(kernel_size, dilation), dilation=dilation, bias=False,
+                         bn=use_bn, relu=use_relu, init_fn=init_conv)
+
+    return make_conv
+
+
+default_conv_block = conv_with_kaiming_uniform(use_bn=False, use_relu=False)
+conv_bn_block = conv_with_kaiming_uniform(use_bn=True, use_relu=False)
+conv_bn_relu_block = conv_with_kaiming_uniform(use_bn=True, use_relu=True)
+
+
+class FPN(nn.Module):
+    def __init__(self, in_channels_list, out_channels, conv_block=default_conv_block, top_blocks=None):
+        super().__init__()
+        if top_blocks is not None:
+            raise NotImplementedError('ever_amd FPN: top_blocks (P6/P7, LastLevelMaxPool) are not on the FarSeg '
+                                      'path and have no HIP kernel')
+        self.inner_blocks, self.layer_blocks = [], []
+        for idx, cin in enumerate(in_channels_list, 1):
+            inner, layer = f'fpn_inner{idx}', f'fpn_layer{idx}'
+            if cin == 0:
+                continue
+            self.add_module(inner, conv_block(cin, out_channels, 1))
+            self.add_module(layer, conv_block(out_channels, out_channels, 3, 1))
+            self.inner_blocks.append(inner)
+            self.layer_blocks.append(layer)
+        self.top_blocks = None
+
+    def forward(self, x):
+        """x: feature maps, highest resolution first -> tuple of FPN maps, highest resolution first."""
+        last_inner = getattr(self, self.inner_blocks[-1])(x[-1])
+        results = [getattr(self, self.layer_blocks[-1])(last_inner)]
+        for feat, inner, layer in zip(x[:-1][::-1], self.inner_blocks[:-1][::-1], self.layer_blocks[:-1][::-1]):
+            lateral = getattr(self, inner)(feat)
+            last_inner = HF.upsample_nearest2x_add(last_inner, lateral)  # lateral + nearest_x2(top), one pass
+            results.insert(0, getattr(self, layer)(last_inner))
+        return tuple(results)
+
+
+class AssymetricDecoder(nn.Module):
+    def __init__(self, in_channels, out_channels, in_feat_output_strides=(4, 8, 16, 32), out_feat_output_stride=4,
+                 norm_fn=nn.BatchNorm2d, classifier_config=None):
+        super().__init__()
+        if norm_fn not in (nn.BatchNorm2d, BatchNorm2d):
+            raise NotImplementedError('ever_amd AssymetricDecoder: only norm_fn=BatchNorm2d (+ReLU) has HIP kernels')
+        self.cls_cfg = classifier_config
+        self.blocks = nn.ModuleList()
+        for os_in in in_feat_output_strides:
+            n_up = int(math.log2(int(os_in))) - int(math.log2(int(out_feat_output_stride)))
+            n_layers = n_up if n_up != 0 else 1
+            self.blocks.append(HipSequential(*[
+                HipSequential(
+                    Conv2d(in_channels if i == 0 else out_channels, out_channels, 3, 1, 1, bias=False),
+                    BatchNorm2d(num_features=out_channels),
+                    ReLU(True),
+                    Bf16compatible(UpsamplingBilinear2d(scale_factor=2)) if n_up != 0 else nn.Identity(),
+                ) for i in range(n_layers)]))
+        if self.cls_cfg:
+            scale_factor = classifier_config.get('scale_factor', 1)
+            num_classes = classifier_config.get('num_classes', -1)
+            kernel_size = classifier_config.get('kernel_size', 1)
+            dropout_rate = classifier_config.get('dropout_rate', -1)
+            if dropout_rate > 0:
+                raise NotImplementedError('ever_amd AssymetricDecoder: dropout_rate > 0 has no HIP kernel yet')
+            self.dropout = nn.Identity()
+            self.classifier = HipSequential(
+                Conv2d(out_channels, num_classes, kernel_size, padding=(kernel_size - 1) // 2),
+                Bf16compatible(UpsamplingBilinear2d(scale_factor=scale_factor)) if scale_factor > 1 else nn.Identity())
+
+    def forward(self, feat_list):
+        inner = [block(feat_list[i]) for i, block in enumerate(self.blocks)]
+        if len(inner) == 4:
+            out = HF.mean4(*inner)
+        else:  # generic: running add then scale (same left-to-right association as python sum)
+            out = inner[0]
+            for t in inner[1:]:
+                out = HF.add(out, t)
+            out = _Scale.apply(out, 1.0 / len(inner))
+        if self.cls_cfg:
+            out = self.classifier(self.dropout(out))
+        return out
+
+
+class _Scale:
+    @staticmethod
+    def apply(x, alpha):
+        import torch
+        from .. import _C
+
+        class Fn(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, t):
+                o = torch.empty_like(t)
+                _C.call('evk_scale', t.data_ptr(), alpha, o.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream)
+                return o
+
+            @staticmethod
+            def backward(ctx, g):
+                g = HF.as_nhwc(g)
+                o = torch.empty_like(g)
+                _C.call('evk_scale', g.data_ptr(), alpha, o.data_ptr(), g.numel(), torch.cuda.current_stream().cuda_stream)
+                return o
+
+        return Fn.apply(x)

@@ -1,0 +1,71 @@
+"""Foreground-Scene relation module and FarSegHead (API of reference ever/module/fs_relation.py:8-73,166-206).
+
+scene embedding = GAP(c5) -> per-scale 2-layer 1x1 MLP (bias, ReLU between);
+content / re-encode = 1x1 conv (bias) -> BN -> ReLU on each pyramid level;
+relation r = sigmoid(<scene, content>_channels);  output = r * re-encoded feature  (one fused kernel).
+"""
+import torch.nn as nn
+
+from ..core import registry
+from ..hip import functional as HF
+from ..interface import ERModule
+from .fpn import FPN, AssymetricDecoder
+from .layers import BatchNorm2d, Conv2d, HipSequential, ReLU
+
+__all__ = ['FSRelation', 'FarSegHead']
+
+
+def _mlp(cin, cout):
+    return HipSequential(Conv2d(cin, cout, 1), ReLU(True), Conv2d(cout, cout, 1))
+
+
+def _conv_bn_relu(cin, cout):
+    return HipSequential(Conv2d(cin, cout, 1), BatchNorm2d(cout), ReLU(True))
+
+
+class FSRelation(nn.Module):
+    def __init__(self, scene_embedding_channels, in_channels_list, out_channels, scale_aware_proj=False):
+        super().__init__()
+        self.scale_aware_proj = scale_aware_proj
+        if scale_aware_proj:
+            self.scene_encoder = nn.ModuleList([_mlp(scene_embedding_channels, out_channels)
+                                                for _ in range(len(in_channels_list))])
+        else:
+            self.scene_encoder = _mlp(scene_embedding_channels, out_channels)
+        self.content_encoders = nn.ModuleList([_conv_bn_relu(c, out_channels) for c in in_channels_list])
+        self.feature_reencoders = nn.ModuleList([_conv_bn_relu(c, out_channels) for c in in_channels_list])
+        self.normalizer = nn.Sigmoid()  # parameter-free; the sigmoid runs inside the relation kernel
+
+    def forward(self, scene_feature, features):
+        contents = [enc(f) for enc, f in zip(self.content_encoders, features)]
+        if self.scale_aware_proj:
+            scenes = [enc(scene_feature) for enc in self.scene_encoder]
+        else:
+            scenes = [self.scene_encoder(scene_feature)] * len(contents)
+        feats = [enc(f) for enc, f in zip(self.feature_reencoders, features)]
+        return [HF.fs_relation(s, c, p) for s, c, p in zip(scenes, contents, feats)]
+
+
+@registry.MODEL.register(verbose=False)
+class FarSegHead(ERModule):
+    def __init__(self, config):
+        super().__init__(config)
+        self.fpn = FPN(**self.config.fpn)
+        self.fs_relation = FSRelation(**self.config.fs_relation)
+        self.fpn_decoder = AssymetricDecoder(**self.config.fpn_decoder)
+
+    def forward(self, feature_list):
+        fpn_feats = self.fpn(feature_list)
+        scene = HF.global_avg_pool(feature_list[-1])  # GAP of c5 (encoder output), not of P5
+        refined = self.fs_relation(scene, fpn_feats)
+        return self.fpn_decoder(refined)
+
+    def set_default_config(self):
+        self.config.update(dict(
+            fpn=dict(in_channels_list=(256, 512, 1024, 2048), out_channels=256),
+            fs_relation=dict(scene_embedding_channels=2048, in_channels_list=(256, 256, 256, 256), out_channels=256,
+                             scale_aware_proj=True),
+            fpn_decoder=dict(in_channels=256, out_channels=256, in_feat_output_strides=(4, 8, 16, 32),
+                             out_feat_output_stride=4,
+                             classifier_config=dict(scale_factor=4.0, num_classes=1, kernel_size=1)),
+        ))

@@ -1,0 +1,149 @@
+"""HIP-backed counterparts of the stock torch.nn layers the reference's hot path is built from.
+
+Each class SUBCLASSES its torch.nn namesake and keeps its constructor, parameters, buffers and
+state-dict keys, so (a) reference checkpoints load unchanged, (b) `isinstance(m, nn.BatchNorm2d)`
+style code in user projects (freezing, init loops; e.g. reference ever/module/resnet.py:155-173,
+_resnets.py:164-169) keeps working, and (c) `to_hip(model)` can retarget an existing stock model by
+swapping classes.  Only `forward` changes: it calls the gfx950 kernels through the C-ABI.
+Activations flow as logical-NCHW / memory-NHWC tensors (see hip/functional.py).
+"""
+import torch
+import torch.nn as nn
+
+from ..hip import functional as HF
+
+__all__ = ['Conv2d', 'BatchNorm2d', 'ReLU', 'MaxPool2d', 'UpsamplingBilinear2d', 'AdaptiveAvgPool2d', 'Identity',
+           'HipSequential', 'run_sequence', 'to_hip']
+
+Identity = nn.Identity
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d (groups=1, zero padding) on the MFMA implicit-GEMM kernels; weight kept OHWI in memory."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        _check_conv(self)
+        self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
+
+    def forward(self, x, relu=False):
+        return HF.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, relu=relu)
+
+
+def _check_conv(m):
+    if m.groups != 1:
+        raise NotImplementedError('ever_amd Conv2d: groups != 1 is not on the FarSeg hot path (SURVEY §8) and has '
+                                  'no HIP kernel')
+    if m.padding_mode != 'zeros' or isinstance(m.padding, str):
+        raise NotImplementedError('ever_amd Conv2d: only explicit zero padding is implemented')
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d with optional fused residual add and ReLU (one apply pass over HBM)."""
+
+    def forward(self, x, residual=None, relu=False):
+        if self.momentum is None:
+            raise NotImplementedError('ever_amd BatchNorm2d: cumulative moving average (momentum=None) unsupported')
+        training = self.training or (self.running_mean is None)
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        rm = self.running_mean if (not self.training or self.track_running_stats) else None
+        rv = self.running_var if (not self.training or self.track_running_stats) else None
+        return HF.batch_norm_act(x, self.weight, self.bias, rm, rv, training, self.momentum, self.eps,
+                                 residual=residual, relu=relu)
+
+
+class ReLU(nn.ReLU):
+    def forward(self, x):
+        return HF.relu(x)
+
+
+class MaxPool2d(nn.MaxPool2d):
+    """Only the ResNet stem configuration (kernel 3, stride 2, padding 1) has a kernel."""
+
+    def forward(self, x):
+        cfg = (_one(self.kernel_size), _one(self.stride), _one(self.padding), _one(self.dilation), self.ceil_mode)
+        if cfg != (3, 2, 1, 1, False):
+            raise NotImplementedError(f'ever_amd MaxPool2d: only (k=3,s=2,p=1) is implemented, got {cfg}')
+        return HF.max_pool3x3s2(x)
+
+
+def _one(v):
+    if isinstance(v, (tuple, list)):
+        if len(set(v)) != 1:
+            return tuple(v)
+        return v[0]
+    return v
+
+
+class UpsamplingBilinear2d(nn.UpsamplingBilinear2d):
+    """bilinear, align_corners=True, by scale_factor."""
+
+    def forward(self, x):
+        if self.scale_factor is None:
+            raise NotImplementedError('ever_amd UpsamplingBilinear2d: give scale_factor')
+        return HF.upsample_bilinear(x, self.scale_factor)
+
+
+class AdaptiveAvgPool2d(nn.AdaptiveAvgPool2d):
+    def forward(self, x):
+        if _one(self.output_size) != 1:
+            raise NotImplementedError('ever_amd AdaptiveAvgPool2d: only output_size=1 is implemented')
+        return HF.global_avg_pool(x)
+
+
+def _unwrap(m):
+    # reference ops.Bf16compatible wraps the upsampling module (ever/module/ops.py:152-166); the HIP
+    # path is fp32 end to end so the wrapper is transparent.
+    inner = getattr(m, '_inner_module', None)
+    return inner if inner is not None else m
+
+
+def run_sequence(mods, x):
+    """Run modules in order with peephole fusion: conv->ReLU (epilogue), BN->ReLU (one pass)."""
+    mods = [_unwrap(m) for m in mods]
+    i, n = 0, len(mods)
+    while i < n:
+        m = mods[i]
+        nxt = mods[i + 1] if i + 1 < n else None
+        if isinstance(m, Conv2d) and isinstance(nxt, nn.ReLU):
+            x = m(x, relu=True)
+            i += 2
+        elif isinstance(m, BatchNorm2d) and isinstance(nxt, nn.ReLU):
+            x = m(x, relu=True)
+            i += 2
+        elif isinstance(m, nn.Identity):
+            i += 1
+        else:
+            x = m(x)
+            i += 1
+    return x
+
+
+class HipSequential(nn.Sequential):
+    """nn.Sequential (same child names => same state-dict keys) whose forward fuses neighbours."""
+
+    def forward(self, x):
+        return run_sequence(list(self), x)
+
+
+_SWAP = {
+    nn.Conv2d: Conv2d, nn.BatchNorm2d: BatchNorm2d, nn.ReLU: ReLU, nn.MaxPool2d: MaxPool2d,
+    nn.UpsamplingBilinear2d: UpsamplingBilinear2d, nn.AdaptiveAvgPool2d: AdaptiveAvgPool2d,
+    nn.Sequential: HipSequential,
+}
+
+
+def to_hip(model):
+    """Retarget a model built from stock torch.nn layers onto the HIP kernels, in place, by swapping
+    the class of every supported layer (parameters, buffers and state-dict keys are untouched).
+    Unsupported configurations raise when first executed, never silently fall back."""
+    for m in model.modules():
+        hip_cls = _SWAP.get(type(m))
+        if hip_cls is None:
+            continue
+        m.__class__ = hip_cls
+        if hip_cls is Conv2d:
+            _check_conv(m)
+            m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+    return model

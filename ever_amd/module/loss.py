@@ -1,0 +1,30 @@
+"""Pixel losses with ignore_index (API of reference ever/module/loss.py), HIP-backed masked reductions."""
+from ..hip import functional as HF
+
+__all__ = ['binary_cross_entropy_with_logits', 'dice_loss_with_logits', 'cross_entropy',
+           'label_smoothing_cross_entropy']
+
+
+def binary_cross_entropy_with_logits(output, target, reduction='mean', ignore_index=255, pos_weight=None):
+    """reference loss.py:229-235"""
+    if reduction != 'mean' or pos_weight is not None:
+        raise NotImplementedError('ever_amd BCE: only reduction="mean" without pos_weight has a HIP kernel')
+    return HF.bce_with_logits(output, target, ignore_index=ignore_index)
+
+
+def dice_loss_with_logits(y_pred, y_true, smooth_value=1.0, ignore_index=255, ignore_channel=-1, *,
+                          sync_statistics=True):
+    """reference loss.py:54-75 ; sufficient statistics are summed across ranks before the ratio."""
+    return HF.dice_loss_with_logits(y_pred, y_true, smooth_value, ignore_index, ignore_channel, sync_statistics)
+
+
+def cross_entropy(output, target, ignore_index=255):
+    """F.cross_entropy(output, target, ignore_index=ignore_index) as used by EVer model code."""
+    return HF.cross_entropy(output, target, ignore_index=ignore_index)
+
+
+def label_smoothing_cross_entropy(output, target, eps=0.1, reduction='mean', ignore_index=-1):
+    """reference loss.py:207-219"""
+    if reduction != 'mean':
+        raise NotImplementedError('ever_amd label_smoothing_cross_entropy: only reduction="mean"')
+    return HF.cross_entropy(output, target, ignore_index=ignore_index, label_smoothing=eps)

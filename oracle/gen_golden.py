@@ -1,0 +1,247 @@
+"""TEST INFRASTRUCTURE ONLY — pins the oracle against the REAL reference and writes tests/golden/*.
+
+Runs in the build container only (needs /root/reference; never on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+1. imports Z-Zheng/ever from /root/reference with three in-memory stub modules for its missing,
+   path-irrelevant dependencies (wandb, prettytable, albumentations);
+2. builds the reference ResNetEncoder + FarSegHead and the oracle restatement (oracle/farseg_ref.py),
+   loads the SAME portable weights (oracle/portable.py) into both, runs forward + backward on CPU and
+   requires bit-equality of logits, losses and every parameter gradient  -> the oracle is pinned;
+3. writes the golden vectors (outputs only; weights/inputs are regenerated from the portable hash):
+   per-op known answers, end-to-end logits / losses / gradient digests, LR-schedule and sampler tables.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = '/root/reference'
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+def _install_stubs():
+    wandb = types.ModuleType('wandb')
+    wandb.run = None
+    for fn in ('log', 'init', 'login', 'finish'):
+        setattr(wandb, fn, lambda *a, **k: None)
+    sys.modules['wandb'] = wandb
+    pt = types.ModuleType('prettytable')
+
+    class PrettyTable:
+        def __init__(self, *a, **k):
+            self.field_names, self._rows = [], []
+
+        def add_row(self, r):
+            self._rows.append(r)
+
+        def get_string(self):
+            return ''
+
+    pt.PrettyTable = PrettyTable
+    sys.modules['prettytable'] = pt
+    alb = types.ModuleType('albumentations')
+    alb.RandomScale = type('RandomScale', (), {})
+    alb.DualTransform = type('DualTransform', (), {})
+    albp = types.ModuleType('albumentations.pytorch')
+    albp.ToTensorV2 = type('ToTensorV2', (), {})
+    alb.pytorch = albp
+    sys.modules['albumentations'] = alb
+    sys.modules['albumentations.pytorch'] = albp
+
+
+def import_reference():
+    _install_stubs()
+    sys.path.insert(0, REF)
+    import ever  # noqa
+    return ever
+
+
+def grad_digest(named_params):
+    """Compact, order-stable summary of a gradient set: L2 norm, sum and 4 strided samples per tensor."""
+    d = {}
+    for k, p in named_params:
+        g = p.grad.detach().double().reshape(-1)
+        idx = np.linspace(0, g.numel() - 1, 4).astype(np.int64)
+        d[k] = [float(g.norm()), float(g.sum())] + [float(g[i]) for i in idx]
+    return d
+
+
+def build_pair(er, resnet_type, in_channels, num_classes=1, decoder_channels=256, classifier_kernel=1):
+    from ever.module.resnet import ResNetEncoder
+    from ever.module.fs_relation import FarSegHead
+    from oracle import farseg_ref, portable
+    widths = (64, 128, 256, 512) if resnet_type in ('resnet18', 'resnet34') else (256, 512, 1024, 2048)
+    en = ResNetEncoder(dict(resnet_type=resnet_type, in_channels=in_channels))
+    head = FarSegHead(dict(
+        fpn=dict(in_channels_list=widths, out_channels=256),
+        fs_relation=dict(scene_embedding_channels=widths[-1], in_channels_list=(256,) * 4, out_channels=256,
+                         scale_aware_proj=True),
+        fpn_decoder=dict(in_channels=256, out_channels=decoder_channels, in_feat_output_strides=(4, 8, 16, 32),
+                         out_feat_output_stride=4,
+                         classifier_config=dict(scale_factor=4.0, num_classes=num_classes, kernel_size=classifier_kernel))))
+
+    class RefModel(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.en, self.head = en, head
+
+        def forward(self, x):
+            return self.head(self.en(x))
+
+    ref = RefModel()
+    ora = farseg_ref.FarSegRef(resnet_type, in_channels, num_classes, decoder_channels, classifier_kernel)
+    assert list(ref.state_dict().keys()) == list(ora.state_dict().keys()), 'state-dict keys differ'
+    filled = portable.fill_state_dict(ora.state_dict())
+    farseg_ref.load_portable_weights(ref, filled)
+    farseg_ref.load_portable_weights(ora, filled)
+    return ref, ora
+
+
+def e2e_case(er, name, resnet_type, in_channels, n, hw, num_classes=1, decoder_channels=256, classifier_kernel=1):
+    import ever.module.loss as rloss
+    import torch.nn.functional as F
+    from oracle import portable
+    torch.manual_seed(0)
+    ref, ora = build_pair(er, resnet_type, in_channels, num_classes, decoder_channels, classifier_kernel)
+    x_np, y_np = portable.synthetic_batch(name, n, in_channels, hw, hw, num_classes)
+    x, y = torch.from_numpy(x_np), torch.from_numpy(y_np)
+    ref.train()
+    ora.train()
+    lg_ref = ref(x)
+    if num_classes == 1:
+        losses_ref = dict(bce_loss=rloss.binary_cross_entropy_with_logits(lg_ref, y, ignore_index=255),
+                          dice_loss=rloss.dice_loss_with_logits(lg_ref, y, ignore_index=255))
+    else:
+        losses_ref = dict(cls_loss=F.cross_entropy(lg_ref, y, ignore_index=255))
+    sum(losses_ref.values()).backward()
+    lg_ora = ora.logits(x)
+    losses_ora = ora(x, y)
+    sum(losses_ora.values()).backward()
+    # ---- pin: restatement == reference, bit for bit
+    lg_ora2 = ora.logits(x)  # BN running stats moved; logits in train mode do not depend on them
+    assert torch.equal(lg_ref, lg_ora) and torch.equal(lg_ora, lg_ora2), f'{name}: logits differ from the reference'
+    for k in losses_ref:
+        assert torch.equal(losses_ref[k], losses_ora[k]), f'{name}: {k} differs from the reference'
+    for (ka, pa), (kb, pb) in zip(ref.named_parameters(), ora.named_parameters()):
+        assert ka == kb and torch.equal(pa.grad, pb.grad), f'{name}: grad of {ka} differs from the reference'
+    print(f'[pin] {name}: oracle == reference (logits, losses, {len(list(ref.parameters()))} grads) bit-exact')
+    # eval-mode logits (running statistics after one training step)
+    ref.eval()
+    with torch.no_grad():
+        lg_eval = ref(x)
+    buffers = {k: v for k, v in ref.state_dict().items() if 'running_' in k}
+    bdig = {k: [float(v.double().sum()), float(v.double().norm())] for k, v in buffers.items()}
+    np.savez_compressed(os.path.join(OUT, f'e2e_{name}.npz'), logits=lg_ref.detach().numpy(),
+                        logits_eval=lg_eval.numpy(),
+                        **{k: np.float64(v.item()) for k, v in losses_ref.items()})
+    meta = dict(resnet_type=resnet_type, in_channels=in_channels, n=n, hw=hw, num_classes=num_classes,
+                decoder_channels=decoder_channels, classifier_kernel=classifier_kernel,
+                losses={k: float(v.item()) for k, v in losses_ref.items()},
+                grads=grad_digest(ref.named_parameters()), running=bdig,
+                argmax_margin=float(lg_ref.detach().abs().min()) if num_classes == 1 else None)
+    with open(os.path.join(OUT, f'e2e_{name}.json'), 'w') as f:
+        json.dump(meta, f)
+
+
+def op_kats(er):
+    """Known answers of the in-tree loss / resampling ops on the inputs of SURVEY §8 (a10-a12, c3)."""
+    import ever.module.loss as rloss
+    import torch.nn.functional as F
+    k = {}
+    lg = torch.tensor([[.5, -1.], [2., 0.]]).reshape(1, 1, 2, 2)
+    yb = torch.tensor([[1, 0], [1, 255]]).reshape(1, 2, 2)
+    k['bce'] = rloss.binary_cross_entropy_with_logits(lg, yb).item()
+    k['ls_bce'] = rloss.label_smoothing_binary_cross_entropy(lg, yb).item()
+    k['dice_binary'] = rloss.dice_loss_with_logits(lg, yb).item()
+    l3 = torch.tensor([[[1., 0.], [0., 2.]], [[0., 1.], [0., 0.]], [[-1., 0.], [3., 0.]]]).reshape(1, 3, 2, 2)
+    y3 = torch.tensor([[0, 1], [2, 255]]).reshape(1, 2, 2)
+    k['dice_3class'] = rloss.dice_loss_with_logits(l3, y3).item()
+    k['dice_3class_ignore_ch0'] = rloss.dice_loss_with_logits(l3, y3, ignore_channel=0).item()
+    k['ce_3class'] = F.cross_entropy(l3, y3, ignore_index=255).item()
+    k['ls_ce_3class'] = rloss.label_smoothing_cross_entropy(l3, y3, ignore_index=255).item()
+    k['tversky_a03'] = rloss.tversky_loss_with_logits(l3, y3, alpha=0.3).item()
+    up = torch.nn.UpsamplingBilinear2d(scale_factor=2)(torch.tensor([[0., 1.], [2., 3.]]).reshape(1, 1, 2, 2))
+    k['bilinear2x_of_0123'] = up.reshape(-1).tolist()
+    # schedules (ever/opt/learning_rate.py)
+    from ever.opt.learning_rate import PolyLearningRate, CosineAnnealingLearningRate, MultiStepLearningRate
+
+    class FakeOpt:
+        def __init__(self):
+            self.param_groups = [dict(lr=None)]
+
+    def lr_at(sched, step):
+        o = FakeOpt()
+        sched.step(step, o)
+        return o.param_groups[0]['lr']
+
+    poly = PolyLearningRate(0.007, 0.9, 30000, warmup=dict(type='linear', step=100, ratio=0.1))
+    k['poly'] = {str(s): lr_at(poly, s) for s in (0, 50, 100, 101, 15000, 29999)}
+    k['cosine'] = {str(s): lr_at(CosineAnnealingLearningRate(0.007, 30000, 1e-6), s) for s in (0, 7500, 30000)}
+    ms = MultiStepLearningRate((60000, 80000), 0.02, 0.1)
+    k['multistep'] = {str(s): lr_at(ms, s) for s in (0, 60000, 60001, 80001)}
+    from ever.magic.bigimage.sliding_window import sliding_window
+    k['sliding_window_1000x700_512_256'] = np.asarray(sliding_window((1000, 700), 512, 256)).tolist()
+    with open(os.path.join(OUT, 'op_kats.json'), 'w') as f:
+        json.dump(k, f, indent=1)
+    print('[kat] wrote op_kats.json:', {a: b for a, b in k.items() if isinstance(b, float)})
+
+
+def block_vectors(er):
+    """Per-block golden vectors at toy shapes: FPN, FSRelation, AssymetricDecoder outputs + input grads,
+    taken from the reference modules with portable weights."""
+    from ever.module.fpn import FPN, AssymetricDecoder
+    from ever.module.fs_relation import FSRelation
+    from oracle import portable
+    out = {}
+    feats = [torch.from_numpy(portable.normalish(f'blk/f{i}', (2, c, s, s))).requires_grad_()
+             for i, (c, s) in enumerate([(64, 16), (128, 8), (256, 4), (512, 2)])]
+    fpn = FPN((64, 128, 256, 512), 64)
+    fpn.load_state_dict({k: torch.from_numpy(v) for k, v in portable.fill_state_dict(fpn.state_dict()).items()})
+    rel = FSRelation(512, (64,) * 4, 64, True)
+    rel.load_state_dict({k: torch.from_numpy(v) for k, v in portable.fill_state_dict(rel.state_dict()).items()})
+    dec = AssymetricDecoder(64, 32, classifier_config=dict(scale_factor=4.0, num_classes=3, kernel_size=3))
+    dec.load_state_dict({k: torch.from_numpy(v) for k, v in portable.fill_state_dict(dec.state_dict()).items()})
+    for m in (fpn, rel, dec):
+        m.train()
+    p = fpn(feats)
+    scene = torch.nn.functional.adaptive_avg_pool2d(feats[-1], 1)
+    r = rel(scene, p)
+    o = dec(r)
+    w = torch.from_numpy(portable.normalish('blk/w', tuple(o.shape)))
+    (o * w).sum().backward()
+    for i, t in enumerate(p):
+        out[f'fpn{i}'] = t.detach().numpy()
+    for i, t in enumerate(r):
+        out[f'rel{i}'] = t.detach().numpy()
+    out['dec'] = o.detach().numpy()
+    for i, f in enumerate(feats):
+        out[f'dfeat{i}'] = f.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'blocks.npz'), **out)
+    print('[blk] wrote blocks.npz')
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    er = import_reference()
+    print('reference ever', er.__version__, 'torch', torch.__version__)
+    torch.set_num_threads(8)
+    op_kats(er)
+    block_vectors(er)
+    e2e_case(er, 'r18_4band_64', 'resnet18', 4, 2, 64)
+    e2e_case(er, 'r50_3band_64', 'resnet50', 3, 2, 64)
+    e2e_case(er, 'r50_3band_64_c16', 'resnet50', 3, 2, 64, num_classes=16, decoder_channels=128, classifier_kernel=3)
+    with open(os.path.join(OUT, 'PROVENANCE.json'), 'w') as f:
+        json.dump(dict(reference='Z-Zheng/ever', version=er.__version__, torch=torch.__version__,
+                       generated_by='oracle/gen_golden.py',
+                       note='outputs only; inputs and weights come from oracle/portable.py'), f)
+
+
+if __name__ == '__main__':
+    main()
