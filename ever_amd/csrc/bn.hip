@@ -30,7 +30,9 @@ static BnPlan bn_plan(int64_t rows, int C) {
   return p;
 }
 
-// partial[blk][0][C] = sum x, partial[blk][1][C] = sum x^2
+// partial[blk][0][C] = sum (x - pivot), partial[blk][1][C] = sum (x - pivot)^2 with pivot[c] = x[0][c].
+// Shifting by a sample of the same channel keeps var = E[d^2] - E[d]^2 free of the catastrophic
+// cancellation the raw moments suffer when |mean| >> std (8-sample statistics at 2x2 maps).
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
                                                                int64_t rows, int C, int64_t rows_per_blk, int tpc,
                                                                int rl) {
@@ -41,9 +43,10 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
   const int64_t r1 = min(rows, r0 + rows_per_blk);
   for (int cb = tc; cb < c4; cb += tpc) {
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 pv = *reinterpret_cast<const f32x4*>(x + cb * 4);
     if (tr < rl)
       for (int64_t r = r0 + tr; r < r1; r += rl) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * C + cb * 4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * C + cb * 4) - pv;
         s += v;
         q += v * v;
       }
@@ -63,22 +66,50 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
   }
 }
 
+// Sum the per-workgroup partials of 32 channels with 8 lanes per channel (coalesced 128-byte rows,
+// fp64), then fold the 8 lanes through LDS.  Returns true on the lane that holds the totals.
+constexpr int kFinCh = 32, kFinLanes = 8;
+__device__ __forceinline__ bool reduce_partials(const float* __restrict__ partial, int nblk, int C, int& c, double& s,
+                                                double& q) {
+  __shared__ double red[2][kFinLanes][kFinCh];
+  const int tc = threadIdx.x % kFinCh, tl = threadIdx.x / kFinCh;
+  c = blockIdx.x * kFinCh + tc;
+  s = 0.0;
+  q = 0.0;
+  if (c < C)
+    for (int b = tl; b < nblk; b += kFinLanes) {
+      s += (double)partial[(size_t)b * 2 * C + c];
+      q += (double)partial[(size_t)b * 2 * C + C + c];
+    }
+  red[0][tl][tc] = s;
+  red[1][tl][tc] = q;
+  __syncthreads();
+  if (tl != 0 || c >= C) return false;
+  for (int k = 1; k < kFinLanes; ++k) {
+    s += red[0][k][tc];
+    q += red[1][k][tc];
+  }
+  return true;
+}
+
 // mean / biased var -> save_mean, save_invstd, scale/shift for the apply pass; running stats update
 // follows torch: running = (1-m)*running + m*stat, with the UNBIASED variance (n/(n-1)).
-__global__ void bn_stats_final_kernel(const float* __restrict__ partial, int nblk, int C, double inv_rows,
-                                      double unbias, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                      float* __restrict__ running_mean, float* __restrict__ running_var,
-                                      float momentum, float eps, float* __restrict__ save_mean,
-                                      float* __restrict__ save_invstd, float* __restrict__ scale_shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    s += (double)partial[(size_t)b * 2 * C + c];
-    q += (double)partial[(size_t)b * 2 * C + C + c];
-  }
-  const double mean = s * inv_rows;
-  double var = q * inv_rows - mean * mean;
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ partial, int nblk, int C,
+                                                             double inv_rows, double unbias,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var, float momentum,
+                                                             float eps, float* __restrict__ save_mean,
+                                                             float* __restrict__ save_invstd,
+                                                             float* __restrict__ scale_shift) {
+  int c;
+  double s, q;
+  if (!reduce_partials(partial, nblk, C, c, s, q)) return;
+  const double dm = s * inv_rows;  // mean of (x - pivot)
+  const double mean = (double)x[c] + dm;
+  double var = q * inv_rows - dm * dm;
   if (var < 0.0) var = 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   const float meanf = (float)mean;
@@ -180,17 +211,14 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 }
 
 // coef[0][C] = gamma*invstd ; coef[1][C] = mean(g) ; coef[2][C] = mean(g*xhat)  (0 when !train)
-__global__ void bn_bwd_final_kernel(const float* __restrict__ partial, int nblk, int C, double inv_rows,
-                                    const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef,
-                                    int train) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    s += (double)partial[(size_t)b * 2 * C + c];
-    q += (double)partial[(size_t)b * 2 * C + C + c];
-  }
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                           double inv_rows, const float* __restrict__ gamma,
+                                                           const float* __restrict__ invstd,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           float* __restrict__ coef, int train) {
+  int c;
+  double s, q;
+  if (!reduce_partials(partial, nblk, C, c, s, q)) return;
   if (dbeta) dbeta[c] = (float)s;
   if (dgamma) dgamma[c] = (float)q;
   const float g = gamma ? gamma[c] : 1.f;
@@ -267,7 +295,7 @@ extern "C" int evk_bn_fwd_train(const float* x, const float* residual, const flo
   int rc = check_launch("bn_stats_partial");
   if (rc) return rc;
   const double unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, pl.nblk, C,
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, x, partial, pl.nblk, C,
                      1.0 / (double)rows, unbias, gamma, beta, running_mean, running_var, momentum, eps, save_mean,
                      save_invstd, scale_shift);
   rc = check_launch("bn_stats_final");
@@ -318,7 +346,7 @@ extern "C" int evk_bn_bwd(const float* dy, const float* x, const float* y, const
                      d_residual, partial, rows, C, pl.rows_per_blk, pl.tpc, pl.rl, relu);
   int rc = check_launch("bn_bwd_partial");
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, pl.nblk, C,
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, partial, pl.nblk, C,
                      1.0 / (double)rows, gamma, save_invstd, dgamma, dbeta, coef, train ? 1 : 0);
   rc = check_launch("bn_bwd_final");
   if (rc) return rc;

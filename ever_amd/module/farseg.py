@@ -45,7 +45,7 @@ class FarSeg(ERModule):
                 out['dice_loss'] = L.dice_loss_with_logits(logits, y, ignore_index=cfg.ignore_index)
         else:
             out['cls_loss'] = L.cross_entropy(logits, y, ignore_index=cfg.ignore_index)
-            if cfg.get('dice', False):
+            if cfg.get('multiclass_dice', False):
                 out['dice_loss'] = L.dice_loss_with_logits(logits, y, ignore_index=cfg.ignore_index)
         return out
 

@@ -11,7 +11,7 @@ import torch
 from oracle import farseg_ref, portable
 
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
-CASES = ['r18_4band_64', 'r50_3band_64', 'r50_3band_64_c16']
+CASES = ['r18_4band_64', 'r50_3band_64', 'r50_3band_128', 'r50_3band_64_c16']
 
 
 def _load(name):
