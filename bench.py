@@ -1,0 +1,185 @@
+"""bench.py — FarSeg-R50 training-step throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic tiles already resident in HBM:
+forward (ResNet-50 encoder -> FPN -> FS-Relation -> decoder -> head -> BCE+dice) + backward (+ the
+RCCL gradient all-reduce under DDP, overlapped with backward) + fused SGD update.  Workload =
+BASELINE.json configs[1]: FarSeg ResNet-50 FPN, 3-band 512x512, batch 16 per GPU (weak scaling).
+
+Rank 0 prints ONE JSON line: the contract fields plus
+  roofline     — achieved MFMA rate of the dominant kernel family (conv_igemm: conv forward + data
+                 gradient) = algorithmic FLOPs / HIP-event time of its launches over the timed region,
+                 against the dense fp32-MFMA peak (157.3 TF, v_mfma_f32_32x32x2_f32);
+  cpu_baseline — the CPU oracle (stock PyTorch port of the reference path) timed on this box's host
+                 cores on a bounded sample of the same workload (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-in MFMA peak (= fp32 vector peak)
+GF_FWD_BWD_PER_TILE = 342.7     # conv GFLOP fwd+bwd per 512x512x3 tile, default head
+TILE, BANDS, BATCH = 512, 3, 16
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=20)
+    p.add_argument('--warmup', type=int, default=5)
+    p.add_argument('--batch', type=int, default=BATCH, help='tiles per GPU (default: the BASELINE config)')
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-kernel-timer', action='store_true')
+    return p.parse_args()
+
+
+def make_batch(dev, batch, rank):
+    """N(0,1) image, P(fg)=0.3 labels with an 8x8 ignore(255) corner, seed 2333+rank."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(2333 + rank)
+    x = torch.randn(batch, BANDS, TILE, TILE, device=dev, generator=g)
+    y = (torch.rand(batch, TILE, TILE, device=dev, generator=g) < 0.3).long()
+    y[:, :8, :8] = 255
+    return x, y
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The oracle (CPU port of the reference path, stock torch.nn) on the host cores: FarSeg-R50 fwd+bwd+SGD
+    on 3x512x512 tiles at batch 2 (bounded sample: one warm-up + as many steps as fit the budget)."""
+    from oracle import farseg_ref
+    torch.manual_seed(0)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    net = farseg_ref.FarSegRef('resnet50', BANDS, 1).train()
+    opt = torch.optim.SGD(net.parameters(), lr=0.007, momentum=0.9, weight_decay=1e-4)
+    b = 2
+    x = torch.randn(b, BANDS, TILE, TILE)
+    y = (torch.rand(b, TILE, TILE) < 0.3).long()
+    y[:, :8, :8] = 255
+
+    def step():
+        out = net(x, y)
+        sum(out.values()).backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+
+    step()
+    t0, n = time.time(), 0
+    while True:
+        step()
+        n += 1
+        if time.time() - t0 > seconds_budget or n >= 8:
+            break
+    dt = (time.time() - t0) / n
+    return dict(value=round(b / dt, 3), unit='tiles/s', cores=cores, kind='port',
+                sample=f'oracle FarSegRef-R50 fwd+bwd+SGD, batch {b} of 3x512x512, {n} timed steps after 1 warm-up, '
+                       f'torch {torch.__version__} CPU, {cores} threads')
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (the HIP path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend='nccl', init_method='env://')   # RCCL over xGMI
+    import ever_amd as er
+    from ever_amd import _C
+    from ever_amd.hip import timing
+    _C.load()
+
+    torch.manual_seed(2333)
+    model = er.module.FarSeg(dict()).to(dev).train()      # R50 encoder + FarSegHead reference defaults
+    ddp = model
+    if world > 1:
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
+                                                        bucket_cap_mb=64, gradient_as_bucket_view=True)
+    opt = er.opt.FusedSGD(model.parameters(), lr=0.007, momentum=0.9, weight_decay=1e-4)
+    x, y = make_batch(dev, args.batch, rank)
+
+    def step():
+        out = ddp(x, y)
+        sum(v for k, v in out.items() if k.endswith('loss')).backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    timer = None if args.no_kernel_timer else timing.KernelTimer()
+    if timer is not None:
+        timer.__enter__()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if timer is not None:
+        timer.__exit__()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        tiles_s = world * args.batch * args.steps / elapsed
+        line = {
+            'metric': '512x512 tiles/sec fwd+bwd, FarSeg-R50', 'value': round(tiles_s, 2), 'unit': 'tiles/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'FarSeg ResNet-50 FPN (FarSegHead defaults, BCE+dice), 3-band 512x512, '
+                                   f'batch {args.batch}/GPU, fwd+bwd+SGD step, inputs resident in HBM',
+                       'global_batch': world * args.batch, 'tile': [BANDS, TILE, TILE],
+                       'parallelism': f'dp{world}' if world > 1 else 'single',
+                       'whole_model_tflops': round(tiles_s * GF_FWD_BWD_PER_TILE / 1e3 / world, 2)},
+        }
+        if timer is not None:
+            fam = timer.summary()
+            ig = fam.get('conv_igemm')
+            if ig:
+                ach = ig['flops'] / ig['seconds'] / 1e12
+                line['roofline'] = {
+                    'bound': 'mfma', 'kernel': 'evk::conv_igemm_kernel (conv forward + data-gradient launches)',
+                    'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                    'launches_per_step': ig['launches'] // args.steps,
+                    'avg_launch_us': round(ig['seconds'] / ig['launches'] * 1e6, 2),
+                    'algorithmic_gflop_per_launch': round(ig['flops'] / ig['launches'] / 1e9, 3)}
+            wg = fam.get('conv_wgrad')
+            if wg:
+                ach = wg['flops'] / wg['seconds'] / 1e12
+                line['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'evk::conv_wgrad_kernel (+split-K reduce)',
+                                          'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                          'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                                          'avg_launch_us': round(wg['seconds'] / wg['launches'] * 1e6, 2)}
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

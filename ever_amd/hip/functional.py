@@ -13,6 +13,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _C
+from . import timing
 from .workspace import workspace
 
 __all__ = [
@@ -149,7 +150,12 @@ class _Conv2dFn(Function):
             x_ptr, w_ptr = x.data_ptr(), w_ohwi.data_ptr()
         d = _conv_desc(n, h, w, cin_p, cout, kh, kw, stride, padding, dilation)
         y = empty_nhwc(n, cout, d.Ho, d.Wo, dev)
+        flops = 2.0 * n * d.Ho * d.Wo * cout * cin * kh * kw  # algorithmic (un-padded) FLOPs
+        sp = timing.span('conv_igemm', flops)
         _C.call('evk_conv2d_fwd', ctypes.byref(d), x_ptr, w_ptr, _ptr(bias), y.data_ptr(), 1 if relu else 0, st)
+        if sp is not None:
+            sp.stop()
+        ctx.flops = flops
         ctx.desc = d
         ctx.relu = relu
         ctx.cin = cin
@@ -199,7 +205,10 @@ class _Conv2dFn(Function):
             wt = torch.empty((cin_p, taps, cout_p), device=dev, dtype=torch.float32)
             _C.call('evk_conv2d_pack_dgrad_weight', ctypes.byref(dk), w_src.data_ptr(), wt.data_ptr(), st)
             dxk = empty_nhwc(n, cin_p, d.H, d.W, dev)
+            sp = timing.span('conv_igemm', ctx.flops)
             _C.call('evk_conv2d_dgrad', ctypes.byref(dk), dy_ptr, wt.data_ptr(), dxk.data_ptr(), st)
+            if sp is not None:
+                sp.stop()
             if cin_p != cin:
                 dx = empty_nhwc(n, cin, d.H, d.W, dev)
                 _C.call('evk_unpad_channels', dxk.data_ptr(), dx.data_ptr(), n * d.H * d.W, cin_p, cin, st)
@@ -211,8 +220,11 @@ class _Conv2dFn(Function):
             ws = workspace(dev, ws_bytes)
             dwk = torch.empty((cout_p, taps, cin_p), device=dev, dtype=torch.float32)
             dbk = torch.empty((cout_p,), device=dev, dtype=torch.float32) if need_db else None
+            sp = timing.span('conv_wgrad', ctx.flops)
             _C.call('evk_conv2d_wgrad', ctypes.byref(dk), xk.data_ptr(), dy_ptr, dwk.data_ptr(), _ptr(dbk),
                     ws.data_ptr(), ws_bytes, st)
+            if sp is not None:
+                sp.stop()
             if need_dw:
                 if cin_p != cin:
                     dw2 = torch.empty((cout_p * taps, cin), device=dev, dtype=torch.float32)

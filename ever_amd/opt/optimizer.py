@@ -1,0 +1,112 @@
+"""Optimizer registry (reference ever/opt/optimizer.py:7-15).  'sgd' resolves to `FusedSGD`: torch's
+SGD semantics and state-dict, with the update of ALL parameters done by one HIP launch
+(evk_sgd_multi) and gradient clipping folded into the same pass (evk_sqnorm_multi), when the
+parameters live on the GPU.  CPU parameters (config 1 plumbing) take torch's own step."""
+import torch
+from torch.optim.adam import Adam
+from torch.optim.adamw import AdamW
+from torch.optim.sgd import SGD
+
+from .. import _C
+from ..core import registry
+
+__all__ = ['FusedSGD']
+
+
+class FusedSGD(SGD):
+    def __init__(self, params, lr=1e-3, momentum=0, dampening=0, weight_decay=0, nesterov=False, **kwargs):
+        super().__init__(params, lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay,
+                         nesterov=nesterov, **{k: v for k, v in kwargs.items() if k in ('maximize',)})
+        self._clip = None          # (max_norm,) set by fused_clip for the next step
+        self._clip_bufs = None
+        self.last_grad_norm = None
+
+    # ERModule.clip_grad calls this instead of torch's clip_grad_norm_ (reference module.py:96-108)
+    def fused_clip(self, max_norm=35, norm_type=2):
+        if norm_type != 2:
+            raise NotImplementedError('FusedSGD: only the L2 norm is implemented')
+        params = [p for g in self.param_groups for p in g['params'] if p.grad is not None]
+        if not params or not params[0].is_cuda:
+            self.last_grad_norm = torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm, norm_type=2)
+            self._clip = None
+            return
+        dev = params[0].device
+        lib = _C.load()
+        nb = lib.evk_opt_blocks_per_tensor()
+        grads, sizes = self._tables([p.grad for p in params], dev)
+        partial = torch.empty((nb * len(params),), device=dev, dtype=torch.float64)
+        norm = torch.empty((), device=dev, dtype=torch.float32)
+        coef = torch.empty((), device=dev, dtype=torch.float32)
+        _C.call('evk_sqnorm_multi', grads.data_ptr(), sizes.data_ptr(), len(params), partial.data_ptr(),
+                float(max_norm), norm.data_ptr(), coef.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        self.last_grad_norm = norm       # device scalar: no host sync on the critical path
+        self._clip = coef                # applied inside the SGD kernel
+
+    @staticmethod
+    def _dense(t):
+        return t.is_contiguous() or (t.dim() == 4 and t.permute(0, 2, 3, 1).is_contiguous())
+
+    @classmethod
+    def _tables(cls, tensors, dev):
+        if not all(cls._dense(t) for t in tensors):
+            raise RuntimeError('FusedSGD: parameters / gradients must be dense')
+        ptrs = torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64).to(dev, non_blocking=True)
+        sizes = torch.tensor([t.numel() for t in tensors], dtype=torch.int64).to(dev, non_blocking=True)
+        return ptrs, sizes
+
+    def _launch(self, group, params, first):
+        dev = params[0].device
+        mom = group['momentum']
+        for p in params:
+            g = p.grad
+            same_layout = (g.is_contiguous() and p.is_contiguous()) or (
+                p.dim() == 4 and g.permute(0, 2, 3, 1).is_contiguous() and p.permute(0, 2, 3, 1).is_contiguous())
+            if not same_layout:  # element i of the grad must be element i of the parameter in memory
+                p.grad = torch.empty_like(p).copy_(g)
+        pt, sizes = self._tables(params, dev)
+        gt, _ = self._tables([p.grad for p in params], dev)
+        bt = None
+        if mom != 0:
+            bt, _ = self._tables([self.state[p]['momentum_buffer'] for p in params], dev)
+        _C.call('evk_sgd_multi', pt.data_ptr(), gt.data_ptr(), None if bt is None else bt.data_ptr(),
+                sizes.data_ptr(), len(params), float(group['lr']), float(mom), float(group['dampening']),
+                float(group['weight_decay']), 1 if group['nesterov'] else 0, 1 if first else 0,
+                None if self._clip is None else self._clip.data_ptr(), torch.cuda.current_stream().cuda_stream)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            params = [p for p in group['params'] if p.grad is not None]
+            if not params:
+                continue
+            if not (params[0].is_cuda and all(p.dtype == torch.float32 for p in params)) or group.get('maximize'):
+                # CPU plumbing path (BASELINE config 1): exactly torch.optim.SGD
+                saved = self.param_groups
+                self.param_groups = [group]
+                try:
+                    super().step()
+                finally:
+                    self.param_groups = saved
+                continue
+            fresh, warm = [], params
+            if group['momentum'] != 0:
+                fresh = [p for p in params if self.state[p].get('momentum_buffer') is None]
+                warm = [p for p in params if self.state[p].get('momentum_buffer') is not None]
+                for p in fresh:  # torch: buf = clone(d_p) on first use; the kernel writes it (first_step=1)
+                    self.state[p]['momentum_buffer'] = torch.empty_like(p)
+            if fresh:
+                self._launch(group, fresh, True)
+            if warm:
+                self._launch(group, warm, False)
+        self._clip = None
+        return loss
+
+
+registry.OPT.register('sgd', FusedSGD, verbose=False)
+registry.OPT.register('torch_sgd', SGD, verbose=False)
+registry.OPT.register('adam', Adam, verbose=False)
+registry.OPT.register('adamw', AdamW, verbose=False)

@@ -1,0 +1,54 @@
+"""Data-parallel trainer: one process per GPU, gradients all-reduced by RCCL over xGMI, overlapped
+with the backward of the earlier encoder stages (API of reference ever/trainer/th_ddp_trainer.py:10-40).
+
+On ROCm torch's "nccl" backend IS RCCL.  The DDP reducer buckets gradients in reverse registration
+order, so head buckets fire first and the large layer4 / layer3 buckets last; xGMI links are
+point-to-point (per-link bound ring), so buckets are kept large (`bucket_cap_mb`, default 64 MB:
+129 MB of fp32 gradients = ~3 collectives) to amortise per-collective latency rather than tuned for
+an NVSwitch fabric.  Without a GPU the process group uses gloo and DDP runs on CPU tensors — which
+fixes the reference's CPU-only crash (`device_ids=[local_rank]` without CUDA).
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from ..core.launcher import Launcher
+from . import trainer
+
+
+class THDDPTrainer(trainer.Trainer):
+    def __init__(self, args):
+        super().__init__(args)
+        self._cuda = torch.cuda.is_available()
+        if self._cuda:
+            torch.cuda.set_device(self.args.local_rank)
+        if not dist.is_initialized():
+            dist.init_process_group(backend='nccl' if self._cuda else 'gloo', init_method='env://')
+
+    def make_model(self, model_fn=None):
+        model = super().make_model(model_fn=model_fn)
+        if self.config.train.get('sync_bn', False):
+            raise NotImplementedError('sync_bn: SyncBatchNorm has no HIP kernel yet (SURVEY §8 f2); BN statistics '
+                                      'stay per GPU as in the reference default')
+        model = model.to(self.device)
+        ddp_kwargs = dict(find_unused_parameters=getattr(self.args, 'find_unused_parameters', False),
+                          bucket_cap_mb=self.config.train.get('bucket_cap_mb', 64),
+                          gradient_as_bucket_view=True,
+                          broadcast_buffers=self.config.train.get('broadcast_buffers', True))
+        if self._cuda:
+            ddp_kwargs.update(device_ids=[self.args.local_rank], output_device=self.args.local_rank)
+        model = nn.parallel.DistributedDataParallel(model, **ddp_kwargs)
+        return self.torch_compile(model)
+
+    def torch_compile(self, model):
+        if 'torch_compile' in self.config.train:
+            raise NotImplementedError('torch_compile: the HIP path launches hand-written kernels; there is no '
+                                      'tracing compiler in ever_amd')
+        return model
+
+    def build_launcher(self, model_fn=None, optimizer_fn=None, lr_fn=None):
+        model = self.make_model(model_fn=model_fn)
+        kwargs = dict(model_dir=self.args.model_dir, mixed_precision=self.mixed_precision, model=model)
+        kwargs.update(self.make_lr_optimizer(model.module.custom_param_groups(), lr_fn=lr_fn,
+                                             optimizer_fn=optimizer_fn))
+        return dict(config=self.config, launcher=Launcher(**kwargs))

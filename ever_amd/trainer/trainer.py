@@ -1,0 +1,144 @@
+"""Trainer: config -> model / optimizer / schedule / dataloaders -> Launcher (API of reference
+ever/trainer/trainer.py:38-244).  `build_launcher` passes `mixed_precision` (the reference omits it
+and raises TypeError at HEAD)."""
+import os
+
+import torch
+
+from ..core import config as _config
+from ..core.builder import make_callback, make_dataloader, make_learningrate, make_model, make_optimizer
+from ..core.dist import main_process_only
+from ..core.launcher import Launcher
+from ..util import param_util
+
+__all__ = ['merge_dict', 'Trainer']
+
+
+def merge_dict(dict1, dict2):
+    dup = [k for k in dict1 if k in dict2]
+    if dup:
+        raise ValueError('Duplicate keys: {}'.format(dup))
+    merged = dict1.copy()
+    merged.update(dict2)
+    return _config.AttrDict.from_dict(merged) if isinstance(dict1, _config.AttrDict) else merged
+
+
+class Trainer:
+    def __init__(self, args):
+        self._args = args
+        self._cfg = _config.import_config(args.config_path)
+        if args.opts:
+            self._cfg.update_from_list(args.opts)
+        self.initialize_workspace()
+        self._callbacks = []
+
+    def __call__(self):
+        return self
+
+    @main_process_only
+    def initialize_workspace(self):
+        os.makedirs(self.args.model_dir, exist_ok=True)
+        self.config.to_pickle(os.path.join(self.args.model_dir, 'config.pkl'))
+
+    args = property(lambda self: self._args)
+    config = property(lambda self: self._cfg)
+    cfg = property(lambda self: self._cfg)
+
+    @property
+    def device(self):
+        return torch.device('cuda') if torch.cuda.is_available() else torch.device('cpu')
+
+    @property
+    def mixed_precision(self):
+        return getattr(self.args, 'mixed_precision', 'fp32') or 'fp32'
+
+    # -------------------------------------------------------------- factories
+    def make_model(self, model_fn=None):
+        model = make_model(self.config.model)
+        return model if model_fn is None else model_fn(model)
+
+    def make_dataloader(self):
+        data = self.config.data
+        return dict(traindata_loader=make_dataloader(data.train),
+                    testdata_loader=make_dataloader(data.test) if 'test' in data else None)
+
+    def make_lr_optimizer(self, params, lr_fn=None, optimizer_fn=None):
+        lr_fn = lr_fn or (lambda x: x)
+        optimizer_fn = optimizer_fn or (lambda x: x)
+        lr_cfg, opt_cfg = self.config.learning_rate, self.config.optimizer
+        if hasattr(lr_cfg, 'type') and hasattr(opt_cfg, 'type'):  # one schedule, one optimizer
+            sched = lr_fn(make_learningrate(lr_cfg))
+            opt_cfg.params['lr'] = sched.base_lr
+            return dict(lr_schedule=sched, optimizer=optimizer_fn(make_optimizer(opt_cfg, params=params)))
+        if not hasattr(lr_cfg, 'type') and not hasattr(opt_cfg, 'type'):  # named groups (e.g. GAN G / D)
+            assert isinstance(params, dict)
+            names = list(lr_cfg.keys())
+            assert all(k in names for k in params) and all(k in names for k in opt_cfg.keys())
+            out = dict(lr_schedule={}, optimizer={})
+            for k in names:
+                sched = lr_fn(make_learningrate(lr_cfg[k]))
+                opt_cfg[k].params['lr'] = sched.base_lr
+                out['lr_schedule'][k] = sched
+                out['optimizer'][k] = optimizer_fn(make_optimizer(opt_cfg[k], params=params[k]))
+            return out
+        raise ValueError('Only support (single lr, single opt) and (multiple lr, multiple opt)')
+
+    def build_launcher(self, model_fn=None, optimizer_fn=None, lr_fn=None):
+        model = self.make_model(model_fn=model_fn).to(self.device)
+        kwargs = dict(model_dir=self.args.model_dir, model=model, mixed_precision=self.mixed_precision)
+        kwargs.update(self.make_lr_optimizer(model.custom_param_groups(), lr_fn=lr_fn, optimizer_fn=optimizer_fn))
+        return dict(config=self.config, launcher=Launcher(**kwargs))
+
+    def build_callbacks(self):
+        return [make_callback(c) for c in getattr(self.config.train, 'callbacks', [])]
+
+    # -------------------------------------------------------------- entry points
+    def evaluate(self, test_config=None, after_construct_launcher_callbacks=None):
+        tl = self.build_launcher()['launcher']
+        param_util.trainable_parameters(tl.model, tl.logger)
+        param_util.count_model_parameters(tl.model, tl.logger)
+        if test_config:
+            if not isinstance(test_config, dict):
+                raise ValueError()
+            loader = make_dataloader(_config.AttrDict.from_dict(test_config))
+        else:
+            loader = make_dataloader(self.config.data.test)
+        for f in after_construct_launcher_callbacks or ():
+            f(tl)
+        tl.evaluate(loader, merge_dict(self.config.train, self.config.test))
+        return dict(config=self.config, launcher=tl)
+
+    def run(self, after_construct_launcher_callbacks=None, model_fn=None, optimizer_fn=None, lr_fn=None):
+        loaders = self.make_dataloader()
+        return self.train_with_dataloader(loaders['traindata_loader'], loaders['testdata_loader'],
+                                          after_construct_launcher_callbacks=after_construct_launcher_callbacks,
+                                          model_fn=model_fn, optimizer_fn=optimizer_fn, lr_fn=lr_fn)
+
+    def train_with_dataloader(self, train_dataloader, test_dataloader=None, after_construct_launcher_callbacks=None,
+                              model_fn=None, optimizer_fn=None, lr_fn=None):
+        if self.args.opts:
+            self.config.update_from_list(self.args.opts)
+        tl = self.build_launcher(model_fn=model_fn, optimizer_fn=optimizer_fn, lr_fn=lr_fn)['launcher']
+        if getattr(self.args, 'use_wandb', False):
+            tl.logger.init_wandb(entity=self.args.entity, project=self.args.project, name=self.args.model_dir,
+                                 wandb_dir=self.args.model_dir)
+        param_util.trainable_parameters(tl.model, tl.logger)
+        param_util.count_model_parameters(tl.model, tl.logger)
+        for c in self.build_callbacks():
+            self.register_callback(c)
+        for c in self._callbacks:
+            tl.info(f'callback: {c}')
+            tl.register_callback(c)
+        for f in after_construct_launcher_callbacks or ():
+            f(tl)
+        tl.info('th sync bn: {}'.format('True' if self.config.train.get('sync_bn', False) else 'False'))
+        tl.info('external parameter: {}'.format(self.args.opts))
+        tl.info(f'config: {self.config}')
+        tl.train_by_config(train_dataloader, config=self.config.train, test_data_loader=test_dataloader)
+        return dict(config=self.config, launcher=tl)
+
+    def register_callback(self, callback):
+        self._callbacks.append(callback)
+
+    def reset_callbacks(self):
+        self._callbacks.clear()

@@ -242,13 +242,89 @@ def block_vectors(er):
     print('[blk] wrote blocks.npz')
 
 
+def toy_dataset(n=4, c=4, hw=64):
+    """n hash-generated (image, label) pairs: the dataset of the Launcher pin (both sides build it)."""
+    from oracle import portable
+    xs, ys = [], []
+    for i in range(n):
+        x, y = portable.synthetic_batch(f'toy/{i}', 1, c, hw, hw, 1)
+        xs.append(torch.from_numpy(x[0]))
+        ys.append(torch.from_numpy(y[0]))
+    return xs, ys
+
+
+def launcher_case(er):
+    """Pin of SURVEY §8 c5: the REFERENCE Launcher drives the reference blocks (R18, 4-band, batch 2,
+    SGD m=.9 wd=1e-4, poly lr .01/.9/3 iters, BCE+dice) for 3 iterations on CPU; the unsmoothed
+    per-step losses, the lr sequence and the final weights' digest are the fixture that the build's
+    own Launcher + Trainer must reproduce (tests/test_plumbing_cpu.py)."""
+    import tempfile
+    tb = types.ModuleType('torch.utils.tensorboard')
+    tb.SummaryWriter = type('SummaryWriter', (), {'__init__': lambda s, *a, **k: None,
+                                                  'add_scalar': lambda s, *a, **k: None,
+                                                  'add_histogram': lambda s, *a, **k: None})
+    sys.modules['torch.utils.tensorboard'] = tb
+    import ever.module.loss as rloss
+    from ever.core.launcher import Launcher
+    from ever.opt.learning_rate import PolyLearningRate
+    from ever.core.builder import make_optimizer
+    from oracle import portable
+    ref, _ = build_pair(er, 'resnet18', 4)
+
+    class Model(er.ERModule):
+        def __init__(self, config):
+            super().__init__(config)
+            self.en, self.head = ref.en, ref.head
+
+        def forward(self, x, y=None):
+            lg = self.head(self.en(x))
+            if self.training:
+                return dict(bce_loss=rloss.binary_cross_entropy_with_logits(lg, y, ignore_index=255),
+                            dice_loss=rloss.dice_loss_with_logits(lg, y, ignore_index=255))
+            return lg
+
+        def set_default_config(self):
+            self.config.update(dict())
+
+    model = Model(dict())
+    xs, ys = toy_dataset()
+    loader = torch.utils.data.DataLoader(list(zip(xs, ys)), batch_size=2, shuffle=False)
+    sched = PolyLearningRate(0.01, 0.9, 3)
+    opt_cfg = er.config.AttrDict.from_dict(dict(type='sgd', params=dict(momentum=0.9, weight_decay=1e-4, lr=sched.base_lr)))
+    opt = make_optimizer(opt_cfg, params=model.custom_param_groups())
+    records = []
+    with tempfile.TemporaryDirectory() as d:
+        tl = Launcher(d, model, opt, sched, mixed_precision='fp32')
+        orig = tl._logger.train_log
+
+        def spy(**kw):
+            records.append(dict(step=int(kw['step']), lr=float(kw['lr']), **{k: float(v) for k, v in kw['loss_dict'].items()}))
+            return orig(**kw)
+
+        tl._logger.train_log = spy
+        tl.train_by_config(loader, config=er.config.AttrDict.from_dict(dict(num_iters=3, save_ckpt_interval_epoch=1000)))
+        files = sorted(os.listdir(d))
+        with open(os.path.join(d, 'checkpoint_info.json')) as f:
+            index = json.load(f)
+    digest = {k: [float(v.double().sum()), float(v.double().norm())] for k, v in model.state_dict().items()}
+    with open(os.path.join(OUT, 'launcher_r18.json'), 'w') as f:
+        json.dump(dict(records=records, files=[x for x in files if not x.endswith('.log')], index=index,
+                       final_state=digest), f)
+    print('[launcher] reference Launcher steps:', records)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     er = import_reference()
     print('reference ever', er.__version__, 'torch', torch.__version__)
     torch.set_num_threads(8)
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only == 'launcher':
+        launcher_case(er)
+        return
     op_kats(er)
     block_vectors(er)
+    launcher_case(er)
     e2e_case(er, 'r18_4band_64', 'resnet18', 4, 2, 64)
     e2e_case(er, 'r50_3band_64', 'resnet50', 3, 2, 64)
     e2e_case(er, 'r50_3band_128', 'resnet50', 3, 2, 128)

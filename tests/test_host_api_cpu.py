@@ -1,0 +1,195 @@
+"""CPU: host-side mirror of the reference API — config, registry, builder, schedules, samplers,
+module construction / state-dict compatibility, C-ABI symbol table (no compute calls)."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import ever_amd as er
+from ever_amd import _C
+from oracle import farseg_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+# ------------------------------------------------------------------ config / registry / builder
+def test_attrdict_recursive_update_and_cli_overrides(tmp_path):
+    cfg = er.AttrDict.from_dict(dict(model=dict(type='X', params=dict(a=1, b=dict(c=2))), train=dict(num_iters=10)))
+    cfg.update(dict(model=dict(params=dict(b=dict(d=3)))))
+    assert cfg.model.params.a == 1 and cfg.model.params.b.c == 2 and cfg['model']['params']['b']['d'] == 3
+    cfg.update_from_list(['train.num_iters', '20', 'model.params.b.c', '(1, 2)', 'model.name', 'farseg'])
+    assert cfg.train.num_iters == 20 and cfg.model.params.b.c == (1, 2) and cfg.model.name == 'farseg'
+    cfg.stages = [dict(k=1), dict(k=2)]
+    cfg.update(dict(stages=[dict(k=5)]))
+    assert isinstance(cfg.stages[0], er.AttrDict) and cfg.stages[0].k == 5
+    p = tmp_path / 'c.pkl'
+    cfg.to_pickle(str(p))
+    back = er.config.import_config(str(p))
+    assert back.train.num_iters == 20 and back.to_dict()['model']['params']['a'] == 1
+    (tmp_path / 'cfg.py').write_text('config = dict(model=dict(type="M", params=dict(w=3)))\n')
+    assert er.config.import_config(str(tmp_path / 'cfg.py')).model.params.w == 3
+
+
+def test_registry_decorator_and_builder():
+    reg = er.registry.Registry()
+
+    @reg.register()
+    def foo():
+        return 1
+
+    @reg.register('alias')
+    @reg.register('alias2')
+    def bar():
+        return 2
+
+    reg.register('direct', 3)
+    assert reg['foo']() == 1 and reg['alias']() == 2 and reg['alias2']() == 2 and reg['direct'] == 3
+    with pytest.raises(ValueError):
+        er.builder.make_model(dict(type='__nope__', params={}))
+    m = er.builder.make_model(dict(type='FarSegHead', params=dict()))
+    assert isinstance(m, er.ERModule) and m.config.fpn.out_channels == 256
+    opt = er.builder.make_optimizer(er.AttrDict.from_dict(dict(type='sgd', params=dict(lr=0.1, momentum=0.9),
+                                                               grad_clip=dict(max_norm=35, norm_type=2))),
+                                    params=m.parameters())
+    assert opt.er_config.grad_clip.max_norm == 35
+
+
+def test_lr_schedules_match_reference_tables():
+    with open(os.path.join(GOLD, 'op_kats.json')) as f:
+        k = json.load(f)
+
+    class FakeOpt:
+        def __init__(self):
+            self.param_groups = [dict(lr=None)]
+
+    def lr_at(s, step):
+        o = FakeOpt()
+        s.step(step, o)
+        return o.param_groups[0]['lr']
+
+    poly = er.builder.make_learningrate(dict(type='poly', params=dict(
+        base_lr=0.007, power=0.9, max_iters=30000, warmup=dict(type='linear', step=100, ratio=0.1))))
+    for s, v in k['poly'].items():
+        assert lr_at(poly, int(s)) == pytest.approx(v, rel=1e-12)
+    cos = er.builder.make_learningrate(dict(type='cosine', params=dict(base_lr=0.007, max_iters=30000, eta_min=1e-6)))
+    for s, v in k['cosine'].items():
+        assert lr_at(cos, int(s)) == pytest.approx(v, rel=1e-12)
+    ms = er.builder.make_learningrate(dict(type='multistep', params=dict(steps=(60000, 80000), base_lr=0.02, gamma=0.1)))
+    for s, v in k['multistep'].items():
+        assert lr_at(ms, int(s)) == pytest.approx(v, rel=1e-12)
+    # SURVEY §8 c3 literal pins
+    assert lr_at(poly, 0) == pytest.approx(7e-4) and lr_at(poly, 15000) == pytest.approx(3.762496e-3, rel=1e-6)
+    assert lr_at(cos, 7500) == pytest.approx(5.975020e-3, rel=1e-6)
+    const = er.builder.make_learningrate(dict(type='constant', params=dict(base_lr=0.1)))
+    o = FakeOpt()
+    const.step(5, o)
+    assert o.param_groups[0]['lr'] is None  # ConstantLearningRate never touches the optimizer
+
+
+def test_step_distributed_sampler_shards_are_disjoint_and_step_seeded():
+    from ever_amd.data import StepDistributedSampler
+    s = StepDistributedSampler(range(10))
+    s.set_step(3)
+    assert list(s) == [6, 0, 3, 7, 8, 5, 1, 9, 2, 4]  # SURVEY §8 c3 (torch.randperm, world 1, step 3)
+    shards = []
+    for rank in range(4):
+        s = StepDistributedSampler(range(10))
+        s.num_replicas, s.rank = 4, rank
+        s.num_samples, s.total_size = 3, 12
+        s.set_step(7)
+        shards.append(list(s))
+    flat = sum(shards, [])
+    assert len(flat) == 12 and set(flat) == set(range(10))  # wrap-padded to a multiple of world
+
+
+# ------------------------------------------------------------------ modules: keys, counts, loud failure
+def test_state_dict_keys_equal_the_reference_layout():
+    hip = er.module.FarSeg(dict())
+    ref = farseg_ref.FarSegRef('resnet50', 3, 1)  # pinned key-for-key to the reference in gen_golden.py
+    assert list(hip.state_dict().keys()) == list(ref.state_dict().keys())
+    for (k, a), (_, b) in zip(hip.state_dict().items(), ref.state_dict().items()):
+        assert tuple(a.shape) == tuple(b.shape), k
+    n_params = sum(p.numel() for p in hip.parameters())
+    assert len(list(hip.parameters())) == 238 and abs(n_params / 1e6 - 33.875) < 0.01
+    assert sum(p.numel() for p in hip.en.parameters()) == sum(p.numel() for p in ref.en.parameters())
+    n_bn = sum(isinstance(m, torch.nn.BatchNorm2d) for m in hip.modules())
+    n_conv = sum(isinstance(m, torch.nn.Conv2d) for m in hip.modules())
+    assert (n_bn, n_conv) == (68, 85)
+    for k in ('en.resnet.conv1.weight', 'en.resnet.layer1.0.bn1.running_mean', 'head.fpn.fpn_inner1.0.weight',
+              'head.fs_relation.scene_encoder.0.0.weight', 'head.fpn_decoder.blocks.3.2.0.weight',
+              'head.fpn_decoder.classifier.0.bias'):
+        assert k in hip.state_dict()
+    # reference weights load into the HIP model and back, conv weights stay OHWI in memory
+    sd = {k: torch.randn_like(v) if v.is_floating_point() else v for k, v in ref.state_dict().items()}
+    hip.load_state_dict(sd, strict=True)
+    w = hip.en.resnet.layer1[0].conv2.weight
+    assert w.permute(0, 2, 3, 1).is_contiguous() and torch.equal(w, sd['en.resnet.layer1.0.conv2.weight'])
+
+
+def test_encoder_options_follow_the_reference():
+    enc = er.module.ResNetEncoder(dict(resnet_type='resnet18', in_channels=4, output_stride=16, freeze_at=2,
+                                       batchnorm_trainable=False))
+    assert enc.resnet.conv1.weight.shape == (64, 4, 7, 7) and 'fc' not in dict(enc.resnet.named_children())
+    l4 = enc.resnet.layer4[0]
+    assert l4.conv1.stride == (1, 1) and l4.conv2.dilation == (2, 2) and l4.downsample[0].stride == (1, 1)
+    assert not any(p.requires_grad for p in enc.resnet.layer1.parameters())
+    assert not any(p.requires_grad for m in enc.modules() if isinstance(m, torch.nn.BatchNorm2d) for p in m.parameters())
+    enc.train()
+    assert all(not m.training for m in enc.modules() if isinstance(m, torch.nn.BatchNorm2d))
+    with pytest.raises(ValueError):
+        er.module.ResNetEncoder(dict(output_stride=4))
+
+
+def test_hip_modules_refuse_cpu_tensors():
+    from ever_amd.hip.functional import HipPathError
+    m = er.module.FarSeg(dict(encoder=dict(resnet_type='resnet18'),
+                              head=dict(fpn=dict(in_channels_list=(64, 128, 256, 512), out_channels=256),
+                                        fs_relation=dict(scene_embedding_channels=512))))
+    with pytest.raises(HipPathError):
+        m(torch.randn(1, 3, 64, 64), torch.zeros(1, 64, 64, dtype=torch.long))
+    with pytest.raises(HipPathError):
+        er.module.loss.binary_cross_entropy_with_logits(torch.randn(1, 1, 4, 4), torch.zeros(1, 4, 4).long())
+
+
+def test_to_hip_retargets_a_stock_model():
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.ReLU(True),
+                              torch.nn.MaxPool2d(3, 2, 1))
+    keys = list(net.state_dict())
+    er.module.to_hip(net)
+    assert isinstance(net, er.module.HipSequential) and isinstance(net[0], er.module.Conv2d)
+    assert isinstance(net[1], er.module.BatchNorm2d) and list(net.state_dict()) == keys
+    with pytest.raises(NotImplementedError):
+        er.module.to_hip(torch.nn.Sequential(torch.nn.Conv2d(4, 4, 3, groups=2)))
+
+
+# ------------------------------------------------------------------ the C-ABI
+def _header_symbols():
+    txt = open(os.path.join(ROOT, 'include', 'ever_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(evk_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib_path = _C.lib_path()
+    assert os.path.exists(lib_path), 'libever_hip.so missing: run __graft_entry__.build()'
+    declared = _header_symbols()
+    assert len(declared) >= 40
+    out = subprocess.run(['nm', '-D', '--defined-only', lib_path], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r'\bT (evk_[a-z0-9_]+)', out))
+    missing = [s for s in declared if s not in exported]
+    assert not missing, f'declared in include/ever_hip.h but not exported: {missing}'
+    assert sorted(_C.SIGNATURES) == declared, 'ctypes signature table out of sync with the header'
+    lib = _C.load()
+    assert lib.evk_abi_version() == 1 and lib.evk_build_arch() == b'gfx950'
+    # argument validation happens before any launch: safe without a GPU
+    d = _C.ConvDesc(1, 8, 8, 3, 8, 8, 4, 1, 1, 1, 1, 0, 0, 1, 1)
+    rc = lib.evk_conv2d_fwd(ctypes.byref(d), 1, 1, None, 1, 0, None)
+    assert rc == -2 and b'multiple of 4' in lib.evk_last_error()   # EVK_E_UNSUPPORTED: Cin % 4
+    assert lib.evk_bn_fwd_train(None, None, None, None, None, None, 0.1, 1e-5, None, None, None, 4, 4, 0, None, 0, None) == -1
+    assert lib.evk_conv2d_wgrad_workspace_bytes(ctypes.byref(_C.ConvDesc(2, 8, 8, 64, 8, 8, 64, 3, 3, 1, 1, 1, 1, 1, 1))) > 0
