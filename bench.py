@@ -53,12 +53,25 @@ def make_batch(dev, batch, rank):
     return x, y
 
 
-def cpu_baseline(seconds_budget=25.0):
+def host_cores():
+    """Cores this process may actually use: the cgroup CPU quota if one is set (the GPU box exposes 256
+    logical CPUs under a 16-core quota; oversubscribing it makes oneDNN 100x slower), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(seconds_budget=20.0):
     """The oracle (CPU port of the reference path, stock torch.nn) on the host cores: FarSeg-R50 fwd+bwd+SGD
     on 3x512x512 tiles at batch 2 (bounded sample: one warm-up + as many steps as fit the budget)."""
     from oracle import farseg_ref
     torch.manual_seed(0)
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     net = farseg_ref.FarSegRef('resnet50', BANDS, 1).train()
     opt = torch.optim.SGD(net.parameters(), lr=0.007, momentum=0.9, weight_decay=1e-4)
