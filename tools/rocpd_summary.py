@@ -1,0 +1,35 @@
+"""Summarise a rocprofv3 (ROCm 7.2 rocpd sqlite) --kernel-trace --stats capture into a committed,
+human-readable per-kernel table: calls, total / average / min / max duration, share of GPU time.
+
+    python tools/rocpd_summary.py gpurun_out/prof_r01/farseg_results.db profiles/r01_kernel_stats
+writes <out>.md and <out>.csv
+"""
+import csv
+import sqlite3
+import sys
+
+
+def main(db_path, out):
+    db = sqlite3.connect(db_path)
+    rows = db.execute('select name, count(*), sum(duration), avg(duration), min(duration), max(duration) '
+                      'from kernels group by name order by sum(duration) desc').fetchall()
+    total = sum(r[2] for r in rows)
+    span = db.execute('select min(start), max(end) from kernels').fetchone()
+    with open(out + '.csv', 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['kernel', 'calls', 'total_us', 'avg_us', 'min_us', 'max_us', 'pct'])
+        for n, c, s, a, mn, mx in rows:
+            w.writerow([n, c, round(s / 1e3, 1), round(a / 1e3, 2), round(mn / 1e3, 2), round(mx / 1e3, 2),
+                        round(100.0 * s / total, 2)])
+    with open(out + '.md', 'w') as f:
+        f.write(f'# rocprofv3 --kernel-trace --stats summary\n\nsource: `{db_path}`; {sum(r[1] for r in rows)} '
+                f'dispatches, {total / 1e6:.1f} ms of kernel time over a {(span[1] - span[0]) / 1e6:.1f} ms window\n\n')
+        f.write('| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---:|---:|---:|---:|---:|---:|\n')
+        for n, c, s, a, mn, mx in rows:
+            f.write(f'| `{n[:110]}` | {c} | {s / 1e6:.2f} | {a / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} | '
+                    f'{100.0 * s / total:.2f} |\n')
+    print(open(out + '.md').read()[:6000])
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2])
