@@ -14,7 +14,13 @@
 // Fragment mapping (guide §3): A operand lane l = A[i=l&31][k=l>>5], B lane l = B[k=l>>5][j=l&31];
 // one ds_read_b128 per lane supplies k = 8g+4h .. 8g+4h+3, i.e. four consecutive MFMAs.
 // C/D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+//
+// The gather is branch-free: every 16-byte load is issued unconditionally from a clamped (always
+// valid) address and zeroed by a select, so hipcc emits the step's 8 global_load_dwordx4 back to
+// back instead of one exec-masked branch + wait per load; all indices are 32-bit element offsets
+// (tensors are < 2^31 elements, checked on the host).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace evk {
 
@@ -28,8 +34,6 @@ struct IGemmArgs {
   int Cd;              // GEMM N
   int kh, kw, cpt;     // cpt = Cs/4 (16-byte chunks per tap)
   int sh, sw, ph, pw, dh, dw;
-  int mode;            // 0: forward gather  sy = py*sh - ph + ky*dh
-                       // 1: transposed gather  t = py + ph - ky*dh, sy = t/sh iff t%sh==0
   int M, Ktot;
   int Hd, Wd, dsh, dsw;  // destination row mapping: (n, py*dsh, px*dsw) in an [N,Hd,Wd,Cd] tensor
   int dense_dst;         // 1 => dst row offset = m*Cd
@@ -38,8 +42,12 @@ struct IGemmArgs {
 };
 
 constexpr int BK = 32;
+constexpr int kInvalidRow = -(1 << 28);  // y0 of a row past M: every tap fails the bounds test
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+// MODE 0: forward gather       sy = py*sh - ph + ky*dh
+// MODE 1: transposed, stride 1 sy = py + ph - ky*dh
+// MODE 2: transposed, strided  t = py + ph - ky*dh ; sy = t/sh iff t >= 0 and t % sh == 0
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int NBUF>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const IGemmArgs p) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MB = WM / 32, NB = WN / 32;
@@ -47,8 +55,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IGemmArgs p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                  // [2][BM][32]
-  float* Bs = smem + 2 * BM * BK;    // [2][BN][32]
+  float* As = smem;                     // [NBUF][BM][32]
+  float* Bs = smem + NBUF * BM * BK;    // [NBUF][BN][32]
 
   // XCD-aware tile order: consecutive tile ids (sharing A rows / weights) stay on one XCD's L2.
   const int nwg = gridDim.x;
@@ -66,7 +74,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IGemmArgs p) {
   const int rb = tid >> 3;  // base row 0..31
 
   // ---- per-thread gather state for its A rows
-  int a_nbase[AR], a_y0[AR], a_x0[AR];
+  int a_y0[AR], a_x0[AR], a_base[AR];
 #pragma unroll
   for (int j = 0; j < AR; ++j) {
     const int m = m0 + rb + 32 * j;
@@ -76,76 +84,95 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IGemmArgs p) {
       const int rem = m - n * hw;
       const int py = rem / p.Wm;
       const int px = rem - py * p.Wm;
-      a_nbase[j] = n * p.Hs;
-      if (p.mode == 0) {
+      if (MODE == 0) {
         a_y0[j] = py * p.sh - p.ph;
         a_x0[j] = px * p.sw - p.pw;
       } else {
         a_y0[j] = py + p.ph;
         a_x0[j] = px + p.pw;
       }
+      if (MODE == 2) a_base[j] = n * p.Hs;                                      // image row base
+      else a_base[j] = ((n * p.Hs + a_y0[j]) * p.Ws + a_x0[j]) * p.Cs;          // element offset of tap (0,0)
     } else {
-      a_nbase[j] = -1;
-      a_y0[j] = 0;
+      a_y0[j] = kInvalidRow;
       a_x0[j] = 0;
+      a_base[j] = 0;
     }
   }
-  // B rows
-  const float* b_ptr[BR];
+  // B rows: element offset of this thread's chunk in step 0, or -1 past Cd
+  int b_off[BR];
 #pragma unroll
   for (int j = 0; j < BR; ++j) {
     const int co = n0 + rb + 32 * j;
-    b_ptr[j] = (co < p.Cd) ? p.wgt + (size_t)co * p.Ktot + c8 * 4 : nullptr;
+    b_off[j] = (co < p.Cd) ? co * p.Ktot + c8 * 4 : -1;
   }
 
   // K-chunk cursor of this thread: chunk q = kt*8 + c8  ->  (ky, kx, cc)
-  int cc = c8, kx = 0, ky = 0;
-  while (cc >= p.cpt) {
-    cc -= p.cpt;
-    if (++kx == p.kw) { kx = 0; ++ky; }
+  int cc, kx, ky;
+  {
+    const int tap = c8 / p.cpt;
+    cc = c8 - tap * p.cpt;
+    ky = tap / p.kw;
+    kx = tap - ky * p.kw;
   }
 
   f32x4 ra[AR], rbv[BR];
+  uint32_t okmask = 0;  // bit j: A row j valid; bit 16+j: B row j valid (for the chunk held in ra / rbv)
 
   auto load_tiles = [&](int kt) {
+    okmask = 0;
     const bool kvalid = ky < p.kh;
     const int oy = ky * p.dh, ox = kx * p.dw;
+    const int tapoff = (oy * p.Ws + ox) * p.Cs;
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      bool ok = kvalid && a_nbase[j] >= 0;
-      int sy, sx;
-      if (p.mode == 0) {
-        sy = a_y0[j] + oy;
-        sx = a_x0[j] + ox;
+      bool ok = kvalid;
+      int idx;
+      if (MODE == 0) {
+        const int sy = a_y0[j] + oy, sx = a_x0[j] + ox;
+        ok = ok && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
+        idx = a_base[j] + tapoff + cc * 4;
+      } else if (MODE == 1) {
+        const int sy = a_y0[j] - oy, sx = a_x0[j] - ox;
+        ok = ok && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
+        idx = a_base[j] - tapoff + cc * 4;
       } else {
         const int ty = a_y0[j] - oy, tx = a_x0[j] - ox;
+        int sy, sx;
         ok = ok && ty >= 0 && tx >= 0;
-        if (p.sh == 1) sy = ty;
-        else if (p.sh == 2) { ok = ok && !(ty & 1); sy = ty >> 1; }
+        if (p.sh == 2) { ok = ok && !(ty & 1); sy = ty >> 1; }
         else { sy = ty / p.sh; ok = ok && (sy * p.sh == ty); }
-        if (p.sw == 1) sx = tx;
-        else if (p.sw == 2) { ok = ok && !(tx & 1); sx = tx >> 1; }
+        if (p.sw == 2) { ok = ok && !(tx & 1); sx = tx >> 1; }
         else { sx = tx / p.sw; ok = ok && (sx * p.sw == tx); }
+        ok = ok && sy < p.Hs && sx < p.Ws;
+        idx = ((a_base[j] + sy) * p.Ws + sx) * p.Cs + cc * 4;
       }
-      ok = ok && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
-      if (ok) {
-        const size_t off = ((size_t)(a_nbase[j] + sy) * p.Ws + sx) * p.Cs + cc * 4;
-        v = *reinterpret_cast<const f32x4*>(p.src + off);
-      }
-      ra[j] = v;
+      // unconditional load from a clamped (valid) offset; the zero-fill select is applied when the
+      // chunk is written to LDS, AFTER the MFMA block, so the prefetch stays in flight under it
+      okmask |= ok ? (1u << j) : 0u;
+      ra[j] = *reinterpret_cast<const f32x4*>(p.src + (ok ? idx : 0));
     }
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (kvalid && b_ptr[j]) v = *reinterpret_cast<const f32x4*>(b_ptr[j] + (size_t)kt * BK);
-      rbv[j] = v;
+      const bool ok = kvalid && b_off[j] >= 0;
+      okmask |= ok ? (1u << (16 + j)) : 0u;
+      rbv[j] = *reinterpret_cast<const f32x4*>(p.wgt + (ok ? b_off[j] + kt * BK : 0));
     }
-    // advance the cursor by 8 chunks
-    cc += 8;
-    while (cc >= p.cpt) {
-      cc -= p.cpt;
-      if (++kx == p.kw) { kx = 0; ++ky; }
+    // advance the cursor by 8 chunks (wave-uniform branch on the channel count)
+    if (p.cpt >= 8) {
+      cc += 8;
+      const bool wrap = cc >= p.cpt;
+      cc = wrap ? cc - p.cpt : cc;
+      kx += wrap ? 1 : 0;
+      const bool wrapx = kx == p.kw;
+      kx = wrapx ? 0 : kx;
+      ky += wrapx ? 1 : 0;
+    } else {  // narrow inputs (4-band stem): a step spans several taps
+      const int q = (kt + 1) * 8 + c8;
+      const int tap = q / p.cpt;
+      cc = q - tap * p.cpt;
+      ky = tap / p.kw;
+      kx = tap - ky * p.kw;
     }
   };
 
@@ -156,13 +183,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IGemmArgs p) {
     for (int j = 0; j < AR; ++j) {
       const int row = rb + 32 * j;
       const int pc = c8 ^ ((row >> 1) & 7);
-      *reinterpret_cast<f32x4*>(Ab + row * BK + pc * 4) = ra[j];
+      const bool ok = (okmask >> j) & 1u;
+      f32x4 v = ra[j];
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      *reinterpret_cast<f32x4*>(Ab + row * BK + pc * 4) = v;
     }
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
       const int row = rb + 32 * j;
       const int pc = c8 ^ ((row >> 1) & 7);
-      *reinterpret_cast<f32x4*>(Bb + row * BK + pc * 4) = rbv[j];
+      const bool ok = (okmask >> (16 + j)) & 1u;
+      f32x4 v = rbv[j];
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      *reinterpret_cast<f32x4*>(Bb + row * BK + pc * 4) = v;
     }
   };
 
@@ -185,7 +218,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IGemmArgs p) {
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
+    const int buf = (NBUF == 2) ? (kt & 1) : 0;
     if (kt + 1 < nk) load_tiles(kt + 1);
 
     const float* Ab = As + buf * BM * BK + (wm * WM + li) * BK;
@@ -214,7 +247,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IGemmArgs p) {
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
     }
 
-    if (kt + 1 < nk) store_tiles(buf ^ 1);
+    if (NBUF == 1) __syncthreads();  // single buffer: everyone is done reading before it is overwritten
+    if (kt + 1 < nk) store_tiles((NBUF == 2) ? (buf ^ 1) : 0);
     __syncthreads();
   }
 
@@ -250,15 +284,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IGemmArgs p) {
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int NBUF = 2>
 static int launch_cfg(IGemmArgs& a, hipStream_t stream) {
   a.tiles_m = ceil_div(a.M, BM);
   a.tiles_n = ceil_div(a.Cd, BN);
-  const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
+  const size_t lds = (size_t)NBUF * (BM + BN) * BK * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MODE, NBUF>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const long long nwg = (long long)a.tiles_m * a.tiles_n;
@@ -266,24 +300,44 @@ static int launch_cfg(IGemmArgs& a, hipStream_t stream) {
     set_error("conv_igemm: bad grid %lld", nwg);
     return EVK_E_INVALID;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N>), dim3((unsigned)nwg), dim3(256), lds,
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MODE, NBUF>), dim3((unsigned)nwg), dim3(256), lds,
                      stream, a);
   return check_launch("conv_igemm");
 }
 
-int launch_igemm(IGemmArgs& a, hipStream_t stream) {
+template <int MODE>
+static int launch_mode(IGemmArgs& a, hipStream_t stream) {
   // Tile choice: N tile 64 for narrow outputs, else 128; M tile as large as keeps >= 2 workgroups
   // per CU (256 CUs) in flight.
   const int bn = (a.Cd <= 64) ? 64 : 128;
   const long long tn = ceil_div(a.Cd, bn);
   auto tiles = [&](int bm) { return (long long)ceil_div(a.M, bm) * tn; };
   if (bn == 64) {
-    if (tiles(256) >= 512) return launch_cfg<256, 64, 4, 1>(a, stream);
-    if (tiles(128) >= 512) return launch_cfg<128, 64, 2, 2>(a, stream);
-    return launch_cfg<64, 64, 2, 2>(a, stream);
+    if (tiles(256) >= 512) return launch_cfg<256, 64, 4, 1, MODE>(a, stream);
+    if (tiles(128) >= 512) return launch_cfg<128, 64, 2, 2, MODE>(a, stream);
+    return launch_cfg<64, 64, 2, 2, MODE>(a, stream);
   }
-  if (tiles(128) >= 512) return launch_cfg<128, 128, 2, 2>(a, stream);
-  return launch_cfg<64, 128, 2, 2>(a, stream);
+  static const int exp_cfg = getenv("EVK_IGEMM_CFG") ? atoi(getenv("EVK_IGEMM_CFG")) : 0;
+  if (tiles(128) >= 512) {
+    if (exp_cfg == 1) return launch_cfg<128, 128, 2, 2, MODE, 1>(a, stream);
+    if (exp_cfg == 2) return launch_cfg<128, 64, 2, 2, MODE, 2>(a, stream);
+    if (exp_cfg == 3) return launch_cfg<256, 64, 4, 1, MODE, 2>(a, stream);
+    if (exp_cfg == 4) return launch_cfg<256, 64, 4, 1, MODE, 1>(a, stream);
+    return launch_cfg<128, 128, 2, 2, MODE>(a, stream);
+  }
+  return launch_cfg<64, 128, 2, 2, MODE>(a, stream);
+}
+
+int launch_igemm(IGemmArgs& a, int mode, hipStream_t stream) {
+  const long long src_elems = (long long)a.N * a.Hs * a.Ws * a.Cs;
+  const long long wgt_elems = (long long)a.Cd * a.Ktot;
+  if (src_elems >= 0x7fffffffLL || wgt_elems >= 0x7fffffffLL) {
+    set_error("conv_igemm: tensors of 2^31 or more elements are not supported (%lld / %lld)", src_elems, wgt_elems);
+    return EVK_E_UNSUPPORTED;
+  }
+  if (mode == 0) return launch_mode<0>(a, stream);
+  if (mode == 1) return launch_mode<1>(a, stream);
+  return launch_mode<2>(a, stream);
 }
 
 static int check_desc(const evk_conv_desc* d) {
@@ -319,12 +373,11 @@ extern "C" int evk_conv2d_fwd(const evk_conv_desc* d, const float* x, const floa
   a.Hm = d->Ho; a.Wm = d->Wo; a.Cd = d->Cout;
   a.kh = d->kh; a.kw = d->kw; a.cpt = d->Cin / 4;
   a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
-  a.mode = 0;
   a.M = d->N * d->Ho * d->Wo;
   a.Ktot = d->kh * d->kw * d->Cin;
   a.Hd = d->Ho; a.Wd = d->Wo; a.dsh = 1; a.dsw = 1; a.dense_dst = 1;
   a.relu = (flags & EVK_CONV_RELU) ? 1 : 0;
-  return launch_igemm(a, (hipStream_t)stream);
+  return launch_igemm(a, 0, (hipStream_t)stream);
 }
 
 extern "C" int evk_conv2d_dgrad(const evk_conv_desc* d, const float* dy, const float* wt, float* dx,
@@ -349,21 +402,19 @@ extern "C" int evk_conv2d_dgrad(const evk_conv_desc* d, const float* dy, const f
     if (e != hipSuccess) { set_error("conv2d_dgrad memset: %s", hipGetErrorString(e)); return EVK_E_LAUNCH; }
     a.Hm = d->Ho; a.Wm = d->Wo;
     a.sh = 1; a.sw = 1; a.ph = 0; a.pw = 0; a.dh = 1; a.dw = 1;
-    a.mode = 0;
     a.M = d->N * d->Ho * d->Wo;
     a.dsh = d->stride_h; a.dsw = d->stride_w; a.dense_dst = 0;
-    return launch_igemm(a, st);
+    return launch_igemm(a, 0, st);
   }
   a.Hm = d->H; a.Wm = d->W;
   a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
-  a.mode = 1;
   a.M = d->N * d->H * d->W;
   a.dsh = 1; a.dsw = 1; a.dense_dst = 1;
-  return launch_igemm(a, st);
+  return launch_igemm(a, (d->stride_h == 1 && d->stride_w == 1) ? 1 : 2, st);
 }
 
 // wt[ci][ky][kx][co] = w[co][ky][kx][ci]   (taps are NOT flipped: the transposed gather of
-// conv_igemm mode 1 walks ty = py + pad - ky*dil, which already pairs tap ky with its source row).
+// conv_igemm walks ty = py + pad - ky*dil, which already pairs tap ky with its source row).
 __global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout,
                                          int taps, int Cin) {
   const size_t total = (size_t)Cout * taps * Cin;

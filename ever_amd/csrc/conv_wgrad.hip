@@ -12,6 +12,7 @@
 // split across workgroups (grid.z); partial tiles go to the caller's workspace and are summed in a
 // fixed order by a second kernel => bitwise reproducible, no atomics.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace evk {
 
@@ -38,6 +39,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGradArgs p) {
   constexpr int APASS = BKP * ACH / 256, BPASS = BKP * BCH / 256;
   constexpr int AROWS = 256 / ACH, BROWS = 256 / BCH;  // rows covered per pass
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(MB <= 2 && NB <= 2, "fragment vectors are float or float2");
+  struct alignas(4 * MB) FragA { float v[MB]; };
+  struct alignas(4 * NB) FragB { float v[NB]; };
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                   // [2][32][BM]
@@ -68,43 +72,52 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGradArgs p) {
   }
 
   f32x4 ra[APASS], rb[BPASS];
+  uint32_t okmask = 0;  // bit j: A pass j valid; bit 16+j: B pass j valid
 
+  // Branch-free gathers: every load is issued from a clamped (valid) 32-bit element offset; the
+  // zero-fill select is applied when the chunk is written to LDS (after the MFMA block), so the
+  // prefetch stays in flight under the MFMAs.
   auto load_tiles = [&](int pix0) {
+    okmask = 0;
 #pragma unroll
     for (int j = 0; j < APASS; ++j) {
       const int m = pix0 + a_r + j * AROWS;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (a_cvalid && m < pend) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.Cout + co0 + a_c * 4);
-      ra[j] = v;
+      const bool ok = a_cvalid && m < pend;
+      okmask |= ok ? (1u << j) : 0u;
+      ra[j] = *reinterpret_cast<const f32x4*>(p.dy + (ok ? m * p.Cout + co0 + a_c * 4 : 0));
     }
 #pragma unroll
     for (int j = 0; j < BPASS; ++j) {
       const int m = pix0 + b_r + j * BROWS;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (b_cvalid && m < pend) {
-        const uint32_t n = fdiv((uint32_t)m, p.fd_hw);
-        const uint32_t rem = (uint32_t)m - n * p.fd_hw.div;
-        const uint32_t oy = fdiv(rem, p.fd_w);
-        const uint32_t ox = rem - oy * p.fd_w.div;
-        const int sy = (int)oy * p.sh + b_dy;
-        const int sx = (int)ox * p.sw + b_dx;
-        if ((unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W) {
-          const size_t off = (((size_t)n * p.H + sy) * p.W + sx) * p.Cin + b_cc;
-          v = *reinterpret_cast<const f32x4*>(p.x + off);
-        }
-      }
-      rb[j] = v;
+      const uint32_t mm = (uint32_t)min(m, p.M - 1);
+      const uint32_t n = fdiv(mm, p.fd_hw);
+      const uint32_t rem = mm - n * p.fd_hw.div;
+      const uint32_t oy = fdiv(rem, p.fd_w);
+      const uint32_t ox = rem - oy * p.fd_w.div;
+      const int sy = (int)oy * p.sh + b_dy;
+      const int sx = (int)ox * p.sw + b_dx;
+      const bool ok = b_cvalid && m < pend && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W;
+      okmask |= ok ? (1u << (16 + j)) : 0u;
+      rb[j] = *reinterpret_cast<const f32x4*>(p.x + (ok ? (((int)n * p.H + sy) * p.W + sx) * p.Cin + b_cc : 0));
     }
   };
   auto store_tiles = [&](int buf) {
     float* Ab = As + buf * BKP * BM;
     float* Bb = Bs + buf * BKP * BN;
 #pragma unroll
-    for (int j = 0; j < APASS; ++j)
-      *reinterpret_cast<f32x4*>(Ab + (a_r + j * AROWS) * BM + a_c * 4) = ra[j];
+    for (int j = 0; j < APASS; ++j) {
+      const bool ok = (okmask >> j) & 1u;
+      f32x4 v = ra[j];
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      *reinterpret_cast<f32x4*>(Ab + (a_r + j * AROWS) * BM + a_c * 4) = v;
+    }
 #pragma unroll
-    for (int j = 0; j < BPASS; ++j)
-      *reinterpret_cast<f32x4*>(Bb + (b_r + j * BROWS) * BN + b_c * 4) = rb[j];
+    for (int j = 0; j < BPASS; ++j) {
+      const bool ok = (okmask >> (16 + j)) & 1u;
+      f32x4 v = rb[j];
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      *reinterpret_cast<f32x4*>(Bb + (b_r + j * BROWS) * BN + b_c * 4) = v;
+    }
   };
 
   const int wave = tid >> 6, lane = tid & 63;
@@ -129,20 +142,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGradArgs p) {
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) load_tiles(pbeg + (kt + 1) * BKP);
-    const float* Ab = As + buf * BKP * BM + wm * WM + li;
-    const float* Bb = Bs + buf * BKP * BN + wn * WN + li;
+    // Fragment reads: the wave's 64 (or 32) tile rows are dealt to (MFMA block a, lane row i) as
+    // row = MB*i + a, so ONE ds_read_b64 per operand feeds both blocks of a k-step, and the reads of
+    // step s+1 are issued before the MFMAs of step s (register double buffer) to hide LDS latency.
+    const float* Ab = As + buf * BKP * BM + wm * WM + MB * li;
+    const float* Bb = Bs + buf * BKP * BN + wn * WN + NB * li;
+    FragA fa_cur = *reinterpret_cast<const FragA*>(Ab + lh * BM);
+    FragB fb_cur = *reinterpret_cast<const FragB*>(Bb + lh * BN);
 #pragma unroll
     for (int s = 0; s < BKP / 2; ++s) {
-      float fa[MB], fb[NB];
-#pragma unroll
-      for (int a = 0; a < MB; ++a) fa[a] = Ab[(2 * s + lh) * BM + a * 32];
-#pragma unroll
-      for (int b = 0; b < NB; ++b) fb[b] = Bb[(2 * s + lh) * BN + b * 32];
+      FragA fa_nxt = fa_cur;
+      FragB fb_nxt = fb_cur;
+      if (s + 1 < BKP / 2) {
+        fa_nxt = *reinterpret_cast<const FragA*>(Ab + (2 * s + 2 + lh) * BM);
+        fb_nxt = *reinterpret_cast<const FragB*>(Bb + (2 * s + 2 + lh) * BN);
+      }
 #pragma unroll
       for (int a = 0; a < MB; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_cur.v[a], fb_cur.v[b], acc[a][b], 0, 0, 0);
+      fa_cur = fa_nxt;
+      fb_cur = fb_nxt;
+      // pin the issue order: this step's (prefetch) LDS reads first, then its MFMAs -> the reads'
+      // latency is covered by MB*NB MFMAs (>= 256 cycles) instead of being waited for at once
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, MB * NB, 0);
     }
     if (kt + 1 < nk) store_tiles(buf ^ 1);
     __syncthreads();
@@ -153,11 +178,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGradArgs p) {
   for (int a = 0; a < MB; ++a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = co0 + wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int row = co0 + wm * WM + MB * ((r & 3) + 8 * (r >> 2) + 4 * lh) + a;
       if (row >= p.Cout) continue;
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        const int col = k0 + wn * WN + b * 32 + li;
+        const int col = k0 + wn * WN + NB * li + b;
         if (col < p.Ktot) out[(size_t)row * p.Ktot + col] = acc[a][b][r];
       }
     }
@@ -218,9 +243,16 @@ static WGradPlan plan_wgrad(const evk_conv_desc* d) {
   pl.tiles_co = ceil_div(d->Cout, pl.bm);
   pl.tiles_k = ceil_div(Ktot, pl.bn);
   const int tiles = pl.tiles_co * pl.tiles_k;
-  int want = ceil_div(1024, tiles);
-  int maxsplit = ceil_div(M, 128);  // at least 128 pixels per split
-  int sk = want < 1 ? 1 : want;
+  // Split the pixel reduction so that the grid fills WHOLE rounds of the machine: slots = 256 CUs x
+  // resident workgroups per CU (LDS-limited: 64 KB tiles -> 2, 48 KB -> 3, 32 KB -> 4).  A grid of
+  // 2.04 rounds costs 3 (measured: 1044 workgroups on 512 slots ran at 63 % MFMA utilisation).
+  static const int rounds = getenv("EVK_WG_ROUNDS") ? atoi(getenv("EVK_WG_ROUNDS")) : 1;
+  static const int min_chunk = getenv("EVK_WG_MINCHUNK") ? atoi(getenv("EVK_WG_MINCHUNK")) : 256;
+  const int lds_kb = 2 * BKP * (pl.bm + pl.bn) * 4 / 1024;
+  const int per_cu = lds_kb >= 64 ? 2 : (lds_kb >= 48 ? 3 : 4);
+  const int slots = 256 * per_cu;
+  int maxsplit = ceil_div(M, min_chunk);  // at least min_chunk pixels per split
+  int sk = (rounds * slots) / tiles;      // floor: never spill into an extra, nearly empty round
   if (sk > maxsplit) sk = maxsplit;
   if (sk < 1) sk = 1;
   int chunk = ceil_div(M, sk);
@@ -263,6 +295,9 @@ extern "C" int evk_conv2d_wgrad(const evk_conv_desc* d, const float* x, const fl
   EVK_REQUIRE(workspace_bytes >= evk_conv2d_wgrad_workspace_bytes(d) && (workspace || workspace_bytes == 0),
               EVK_E_WORKSPACE, "conv2d_wgrad: workspace %zu < %zu", workspace_bytes,
               evk_conv2d_wgrad_workspace_bytes(d));
+  EVK_REQUIRE((long long)d->N * d->H * d->W * d->Cin < 0x7fffffffLL &&
+                  (long long)d->N * d->Ho * d->Wo * d->Cout < 0x7fffffffLL,
+              EVK_E_UNSUPPORTED, "conv2d_wgrad: tensors of 2^31 or more elements are not supported");
   hipStream_t st = (hipStream_t)stream;
   const WGradPlan pl = plan_wgrad(d);
   WGradArgs a{};
