@@ -168,9 +168,13 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
                                                              const float* __restrict__ y,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
                                                              float* __restrict__ d_residual,
                                                              float* __restrict__ partial, int64_t rows, int C,
                                                              int64_t rows_per_blk, int tpc, int rl, int relu) {
+  // relu: 0 none, 1 mask from the saved output y, 2 mask recomputed from x (no residual: the
+  // forward's pre-activation is x*sc+sh with the same sc/sh arithmetic as bn_stats_final_kernel)
   __shared__ f32x4 red[2][256];
   const int c4 = C >> 2;
   const int tc = threadIdx.x % tpc, tr = threadIdx.x / tpc;
@@ -179,18 +183,27 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   for (int cb = tc; cb < c4; cb += tpc) {
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + cb * 4);
     const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + cb * 4);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (relu == 2) {
+      const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 g4 = gamma ? *reinterpret_cast<const f32x4*>(gamma + cb * 4) : one;
+      const f32x4 b4 = beta ? *reinterpret_cast<const f32x4*>(beta + cb * 4) : zero;
+      sc = g4 * is;
+      sh = b4 - mu * sc;
+    }
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
     if (tr < rl)
       for (int64_t r = r0 + tr; r < r1; r += rl) {
         const size_t off = (size_t)r * C + cb * 4;
         f32x4 g = *reinterpret_cast<const f32x4*>(dy + off);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
         if (relu) {
-          const f32x4 yy = *reinterpret_cast<const f32x4*>(y + off);
+          const f32x4 yy = (relu == 1) ? *reinterpret_cast<const f32x4*>(y + off) : xv * sc + sh;
           g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
           g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
         }
         if (d_residual) *reinterpret_cast<f32x4*>(d_residual + off) = g;
-        const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + off) - mu) * is;
+        const f32x4 xh = (xv - mu) * is;
         s += g;
         q += g * xh;
       }
@@ -231,15 +244,23 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
-                                                           const float* __restrict__ coef, float* __restrict__ dx,
+                                                           const float* __restrict__ coef,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ dx,
                                                            size_t n4, int C, int relu) {
-  extern __shared__ __attribute__((aligned(16))) float ss[];  // [5][C]: coef0..2, mean, invstd
+  extern __shared__ __attribute__((aligned(16))) float ss[];  // [7][C]: coef0..2, mean, invstd, sc, sh
   for (int i = threadIdx.x; i < 3 * C; i += 256) ss[i] = coef[i];
   for (int i = threadIdx.x; i < C; i += 256) {
-    ss[3 * C + i] = mean[i];
-    ss[4 * C + i] = invstd[i];
+    const float m = mean[i], is_ = invstd[i];
+    ss[3 * C + i] = m;
+    ss[4 * C + i] = is_;
+    const float sc_ = (gamma ? gamma[i] : 1.f) * is_;
+    ss[5 * C + i] = sc_;
+    ss[6 * C + i] = (beta ? beta[i] : 0.f) - m * sc_;
   }
   __syncthreads();
+  const f32x4* sc4 = reinterpret_cast<const f32x4*>(ss + 5 * C);
+  const f32x4* sh4 = reinterpret_cast<const f32x4*>(ss + 6 * C);
   const int c4 = C >> 2;
   const f32x4* k0 = reinterpret_cast<const f32x4*>(ss);
   const f32x4* k1 = reinterpret_cast<const f32x4*>(ss + C);
@@ -253,12 +274,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     const int cb = (int)(i % c4);
     f32x4 g = dy4[i];
+    const f32x4 xv = x4[i];
     if (relu) {
-      const f32x4 yy = y4[i];
+      const f32x4 yy = (relu == 1) ? y4[i] : xv * sc4[cb] + sh4[cb];
       g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
       g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
     }
-    const f32x4 xh = (x4[i] - mu[cb]) * is[cb];
+    const f32x4 xh = (xv - mu[cb]) * is[cb];
     dx4[i] = k0[cb] * (g - k1[cb] - xh * k2[cb]);
   }
 }
@@ -327,13 +349,15 @@ extern "C" int evk_bn_fwd_eval(const float* x, const float* residual, const floa
   return check_launch("bn_apply");
 }
 
-extern "C" int evk_bn_bwd(const float* dy, const float* x, const float* y, const float* gamma,
+extern "C" int evk_bn_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
                           const float* save_mean, const float* save_invstd, float* dx, float* d_residual,
                           float* dgamma, float* dbeta, int64_t rows, int32_t C, uint32_t flags, int32_t train,
                           void* workspace, size_t workspace_bytes, void* stream) {
   EVK_REQUIRE(dy && x && save_mean && save_invstd && dx, EVK_E_INVALID, "bn_bwd: null pointer");
-  const int relu = (flags & EVK_BN_RELU) ? 1 : 0;
-  EVK_REQUIRE(!relu || y, EVK_E_INVALID, "bn_bwd: ReLU mask needs the forward output y");
+  // ReLU mask: from the saved output y when given (needed with a residual), else recomputed from x
+  const int relu = (flags & EVK_BN_RELU) ? (y ? 1 : 2) : 0;
+  EVK_REQUIRE(relu != 2 || !d_residual, EVK_E_INVALID,
+              "bn_bwd: a residual branch needs the forward output y for the ReLU mask");
   EVK_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 2048, EVK_E_UNSUPPORTED, "bn_bwd: rows=%lld C=%d",
               (long long)rows, C);
   EVK_REQUIRE(workspace && workspace_bytes >= evk_bn_workspace_bytes(rows, C), EVK_E_WORKSPACE,
@@ -343,7 +367,7 @@ extern "C" int evk_bn_bwd(const float* dy, const float* x, const float* y, const
   float* partial = (float*)workspace;
   float* coef = partial + (size_t)kMaxStatBlocks * 2 * C;
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(pl.nblk), dim3(256), 0, st, dy, x, y, save_mean, save_invstd,
-                     d_residual, partial, rows, C, pl.rows_per_blk, pl.tpc, pl.rl, relu);
+                     gamma, beta, d_residual, partial, rows, C, pl.rows_per_blk, pl.tpc, pl.rl, relu);
   int rc = check_launch("bn_bwd_partial");
   if (rc) return rc;
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, partial, pl.nblk, C,
@@ -354,7 +378,7 @@ extern "C" int evk_bn_bwd(const float* dy, const float* x, const float* y, const
   // when d_residual holds g already, stage 3 can read it instead of re-masking dy
   const float* gsrc = d_residual ? d_residual : dy;
   const int relu3 = d_residual ? 0 : relu;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(256), 5 * C * sizeof(float), st, gsrc, x, y,
-                     save_mean, save_invstd, coef, dx, n4, C, relu3);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(256), 7 * C * sizeof(float), st, gsrc, x, y,
+                     save_mean, save_invstd, coef, gamma, beta, dx, n4, C, relu3);
   return check_launch("bn_bwd_apply");
 }

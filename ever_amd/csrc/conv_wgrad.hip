@@ -223,12 +223,21 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     __syncthreads();
   }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// 32 channels x 8 partial-lanes per workgroup: coalesced 128-byte rows, fp64, LDS fold
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                           int nblk, int C) {
+  __shared__ double red[8][32];
+  const int tc = threadIdx.x & 31, tl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + tc;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * C + c];
-  out[c] = (float)s;
+  if (c < C)
+    for (int b = tl; b < nblk; b += 8) s += (double)partial[(size_t)b * C + c];
+  red[tl][tc] = s;
+  __syncthreads();
+  if (tl == 0 && c < C) {
+    for (int k = 1; k < 8; ++k) s += red[k][tc];
+    out[c] = (float)s;
+  }
 }
 
 struct WGradPlan {
@@ -333,7 +342,7 @@ extern "C" int evk_conv2d_wgrad(const evk_conv_desc* d, const float* x, const fl
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, st, dy, (float*)workspace, rows, d->Cout, rpb);
     rc = check_launch("colsum_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((d->Cout + 255) / 256), dim3(256), 0, st, (const float*)workspace,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((d->Cout + 31) / 32), dim3(256), 0, st, (const float*)workspace,
                        dbias, nblk, d->Cout);
     rc = check_launch("colsum_final");
   }

@@ -275,14 +275,15 @@ class _BatchNormActFn(Function):
         ctx.training = training
         ctx.relu = relu
         ctx.has_res = residual is not None
-        ctx.save_for_backward(x, y if relu else None, weight, save_mean, save_invstd)
+        # the ReLU mask is recomputed from x in backward unless a residual was added (then y is needed)
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, weight, bias, save_mean, save_invstd)
         ctx.mark_non_differentiable(*[t for t in (running_mean, running_var) if t is not None])
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x, y, weight, save_mean, save_invstd = ctx.saved_tensors
+        x, y, weight, bias, save_mean, save_invstd = ctx.saved_tensors
         n, c, h, w = x.shape
         rows = n * h * w
         dev = x.device
@@ -297,7 +298,7 @@ class _BatchNormActFn(Function):
         has_affine = weight is not None
         dgamma = torch.empty((c,), device=dev, dtype=torch.float32) if has_affine else None
         dbeta = torch.empty((c,), device=dev, dtype=torch.float32) if has_affine else None
-        _C.call('evk_bn_bwd', dy.data_ptr(), x.data_ptr(), _ptr(y), _ptr(weight), save_mean.data_ptr(),
+        _C.call('evk_bn_bwd', dy.data_ptr(), x.data_ptr(), _ptr(y), _ptr(weight), _ptr(bias), save_mean.data_ptr(),
                 save_invstd.data_ptr(), dx.data_ptr(), _ptr(dres), _ptr(dgamma), _ptr(dbeta), rows, c,
                 1 if ctx.relu else 0, 1 if ctx.training else 0, ws.data_ptr(), ws_bytes, st)
         if ctx.has_res and not need_res:

@@ -46,11 +46,28 @@ class BatchNorm2d(nn.BatchNorm2d):
             raise NotImplementedError('ever_amd BatchNorm2d: cumulative moving average (momentum=None) unsupported')
         training = self.training or (self.running_mean is None)
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
+            # counted on the host and folded into the buffer when it is read (state_dict / checkpoint):
+            # 68 one-element device increments per step would be 68 extra launches on the stream
+            self._nbt_pending = getattr(self, '_nbt_pending', 0) + 1
         rm = self.running_mean if (not self.training or self.track_running_stats) else None
         rv = self.running_var if (not self.training or self.track_running_stats) else None
         return HF.batch_norm_act(x, self.weight, self.bias, rm, rv, training, self.momentum, self.eps,
                                  residual=residual, relu=relu)
+
+
+    def flush_num_batches_tracked(self):
+        pending = getattr(self, '_nbt_pending', 0)
+        if pending and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(pending)
+        self._nbt_pending = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self.flush_num_batches_tracked()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._nbt_pending = 0
+        super()._load_from_state_dict(*args, **kwargs)
 
 
 class ReLU(nn.ReLU):

@@ -104,10 +104,11 @@ int evk_bn_fwd_eval(const float* x, const float* residual, const float* gamma, c
                     float* save_mean /* may be NULL */, float* save_invstd /* may be NULL */,
                     int64_t rows, int32_t C, uint32_t flags, void* workspace, size_t workspace_bytes,
                     void* stream);
-/* Backward of the training forward.  y is the forward output (ReLU mask; may be NULL when
- * !EVK_BN_RELU).  d_residual (may be NULL) receives the masked upstream gradient.
- * `train`=0 differentiates the eval forward (statistics are constants). */
-int evk_bn_bwd(const float* dy, const float* x, const float* y, const float* gamma,
+/* Backward of the training forward.  ReLU mask: taken from the forward output y when y != NULL
+ * (required when the forward had a residual), else recomputed from x, gamma, beta and the saved
+ * statistics (one HBM read less per pass).  d_residual (may be NULL) receives the masked upstream
+ * gradient.  `train`=0 differentiates the eval forward (statistics are constants). */
+int evk_bn_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
                const float* save_mean, const float* save_invstd, float* dx, float* d_residual,
                float* dgamma, float* dbeta, int64_t rows, int32_t C, uint32_t flags, int32_t train,
                void* workspace, size_t workspace_bytes, void* stream);
