@@ -1,6 +1,6 @@
 // Implicit-GEMM convolution (forward and data-gradient) for gfx950 on v_mfma_f32_32x32x2_f32.
 //
-//   dst[m][co] = sum_k  gather(src)[m][k] * wgt[co][k]      m = (n, py, px),  k = (ky, kx, ci)
+//   dst[m][co] = sum_k  gather(src)[m][k] * wgt[co][k]      m = (n, gy, gx),  k = (jy, jx, ci)
 //
 // Replaces aten::convolution / aten::convolution_backward(input) issued by nn.Conv2d at
 // reference ever/module/_resnets.py:21-29,149 ; fpn.py:23-37,72-73,165,179 ; fs_relation.py:23-53.
@@ -15,12 +15,19 @@
 // one ds_read_b128 per lane supplies k = 8g+4h .. 8g+4h+3, i.e. four consecutive MFMAs.
 // C/D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 //
-// The gather is branch-free: every 16-byte load is issued unconditionally from a clamped (always
-// valid) address and zeroed by a select, so hipcc emits the step's 8 global_load_dwordx4 back to
-// back instead of one exec-masked branch + wait per load; all indices are 32-bit element offsets
-// (tensors are < 2^31 elements, checked on the host).
+// ONE gather form serves every use: source pixel of GEMM row (n, gy, gx) and tap (jy, jx) is
+//     sy = gy*ash + oy0 + jy*oys ,   sx = gx*asw + ox0 + jx*oxs            (affine in the tap index)
+//   forward            ash = stride, oy0 = -pad,  oys = dilation
+//   dgrad, stride 1    ash = 1,      oy0 = +pad,  oys = -dilation          (taps are not flipped: the
+//                                                                           sign of oys does it)
+//   dgrad, stride s    one launch per residue class (cy, cx) of the input pixel mod s: only the taps
+//                      with (cy + pad - ky*dil) % s == 0 reach that class, they are ky = ky0 + j*kstep
+//                      and their source row is gy + (cy+pad-ky0*dil)/s - j*dil/g : again affine.  No
+//                      MFMA is spent on the (s*s-1)/(s*s) structurally-zero products.
+// The gather is branch-free: every 16-byte load is issued from a clamped (valid) 32-bit element
+// offset and the zero fill is applied when the chunk is written to LDS, after the MFMA block, so the
+// prefetch stays in flight under the MFMAs.
 #include "common.hpp"
-#include <stdlib.h>
 
 namespace evk {
 
@@ -29,14 +36,15 @@ struct IGemmArgs {
   const float* wgt;
   const float* bias;
   float* dst;
-  int N, Hs, Ws, Cs;   // gathered tensor
-  int Hm, Wm;          // GEMM-row grid
-  int Cd;              // GEMM N
-  int kh, kw, cpt;     // cpt = Cs/4 (16-byte chunks per tap)
-  int sh, sw, ph, pw, dh, dw;
+  int N, Hs, Ws, Cs;        // gathered tensor
+  int Hm, Wm;               // GEMM-row grid
+  int Cd;                   // GEMM N
+  int kh, kw, cpt;          // taps of this launch; cpt = Cs/4 (16-byte chunks per tap)
+  int ash, asw;             // row-grid -> source scale
+  int oy0, oys, ox0, oxs;   // tap -> source offset (affine)
   int M, Ktot;
-  int Hd, Wd, dsh, dsw;  // destination row mapping: (n, py*dsh, px*dsw) in an [N,Hd,Wd,Cd] tensor
-  int dense_dst;         // 1 => dst row offset = m*Cd
+  int Hd, Wd, dsh, dsw, doy, dox;  // destination pixel = (gy*dsh + doy, gx*dsw + dox) in [N,Hd,Wd,Cd]
+  int dense_dst;            // 1 => dst row offset = m*Cd
   int relu;
   int tiles_m, tiles_n;
 };
@@ -44,10 +52,7 @@ struct IGemmArgs {
 constexpr int BK = 32;
 constexpr int kInvalidRow = -(1 << 28);  // y0 of a row past M: every tap fails the bounds test
 
-// MODE 0: forward gather       sy = py*sh - ph + ky*dh
-// MODE 1: transposed, stride 1 sy = py + ph - ky*dh
-// MODE 2: transposed, strided  t = py + ph - ky*dh ; sy = t/sh iff t >= 0 and t % sh == 0
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int NBUF>
+template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const IGemmArgs p) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MB = WM / 32, NB = WN / 32;
@@ -55,8 +60,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IGemmArgs p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                     // [NBUF][BM][32]
-  float* Bs = smem + NBUF * BM * BK;    // [NBUF][BN][32]
+  float* As = smem;                  // [2][BM][32]
+  float* Bs = smem + 2 * BM * BK;    // [2][BN][32]
 
   // XCD-aware tile order: consecutive tile ids (sharing A rows / weights) stay on one XCD's L2.
   const int nwg = gridDim.x;
@@ -82,17 +87,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IGemmArgs p) {
       const int hw = p.Hm * p.Wm;
       const int n = m / hw;
       const int rem = m - n * hw;
-      const int py = rem / p.Wm;
-      const int px = rem - py * p.Wm;
-      if (MODE == 0) {
-        a_y0[j] = py * p.sh - p.ph;
-        a_x0[j] = px * p.sw - p.pw;
-      } else {
-        a_y0[j] = py + p.ph;
-        a_x0[j] = px + p.pw;
-      }
-      if (MODE == 2) a_base[j] = n * p.Hs;                                      // image row base
-      else a_base[j] = ((n * p.Hs + a_y0[j]) * p.Ws + a_x0[j]) * p.Cs;          // element offset of tap (0,0)
+      const int gy = rem / p.Wm;
+      const int gx = rem - gy * p.Wm;
+      a_y0[j] = gy * p.ash + p.oy0;
+      a_x0[j] = gx * p.asw + p.ox0;
+      a_base[j] = ((n * p.Hs + a_y0[j]) * p.Ws + a_x0[j]) * p.Cs;  // element offset of tap (0,0)
     } else {
       a_y0[j] = kInvalidRow;
       a_x0[j] = 0;
@@ -122,35 +121,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IGemmArgs p) {
   auto load_tiles = [&](int kt) {
     okmask = 0;
     const bool kvalid = ky < p.kh;
-    const int oy = ky * p.dh, ox = kx * p.dw;
-    const int tapoff = (oy * p.Ws + ox) * p.Cs;
+    const int oy = ky * p.oys, ox = kx * p.oxs;
+    const int tapoff = (oy * p.Ws + ox) * p.Cs + cc * 4;
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
-      bool ok = kvalid;
-      int idx;
-      if (MODE == 0) {
-        const int sy = a_y0[j] + oy, sx = a_x0[j] + ox;
-        ok = ok && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
-        idx = a_base[j] + tapoff + cc * 4;
-      } else if (MODE == 1) {
-        const int sy = a_y0[j] - oy, sx = a_x0[j] - ox;
-        ok = ok && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
-        idx = a_base[j] - tapoff + cc * 4;
-      } else {
-        const int ty = a_y0[j] - oy, tx = a_x0[j] - ox;
-        int sy, sx;
-        ok = ok && ty >= 0 && tx >= 0;
-        if (p.sh == 2) { ok = ok && !(ty & 1); sy = ty >> 1; }
-        else { sy = ty / p.sh; ok = ok && (sy * p.sh == ty); }
-        if (p.sw == 2) { ok = ok && !(tx & 1); sx = tx >> 1; }
-        else { sx = tx / p.sw; ok = ok && (sx * p.sw == tx); }
-        ok = ok && sy < p.Hs && sx < p.Ws;
-        idx = ((a_base[j] + sy) * p.Ws + sx) * p.Cs + cc * 4;
-      }
-      // unconditional load from a clamped (valid) offset; the zero-fill select is applied when the
-      // chunk is written to LDS, AFTER the MFMA block, so the prefetch stays in flight under it
+      const int sy = a_y0[j] + oy, sx = a_x0[j] + ox;
+      const bool ok = kvalid && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
       okmask |= ok ? (1u << j) : 0u;
-      ra[j] = *reinterpret_cast<const f32x4*>(p.src + (ok ? idx : 0));
+      ra[j] = *reinterpret_cast<const f32x4*>(p.src + (ok ? a_base[j] + tapoff : 0));
     }
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
@@ -218,7 +196,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IGemmArgs p) {
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = (NBUF == 2) ? (kt & 1) : 0;
+    const int buf = kt & 1;
     if (kt + 1 < nk) load_tiles(kt + 1);
 
     const float* Ab = As + buf * BM * BK + (wm * WM + li) * BK;
@@ -247,8 +225,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IGemmArgs p) {
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
     }
 
-    if (NBUF == 1) __syncthreads();  // single buffer: everyone is done reading before it is overwritten
-    if (kt + 1 < nk) store_tiles((NBUF == 2) ? (buf ^ 1) : 0);
+    if (kt + 1 < nk) store_tiles(buf ^ 1);
     __syncthreads();
   }
 
@@ -266,9 +243,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IGemmArgs p) {
         const int hw = p.Hm * p.Wm;
         const int n = row / hw;
         const int rem = row - n * hw;
-        const int py = rem / p.Wm;
-        const int px = rem - py * p.Wm;
-        roff = (((size_t)n * p.Hd + (size_t)py * p.dsh) * p.Wd + (size_t)px * p.dsw) * p.Cd;
+        const int gy = rem / p.Wm;
+        const int gx = rem - gy * p.Wm;
+        roff = (((size_t)n * p.Hd + (size_t)(gy * p.dsh + p.doy)) * p.Wd + (size_t)(gx * p.dsw + p.dox)) * p.Cd;
       }
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
@@ -284,14 +261,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IGemmArgs p) {
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int NBUF = 2>
+template <int BM, int BN, int WAVES_M, int WAVES_N>
 static int launch_cfg(IGemmArgs& a, hipStream_t stream) {
   a.tiles_m = ceil_div(a.M, BM);
   a.tiles_n = ceil_div(a.Cd, BN);
-  const size_t lds = (size_t)NBUF * (BM + BN) * BK * sizeof(float);
+  const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MODE, NBUF>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -300,44 +277,75 @@ static int launch_cfg(IGemmArgs& a, hipStream_t stream) {
     set_error("conv_igemm: bad grid %lld", nwg);
     return EVK_E_INVALID;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MODE, NBUF>), dim3((unsigned)nwg), dim3(256), lds,
-                     stream, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N>), dim3((unsigned)nwg), dim3(256), lds, stream, a);
   return check_launch("conv_igemm");
 }
 
-template <int MODE>
-static int launch_mode(IGemmArgs& a, hipStream_t stream) {
-  // Tile choice: N tile 64 for narrow outputs, else 128; M tile as large as keeps >= 2 workgroups
-  // per CU (256 CUs) in flight.
-  const int bn = (a.Cd <= 64) ? 64 : 128;
-  const long long tn = ceil_div(a.Cd, bn);
-  auto tiles = [&](int bm) { return (long long)ceil_div(a.M, bm) * tn; };
-  if (bn == 64) {
-    if (tiles(256) >= 512) return launch_cfg<256, 64, 4, 1, MODE>(a, stream);
-    if (tiles(128) >= 512) return launch_cfg<128, 64, 2, 2, MODE>(a, stream);
-    return launch_cfg<64, 64, 2, 2, MODE>(a, stream);
+// 1x1 convolution on a handful of rows (the FS-Relation scene MLP on 1x1 maps: M = batch, K up to
+// 2048; reference fs_relation.py:23-29).  An MFMA tile would be >90 % padding and latency bound on a
+// 64-step K loop in 2-4 workgroups; here one workgroup owns one output column and all rows, streams
+// its weight row once with 16-byte loads and reduces across the block.
+constexpr int kSmallM = 32;
+__global__ __launch_bounds__(256) void conv1x1_smallm_kernel(const float* __restrict__ src,
+                                                             const float* __restrict__ wgt,
+                                                             const float* __restrict__ bias, float* __restrict__ dst,
+                                                             int M, int K, int Cd, int relu) {
+  __shared__ float red[4][kSmallM];
+  const int n = blockIdx.x;
+  const int k4 = K >> 2;
+  float acc[kSmallM];
+#pragma unroll
+  for (int m = 0; m < kSmallM; ++m) acc[m] = 0.f;
+  for (int kc = threadIdx.x; kc < k4; kc += 256) {
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wgt + (size_t)n * K + kc * 4);
+#pragma unroll
+    for (int m = 0; m < kSmallM; ++m)
+      if (m < M) {
+        const f32x4 x4 = *reinterpret_cast<const f32x4*>(src + (size_t)m * K + kc * 4);
+        acc[m] += w4.x * x4.x + w4.y * x4.y + w4.z * x4.z + w4.w * x4.w;
+      }
   }
-  static const int exp_cfg = getenv("EVK_IGEMM_CFG") ? atoi(getenv("EVK_IGEMM_CFG")) : 0;
-  if (tiles(128) >= 512) {
-    if (exp_cfg == 1) return launch_cfg<128, 128, 2, 2, MODE, 1>(a, stream);
-    if (exp_cfg == 2) return launch_cfg<128, 64, 2, 2, MODE, 2>(a, stream);
-    if (exp_cfg == 3) return launch_cfg<256, 64, 4, 1, MODE, 2>(a, stream);
-    if (exp_cfg == 4) return launch_cfg<256, 64, 4, 1, MODE, 1>(a, stream);
-    return launch_cfg<128, 128, 2, 2, MODE>(a, stream);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int m = 0; m < kSmallM; ++m) {
+    const float s = wave_sum(acc[m]);
+    if (lane == 0) red[wave][m] = s;
   }
-  return launch_cfg<64, 128, 2, 2, MODE>(a, stream);
+  __syncthreads();
+  if (threadIdx.x < M) {
+    const int m = threadIdx.x;
+    float v = (red[0][m] + red[1][m]) + (red[2][m] + red[3][m]);
+    if (bias) v += bias[n];
+    if (relu) v = fmaxf(v, 0.f);
+    dst[(size_t)m * Cd + n] = v;
+  }
 }
 
-int launch_igemm(IGemmArgs& a, int mode, hipStream_t stream) {
+int launch_igemm(IGemmArgs& a, hipStream_t stream) {
   const long long src_elems = (long long)a.N * a.Hs * a.Ws * a.Cs;
   const long long wgt_elems = (long long)a.Cd * a.Ktot;
   if (src_elems >= 0x7fffffffLL || wgt_elems >= 0x7fffffffLL) {
     set_error("conv_igemm: tensors of 2^31 or more elements are not supported (%lld / %lld)", src_elems, wgt_elems);
     return EVK_E_UNSUPPORTED;
   }
-  if (mode == 0) return launch_mode<0>(a, stream);
-  if (mode == 1) return launch_mode<1>(a, stream);
-  return launch_mode<2>(a, stream);
+  if (a.kh == 1 && a.kw == 1 && a.M <= kSmallM && a.dense_dst && a.ash == 1 && a.asw == 1 && a.oy0 == 0 &&
+      a.ox0 == 0 && a.Hm == a.Hs && a.Wm == a.Ws) {
+    hipLaunchKernelGGL(conv1x1_smallm_kernel, dim3(a.Cd), dim3(256), 0, stream, a.src, a.wgt, a.bias, a.dst, a.M,
+                       a.Ktot, a.Cd, a.relu);
+    return check_launch("conv1x1_smallm");
+  }
+  // Tile choice: N tile 64 for narrow outputs, else 128; M tile as large as keeps >= 2 workgroups
+  // per CU (256 CUs) in flight.
+  const int bn = (a.Cd <= 64) ? 64 : 128;
+  const long long tn = ceil_div(a.Cd, bn);
+  auto tiles = [&](int bm) { return (long long)ceil_div(a.M, bm) * tn; };
+  if (bn == 64) {
+    if (tiles(256) >= 512) return launch_cfg<256, 64, 4, 1>(a, stream);
+    if (tiles(128) >= 512) return launch_cfg<128, 64, 2, 2>(a, stream);
+    return launch_cfg<64, 64, 2, 2>(a, stream);
+  }
+  if (tiles(128) >= 512) return launch_cfg<128, 128, 2, 2>(a, stream);
+  return launch_cfg<64, 128, 2, 2>(a, stream);
 }
 
 static int check_desc(const evk_conv_desc* d) {
@@ -358,6 +366,28 @@ static int check_desc(const evk_conv_desc* d) {
   return EVK_OK;
 }
 
+// One axis of the strided data gradient, for input pixels congruent to c (mod stride):
+// taps k = k0 + j*kstep (j < nt) reach them, from source row  g + o0 + j*ostep.
+struct AxisPlan {
+  int k0, kstep, nt, o0, ostep;
+};
+static int gcd_i(int a, int b) { return b == 0 ? a : gcd_i(b, a % b); }
+static AxisPlan plan_axis(int c, int pad, int dil, int stride, int ksize) {
+  AxisPlan ap{0, 1, 0, 0, 0};
+  const int g = gcd_i(dil, stride);
+  if ((c + pad) % g != 0) return ap;  // no tap reaches this class
+  ap.kstep = stride / g;
+  int k0 = -1;
+  for (int k = 0; k < ap.kstep && k < ksize; ++k)
+    if ((c + pad - k * dil) % stride == 0) { k0 = k; break; }
+  if (k0 < 0) return ap;
+  ap.k0 = k0;
+  ap.nt = (ksize - 1 - k0) / ap.kstep + 1;
+  ap.o0 = (c + pad - k0 * dil) / stride;  // exact; may be negative
+  ap.ostep = -(dil / g);
+  return ap;
+}
+
 }  // namespace evk
 
 using namespace evk;
@@ -372,12 +402,13 @@ extern "C" int evk_conv2d_fwd(const evk_conv_desc* d, const float* x, const floa
   a.N = d->N; a.Hs = d->H; a.Ws = d->W; a.Cs = d->Cin;
   a.Hm = d->Ho; a.Wm = d->Wo; a.Cd = d->Cout;
   a.kh = d->kh; a.kw = d->kw; a.cpt = d->Cin / 4;
-  a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
+  a.ash = d->stride_h; a.asw = d->stride_w;
+  a.oy0 = -d->pad_h; a.oys = d->dil_h; a.ox0 = -d->pad_w; a.oxs = d->dil_w;
   a.M = d->N * d->Ho * d->Wo;
   a.Ktot = d->kh * d->kw * d->Cin;
   a.Hd = d->Ho; a.Wd = d->Wo; a.dsh = 1; a.dsw = 1; a.dense_dst = 1;
   a.relu = (flags & EVK_CONV_RELU) ? 1 : 0;
-  return launch_igemm(a, 0, (hipStream_t)stream);
+  return launch_igemm(a, (hipStream_t)stream);
 }
 
 extern "C" int evk_conv2d_dgrad(const evk_conv_desc* d, const float* dy, const float* wt, float* dx,
@@ -387,52 +418,80 @@ extern "C" int evk_conv2d_dgrad(const evk_conv_desc* d, const float* dy, const f
   EVK_REQUIRE(dy && wt && dx, EVK_E_INVALID, "conv2d_dgrad: null pointer");
   EVK_REQUIRE(d->Cout % 4 == 0, EVK_E_UNSUPPORTED, "conv2d_dgrad: Cout=%d must be a multiple of 4", d->Cout);
   hipStream_t st = (hipStream_t)stream;
-  IGemmArgs a{};
-  a.src = dy; a.wgt = wt; a.bias = nullptr; a.dst = dx;
-  a.N = d->N; a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Cout;
-  a.Cd = d->Cin;
-  a.kh = d->kh; a.kw = d->kw; a.cpt = d->Cout / 4;
-  a.Ktot = d->kh * d->kw * d->Cout;
-  a.relu = 0;
-  a.Hd = d->H; a.Wd = d->W;
-  if (d->kh == 1 && d->kw == 1 && d->pad_h == 0 && d->pad_w == 0 && (d->stride_h > 1 || d->stride_w > 1)) {
-    // 1x1 strided: only pixels (oy*s, ox*s) receive gradient.  GEMM over the output grid and a
-    // scattered store into the zero-filled dx (no wasted MFMAs on the 3/4 empty rows).
+  const int sh = d->stride_h, sw = d->stride_w;
+  // does every residue class receive at least one tap?  if not, those pixels of dx are plain zeros
+  bool all_covered = true;
+  for (int cy = 0; cy < sh; ++cy) all_covered = all_covered && plan_axis(cy, d->pad_h, d->dil_h, sh, d->kh).nt > 0;
+  for (int cx = 0; cx < sw; ++cx) all_covered = all_covered && plan_axis(cx, d->pad_w, d->dil_w, sw, d->kw).nt > 0;
+  if (!all_covered) {
     hipError_t e = hipMemsetAsync(dx, 0, (size_t)d->N * d->H * d->W * d->Cin * sizeof(float), st);
     if (e != hipSuccess) { set_error("conv2d_dgrad memset: %s", hipGetErrorString(e)); return EVK_E_LAUNCH; }
-    a.Hm = d->Ho; a.Wm = d->Wo;
-    a.sh = 1; a.sw = 1; a.ph = 0; a.pw = 0; a.dh = 1; a.dw = 1;
-    a.M = d->N * d->Ho * d->Wo;
-    a.dsh = d->stride_h; a.dsw = d->stride_w; a.dense_dst = 0;
-    return launch_igemm(a, 0, st);
   }
-  a.Hm = d->H; a.Wm = d->W;
-  a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
-  a.M = d->N * d->H * d->W;
-  a.dsh = 1; a.dsw = 1; a.dense_dst = 1;
-  return launch_igemm(a, (d->stride_h == 1 && d->stride_w == 1) ? 1 : 2, st);
+  size_t woff = 0;  // class weights are packed back to back by evk_conv2d_pack_dgrad_weight
+  for (int cy = 0; cy < sh; ++cy)
+    for (int cx = 0; cx < sw; ++cx) {
+      const AxisPlan py = plan_axis(cy, d->pad_h, d->dil_h, sh, d->kh);
+      const AxisPlan px = plan_axis(cx, d->pad_w, d->dil_w, sw, d->kw);
+      const int Hm = d->H > cy ? (d->H - cy + sh - 1) / sh : 0;
+      const int Wm = d->W > cx ? (d->W - cx + sw - 1) / sw : 0;
+      const size_t wsize = (size_t)d->Cin * py.nt * px.nt * d->Cout;
+      if (py.nt > 0 && px.nt > 0 && Hm > 0 && Wm > 0) {
+        IGemmArgs a{};
+        a.src = dy; a.wgt = wt + woff; a.bias = nullptr; a.dst = dx;
+        a.N = d->N; a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Cout;
+        a.Hm = Hm; a.Wm = Wm; a.Cd = d->Cin;
+        a.kh = py.nt; a.kw = px.nt; a.cpt = d->Cout / 4;
+        a.ash = 1; a.asw = 1;
+        a.oy0 = py.o0; a.oys = py.ostep; a.ox0 = px.o0; a.oxs = px.ostep;
+        a.M = d->N * Hm * Wm;
+        a.Ktot = py.nt * px.nt * d->Cout;
+        a.Hd = d->H; a.Wd = d->W; a.dsh = sh; a.dsw = sw; a.doy = cy; a.dox = cx;
+        a.dense_dst = (sh == 1 && sw == 1) ? 1 : 0;
+        a.relu = 0;
+        rc = launch_igemm(a, st);
+        if (rc) return rc;
+      }
+      woff += wsize;
+    }
+  return EVK_OK;
 }
 
-// wt[ci][ky][kx][co] = w[co][ky][kx][ci]   (taps are NOT flipped: the transposed gather of
-// conv_igemm walks ty = py + pad - ky*dil, which already pairs tap ky with its source row).
-__global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout,
-                                         int taps, int Cin) {
-  const size_t total = (size_t)Cout * taps * Cin;
+// Class-ordered data-gradient weights: for each residue class (cy, cx) in row-major order a block
+// wt_c[ci][jy][jx][co] = w[co][ky0 + jy*kstep_y][kx0 + jx*kstep_x][ci].  Every tap belongs to exactly
+// one class, so the total size is Cin*kh*kw*Cout; for stride 1 it is the plain [Cin][kh][kw][Cout].
+__global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int kh, int kw,
+                                         int Cin, int ky0, int ksy, int nty, int kx0, int ksx, int ntx) {
+  const size_t total = (size_t)Cin * nty * ntx * Cout;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    // i indexes wt: ((ci*taps + t)*Cout + co)
     const int co = (int)(i % Cout);
-    const size_t r = i / Cout;
-    const int t = (int)(r % taps);
-    const int ci = (int)(r / taps);
-    wt[i] = w[((size_t)co * taps + t) * Cin + ci];
+    size_t r = i / Cout;
+    const int jx = (int)(r % ntx);
+    r /= ntx;
+    const int jy = (int)(r % nty);
+    const int ci = (int)(r / nty);
+    const int ky = ky0 + jy * ksy, kx = kx0 + jx * ksx;
+    wt[i] = w[(((size_t)co * kh + ky) * kw + kx) * Cin + ci];
   }
 }
 
 extern "C" int evk_conv2d_pack_dgrad_weight(const evk_conv_desc* d, const float* w, float* wt, void* stream) {
   EVK_REQUIRE(d && w && wt, EVK_E_INVALID, "pack_dgrad_weight: null pointer");
-  const size_t total = (size_t)d->Cout * d->kh * d->kw * d->Cin;
-  const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-  hipLaunchKernelGGL(pack_dgrad_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wt, d->Cout,
-                     d->kh * d->kw, d->Cin);
-  return check_launch("pack_dgrad_weight");
+  EVK_REQUIRE(d->stride_h > 0 && d->stride_w > 0 && d->dil_h > 0 && d->dil_w > 0, EVK_E_INVALID,
+              "pack_dgrad_weight: bad stride/dilation");
+  size_t woff = 0;
+  for (int cy = 0; cy < d->stride_h; ++cy)
+    for (int cx = 0; cx < d->stride_w; ++cx) {
+      const AxisPlan py = plan_axis(cy, d->pad_h, d->dil_h, d->stride_h, d->kh);
+      const AxisPlan px = plan_axis(cx, d->pad_w, d->dil_w, d->stride_w, d->kw);
+      const size_t total = (size_t)d->Cin * py.nt * px.nt * d->Cout;
+      if (total > 0) {
+        const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+        hipLaunchKernelGGL(pack_dgrad_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wt + woff,
+                           d->Cout, d->kh, d->kw, d->Cin, py.k0, py.kstep, py.nt, px.k0, px.kstep, px.nt);
+        int rc = check_launch("pack_dgrad_weight");
+        if (rc) return rc;
+      }
+      woff += total;
+    }
+  return EVK_OK;
 }
