@@ -13,7 +13,8 @@
 // 16-lane group hit 16 distinct 16-byte slots of the 256-byte bank row.
 // Fragment mapping (guide §3): A operand lane l = A[i=l&31][k=l>>5], B lane l = B[k=l>>5][j=l&31];
 // one ds_read_b128 per lane supplies k = 8g+4h .. 8g+4h+3, i.e. four consecutive MFMAs.
-// C/D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// C/D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5); the MFMA is issued as W_tile x X_tile^T so
+// that rows = output channels (4 consecutive per lane and register quad => 16-byte stores).
 //
 // ONE gather form serves every use: source pixel of GEMM row (n, gy, gx) and tap (jy, jx) is
 //     sy = gy*ash + oy0 + jy*oys ,   sx = gx*asw + ox0 + jx*oxs            (affine in the tap index)
@@ -195,66 +196,86 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IGemmArgs p) {
   store_tiles(0);
   __syncthreads();
 
+  // One K step.  The staging work of the NEXT tile is threaded through this tile's MFMA groups so
+  // that it issues in the shadow of the matrix pipe (an in-order wave can issue VALU / VMEM / LDS
+  // right behind an MFMA while that MFMA occupies the pipe for 64 cycles):
+  //   g0 | address math + 8 global loads (tile kt+1) | g1 | g2 | vmcnt + zero-fill + 8 ds_write | g3 | barrier
+  // Writing buffer buf^1 during the step is safe: its last readers passed the previous barrier.
+  auto mfma_group = [&](const float* Ab, const float* Bb, int g) {
+    f32x4 fa[MB], fb[NB];
+#pragma unroll
+    for (int a = 0; a < MB; ++a) {
+      const int row = wm * WM + a * 32 + li;
+      const int pc = (2 * g + lh) ^ ((row >> 1) & 7);
+      fa[a] = *reinterpret_cast<const f32x4*>(Ab + a * 32 * BK + pc * 4);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int row = wn * WN + b * 32 + li;
+      const int pc = (2 * g + lh) ^ ((row >> 1) & 7);
+      fb[b] = *reinterpret_cast<const f32x4*>(Bb + b * 32 * BK + pc * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int a = 0; a < MB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[b][j], fa[a][j], acc[a][b], 0, 0, 0);
+  };
+
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tiles(kt + 1);
-
+    const bool more = kt + 1 < nk;
     const float* Ab = As + buf * BM * BK + (wm * WM + li) * BK;
     const float* Bb = Bs + buf * BN * BK + (wn * WN + li) * BK;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 fa[MB], fb[NB];
-#pragma unroll
-      for (int a = 0; a < MB; ++a) {
-        const int row = wm * WM + a * 32 + li;
-        const int pc = (2 * g + lh) ^ ((row >> 1) & 7);
-        fa[a] = *reinterpret_cast<const f32x4*>(Ab + a * 32 * BK + pc * 4);
-      }
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int row = wn * WN + b * 32 + li;
-        const int pc = (2 * g + lh) ^ ((row >> 1) & 7);
-        fb[b] = *reinterpret_cast<const f32x4*>(Bb + b * 32 * BK + pc * 4);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int a = 0; a < MB; ++a)
-#pragma unroll
-          for (int b = 0; b < NB; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
-    }
-
-    if (kt + 1 < nk) store_tiles(buf ^ 1);
+    mfma_group(Ab, Bb, 0);
+    if (more) load_tiles(kt + 1);
+    mfma_group(Ab, Bb, 1);
+    mfma_group(Ab, Bb, 2);
+    if (more) store_tiles(buf ^ 1);
+    mfma_group(Ab, Bb, 3);
     __syncthreads();
   }
 
-  // ---- epilogue
+  // ---- epilogue.  The MFMAs were issued as D = W_tile * X_tile^T, so a lane holds ONE pixel
+  // (column lane&31) and, per accumulator quad r4, FOUR consecutive output channels
+  // co = 8*r4 + 4*(lane>>5) + {0..3}: one 16-byte store per quad (4x fewer store instructions than
+  // the row-per-register layout; the small-K 1x1 convolutions are store-issue bound).
 #pragma unroll
   for (int a = 0; a < MB; ++a) {
+    const int row = m0 + wm * WM + a * 32 + li;
+    if (row >= p.M) continue;
+    size_t roff;
+    if (p.dense_dst) {
+      roff = (size_t)row * p.Cd;
+    } else {
+      const int hw = p.Hm * p.Wm;
+      const int n = row / hw;
+      const int rem = row - n * hw;
+      const int gy = rem / p.Wm;
+      const int gx = rem - gy * p.Wm;
+      roff = (((size_t)n * p.Hd + (size_t)(gy * p.dsh + p.doy)) * p.Wd + (size_t)(gx * p.dsw + p.dox)) * p.Cd;
+    }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (row >= p.M) continue;
-      size_t roff;
-      if (p.dense_dst) {
-        roff = (size_t)row * p.Cd;
-      } else {
-        const int hw = p.Hm * p.Wm;
-        const int n = row / hw;
-        const int rem = row - n * hw;
-        const int gy = rem / p.Wm;
-        const int gx = rem - gy * p.Wm;
-        roff = (((size_t)n * p.Hd + (size_t)(gy * p.dsh + p.doy)) * p.Wd + (size_t)(gx * p.dsw + p.dox)) * p.Cd;
-      }
+    for (int b = 0; b < NB; ++b) {
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int col = n0 + wn * WN + b * 32 + li;
-        if (col < p.Cd) {
-          float v = acc[a][b][r];
-          if (p.bias) v += p.bias[col];
-          if (p.relu) v = fmaxf(v, 0.f);
-          p.dst[roff + col] = v;
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int col = n0 + wn * WN + b * 32 + 8 * r4 + 4 * lh;
+        f32x4 v = {acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
+        if (col + 3 < p.Cd && (p.Cd & 3) == 0) {
+          if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+          if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          *reinterpret_cast<f32x4*>(p.dst + roff + col) = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (col + e < p.Cd) {
+              float s = v[e];
+              if (p.bias) s += p.bias[col + e];
+              if (p.relu) s = fmaxf(s, 0.f);
+              p.dst[roff + col + e] = s;
+            }
         }
       }
     }

@@ -195,7 +195,13 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __rest
   f32x4* o4 = reinterpret_cast<f32x4*>(out);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     f32x4 s = w4[i];
-    for (int z = 1; z < splitk; ++z) s += w4[(size_t)z * stride4 + i];
+    int z = 1;
+    for (; z + 3 < splitk; z += 4) {  // four independent 16-byte loads in flight, fixed summation order
+      const f32x4 a = w4[(size_t)z * stride4 + i], b = w4[(size_t)(z + 1) * stride4 + i];
+      const f32x4 c = w4[(size_t)(z + 2) * stride4 + i], d = w4[(size_t)(z + 3) * stride4 + i];
+      s += (a + b) + (c + d);
+    }
+    for (; z < splitk; ++z) s += w4[(size_t)z * stride4 + i];
     o4[i] = s;
   }
 }

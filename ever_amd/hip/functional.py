@@ -156,6 +156,7 @@ class _Conv2dFn(Function):
         if sp is not None:
             sp.stop()
         ctx.flops = flops
+        ctx.w_stride = tuple(weight.stride())
         ctx.desc = d
         ctx.relu = relu
         ctx.cin = cin
@@ -232,6 +233,11 @@ class _Conv2dFn(Function):
                     dwk = dw2.reshape(cout_p, taps, cin)
                 # logical OIHW view over OHWI memory (matches a channels_last parameter)
                 dw = dwk[:cout].reshape(cout, kh, kw, cin).permute(0, 3, 1, 2)
+                ws = ctx.w_stride
+                if kh * kw == 1 and dw.stride() != ws and ws[0] == cin and ws[1] == 1:
+                    # 1x1 kernels: the size-1 dims make the stride tuple ambiguous; present exactly the
+                    # parameter's strides so AccumulateGrad / DDP bucket views alias instead of copying
+                    dw = dw.as_strided(dw.shape, ws)
             if need_db:
                 db = dbk[:cout]
         return dx, dw, db, None, None, None, None
