@@ -53,6 +53,16 @@ def make_batch(dev, batch, rank):
     return x, y
 
 
+def pmc_traffic(family):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE x2 +
+    WRITE_SIZE, MI355X_MICROARCH.md §HBM; see profiles/r01_traffic.json for the method); None if absent."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as f:
+            return json.load(f)[family]['hbm_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def host_cores():
     """Cores this process may actually use: the cgroup CPU quota if one is set (the GPU box exposes 256
     logical CPUs under a 16-core quota; oversubscribing it makes oneDNN 100x slower), else the affinity mask."""
@@ -180,7 +190,9 @@ def main():
                 line['roofline'] = {
                     'bound': 'mfma', 'kernel': 'evk::conv_igemm_kernel (conv forward + data-gradient launches)',
                     'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                    'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic('conv_igemm'),
+                    'traffic_unit': 'HBM bytes per launch (PMC, profiles/r01_traffic.json)',
+                    'algorithmic_bytes_per_launch': round(ig['bytes'] / ig['launches']),
                     'launches_per_step': ig['launches'] // max(1, sampled), 'sampled_steps': sampled,
                     'avg_launch_us': round(ig['seconds'] / ig['launches'] * 1e6, 2),
                     'algorithmic_gflop_per_launch': round(ig['flops'] / ig['launches'] / 1e9, 3)}

@@ -151,11 +151,14 @@ class _Conv2dFn(Function):
         d = _conv_desc(n, h, w, cin_p, cout, kh, kw, stride, padding, dilation)
         y = empty_nhwc(n, cout, d.Ho, d.Wo, dev)
         flops = 2.0 * n * d.Ho * d.Wo * cout * cin * kh * kw  # algorithmic (un-padded) FLOPs
-        sp = timing.span('conv_igemm', flops)
+        # algorithmic bytes: input + output + weights, each touched once
+        abytes = 4.0 * (n * h * w * cin + n * d.Ho * d.Wo * cout + cout * cin * kh * kw)
+        sp = timing.span('conv_igemm', flops, abytes)
         _C.call('evk_conv2d_fwd', ctypes.byref(d), x_ptr, w_ptr, _ptr(bias), y.data_ptr(), 1 if relu else 0, st)
         if sp is not None:
             sp.stop()
         ctx.flops = flops
+        ctx.abytes = abytes
         ctx.w_stride = tuple(weight.stride())
         ctx.desc = d
         ctx.relu = relu
@@ -206,7 +209,7 @@ class _Conv2dFn(Function):
             wt = torch.empty((cin_p, taps, cout_p), device=dev, dtype=torch.float32)
             _C.call('evk_conv2d_pack_dgrad_weight', ctypes.byref(dk), w_src.data_ptr(), wt.data_ptr(), st)
             dxk = empty_nhwc(n, cin_p, d.H, d.W, dev)
-            sp = timing.span('conv_igemm', ctx.flops)
+            sp = timing.span('conv_igemm', ctx.flops, ctx.abytes)
             _C.call('evk_conv2d_dgrad', ctypes.byref(dk), dy_ptr, wt.data_ptr(), dxk.data_ptr(), st)
             if sp is not None:
                 sp.stop()
@@ -221,7 +224,7 @@ class _Conv2dFn(Function):
             ws = workspace(dev, ws_bytes)
             dwk = torch.empty((cout_p, taps, cin_p), device=dev, dtype=torch.float32)
             dbk = torch.empty((cout_p,), device=dev, dtype=torch.float32) if need_db else None
-            sp = timing.span('conv_wgrad', ctx.flops)
+            sp = timing.span('conv_wgrad', ctx.flops, ctx.abytes)
             _C.call('evk_conv2d_wgrad', ctypes.byref(dk), xk.data_ptr(), dy_ptr, dwk.data_ptr(), _ptr(dbk),
                     ws.data_ptr(), ws_bytes, st)
             if sp is not None:

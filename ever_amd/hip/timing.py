@@ -8,7 +8,7 @@ _active = None
 
 class KernelTimer:
     def __init__(self):
-        self.records = []  # (family, flops, start_event, stop_event)
+        self.records = []  # (family, flops, algorithmic_bytes, start_event, stop_event)
 
     def __enter__(self):
         global _active
@@ -22,28 +22,29 @@ class KernelTimer:
     def summary(self):
         """{family: dict(launches, flops, seconds)} — call after torch.cuda.synchronize()."""
         out = {}
-        for fam, flops, s, e in self.records:
-            d = out.setdefault(fam, dict(launches=0, flops=0.0, seconds=0.0))
+        for fam, flops, nbytes, s, e in self.records:
+            d = out.setdefault(fam, dict(launches=0, flops=0.0, bytes=0.0, seconds=0.0))
             d['launches'] += 1
             d['flops'] += flops
+            d['bytes'] += nbytes
             d['seconds'] += s.elapsed_time(e) * 1e-3
         return out
 
 
 class _Span:
-    __slots__ = ('fam', 'flops', 'start')
+    __slots__ = ('fam', 'flops', 'nbytes', 'start')
 
-    def __init__(self, fam, flops):
-        self.fam, self.flops = fam, flops
+    def __init__(self, fam, flops, nbytes):
+        self.fam, self.flops, self.nbytes = fam, flops, nbytes
         self.start = torch.cuda.Event(enable_timing=True)
         self.start.record()
 
     def stop(self):
         e = torch.cuda.Event(enable_timing=True)
         e.record()
-        _active.records.append((self.fam, self.flops, self.start, e))
+        _active.records.append((self.fam, self.flops, self.nbytes, self.start, e))
 
 
-def span(family, flops):
-    """Start timing one launch; returns None when no timer is active."""
-    return _Span(family, flops) if _active is not None else None
+def span(family, flops, nbytes=0.0):
+    """Start timing one launch (algorithmic FLOPs and bytes attached); None when no timer is active."""
+    return _Span(family, flops, nbytes) if _active is not None else None
