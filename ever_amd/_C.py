@@ -59,8 +59,10 @@ SIGNATURES = {
     'evk_relation_bwd': (c_int, [P, P, P, P, P, P, P, P, c_i32, c_i32, c_i32, P, c_size_t, P]),
     'evk_mean4_fwd': (c_int, [P, P, P, P, P, c_i64, P]),
     'evk_loss_stats_doubles': (c_i64, [c_i32]),
-    'evk_bce_fwd': (c_int, [P, P, c_i64, c_i64, P, P, P]),
-    'evk_bce_bwd': (c_int, [P, P, c_i64, c_i64, P, P, P, c_i32, P]),
+    'evk_bce_fwd': (c_int, [P, P, c_i64, c_i64, c_f32, P, P, P]),
+    'evk_bce_bwd': (c_int, [P, P, c_i64, c_i64, c_f32, P, P, P, c_i32, P]),
+    'evk_soft_ce_fwd': (c_int, [P, P, c_i64, c_i32, P, P, P]),
+    'evk_soft_ce_bwd': (c_int, [P, P, c_i64, c_i32, P, P, P]),
     'evk_dice_stats': (c_int, [P, P, c_i64, c_i32, c_i64, P, P]),
     'evk_dice_finish': (c_int, [P, c_i32, c_f32, c_i32, P, P]),
     'evk_dice_bwd': (c_int, [P, P, c_i64, c_i32, c_i64, P, c_f32, c_i32, P, P, c_i32, P]),

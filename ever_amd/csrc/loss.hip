@@ -49,12 +49,13 @@ __device__ __forceinline__ float bce_term(float x, float y) {
 }
 __global__ __launch_bounds__(256) void bce_partial_kernel(const float* __restrict__ logits,
                                                           const int64_t* __restrict__ labels, int64_t npix,
-                                                          int64_t ignore, double* __restrict__ stats) {
+                                                          int64_t ignore, float eps, double* __restrict__ stats) {
   double v[2] = {0.0, 0.0};
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
     const int64_t t = labels[i];
     if (t != ignore) {
-      v[0] += (double)bce_term(logits[i], (float)t);
+      const float y = (t == 0) ? eps : (float)t - eps;  // label smoothing (eps = 0: plain BCE)
+      v[0] += (double)bce_term(logits[i], y);
       v[1] += 1.0;
     }
   }
@@ -65,7 +66,7 @@ __global__ void mean_loss_kernel(const double* stats, float* loss) {
 }
 __global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ logits,
                                                       const int64_t* __restrict__ labels, int64_t npix, int64_t ignore,
-                                                      const double* __restrict__ stats,
+                                                      float eps, const double* __restrict__ stats,
                                                       const float* __restrict__ grad_scale, float* __restrict__ dlogits,
                                                       int accumulate) {
   const float k = (grad_scale ? *grad_scale : 1.f) / (float)stats[1];
@@ -74,7 +75,8 @@ __global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ 
     float g = 0.f;
     if (t != ignore) {
       const float p = 1.f / (1.f + expf(-logits[i]));
-      g = (p - (float)t) * k;
+      const float y = (t == 0) ? eps : (float)t - eps;
+      g = (p - y) * k;
     }
     dlogits[i] = accumulate ? dlogits[i] + g : g;
   }
@@ -255,28 +257,94 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
   }
 }
 
+// ---------------------------------------------------------------- soft cross entropy --------------
+// reference loss.py:238-242: -(target * log_softmax(input, 1)).mean(dim=(0,2,3)).sum()
+//   = -sum_{pixels, c} t_c * logp_c / npix.   stats final: [0] = sum_{p,c} t_c * (lse - x_c)
+__global__ __launch_bounds__(256) void soft_ce_partial_kernel(const float* __restrict__ logits,
+                                                              const float* __restrict__ target, int64_t npix, int C,
+                                                              double* __restrict__ stats) {
+  double v[1] = {0.0};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+    const float* x = logits + i * C;
+    const float* t = target + i * C;
+    float m = x[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(x[c] - m);
+    const float lse = m + logf(se);
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) acc += t[c] * (lse - x[c]);
+    v[0] += (double)acc;
+  }
+  block_reduce_store<1>(v, stats + 1 + (size_t)blockIdx.x);
+}
+__global__ void soft_ce_finish_kernel(const double* stats, double inv_npix, float* loss) {
+  if (threadIdx.x == 0) *loss = (float)(stats[0] * inv_npix);
+}
+__global__ __launch_bounds__(256) void soft_ce_bwd_kernel(const float* __restrict__ logits,
+                                                          const float* __restrict__ target, int64_t npix, int C,
+                                                          float inv_npix, const float* __restrict__ grad_scale,
+                                                          float* __restrict__ dlogits) {
+  const float k = (grad_scale ? *grad_scale : 1.f) * inv_npix;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+    const float* x = logits + i * C;
+    const float* t = target + i * C;
+    float* d = dlogits + i * C;
+    float m = x[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+    float se = 0.f, ts = 0.f;
+    for (int c = 0; c < C; ++c) {
+      se += expf(x[c] - m);
+      ts += t[c];
+    }
+    const float lse = m + logf(se);
+    for (int c = 0; c < C; ++c) d[c] = k * (expf(x[c] - lse) * ts - t[c]);
+  }
+}
+
 }  // namespace evk
 
 using namespace evk;
 
+extern "C" int evk_soft_ce_fwd(const float* logits, const float* target, int64_t npix, int32_t C, float* loss,
+                               double* stats, void* stream) {
+  EVK_REQUIRE(logits && target && loss && stats && npix > 0 && C >= 1, EVK_E_INVALID, "soft_ce_fwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = loss_grid(npix);
+  hipLaunchKernelGGL(soft_ce_partial_kernel, dim3(nb), dim3(256), 0, st, logits, target, npix, C, stats);
+  hipLaunchKernelGGL(finalize_partials_kernel, dim3(1), dim3(64), 0, st, stats, 1, nb);
+  hipLaunchKernelGGL(soft_ce_finish_kernel, dim3(1), dim3(64), 0, st, (const double*)stats, 1.0 / (double)npix, loss);
+  return check_launch("soft_ce_fwd");
+}
+extern "C" int evk_soft_ce_bwd(const float* logits, const float* target, int64_t npix, int32_t C,
+                               const float* grad_scale, float* dlogits, void* stream) {
+  EVK_REQUIRE(logits && target && dlogits && npix > 0 && C >= 1, EVK_E_INVALID, "soft_ce_bwd: bad argument");
+  const int nb = (int)((npix + 255) / 256 > 4096 ? 4096 : (npix + 255) / 256);
+  hipLaunchKernelGGL(soft_ce_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, logits, target, npix, C,
+                     (float)(1.0 / (double)npix), grad_scale, dlogits);
+  return check_launch("soft_ce_bwd");
+}
+
 extern "C" int64_t evk_loss_stats_doubles(int32_t K) { return (int64_t)K * (1 + kLossBlocks); }
 
-extern "C" int evk_bce_fwd(const float* logits, const int64_t* labels, int64_t npix, int64_t ignore_index, float* loss,
-                           double* stats, void* stream) {
+extern "C" int evk_bce_fwd(const float* logits, const int64_t* labels, int64_t npix, int64_t ignore_index,
+                           float label_smoothing, float* loss, double* stats, void* stream) {
   EVK_REQUIRE(logits && labels && loss && stats && npix > 0, EVK_E_INVALID, "bce_fwd: bad argument");
   hipStream_t st = (hipStream_t)stream;
   const int nb = loss_grid(npix);
-  hipLaunchKernelGGL(bce_partial_kernel, dim3(nb), dim3(256), 0, st, logits, labels, npix, ignore_index, stats);
+  hipLaunchKernelGGL(bce_partial_kernel, dim3(nb), dim3(256), 0, st, logits, labels, npix, ignore_index,
+                     label_smoothing, stats);
   hipLaunchKernelGGL(finalize_partials_kernel, dim3(1), dim3(64), 0, st, stats, 2, nb);
   hipLaunchKernelGGL(mean_loss_kernel, dim3(1), dim3(64), 0, st, (const double*)stats, loss);
   return check_launch("bce_fwd");
 }
 extern "C" int evk_bce_bwd(const float* logits, const int64_t* labels, int64_t npix, int64_t ignore_index,
-                           const double* stats, const float* grad_scale, float* dlogits, int32_t accumulate,
-                           void* stream) {
+                           float label_smoothing, const double* stats, const float* grad_scale, float* dlogits,
+                           int32_t accumulate, void* stream) {
   EVK_REQUIRE(logits && labels && stats && dlogits && npix > 0, EVK_E_INVALID, "bce_bwd: bad argument");
   hipLaunchKernelGGL(bce_bwd_kernel, dim3((int)((npix + 255) / 256 > 4096 ? 4096 : (npix + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, logits, labels, npix, ignore_index, stats, grad_scale, dlogits, accumulate);
+                     (hipStream_t)stream, logits, labels, npix, ignore_index, label_smoothing, stats, grad_scale, dlogits,
+                     accumulate);
   return check_launch("bce_bwd");
 }
 

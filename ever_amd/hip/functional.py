@@ -19,7 +19,7 @@ from .workspace import workspace
 __all__ = [
     'HipPathError', 'empty_nhwc', 'as_nhwc', 'is_nhwc', 'image_to_nhwc', 'conv2d', 'batch_norm_act', 'relu',
     'max_pool3x3s2', 'upsample_nearest2x_add', 'upsample_bilinear', 'global_avg_pool', 'fs_relation',
-    'mean4', 'add', 'bce_with_logits', 'dice_loss_with_logits', 'cross_entropy',
+    'mean4', 'add', 'bce_with_logits', 'dice_loss_with_logits', 'cross_entropy', 'soft_cross_entropy',
 ]
 
 
@@ -578,14 +578,15 @@ def _labels(y_true, npix, what):
 
 class _BceFn(Function):
     @staticmethod
-    def forward(ctx, logits, labels, ignore_index):
+    def forward(ctx, logits, labels, ignore_index, eps):
         npix = logits.numel()
         stats = _stats_buf(2, logits.device)
         loss = torch.empty((), device=logits.device, dtype=torch.float32)
-        _C.call('evk_bce_fwd', logits.data_ptr(), labels.data_ptr(), npix, ignore_index, loss.data_ptr(),
+        _C.call('evk_bce_fwd', logits.data_ptr(), labels.data_ptr(), npix, ignore_index, eps, loss.data_ptr(),
                 stats.data_ptr(), _stream())
         ctx.save_for_backward(logits, labels, stats)
         ctx.ignore_index = ignore_index
+        ctx.eps = eps
         return loss
 
     @staticmethod
@@ -594,13 +595,14 @@ class _BceFn(Function):
         logits, labels, stats = ctx.saved_tensors
         g = g.contiguous().float()
         d = torch.empty_like(logits)
-        _C.call('evk_bce_bwd', logits.data_ptr(), labels.data_ptr(), logits.numel(), ctx.ignore_index,
+        _C.call('evk_bce_bwd', logits.data_ptr(), labels.data_ptr(), logits.numel(), ctx.ignore_index, ctx.eps,
                 stats.data_ptr(), g.data_ptr(), d.data_ptr(), 0, _stream())
-        return d, None, None
+        return d, None, None, None
 
 
-def bce_with_logits(y_pred, y_true, ignore_index=255):
-    """reference ever/module/loss.py:229-235 (reduction='mean', pos_weight=None)."""
+def bce_with_logits(y_pred, y_true, ignore_index=255, label_smoothing=0.0):
+    """reference ever/module/loss.py:229-235 (reduction='mean', pos_weight=None); label_smoothing > 0 gives
+    label_smoothing_binary_cross_entropy (loss.py:222-226)."""
     _require_cuda(y_pred, 'binary_cross_entropy_with_logits')
     if y_pred.dim() == 4:
         if y_pred.shape[1] != 1:
@@ -609,7 +611,7 @@ def bce_with_logits(y_pred, y_true, ignore_index=255):
     else:
         y_pred = y_pred.contiguous()
     labels = _labels(y_true, y_pred.numel(), 'bce')
-    return _BceFn.apply(y_pred, labels, int(ignore_index))
+    return _BceFn.apply(y_pred, labels, int(ignore_index), float(label_smoothing))
 
 
 class _DiceFn(Function):
@@ -684,6 +686,37 @@ class _CeFn(Function):
         _C.call('evk_ce_bwd', logits.data_ptr(), labels.data_ptr(), n * h * w, c, ignore_index, eps, stats.data_ptr(),
                 g.data_ptr(), d.data_ptr(), 0, _stream())
         return d, None, None, None
+
+
+class _SoftCeFn(Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        n, c, h, w = logits.shape
+        stats = _stats_buf(1, logits.device)
+        loss = torch.empty((), device=logits.device, dtype=torch.float32)
+        _C.call('evk_soft_ce_fwd', logits.data_ptr(), target.data_ptr(), n * h * w, c, loss.data_ptr(),
+                stats.data_ptr(), _stream())
+        ctx.save_for_backward(logits, target)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        logits, target = ctx.saved_tensors
+        n, c, h, w = logits.shape
+        g = g.contiguous().float()
+        d = torch.empty_like(logits)
+        _C.call('evk_soft_ce_bwd', logits.data_ptr(), target.data_ptr(), n * h * w, c, g.data_ptr(), d.data_ptr(),
+                _stream())
+        return d, None
+
+
+def soft_cross_entropy(y_pred, target):
+    """reference ever/module/loss.py:238-242 (target is a per-pixel distribution [N,C,H,W]; no gradient to it)."""
+    _require_cuda(y_pred, 'soft_cross_entropy')
+    assert y_pred.dim() == 4 and target.dim() == 4
+    y_pred, target = as_nhwc(y_pred, 'soft_ce'), as_nhwc(target.detach(), 'soft_ce.target')
+    return _SoftCeFn.apply(y_pred, target)
 
 
 def cross_entropy(y_pred, y_true, ignore_index=255, label_smoothing=0.0):

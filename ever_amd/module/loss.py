@@ -2,7 +2,7 @@
 from ..hip import functional as HF
 
 __all__ = ['binary_cross_entropy_with_logits', 'dice_loss_with_logits', 'cross_entropy',
-           'label_smoothing_cross_entropy']
+           'label_smoothing_cross_entropy', 'label_smoothing_binary_cross_entropy', 'soft_cross_entropy']
 
 
 def binary_cross_entropy_with_logits(output, target, reduction='mean', ignore_index=255, pos_weight=None):
@@ -28,3 +28,15 @@ def label_smoothing_cross_entropy(output, target, eps=0.1, reduction='mean', ign
     if reduction != 'mean':
         raise NotImplementedError('ever_amd label_smoothing_cross_entropy: only reduction="mean"')
     return HF.cross_entropy(output, target, ignore_index=ignore_index, label_smoothing=eps)
+
+
+def label_smoothing_binary_cross_entropy(output, target, eps=0.1, reduction='mean', ignore_index=255):
+    """reference loss.py:222-226"""
+    if reduction != 'mean':
+        raise NotImplementedError('ever_amd label_smoothing_binary_cross_entropy: only reduction="mean"')
+    return HF.bce_with_logits(output, target, ignore_index=ignore_index, label_smoothing=eps)
+
+
+def soft_cross_entropy(input, target):
+    """reference loss.py:238-242"""
+    return HF.soft_cross_entropy(input, target)

@@ -170,12 +170,14 @@ int evk_mean4_fwd(const float* a, const float* b, const float* c, const float* d
  * partials); K = 2 (BCE), 2*C (dice), 3 (CE).  Only the first K are meaningful to the caller. */
 int64_t evk_loss_stats_doubles(int32_t K);
 
-/* binary_cross_entropy_with_logits(ignore) — loss.py:229-235. C == 1. stats: double[2]={sum,count} */
+/* binary_cross_entropy_with_logits(ignore) — loss.py:229-235; with label_smoothing > 0 it is
+ * label_smoothing_binary_cross_entropy — loss.py:222-226 (target 0 -> eps, 1 -> 1-eps).
+ * C == 1. stats: double[2]={sum,count} */
 int evk_bce_fwd(const float* logits, const int64_t* labels, int64_t npix, int64_t ignore_index,
-                float* loss, double* stats, void* stream);
+                float label_smoothing, float* loss, double* stats, void* stream);
 int evk_bce_bwd(const float* logits, const int64_t* labels, int64_t npix, int64_t ignore_index,
-                const double* stats, const float* grad_scale, float* dlogits, int32_t accumulate,
-                void* stream);
+                float label_smoothing, const double* stats, const float* grad_scale, float* dlogits,
+                int32_t accumulate, void* stream);
 
 /* dice_loss_with_logits — loss.py:40-75.  C==1: p=sigmoid; C>1: p=softmax, one-hot target.
  * stats: double[2*C] = {inter[c], z[c]} (z = sum p + sum y, before smoothing).  In distributed
@@ -196,6 +198,13 @@ int evk_ce_fwd(const float* logits, const int64_t* labels, int64_t npix, int32_t
 int evk_ce_bwd(const float* logits, const int64_t* labels, int64_t npix, int32_t C,
                int64_t ignore_index, float label_smoothing, const double* stats,
                const float* grad_scale, float* dlogits, int32_t accumulate, void* stream);
+
+/* soft_cross_entropy(input, target) — loss.py:238-242: -(target*log_softmax(input,1)).mean((0,2,3)).sum().
+ * target: float [N*H*W, C] (NHWC, same layout as logits).  stats: K = 1. */
+int evk_soft_ce_fwd(const float* logits, const float* target, int64_t npix, int32_t C, float* loss,
+                    double* stats, void* stream);
+int evk_soft_ce_bwd(const float* logits, const float* target, int64_t npix, int32_t C,
+                    const float* grad_scale, float* dlogits, void* stream);
 
 /* ------------------------------------------------------------------ optimizer -------------- */
 /* torch.optim.SGD step over a flat list of tensors (opt/optimizer.py:7) and

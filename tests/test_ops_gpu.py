@@ -303,6 +303,46 @@ def test_loss_kats(cuda):
     assert abs(F.cross_entropy(l3, y3, label_smoothing=0.1).item() - 0.4735466838) < 1e-6
 
 
+def test_soft_ce_and_label_smoothing_bce(cuda):
+    """reference loss.py:222-226 (LS-BCE) and :238-242 (soft CE) incl. the KATs captured from the reference."""
+    import json
+    import os
+    from ever_amd.module import loss as L
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'op_kats.json')) as f:
+        k = json.load(f)
+    logits = torch.tensor([[.5, -1.], [2., 0.]]).reshape(1, 1, 2, 2).to(cuda)
+    labels = torch.tensor([[1, 0], [1, 255]]).reshape(1, 2, 2).to(cuda)
+    assert abs(L.label_smoothing_binary_cross_entropy(logits, labels).item() - k['ls_bce']) < 1e-6
+    l3 = torch.tensor([[[1., 0.], [0., 2.]], [[0., 1.], [0., 0.]], [[-1., 0.], [3., 0.]]]).reshape(1, 3, 2, 2)
+    tgt = torch.softmax(l3.flip(1), dim=1)
+    assert abs(L.soft_cross_entropy(l3.to(cuda), tgt.to(cuda)).item() - 1.9859406948) < 1e-6   # SURVEY §8 c3
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 5, 9, 7, generator=g)
+    t = torch.softmax(torch.randn(2, 5, 9, 7, generator=g), dim=1)
+    xr = x.clone().requires_grad_()
+    ref = -(t * TF.log_softmax(xr, dim=1)).mean(dim=(0, 2, 3)).sum()
+    (ref * 0.7).backward()
+    xg = x.to(cuda).requires_grad_()
+    out = L.soft_cross_entropy(xg, t.to(cuda))
+    (out * 0.7).backward()
+    _close(out, ref, what='soft ce', rtol=1e-5)
+    _close(xg.grad, xr.grad, what='d soft ce', rtol=1e-4, atol=1e-9)
+    yb = torch.randint(0, 2, (2, 9, 7), generator=g)
+    yb[:, :2, :2] = 255
+    xb = torch.randn(2, 1, 9, 7, generator=g)
+    xr = xb.clone().requires_grad_()
+    v = yb.reshape(-1) != 255
+    tt = yb.reshape(-1)[v].float()
+    tt = torch.where(tt == 0, tt + 0.1, tt - 0.1)
+    ref = TF.binary_cross_entropy_with_logits(xr.reshape(-1)[v], tt)
+    ref.backward()
+    xg = xb.to(cuda).requires_grad_()
+    out = L.label_smoothing_binary_cross_entropy(xg, yb.to(cuda))
+    out.backward()
+    _close(out, ref, what='ls bce', rtol=1e-5)
+    _close(xg.grad, xr.grad, what='d ls bce', rtol=1e-4, atol=1e-9)
+
+
 def test_all_ignored_is_nan(cuda):
     from ever_amd.hip import functional as F
     logits = torch.randn(1, 1, 4, 4).to(cuda)
