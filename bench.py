@@ -118,9 +118,13 @@ def main():
         raise SystemExit('bench.py needs an MI355X (the HIP path has no CPU fallback)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    use_ddp = world > 1 or os.environ.get('EVK_BENCH_FORCE_DDP') == '1'   # the env knob runs the DDP path on 1 GPU (tests)
+    if use_ddp:
         import torch.distributed as dist
-        dist.init_process_group(backend='nccl', init_method='env://')   # RCCL over xGMI
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        dist.init_process_group(backend='nccl', init_method='env://', rank=rank, world_size=world,
+                                device_id=dev)   # RCCL over xGMI, communicator bound to this rank's GPU
     import ever_amd as er
     from ever_amd import _C
     from ever_amd.hip import timing
@@ -129,7 +133,7 @@ def main():
     torch.manual_seed(2333)
     model = er.module.FarSeg(dict()).to(dev).train()      # R50 encoder + FarSegHead reference defaults
     ddp = model
-    if world > 1:
+    if use_ddp:
         ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
                                                         bucket_cap_mb=64, gradient_as_bucket_view=True)
     opt = er.opt.FusedSGD(model.parameters(), lr=0.007, momentum=0.9, weight_decay=1e-4)
@@ -143,7 +147,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_ddp:
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
@@ -164,7 +168,7 @@ def main():
             step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_ddp:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -206,7 +210,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_ddp:
         torch.distributed.destroy_process_group()
 
 

@@ -30,7 +30,7 @@ SIGNATURES = {
     'evk_abi_version': (c_int, []),
     'evk_build_arch': (C.c_char_p, []),
     'evk_conv2d_fwd': (c_int, [_DP, P, P, P, P, c_u32, P]),
-    'evk_conv2d_dgrad': (c_int, [_DP, P, P, P, P]),
+    'evk_conv2d_dgrad': (c_int, [_DP, P, P, P, P, P]),
     'evk_conv2d_pack_dgrad_weight': (c_int, [_DP, P, P, P]),
     'evk_conv2d_wgrad_workspace_bytes': (c_size_t, [_DP]),
     'evk_conv2d_wgrad': (c_int, [_DP, P, P, P, P, P, c_size_t, P]),

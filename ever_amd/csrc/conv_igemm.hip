@@ -36,6 +36,7 @@ struct IGemmArgs {
   const float* src;
   const float* wgt;
   const float* bias;
+  const float* accum;       // optional tensor with dst's shape, added in the epilogue (dst = conv + accum)
   float* dst;
   int N, Hs, Ws, Cs;        // gathered tensor
   int Hm, Wm;               // GEMM-row grid
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IGemmArgs p) {
         f32x4 v = {acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
         if (col + 3 < p.Cd && (p.Cd & 3) == 0) {
           if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+          if (p.accum) v += *reinterpret_cast<const f32x4*>(p.accum + roff + col);
           if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
           *reinterpret_cast<f32x4*>(p.dst + roff + col) = v;
         } else {
@@ -273,6 +275,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IGemmArgs p) {
             if (col + e < p.Cd) {
               float s = v[e];
               if (p.bias) s += p.bias[col + e];
+              if (p.accum) s += p.accum[roff + col + e];
               if (p.relu) s = fmaxf(s, 0.f);
               p.dst[roff + col + e] = s;
             }
@@ -349,7 +352,7 @@ int launch_igemm(IGemmArgs& a, hipStream_t stream) {
     set_error("conv_igemm: tensors of 2^31 or more elements are not supported (%lld / %lld)", src_elems, wgt_elems);
     return EVK_E_UNSUPPORTED;
   }
-  if (a.kh == 1 && a.kw == 1 && a.M <= kSmallM && a.dense_dst && a.ash == 1 && a.asw == 1 && a.oy0 == 0 &&
+  if (a.kh == 1 && a.kw == 1 && a.M <= kSmallM && a.dense_dst && !a.accum && a.ash == 1 && a.asw == 1 && a.oy0 == 0 &&
       a.ox0 == 0 && a.Hm == a.Hs && a.Wm == a.Ws) {
     hipLaunchKernelGGL(conv1x1_smallm_kernel, dim3(a.Cd), dim3(256), 0, stream, a.src, a.wgt, a.bias, a.dst, a.M,
                        a.Ktot, a.Cd, a.relu);
@@ -432,8 +435,8 @@ extern "C" int evk_conv2d_fwd(const evk_conv_desc* d, const float* x, const floa
   return launch_igemm(a, (hipStream_t)stream);
 }
 
-extern "C" int evk_conv2d_dgrad(const evk_conv_desc* d, const float* dy, const float* wt, float* dx,
-                                void* stream) {
+extern "C" int evk_conv2d_dgrad(const evk_conv_desc* d, const float* dy, const float* wt, const float* accum,
+                                float* dx, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   EVK_REQUIRE(dy && wt && dx, EVK_E_INVALID, "conv2d_dgrad: null pointer");
@@ -444,9 +447,11 @@ extern "C" int evk_conv2d_dgrad(const evk_conv_desc* d, const float* dy, const f
   bool all_covered = true;
   for (int cy = 0; cy < sh; ++cy) all_covered = all_covered && plan_axis(cy, d->pad_h, d->dil_h, sh, d->kh).nt > 0;
   for (int cx = 0; cx < sw; ++cx) all_covered = all_covered && plan_axis(cx, d->pad_w, d->dil_w, sw, d->kw).nt > 0;
-  if (!all_covered) {
-    hipError_t e = hipMemsetAsync(dx, 0, (size_t)d->N * d->H * d->W * d->Cin * sizeof(float), st);
-    if (e != hipSuccess) { set_error("conv2d_dgrad memset: %s", hipGetErrorString(e)); return EVK_E_LAUNCH; }
+  EVK_REQUIRE(accum != dx, EVK_E_INVALID, "conv2d_dgrad: accum must not alias dx");
+  if (!all_covered) {  // pixels no tap reaches: dx = 0 (+ accum)
+    const size_t bytes = (size_t)d->N * d->H * d->W * d->Cin * sizeof(float);
+    hipError_t e = accum ? hipMemcpyAsync(dx, accum, bytes, hipMemcpyDeviceToDevice, st) : hipMemsetAsync(dx, 0, bytes, st);
+    if (e != hipSuccess) { set_error("conv2d_dgrad fill: %s", hipGetErrorString(e)); return EVK_E_LAUNCH; }
   }
   size_t woff = 0;  // class weights are packed back to back by evk_conv2d_pack_dgrad_weight
   for (int cy = 0; cy < sh; ++cy)
@@ -458,7 +463,7 @@ extern "C" int evk_conv2d_dgrad(const evk_conv_desc* d, const float* dy, const f
       const size_t wsize = (size_t)d->Cin * py.nt * px.nt * d->Cout;
       if (py.nt > 0 && px.nt > 0 && Hm > 0 && Wm > 0) {
         IGemmArgs a{};
-        a.src = dy; a.wgt = wt + woff; a.bias = nullptr; a.dst = dx;
+        a.src = dy; a.wgt = wt + woff; a.bias = nullptr; a.accum = accum; a.dst = dx;
         a.N = d->N; a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Cout;
         a.Hm = Hm; a.Wm = Wm; a.Cd = d->Cin;
         a.kh = py.nt; a.kw = px.nt; a.cpt = d->Cout / 4;

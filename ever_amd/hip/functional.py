@@ -17,7 +17,7 @@ from . import timing
 from .workspace import workspace
 
 __all__ = [
-    'HipPathError', 'empty_nhwc', 'as_nhwc', 'is_nhwc', 'image_to_nhwc', 'conv2d', 'batch_norm_act', 'relu',
+    'HipPathError', 'empty_nhwc', 'as_nhwc', 'is_nhwc', 'image_to_nhwc', 'conv2d', 'conv2d_fork', 'batch_norm_act', 'relu',
     'max_pool3x3s2', 'upsample_nearest2x_add', 'upsample_bilinear', 'global_avg_pool', 'fs_relation',
     'mean4', 'add', 'bce_with_logits', 'dice_loss_with_logits', 'cross_entropy', 'soft_cross_entropy',
 ]
@@ -124,6 +124,127 @@ def _weight_ohwi(weight):
     return out
 
 
+class _ConvState:
+    """What one convolution's backward needs (kept on the autograd ctx)."""
+    __slots__ = ('desc', 'relu', 'cin', 'has_bias', 'flops', 'abytes', 'w_stride', 'xk', 'w_ohwi', 'y')
+
+
+def _conv_forward(x, weight, bias, stride, padding, dilation, relu):
+    """evk_conv2d_fwd on NHWC x / OHWI weight -> (y, _ConvState)."""
+    n, cin, h, w = x.shape
+    cout, cin_w, kh, kw = weight.shape
+    if cin_w != cin:
+        raise ValueError(f'conv2d: input has {cin} channels but weight expects {cin_w} (groups != 1 unsupported)')
+    dev = x.device
+    st = _stream()
+    w_ohwi = _weight_ohwi(weight.detach())
+    cin_p = _pad4(cin)
+    if cin_p != cin:
+        xk = _pad_last(x.data_ptr(), n * h * w, cin, cin_p, dev)
+        wk = _pad_last(w_ohwi.data_ptr(), cout * kh * kw, cin, cin_p, dev)
+        x_ptr, w_ptr = xk.data_ptr(), wk.data_ptr()
+    else:
+        xk = x
+        x_ptr, w_ptr = x.data_ptr(), w_ohwi.data_ptr()
+    d = _conv_desc(n, h, w, cin_p, cout, kh, kw, stride, padding, dilation)
+    y = empty_nhwc(n, cout, d.Ho, d.Wo, dev)
+    cs = _ConvState()
+    cs.flops = 2.0 * n * d.Ho * d.Wo * cout * cin * kh * kw  # algorithmic (un-padded) FLOPs
+    # algorithmic bytes: input + output + weights, each touched once
+    cs.abytes = 4.0 * (n * h * w * cin + n * d.Ho * d.Wo * cout + cout * cin * kh * kw)
+    sp = timing.span('conv_igemm', cs.flops, cs.abytes)
+    _C.call('evk_conv2d_fwd', ctypes.byref(d), x_ptr, w_ptr, _ptr(bias), y.data_ptr(), 1 if relu else 0, st)
+    if sp is not None:
+        sp.stop()
+    cs.desc, cs.relu, cs.cin, cs.has_bias = d, relu, cin, bias is not None
+    cs.w_stride = tuple(weight.stride())
+    # xk (channel-padded copy when Cin % 4 != 0) is what wgrad reads
+    cs.xk, cs.w_ohwi, cs.y = xk, w_ohwi, (y if relu else None)
+    return y, cs
+
+
+def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None):
+    """(dx, dw, db) of one convolution.  `accum` (a tensor of x's shape or None) is added to dx inside
+    the data-gradient epilogue: dx = conv_transpose(dy, w) + accum."""
+    d, xk, w_ohwi = cs.desc, cs.xk, cs.w_ohwi
+    dev = dy.device
+    st = _stream()
+    n, cin_p, cout, kh, kw = d.N, d.Cin, d.Cout, d.kh, d.kw
+    cin = cs.cin
+    dy = as_nhwc(dy, 'conv2d.backward')
+    if cs.relu:
+        g = torch.empty_like(dy)
+        _C.call('evk_relu_bwd', dy.data_ptr(), cs.y.data_ptr(), g.data_ptr(), dy.numel(), st)
+        dy = g
+    rows_o = n * d.Ho * d.Wo
+    cout_p = _pad4(cout)
+    if cout_p != cout:
+        # narrow heads (classifier Cout=1): pad dy / weight rows to 4 output channels
+        dyk = _pad_last(dy.data_ptr(), rows_o, cout, cout_p, dev)
+        dy_ptr = dyk.data_ptr()
+    else:
+        dyk = dy
+        dy_ptr = dy.data_ptr()
+    dk = _C.ConvDesc(d.N, d.H, d.W, cin_p, d.Ho, d.Wo, cout_p, kh, kw, d.stride_h, d.stride_w, d.pad_h, d.pad_w,
+                     d.dil_h, d.dil_w)
+    dx = dw = db = None
+    taps = kh * kw
+    if need_dx:
+        # weights as [cout_p][taps][cin_p]
+        if cin_p != cin or cout_p != cout:
+            wfull = torch.zeros((cout_p, taps, cin_p), device=dev, dtype=torch.float32)
+            tmp = (_pad_last(w_ohwi.data_ptr(), cout * taps, cin, cin_p, dev) if cin_p != cin
+                   else w_ohwi.permute(0, 2, 3, 1))  # OHWI memory order
+            wfull[:cout].copy_(tmp.reshape(cout, taps, cin_p))
+            w_src = wfull
+        else:
+            w_src = w_ohwi
+        wt = torch.empty((cin_p, taps, cout_p), device=dev, dtype=torch.float32)
+        _C.call('evk_conv2d_pack_dgrad_weight', ctypes.byref(dk), w_src.data_ptr(), wt.data_ptr(), st)
+        acc_ptr = None
+        if accum is not None:
+            if cin_p != cin:
+                raise HipPathError('conv2d.backward: accum with channel-padded inputs is not supported')
+            accum = as_nhwc(accum, 'conv2d.backward.accum')
+            acc_ptr = accum.data_ptr()
+        dxk = empty_nhwc(n, cin_p, d.H, d.W, dev)
+        sp = timing.span('conv_igemm', cs.flops, cs.abytes)
+        _C.call('evk_conv2d_dgrad', ctypes.byref(dk), dy_ptr, wt.data_ptr(), acc_ptr, dxk.data_ptr(), st)
+        if sp is not None:
+            sp.stop()
+        if cin_p != cin:
+            dx = empty_nhwc(n, cin, d.H, d.W, dev)
+            _C.call('evk_unpad_channels', dxk.data_ptr(), dx.data_ptr(), n * d.H * d.W, cin_p, cin, st)
+        else:
+            dx = dxk
+    if need_dw or need_db:
+        lib = _C.load()
+        ws_bytes = lib.evk_conv2d_wgrad_workspace_bytes(ctypes.byref(dk))
+        ws = workspace(dev, ws_bytes)
+        dwk = torch.empty((cout_p, taps, cin_p), device=dev, dtype=torch.float32)
+        dbk = torch.empty((cout_p,), device=dev, dtype=torch.float32) if need_db else None
+        sp = timing.span('conv_wgrad', cs.flops, cs.abytes)
+        _C.call('evk_conv2d_wgrad', ctypes.byref(dk), xk.data_ptr(), dy_ptr, dwk.data_ptr(), _ptr(dbk),
+                ws.data_ptr(), ws_bytes, st)
+        if sp is not None:
+            sp.stop()
+        if need_dw:
+            if cin_p != cin:
+                dw2 = torch.empty((cout_p * taps, cin), device=dev, dtype=torch.float32)
+                _C.call('evk_unpad_channels', dwk.data_ptr(), dw2.data_ptr(), cout_p * taps, cin_p, cin, st)
+                dwk = dw2.reshape(cout_p, taps, cin)
+            # logical OIHW view over OHWI memory (matches a channels_last parameter)
+            dw = dwk[:cout].reshape(cout, kh, kw, cin).permute(0, 3, 1, 2)
+            wstr = cs.w_stride
+            if kh * kw == 1 and dw.stride() != wstr and wstr[0] == cin and wstr[1] == 1:
+                # 1x1 kernels: the size-1 dims make the stride tuple ambiguous; present exactly the
+                # parameter's strides so AccumulateGrad / DDP bucket views alias instead of copying
+                dw = dw.as_strided(dw.shape, wstr)
+        if need_db:
+            db = dbk[:cout]
+    return dx, dw, db
+
+
 class _Conv2dFn(Function):
     """nn.Conv2d forward/backward on the MFMA implicit-GEMM kernels.
 
@@ -133,116 +254,16 @@ class _Conv2dFn(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation, relu):
-        n, cin, h, w = x.shape
-        cout, cin_w, kh, kw = weight.shape
-        if cin_w != cin:
-            raise ValueError(f'conv2d: input has {cin} channels but weight expects {cin_w} (groups != 1 unsupported)')
-        dev = x.device
-        st = _stream()
-        w_ohwi = _weight_ohwi(weight.detach())
-        cin_p = _pad4(cin)
-        if cin_p != cin:
-            xk = _pad_last(x.data_ptr(), n * h * w, cin, cin_p, dev)
-            wk = _pad_last(w_ohwi.data_ptr(), cout * kh * kw, cin, cin_p, dev)
-            x_ptr, w_ptr = xk.data_ptr(), wk.data_ptr()
-        else:
-            xk = x
-            x_ptr, w_ptr = x.data_ptr(), w_ohwi.data_ptr()
-        d = _conv_desc(n, h, w, cin_p, cout, kh, kw, stride, padding, dilation)
-        y = empty_nhwc(n, cout, d.Ho, d.Wo, dev)
-        flops = 2.0 * n * d.Ho * d.Wo * cout * cin * kh * kw  # algorithmic (un-padded) FLOPs
-        # algorithmic bytes: input + output + weights, each touched once
-        abytes = 4.0 * (n * h * w * cin + n * d.Ho * d.Wo * cout + cout * cin * kh * kw)
-        sp = timing.span('conv_igemm', flops, abytes)
-        _C.call('evk_conv2d_fwd', ctypes.byref(d), x_ptr, w_ptr, _ptr(bias), y.data_ptr(), 1 if relu else 0, st)
-        if sp is not None:
-            sp.stop()
-        ctx.flops = flops
-        ctx.abytes = abytes
-        ctx.w_stride = tuple(weight.stride())
-        ctx.desc = d
-        ctx.relu = relu
-        ctx.cin = cin
-        ctx.has_bias = bias is not None
-        # xk (channel-padded copy when Cin % 4 != 0) is what wgrad reads
-        ctx.save_for_backward(xk, w_ohwi, y if relu else None)
+        y, cs = _conv_forward(x, weight, bias, stride, padding, dilation, relu)
+        ctx.cs = cs
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        xk, w_ohwi, y = ctx.saved_tensors
-        d = ctx.desc
-        dev = dy.device
-        st = _stream()
-        n, cin_p, cout, kh, kw = d.N, d.Cin, d.Cout, d.kh, d.kw
-        cin = ctx.cin
-        dy = as_nhwc(dy, 'conv2d.backward')
-        if ctx.relu:
-            g = torch.empty_like(dy)
-            _C.call('evk_relu_bwd', dy.data_ptr(), y.data_ptr(), g.data_ptr(), dy.numel(), st)
-            dy = g
-        rows_o = n * d.Ho * d.Wo
-        cout_p = _pad4(cout)
-        if cout_p != cout:
-            # narrow heads (classifier Cout=1): pad dy / weight rows to 4 output channels
-            dyk = _pad_last(dy.data_ptr(), rows_o, cout, cout_p, dev)
-            dy_ptr = dyk.data_ptr()
-        else:
-            dyk = dy
-            dy_ptr = dy.data_ptr()
-        dk = _C.ConvDesc(d.N, d.H, d.W, cin_p, d.Ho, d.Wo, cout_p, kh, kw, d.stride_h, d.stride_w, d.pad_h, d.pad_w,
-                         d.dil_h, d.dil_w)
-        dx = dw = db = None
-        need_dx, need_dw, need_db = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        taps = kh * kw
-        if need_dx:
-            # weights as [cout_p][taps][cin_p]
-            if cin_p != cin or cout_p != cout:
-                wfull = torch.zeros((cout_p, taps, cin_p), device=dev, dtype=torch.float32)
-                tmp = (_pad_last(w_ohwi.data_ptr(), cout * taps, cin, cin_p, dev) if cin_p != cin
-                       else w_ohwi.permute(0, 2, 3, 1))  # OHWI memory order
-                wfull[:cout].copy_(tmp.reshape(cout, taps, cin_p))
-                w_src = wfull
-            else:
-                w_src = w_ohwi
-            wt = torch.empty((cin_p, taps, cout_p), device=dev, dtype=torch.float32)
-            _C.call('evk_conv2d_pack_dgrad_weight', ctypes.byref(dk), w_src.data_ptr(), wt.data_ptr(), st)
-            dxk = empty_nhwc(n, cin_p, d.H, d.W, dev)
-            sp = timing.span('conv_igemm', ctx.flops, ctx.abytes)
-            _C.call('evk_conv2d_dgrad', ctypes.byref(dk), dy_ptr, wt.data_ptr(), dxk.data_ptr(), st)
-            if sp is not None:
-                sp.stop()
-            if cin_p != cin:
-                dx = empty_nhwc(n, cin, d.H, d.W, dev)
-                _C.call('evk_unpad_channels', dxk.data_ptr(), dx.data_ptr(), n * d.H * d.W, cin_p, cin, st)
-            else:
-                dx = dxk
-        if need_dw or need_db:
-            lib = _C.load()
-            ws_bytes = lib.evk_conv2d_wgrad_workspace_bytes(ctypes.byref(dk))
-            ws = workspace(dev, ws_bytes)
-            dwk = torch.empty((cout_p, taps, cin_p), device=dev, dtype=torch.float32)
-            dbk = torch.empty((cout_p,), device=dev, dtype=torch.float32) if need_db else None
-            sp = timing.span('conv_wgrad', ctx.flops, ctx.abytes)
-            _C.call('evk_conv2d_wgrad', ctypes.byref(dk), xk.data_ptr(), dy_ptr, dwk.data_ptr(), _ptr(dbk),
-                    ws.data_ptr(), ws_bytes, st)
-            if sp is not None:
-                sp.stop()
-            if need_dw:
-                if cin_p != cin:
-                    dw2 = torch.empty((cout_p * taps, cin), device=dev, dtype=torch.float32)
-                    _C.call('evk_unpad_channels', dwk.data_ptr(), dw2.data_ptr(), cout_p * taps, cin_p, cin, st)
-                    dwk = dw2.reshape(cout_p, taps, cin)
-                # logical OIHW view over OHWI memory (matches a channels_last parameter)
-                dw = dwk[:cout].reshape(cout, kh, kw, cin).permute(0, 3, 1, 2)
-                ws = ctx.w_stride
-                if kh * kw == 1 and dw.stride() != ws and ws[0] == cin and ws[1] == 1:
-                    # 1x1 kernels: the size-1 dims make the stride tuple ambiguous; present exactly the
-                    # parameter's strides so AccumulateGrad / DDP bucket views alias instead of copying
-                    dw = dw.as_strided(dw.shape, ws)
-            if need_db:
-                db = dbk[:cout]
+        cs = ctx.cs
+        dx, dw, db = _conv_backward(cs, dy, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                    cs.has_bias and ctx.needs_input_grad[2])
         return dx, dw, db, None, None, None, None
 
 
@@ -250,6 +271,55 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False):
     _require_cuda(x, 'conv2d')
     x = as_nhwc(x, 'conv2d')
     return _Conv2dFn.apply(x, weight, bias, _pair(stride), _pair(padding), _pair(dilation), bool(relu))
+
+
+class _ConvForkFn(Function):
+    """A residual block's fork: x feeds the main-branch conv AND the shortcut (identity, or the
+    down-sampling 1x1 conv; reference _resnets.py:52-69, 92-112, 188-192).  Seeing both consumers in
+    one autograd node lets the backward fold the sum of the two input gradients into the epilogue of
+    the last data-gradient kernel (dx = dgrad(dy_main) + d_shortcut) instead of a separate add pass
+    over the block input."""
+
+    @staticmethod
+    def forward(ctx, x, w_main, w_short, cfg_main, cfg_short):
+        y, cs = _conv_forward(x, w_main, None, *cfg_main, False)
+        ctx.cs_main = cs
+        if w_short is None:
+            ctx.cs_short = None
+            return y, x.view_as(x)
+        ys, css = _conv_forward(x, w_short, None, *cfg_short, False)
+        ctx.cs_short = css
+        return y, ys
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy, dshort):
+        need_dx = ctx.needs_input_grad[0]
+        dws = None
+        acc = None
+        if ctx.cs_short is None:
+            acc = dshort  # gradient of the identity shortcut
+        elif dshort is not None:
+            acc, dws, _ = _conv_backward(ctx.cs_short, dshort, need_dx, ctx.needs_input_grad[2], False)
+        dx, dw, _ = _conv_backward(ctx.cs_main, dy, need_dx, ctx.needs_input_grad[1], False,
+                                   accum=acc if need_dx else None)
+        return dx, dw, dws, None, None
+
+
+def conv2d_fork(x, conv_main, conv_short=None):
+    """(conv_main(x), conv_short(x) or x) with a fused input-gradient sum; both convs bias-free."""
+    _require_cuda(x, 'conv2d_fork')
+    x = as_nhwc(x, 'conv2d_fork')
+    if conv_main.bias is not None or (conv_short is not None and conv_short.bias is not None) or x.shape[1] % 4:
+        y = conv2d(x, conv_main.weight, conv_main.bias, conv_main.stride, conv_main.padding, conv_main.dilation)
+        s = x if conv_short is None else conv2d(x, conv_short.weight, conv_short.bias, conv_short.stride,
+                                                conv_short.padding, conv_short.dilation)
+        return y, s
+    cfg_m = (_pair(conv_main.stride), _pair(conv_main.padding), _pair(conv_main.dilation))
+    if conv_short is None:
+        return _ConvForkFn.apply(x, conv_main.weight, None, cfg_m, None)
+    cfg_s = (_pair(conv_short.stride), _pair(conv_short.padding), _pair(conv_short.dilation))
+    return _ConvForkFn.apply(x, conv_main.weight, conv_short.weight, cfg_m, cfg_s)
 
 
 # ------------------------------------------------------------------------------------ batch norm

@@ -7,6 +7,7 @@ conv -> [BN+ReLU] -> conv -> [BN+ReLU] -> conv -> [BN + identity add + ReLU].
 """
 import torch.nn as nn
 
+from ..hip import functional as HF
 from .layers import AdaptiveAvgPool2d, BatchNorm2d, Conv2d, HipSequential, MaxPool2d, ReLU
 
 __all__ = ['ResNet', 'BasicBlock', 'Bottleneck', 'resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152',
@@ -28,8 +29,13 @@ def _norm(norm_layer):
     raise NotImplementedError(f'ever_amd ResNet: norm_layer {norm_layer} has no HIP kernel (BatchNorm2d only)')
 
 
-def _shortcut(block, x):
-    return x if block.downsample is None else block.downsample[1](block.downsample[0](x))
+def _fork(block, x):
+    """(conv1(x), shortcut) — the block input feeds both; one autograd node so that the two input
+    gradients are summed inside the data-gradient kernel (hip/functional.py:_ConvForkFn)."""
+    if block.downsample is None:
+        return HF.conv2d_fork(x, block.conv1)
+    h, s = HF.conv2d_fork(x, block.conv1, block.downsample[0])
+    return h, block.downsample[1](s)
 
 
 class BasicBlock(nn.Module):
@@ -52,8 +58,9 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = self.bn1(self.conv1(x), relu=True)
-        return self.bn2(self.conv2(out), residual=_shortcut(self, x), relu=True)
+        h, shortcut = _fork(self, x)
+        out = self.bn1(h, relu=True)
+        return self.bn2(self.conv2(out), residual=shortcut, relu=True)
 
 
 class Bottleneck(nn.Module):
@@ -75,9 +82,10 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = self.bn1(self.conv1(x), relu=True)
+        h, shortcut = _fork(self, x)
+        out = self.bn1(h, relu=True)
         out = self.bn2(self.conv2(out), relu=True)
-        return self.bn3(self.conv3(out), residual=_shortcut(self, x), relu=True)
+        return self.bn3(self.conv3(out), residual=shortcut, relu=True)
 
 
 class ResNet(nn.Module):

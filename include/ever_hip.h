@@ -65,9 +65,11 @@ int evk_conv2d_fwd(const evk_conv_desc* d, const float* x, const float* w, const
 /* dx = conv_transpose(dy, w)  (autograd of nn.Conv2d wrt input; aten::convolution_backward).
  * wt is the weight re-packed by evk_conv2d_pack_dgrad_weight: [Cin][kh][kw][Cout] (K = taps x Cout
  * contiguous per input channel).
- * dx is fully overwritten. */
-int evk_conv2d_dgrad(const evk_conv_desc* d, const float* dy, const float* wt, float* dx,
-                     void* stream);
+ * dx is fully overwritten.  `accum` folds the sum with another gradient of the same tensor (the
+ * residual branch of a ResNet block) into the epilogue instead of a separate add pass. */
+int evk_conv2d_dgrad(const evk_conv_desc* d, const float* dy, const float* wt,
+                     const float* accum /* NULL, or a tensor of dx's shape: dx = dgrad + accum */,
+                     float* dx, void* stream);
 int evk_conv2d_pack_dgrad_weight(const evk_conv_desc* d, const float* w, float* wt, void* stream);
 
 /* dw[Cout][kh][kw][Cin] = sum_pixels dy (x) im2col(x); dbias[Cout] = sum_pixels dy (dbias may be

@@ -65,7 +65,7 @@ def main():
         gf = 2.0 * n * ho * wo * cout * cin * k * k / 1e9
         tf = timeit(lambda: _C.call('evk_conv2d_fwd', ctypes.byref(d), x.data_ptr(), wt.data_ptr(), None, y.data_ptr(), 0, st))
         _C.call('evk_conv2d_pack_dgrad_weight', ctypes.byref(d), wt.data_ptr(), wtt.data_ptr(), st)
-        td = timeit(lambda: _C.call('evk_conv2d_dgrad', ctypes.byref(d), dy.data_ptr(), wtt.data_ptr(), dx.data_ptr(), st))
+        td = timeit(lambda: _C.call('evk_conv2d_dgrad', ctypes.byref(d), dy.data_ptr(), wtt.data_ptr(), None, dx.data_ptr(), st))
         tw = timeit(lambda: _C.call('evk_conv2d_wgrad', ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None,
                                     ws.data_ptr(), ws_bytes, st))
         print(f'{name:22s} {gf:8.1f} | {tf*1e3:8.3f} {gf/tf/1e3:6.1f} | {td*1e3:8.3f} {gf/td/1e3:6.1f} | {tw*1e3:8.3f} {gf/tw/1e3:6.1f}')

@@ -38,7 +38,7 @@ for cnt, h, w, cin, cout, k, s, p in L:
         t = timeit(lambda: _C.call('evk_conv2d_fwd', ctypes.byref(d), x.data_ptr(), wt.data_ptr(), None, y.data_ptr(), 0, st))
     else:
         _C.call('evk_conv2d_pack_dgrad_weight', ctypes.byref(d), wt.data_ptr(), wtt.data_ptr(), st)
-        t = timeit(lambda: _C.call('evk_conv2d_dgrad', ctypes.byref(d), dy.data_ptr(), wtt.data_ptr(), dx.data_ptr(), st))
+        t = timeit(lambda: _C.call('evk_conv2d_dgrad', ctypes.byref(d), dy.data_ptr(), wtt.data_ptr(), None, dx.data_ptr(), st))
     rows.append((cnt*t, f'{cnt}x {h}x{w} {cin}->{cout} k{k}s{s}: {t*1e3:.3f} ms {gf/t/1e3:.1f} TF  (x{cnt} = {cnt*t*1e3:.2f} ms)'))
     tot_t += cnt*t; tot_gf += cnt*gf
 for _, r in sorted(rows, reverse=True)[:int(os.environ.get('TOP', 12))]: print(r)
