@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-in MFMA peak (= fp32 vector peak)
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable on a float4 copy)
 GF_FWD_BWD_PER_TILE = 342.7     # conv GFLOP fwd+bwd per 512x512x3 tile, default head
 TILE, BANDS, BATCH = 512, 3, 16
 
@@ -207,6 +208,16 @@ def main():
                                           'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                           'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                                           'avg_launch_us': round(wg['seconds'] / wg['launches'] * 1e6, 2)}
+            for fam_name, label in (('bn', 'evk::bn_* (BatchNorm+residual+ReLU forward/backward passes)'),
+                                    ('resample_loss', 'evk::bilinear_fwd/bwd + bce/dice kernels (upsample x2/x4, pixel losses)')):
+                hb = fam.get(fam_name)
+                if hb and hb['seconds'] > 0:
+                    gbs = hb['bytes'] / hb['seconds'] / 1e9
+                    line['roofline_hbm_' + fam_name] = {
+                        'bound': 'hbm', 'kernel': label, 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                        'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': None,
+                        'algorithmic_bytes_per_call': round(hb['bytes'] / hb['launches']),
+                        'avg_call_us': round(hb['seconds'] / hb['launches'] * 1e6, 2)}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)

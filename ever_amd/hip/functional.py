@@ -35,6 +35,15 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def _timed_call(family, nbytes, name, *args):
+    """_C.call bracketed by HIP events when bench.py's KernelTimer is active (HBM-bound families:
+    `nbytes` = algorithmic bytes of the call)."""
+    sp = timing.span(family, 0.0, nbytes)
+    _C.call(name, *args)
+    if sp is not None:
+        sp.stop()
+
+
 def _require_cuda(t, what):
     if not t.is_cuda:
         raise HipPathError(
@@ -343,12 +352,14 @@ class _BatchNormActFn(Function):
         save_mean = torch.empty((c,), device=dev, dtype=torch.float32)
         save_invstd = torch.empty((c,), device=dev, dtype=torch.float32)
         flags = 1 if relu else 0
+        # algorithmic bytes (fp32): statistics read + apply read/write (+ residual read)
+        nb = 4.0 * x.numel() * ((3 if training else 2) + (1 if residual is not None else 0))
         if training:
-            _C.call('evk_bn_fwd_train', x.data_ptr(), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(running_mean),
+            _timed_call('bn', nb, 'evk_bn_fwd_train', x.data_ptr(), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(running_mean),
                     _ptr(running_var), float(momentum), float(eps), y.data_ptr(), save_mean.data_ptr(),
                     save_invstd.data_ptr(), rows, c, flags, ws.data_ptr(), ws_bytes, st)
         else:
-            _C.call('evk_bn_fwd_eval', x.data_ptr(), _ptr(residual), _ptr(weight), _ptr(bias), running_mean.data_ptr(),
+            _timed_call('bn', nb, 'evk_bn_fwd_eval', x.data_ptr(), _ptr(residual), _ptr(weight), _ptr(bias), running_mean.data_ptr(),
                     running_var.data_ptr(), float(eps), y.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(),
                     rows, c, flags, ws.data_ptr(), ws_bytes, st)
         ctx.training = training
@@ -377,7 +388,9 @@ class _BatchNormActFn(Function):
         has_affine = weight is not None
         dgamma = torch.empty((c,), device=dev, dtype=torch.float32) if has_affine else None
         dbeta = torch.empty((c,), device=dev, dtype=torch.float32) if has_affine else None
-        _C.call('evk_bn_bwd', dy.data_ptr(), x.data_ptr(), _ptr(y), _ptr(weight), _ptr(bias), save_mean.data_ptr(),
+        # reduce pass reads dy, x (+y mask); apply pass reads g, x and writes dx (+ the residual gradient write)
+        nb = 4.0 * x.numel() * (5 + (1 if y is not None else 0) + (1 if need_res else 0))
+        _timed_call('bn', nb, 'evk_bn_bwd', dy.data_ptr(), x.data_ptr(), _ptr(y), _ptr(weight), _ptr(bias), save_mean.data_ptr(),
                 save_invstd.data_ptr(), dx.data_ptr(), _ptr(dres), _ptr(dgamma), _ptr(dbeta), rows, c,
                 1 if ctx.relu else 0, 1 if ctx.training else 0, ws.data_ptr(), ws_bytes, st)
         if ctx.has_res and not need_res:
@@ -517,7 +530,8 @@ class _BilinearFn(Function):
     def forward(ctx, x, ho, wo):
         n, c, h, w = x.shape
         y = empty_nhwc(n, c, ho, wo, x.device)
-        _C.call('evk_upsample_bilinear_fwd', x.data_ptr(), y.data_ptr(), n, h, w, ho, wo, c, _stream())
+        _timed_call('resample_loss', 4.0 * (x.numel() + y.numel()), 'evk_upsample_bilinear_fwd', x.data_ptr(),
+                    y.data_ptr(), n, h, w, ho, wo, c, _stream())
         ctx.dims = (n, c, h, w, ho, wo)
         return y
 
@@ -527,7 +541,8 @@ class _BilinearFn(Function):
         n, c, h, w, ho, wo = ctx.dims
         dy = as_nhwc(dy, 'bilinear.backward')
         dx = empty_nhwc(n, c, h, w, dy.device)
-        _C.call('evk_upsample_bilinear_bwd', dy.data_ptr(), dx.data_ptr(), n, h, w, ho, wo, c, _stream())
+        _timed_call('resample_loss', 4.0 * (dy.numel() + dx.numel()), 'evk_upsample_bilinear_bwd', dy.data_ptr(),
+                    dx.data_ptr(), n, h, w, ho, wo, c, _stream())
         return dx, None, None
 
 
@@ -652,7 +667,7 @@ class _BceFn(Function):
         npix = logits.numel()
         stats = _stats_buf(2, logits.device)
         loss = torch.empty((), device=logits.device, dtype=torch.float32)
-        _C.call('evk_bce_fwd', logits.data_ptr(), labels.data_ptr(), npix, ignore_index, eps, loss.data_ptr(),
+        _timed_call('resample_loss', 12.0 * npix, 'evk_bce_fwd', logits.data_ptr(), labels.data_ptr(), npix, ignore_index, eps, loss.data_ptr(),
                 stats.data_ptr(), _stream())
         ctx.save_for_backward(logits, labels, stats)
         ctx.ignore_index = ignore_index
@@ -665,7 +680,7 @@ class _BceFn(Function):
         logits, labels, stats = ctx.saved_tensors
         g = g.contiguous().float()
         d = torch.empty_like(logits)
-        _C.call('evk_bce_bwd', logits.data_ptr(), labels.data_ptr(), logits.numel(), ctx.ignore_index, ctx.eps,
+        _timed_call('resample_loss', 16.0 * logits.numel(), 'evk_bce_bwd', logits.data_ptr(), labels.data_ptr(), logits.numel(), ctx.ignore_index, ctx.eps,
                 stats.data_ptr(), g.data_ptr(), d.data_ptr(), 0, _stream())
         return d, None, None, None
 
@@ -691,7 +706,7 @@ class _DiceFn(Function):
         npix = n * h * w
         stats = _stats_buf(2 * c, logits.device)
         st = _stream()
-        _C.call('evk_dice_stats', logits.data_ptr(), labels.data_ptr(), npix, c, ignore_index, stats.data_ptr(), st)
+        _timed_call('resample_loss', (4.0 * c + 8.0) * npix, 'evk_dice_stats', logits.data_ptr(), labels.data_ptr(), npix, c, ignore_index, stats.data_ptr(), st)
         world = 1
         if sync:
             import torch.distributed as dist
@@ -717,7 +732,7 @@ class _DiceFn(Function):
             g = g.clone()
             dist.all_reduce(g)
         d = torch.empty_like(logits)
-        _C.call('evk_dice_bwd', logits.data_ptr(), labels.data_ptr(), n * h * w, c, ignore_index, stats.data_ptr(),
+        _timed_call('resample_loss', (8.0 * c + 8.0) * n * h * w, 'evk_dice_bwd', logits.data_ptr(), labels.data_ptr(), n * h * w, c, ignore_index, stats.data_ptr(),
                 smooth, ignore_channel, g.data_ptr(), d.data_ptr(), 0, _stream())
         return d, None, None, None, None, None
 
