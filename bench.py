@@ -28,6 +28,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-in MFMA peak (= fp32 vector peak)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
+X3_PASSES = 6                   # bf16 MFMA partial products per fp32 product in the split kernels
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable on a float4 copy)
 GF_FWD_BWD_PER_TILE = 342.7     # conv GFLOP fwd+bwd per 512x512x3 tile, default head
 TILE, BANDS, BATCH = 512, 3, 16
@@ -40,6 +42,8 @@ def parse():
     p.add_argument('--warmup', type=int, default=5)
     p.add_argument('--batch', type=int, default=BATCH, help='tiles per GPU (default: the BASELINE config)')
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--conv-math', choices=['bf16x3', 'f32'], default=None,
+                   help='convolution arithmetic (default: ever_amd default = bf16x3 split MFMA; f32 = exact fp32 MFMA)')
     p.add_argument('--no-kernel-timer', action='store_true')
     return p.parse_args()
 
@@ -129,6 +133,10 @@ def main():
     import ever_amd as er
     from ever_amd import _C
     from ever_amd.hip import timing
+    from ever_amd.hip import functional as HF
+    if args.conv_math:
+        HF.set_conv_math(args.conv_math)
+    conv_math = HF.get_conv_math()
     _C.load()
 
     torch.manual_seed(2333)
@@ -185,28 +193,39 @@ def main():
                                    f'batch {args.batch}/GPU, fwd+bwd+SGD step, inputs resident in HBM',
                        'global_batch': world * args.batch, 'tile': [BANDS, TILE, TILE],
                        'parallelism': f'dp{world}' if world > 1 else 'single',
+                       'arithmetic': ('fp32 in / fp32 accumulate / fp32 out; conv products from an exact 3-term bf16 split, '
+                                      '6 bf16-MFMA partial products each (error < 2^-24 per product)') if conv_math == 'bf16x3'
+                       else 'fp32 MFMA (exact fmaf chain)',
                        'whole_model_tflops': round(tiles_s * GF_FWD_BWD_PER_TILE / 1e3 / world, 2)},
         }
         if timer is not None:
             fam = timer.summary()
-            ig = fam.get('conv_igemm')
+            x3 = conv_math == 'bf16x3'
+            # split kernels: every algorithmic fp32 FLOP costs X3_PASSES bf16 MFMA FLOPs, so the roofline for
+            # algorithmic FLOP/s is the dense bf16 MFMA peak / X3_PASSES
+            peak = PEAK_BF16_MFMA_TFLOPS / X3_PASSES if x3 else PEAK_FP32_MFMA_TFLOPS
+            peak_note = (f'dense bf16 MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} TF / {X3_PASSES} partial products per fp32 product'
+                         if x3 else 'dense f32-input MFMA peak (v_mfma_f32_32x32x2_f32)')
+            ig = fam.get('conv_igemm' if x3 else 'conv_igemm_f32')
             if ig:
                 ach = ig['flops'] / ig['seconds'] / 1e12
                 line['roofline'] = {
-                    'bound': 'mfma', 'kernel': 'evk::conv_igemm_kernel (conv forward + data-gradient launches)',
-                    'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic('conv_igemm'),
+                    'bound': 'mfma', 'kernel': ('evk::conv_igemm_x3_kernel' if x3 else 'evk::conv_igemm_kernel') +
+                    ' (conv forward + data-gradient launches)',
+                    'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'peak_note': peak_note,
+                    'frac': round(ach / peak, 4), 'traffic': pmc_traffic('conv_igemm'),
                     'traffic_unit': 'HBM bytes per launch (PMC, profiles/r01_traffic.json)',
                     'algorithmic_bytes_per_launch': round(ig['bytes'] / ig['launches']),
                     'launches_per_step': ig['launches'] // max(1, sampled), 'sampled_steps': sampled,
                     'avg_launch_us': round(ig['seconds'] / ig['launches'] * 1e6, 2),
                     'algorithmic_gflop_per_launch': round(ig['flops'] / ig['launches'] / 1e9, 3)}
-            wg = fam.get('conv_wgrad')
+            wg = fam.get('conv_wgrad' if x3 else 'conv_wgrad_f32')
             if wg:
                 ach = wg['flops'] / wg['seconds'] / 1e12
-                line['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'evk::conv_wgrad_kernel (+split-K reduce)',
-                                          'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                                          'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                line['roofline_wgrad'] = {'bound': 'mfma', 'kernel': ('evk::conv_wgrad_x3_kernel' if x3 else
+                                                                      'evk::conv_wgrad_kernel') + ' (+split-K reduce)',
+                                          'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                                          'frac': round(ach / peak, 4),
                                           'avg_launch_us': round(wg['seconds'] / wg['launches'] * 1e6, 2)}
             for fam_name, label in (('bn', 'evk::bn_* (BatchNorm+residual+ReLU forward/backward passes)'),
                                     ('resample_loss', 'evk::bilinear_fwd/bwd + bce/dice kernels (upsample x2/x4, pixel losses)')):

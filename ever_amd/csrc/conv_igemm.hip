@@ -28,28 +28,9 @@
 // The gather is branch-free: every 16-byte load is issued from a clamped (valid) 32-bit element
 // offset and the zero fill is applied when the chunk is written to LDS, after the MFMA block, so the
 // prefetch stays in flight under the MFMAs.
-#include "common.hpp"
+#include "igemm_common.hpp"
 
 namespace evk {
-
-struct IGemmArgs {
-  const float* src;
-  const float* wgt;
-  const float* bias;
-  const float* accum;       // optional tensor with dst's shape, added in the epilogue (dst = conv + accum)
-  float* dst;
-  int N, Hs, Ws, Cs;        // gathered tensor
-  int Hm, Wm;               // GEMM-row grid
-  int Cd;                   // GEMM N
-  int kh, kw, cpt;          // taps of this launch; cpt = Cs/4 (16-byte chunks per tap)
-  int ash, asw;             // row-grid -> source scale
-  int oy0, oys, ox0, oxs;   // tap -> source offset (affine)
-  int M, Ktot;
-  int Hd, Wd, dsh, dsw, doy, dox;  // destination pixel = (gy*dsh + doy, gx*dsw + dox) in [N,Hd,Wd,Cd]
-  int dense_dst;            // 1 => dst row offset = m*Cd
-  int relu;
-  int tiles_m, tiles_n;
-};
 
 constexpr int BK = 32;
 constexpr int kInvalidRow = -(1 << 28);  // y0 of a row past M: every tap fails the bounds test
@@ -65,13 +46,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IGemmArgs p) {
   float* As = smem;                  // [2][BM][32]
   float* Bs = smem + 2 * BM * BK;    // [2][BN][32]
 
-  // XCD-aware tile order: consecutive tile ids (sharing A rows / weights) stay on one XCD's L2.
-  const int nwg = gridDim.x;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-  }
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = bid % p.tiles_n;
   const int tile_m = bid / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -239,50 +214,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IGemmArgs p) {
     __syncthreads();
   }
 
-  // ---- epilogue.  The MFMAs were issued as D = W_tile * X_tile^T, so a lane holds ONE pixel
-  // (column lane&31) and, per accumulator quad r4, FOUR consecutive output channels
-  // co = 8*r4 + 4*(lane>>5) + {0..3}: one 16-byte store per quad (4x fewer store instructions than
-  // the row-per-register layout; the small-K 1x1 convolutions are store-issue bound).
-#pragma unroll
-  for (int a = 0; a < MB; ++a) {
-    const int row = m0 + wm * WM + a * 32 + li;
-    if (row >= p.M) continue;
-    size_t roff;
-    if (p.dense_dst) {
-      roff = (size_t)row * p.Cd;
-    } else {
-      const int hw = p.Hm * p.Wm;
-      const int n = row / hw;
-      const int rem = row - n * hw;
-      const int gy = rem / p.Wm;
-      const int gx = rem - gy * p.Wm;
-      roff = (((size_t)n * p.Hd + (size_t)(gy * p.dsh + p.doy)) * p.Wd + (size_t)(gx * p.dsw + p.dox)) * p.Cd;
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int col = n0 + wn * WN + b * 32 + 8 * r4 + 4 * lh;
-        f32x4 v = {acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
-        if (col + 3 < p.Cd && (p.Cd & 3) == 0) {
-          if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
-          if (p.accum) v += *reinterpret_cast<const f32x4*>(p.accum + roff + col);
-          if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          *reinterpret_cast<f32x4*>(p.dst + roff + col) = v;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (col + e < p.Cd) {
-              float s = v[e];
-              if (p.bias) s += p.bias[col + e];
-              if (p.accum) s += p.accum[roff + col + e];
-              if (p.relu) s = fmaxf(s, 0.f);
-              p.dst[roff + col + e] = s;
-            }
-        }
-      }
-    }
-  }
+  igemm_epilogue<MB, NB, WM, WN>(p, acc, m0, n0, wm, wn, li, lh);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -390,13 +322,8 @@ static int check_desc(const evk_conv_desc* d) {
   return EVK_OK;
 }
 
-// One axis of the strided data gradient, for input pixels congruent to c (mod stride):
-// taps k = k0 + j*kstep (j < nt) reach them, from source row  g + o0 + j*ostep.
-struct AxisPlan {
-  int k0, kstep, nt, o0, ostep;
-};
 static int gcd_i(int a, int b) { return b == 0 ? a : gcd_i(b, a % b); }
-static AxisPlan plan_axis(int c, int pad, int dil, int stride, int ksize) {
+AxisPlan plan_axis(int c, int pad, int dil, int stride, int ksize) {
   AxisPlan ap{0, 1, 0, 0, 0};
   const int g = gcd_i(dil, stride);
   if ((c + pad) % g != 0) return ap;  // no tap reaches this class
@@ -416,13 +343,16 @@ static AxisPlan plan_axis(int c, int pad, int dil, int stride, int ksize) {
 
 using namespace evk;
 
-extern "C" int evk_conv2d_fwd(const evk_conv_desc* d, const float* x, const float* w, const float* bias,
-                              float* y, uint32_t flags, void* stream) {
+static inline int kpad32(int k) { return (k + 31) & ~31; }
+
+// w3 != nullptr selects the bf16-split kernel (conv_igemm_x3.hip) on pre-split weight planes
+static int conv_fwd_any(const evk_conv_desc* d, const float* x, const float* w, const uint16_t* w3, const float* bias,
+                        float* y, uint32_t flags, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
-  EVK_REQUIRE(x && w && y, EVK_E_INVALID, "conv2d_fwd: null pointer");
+  EVK_REQUIRE(x && (w || w3) && y, EVK_E_INVALID, "conv2d_fwd: null pointer");
   IGemmArgs a{};
-  a.src = x; a.wgt = w; a.bias = bias; a.dst = y;
+  a.src = x; a.wgt = w; a.wgt3 = w3; a.bias = bias; a.dst = y;
   a.N = d->N; a.Hs = d->H; a.Ws = d->W; a.Cs = d->Cin;
   a.Hm = d->Ho; a.Wm = d->Wo; a.Cd = d->Cout;
   a.kh = d->kh; a.kw = d->kw; a.cpt = d->Cin / 4;
@@ -432,14 +362,26 @@ extern "C" int evk_conv2d_fwd(const evk_conv_desc* d, const float* x, const floa
   a.Ktot = d->kh * d->kw * d->Cin;
   a.Hd = d->Ho; a.Wd = d->Wo; a.dsh = 1; a.dsw = 1; a.dense_dst = 1;
   a.relu = (flags & EVK_CONV_RELU) ? 1 : 0;
-  return launch_igemm(a, (hipStream_t)stream);
+  a.Kpad = kpad32(a.Ktot);
+  return w3 ? launch_igemm_x3(a, (hipStream_t)stream) : launch_igemm(a, (hipStream_t)stream);
 }
 
-extern "C" int evk_conv2d_dgrad(const evk_conv_desc* d, const float* dy, const float* wt, const float* accum,
-                                float* dx, void* stream) {
+extern "C" int evk_conv2d_fwd(const evk_conv_desc* d, const float* x, const float* w, const float* bias,
+                              float* y, uint32_t flags, void* stream) {
+  return conv_fwd_any(d, x, w, nullptr, bias, y, flags, stream);
+}
+
+extern "C" int evk_conv2d_fwd_x3(const evk_conv_desc* d, const float* x, const void* wsplit, const float* bias,
+                                 float* y, uint32_t flags, void* stream) {
+  EVK_REQUIRE(wsplit, EVK_E_INVALID, "conv2d_fwd_x3: null weight planes");
+  return conv_fwd_any(d, x, nullptr, reinterpret_cast<const uint16_t*>(wsplit), bias, y, flags, stream);
+}
+
+static int conv_dgrad_any(const evk_conv_desc* d, const float* dy, const float* wt, const uint16_t* wt3,
+                          const float* accum, float* dx, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
-  EVK_REQUIRE(dy && wt && dx, EVK_E_INVALID, "conv2d_dgrad: null pointer");
+  EVK_REQUIRE(dy && (wt || wt3) && dx, EVK_E_INVALID, "conv2d_dgrad: null pointer");
   EVK_REQUIRE(d->Cout % 4 == 0, EVK_E_UNSUPPORTED, "conv2d_dgrad: Cout=%d must be a multiple of 4", d->Cout);
   hipStream_t st = (hipStream_t)stream;
   const int sh = d->stride_h, sw = d->stride_w;
@@ -453,7 +395,8 @@ extern "C" int evk_conv2d_dgrad(const evk_conv_desc* d, const float* dy, const f
     hipError_t e = accum ? hipMemcpyAsync(dx, accum, bytes, hipMemcpyDeviceToDevice, st) : hipMemsetAsync(dx, 0, bytes, st);
     if (e != hipSuccess) { set_error("conv2d_dgrad fill: %s", hipGetErrorString(e)); return EVK_E_LAUNCH; }
   }
-  size_t woff = 0;  // class weights are packed back to back by evk_conv2d_pack_dgrad_weight
+  size_t woff = 0;   // class weights are packed back to back by evk_conv2d_pack_dgrad_weight
+  size_t woff3 = 0;  // ... and the class planes by evk_conv2d_split_weight(for_dgrad = 1)
   for (int cy = 0; cy < sh; ++cy)
     for (int cx = 0; cx < sw; ++cx) {
       const AxisPlan py = plan_axis(cy, d->pad_h, d->dil_h, sh, d->kh);
@@ -463,7 +406,8 @@ extern "C" int evk_conv2d_dgrad(const evk_conv_desc* d, const float* dy, const f
       const size_t wsize = (size_t)d->Cin * py.nt * px.nt * d->Cout;
       if (py.nt > 0 && px.nt > 0 && Hm > 0 && Wm > 0) {
         IGemmArgs a{};
-        a.src = dy; a.wgt = wt + woff; a.bias = nullptr; a.accum = accum; a.dst = dx;
+        a.src = dy; a.wgt = wt ? wt + woff : nullptr; a.wgt3 = wt3 ? wt3 + woff3 : nullptr;
+        a.bias = nullptr; a.accum = accum; a.dst = dx;
         a.N = d->N; a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Cout;
         a.Hm = Hm; a.Wm = Wm; a.Cd = d->Cin;
         a.kh = py.nt; a.kw = px.nt; a.cpt = d->Cout / 4;
@@ -474,12 +418,25 @@ extern "C" int evk_conv2d_dgrad(const evk_conv_desc* d, const float* dy, const f
         a.Hd = d->H; a.Wd = d->W; a.dsh = sh; a.dsw = sw; a.doy = cy; a.dox = cx;
         a.dense_dst = (sh == 1 && sw == 1) ? 1 : 0;
         a.relu = 0;
-        rc = launch_igemm(a, st);
+        a.Kpad = kpad32(a.Ktot);
+        rc = wt3 ? launch_igemm_x3(a, st) : launch_igemm(a, st);
         if (rc) return rc;
       }
       woff += wsize;
+      woff3 += (size_t)3 * d->Cin * kpad32(py.nt * px.nt * d->Cout);
     }
   return EVK_OK;
+}
+
+extern "C" int evk_conv2d_dgrad(const evk_conv_desc* d, const float* dy, const float* wt, const float* accum,
+                                float* dx, void* stream) {
+  return conv_dgrad_any(d, dy, wt, nullptr, accum, dx, stream);
+}
+
+extern "C" int evk_conv2d_dgrad_x3(const evk_conv_desc* d, const float* dy, const void* wsplit_t, const float* accum,
+                                   float* dx, void* stream) {
+  EVK_REQUIRE(wsplit_t, EVK_E_INVALID, "conv2d_dgrad_x3: null weight planes");
+  return conv_dgrad_any(d, dy, nullptr, reinterpret_cast<const uint16_t*>(wsplit_t), accum, dx, stream);
 }
 
 // Class-ordered data-gradient weights: for each residue class (cy, cx) in row-major order a block

@@ -11,25 +11,10 @@
 // so tiles are staged [32 pixels][BM or BN channels] without any transpose.  The pixel range is
 // split across workgroups (grid.z); partial tiles go to the caller's workspace and are summed in a
 // fixed order by a second kernel => bitwise reproducible, no atomics.
-#include "common.hpp"
+#include "wgrad_common.hpp"
 #include <stdlib.h>
 
 namespace evk {
-
-struct WGradArgs {
-  const float* x;
-  const float* dy;
-  float* out;  // dw (splitk==1) or workspace [splitk][Cout][Ktot]
-  int N, H, W, Cin, Ho, Wo, Cout;
-  int kh, kw, cpt;
-  int sh, sw, ph, pw, dh, dw;
-  int M, Ktot;
-  int chunk;  // pixels per split (multiple of 32)
-  int tiles_co, tiles_k, splitk;
-  FastDiv fd_hw, fd_w;
-};
-
-constexpr int BKP = 32;  // pixels per step
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGradArgs p) {
@@ -246,10 +231,7 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
   }
 }
 
-struct WGradPlan {
-  int bm, bn, tiles_co, tiles_k, splitk, chunk;
-};
-static WGradPlan plan_wgrad(const evk_conv_desc* d) {
+WGradPlan plan_wgrad(const evk_conv_desc* d, int x3) {
   WGradPlan pl;
   const int Ktot = d->kh * d->kw * d->Cin;
   const int M = d->N * d->Ho * d->Wo;
@@ -264,7 +246,9 @@ static WGradPlan plan_wgrad(const evk_conv_desc* d) {
   static const int rounds = getenv("EVK_WG_ROUNDS") ? atoi(getenv("EVK_WG_ROUNDS")) : 1;
   static const int min_chunk = getenv("EVK_WG_MINCHUNK") ? atoi(getenv("EVK_WG_MINCHUNK")) : 256;
   const int lds_kb = 2 * BKP * (pl.bm + pl.bn) * 4 / 1024;
-  const int per_cu = lds_kb >= 64 ? 2 : (lds_kb >= 48 ? 3 : 4);
+  // split kernel: single-buffered 3-plane bf16 stage (48 KB at 128x128), residency set by its VGPRs
+  const int per_cu = x3 ? (pl.bm + pl.bn >= 256 ? 3 : 4)
+                        : (lds_kb >= 64 ? 2 : (lds_kb >= 48 ? 3 : 4));
   const int slots = 256 * per_cu;
   int maxsplit = ceil_div(M, min_chunk);  // at least min_chunk pixels per split
   int sk = (rounds * slots) / tiles;      // floor: never spill into an extra, nearly empty round
@@ -293,28 +277,30 @@ static int launch_wgrad(const WGradArgs& a, hipStream_t stream) {
 
 using namespace evk;
 
-extern "C" size_t evk_conv2d_wgrad_workspace_bytes(const evk_conv_desc* d) {
+static size_t wgrad_ws_bytes(const evk_conv_desc* d, int x3) {
   if (!d) return 0;
-  const WGradPlan pl = plan_wgrad(d);
+  const WGradPlan pl = plan_wgrad(d, x3);
   const size_t Ktot = (size_t)d->kh * d->kw * d->Cin;
   size_t a = pl.splitk > 1 ? (size_t)pl.splitk * d->Cout * Ktot * sizeof(float) : 0;
   size_t b = (size_t)colsum_blocks((int64_t)d->N * d->Ho * d->Wo) * d->Cout * sizeof(float);
   return (a > b ? a : b) + 256;
 }
 
-extern "C" int evk_conv2d_wgrad(const evk_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
-                                void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" size_t evk_conv2d_wgrad_workspace_bytes(const evk_conv_desc* d) { return wgrad_ws_bytes(d, 0); }
+extern "C" size_t evk_conv2d_wgrad_x3_workspace_bytes(const evk_conv_desc* d) { return wgrad_ws_bytes(d, 1); }
+
+static int conv_wgrad_any(const evk_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                          void* workspace, size_t workspace_bytes, void* stream, int x3) {
   EVK_REQUIRE(d && x && dy && dw, EVK_E_INVALID, "conv2d_wgrad: null pointer");
   EVK_REQUIRE(d->Cin % 4 == 0 && d->Cout % 4 == 0, EVK_E_UNSUPPORTED,
               "conv2d_wgrad: Cin=%d and Cout=%d must be multiples of 4", d->Cin, d->Cout);
-  EVK_REQUIRE(workspace_bytes >= evk_conv2d_wgrad_workspace_bytes(d) && (workspace || workspace_bytes == 0),
-              EVK_E_WORKSPACE, "conv2d_wgrad: workspace %zu < %zu", workspace_bytes,
-              evk_conv2d_wgrad_workspace_bytes(d));
+  EVK_REQUIRE(workspace_bytes >= wgrad_ws_bytes(d, x3) && (workspace || workspace_bytes == 0), EVK_E_WORKSPACE,
+              "conv2d_wgrad: workspace %zu < %zu", workspace_bytes, wgrad_ws_bytes(d, x3));
   EVK_REQUIRE((long long)d->N * d->H * d->W * d->Cin < 0x7fffffffLL &&
                   (long long)d->N * d->Ho * d->Wo * d->Cout < 0x7fffffffLL,
               EVK_E_UNSUPPORTED, "conv2d_wgrad: tensors of 2^31 or more elements are not supported");
   hipStream_t st = (hipStream_t)stream;
-  const WGradPlan pl = plan_wgrad(d);
+  const WGradPlan pl = plan_wgrad(d, x3);
   WGradArgs a{};
   a.x = x; a.dy = dy;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
@@ -327,7 +313,8 @@ extern "C" int evk_conv2d_wgrad(const evk_conv_desc* d, const float* x, const fl
   a.fd_w = make_fastdiv((uint32_t)d->Wo);
   a.out = pl.splitk > 1 ? (float*)workspace : dw;
   int rc;
-  if (pl.bm == 128 && pl.bn == 128) rc = launch_wgrad<128, 128, 2, 2>(a, st);
+  if (x3) rc = launch_wgrad_x3(a, pl, st);
+  else if (pl.bm == 128 && pl.bn == 128) rc = launch_wgrad<128, 128, 2, 2>(a, st);
   else if (pl.bm == 64 && pl.bn == 128) rc = launch_wgrad<64, 128, 2, 2>(a, st);
   else if (pl.bm == 128 && pl.bn == 64) rc = launch_wgrad<128, 64, 2, 2>(a, st);
   else rc = launch_wgrad<64, 64, 2, 2>(a, st);
@@ -353,4 +340,15 @@ extern "C" int evk_conv2d_wgrad(const evk_conv_desc* d, const float* x, const fl
     rc = check_launch("colsum_final");
   }
   return rc;
+}
+
+extern "C" int evk_conv2d_wgrad(const evk_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  return conv_wgrad_any(d, x, dy, dw, dbias, workspace, workspace_bytes, stream, 0);
+}
+
+extern "C" int evk_conv2d_wgrad_x3(const evk_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  EVK_REQUIRE(d && d->Cin % 4 == 0 && d->Cout % 4 == 0, EVK_E_UNSUPPORTED, "conv2d_wgrad_x3: channels must be multiples of 4");
+  return conv_wgrad_any(d, x, dy, dw, dbias, workspace, workspace_bytes, stream, 1);
 }

@@ -1,0 +1,29 @@
+// Shared pieces of the weight-gradient kernels (fp32 MFMA and 3-way-bf16-split MFMA).
+#pragma once
+#include "common.hpp"
+
+namespace evk {
+
+struct WGradArgs {
+  const float* x;
+  const float* dy;
+  float* out;  // dw (splitk==1) or workspace [splitk][Cout][Ktot]
+  int N, H, W, Cin, Ho, Wo, Cout;
+  int kh, kw, cpt;
+  int sh, sw, ph, pw, dh, dw;
+  int M, Ktot;
+  int chunk;  // pixels per split (multiple of 32)
+  int tiles_co, tiles_k, splitk;
+  FastDiv fd_hw, fd_w;
+};
+
+constexpr int BKP = 32;  // pixels per step
+
+struct WGradPlan {
+  int bm, bn, tiles_co, tiles_k, splitk, chunk;
+};
+// x3 = 1: plan for the bf16-split kernel (different LDS footprint => different residency)
+WGradPlan plan_wgrad(const evk_conv_desc* d, int x3);
+int launch_wgrad_x3(const WGradArgs& a, const WGradPlan& pl, hipStream_t stream);
+
+}  // namespace evk

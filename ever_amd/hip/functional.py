@@ -7,6 +7,7 @@ OHWI memory.  There is no CPU implementation: a CPU tensor raises `HipPathError`
 Reference call sites replaced (ever/module/...): see the per-function docstrings.
 """
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -25,6 +26,26 @@ __all__ = [
 
 class HipPathError(RuntimeError):
     """Raised when the HIP path is asked to run on something it cannot (CPU tensor, wrong dtype)."""
+
+
+# Arithmetic of the convolution GEMMs.  Both are fp32 in, fp32 out, fp32 accumulate:
+#   'bf16x3' (default) each fp32 operand is split exactly into three bf16 terms and the product is rebuilt from
+#            six bf16 MFMA partial products (error per product < 2^-24: below one fp32 rounding), on the
+#            v_mfma_f32_32x32x16_bf16 pipe;
+#   'f32'    v_mfma_f32_32x32x2_f32, an exact fmaf chain (the parity yardstick for the split kernels).
+_CONV_MATH = os.environ.get('EVK_CONV_MATH', 'bf16x3')
+
+
+def set_conv_math(mode):
+    global _CONV_MATH
+    if mode not in ('bf16x3', 'f32'):
+        raise ValueError(f"conv math must be 'bf16x3' or 'f32', got {mode!r}")
+    prev, _CONV_MATH = _CONV_MATH, mode
+    return prev
+
+
+def get_conv_math():
+    return _CONV_MATH
 
 
 def _stream():
@@ -161,8 +182,17 @@ def _conv_forward(x, weight, bias, stride, padding, dilation, relu):
     cs.flops = 2.0 * n * d.Ho * d.Wo * cout * cin * kh * kw  # algorithmic (un-padded) FLOPs
     # algorithmic bytes: input + output + weights, each touched once
     cs.abytes = 4.0 * (n * h * w * cin + n * d.Ho * d.Wo * cout + cout * cin * kh * kw)
-    sp = timing.span('conv_igemm', cs.flops, cs.abytes)
-    _C.call('evk_conv2d_fwd', ctypes.byref(d), x_ptr, w_ptr, _ptr(bias), y.data_ptr(), 1 if relu else 0, st)
+    if _CONV_MATH == 'bf16x3' and cin_p == cin and cin % 8 == 0:
+        # weights -> three bf16 planes (transient: they change every optimiser step), then the split-MFMA kernel
+        lib = _C.load()
+        planes = workspace(dev, lib.evk_conv2d_split_weight_bytes(ctypes.byref(d), 0))
+        _C.call('evk_conv2d_split_weight', ctypes.byref(d), w_ptr, 0, planes.data_ptr(), st)
+        sp = timing.span('conv_igemm', cs.flops, cs.abytes)
+        _C.call('evk_conv2d_fwd_x3', ctypes.byref(d), x_ptr, planes.data_ptr(), _ptr(bias), y.data_ptr(),
+                1 if relu else 0, st)
+    else:
+        sp = timing.span('conv_igemm_f32', cs.flops, cs.abytes)
+        _C.call('evk_conv2d_fwd', ctypes.byref(d), x_ptr, w_ptr, _ptr(bias), y.data_ptr(), 1 if relu else 0, st)
     if sp is not None:
         sp.stop()
     cs.desc, cs.relu, cs.cin, cs.has_bias = d, relu, cin, bias is not None
@@ -198,7 +228,21 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None):
                      d.dil_h, d.dil_w)
     dx = dw = db = None
     taps = kh * kw
-    if need_dx:
+    x3 = _CONV_MATH == 'bf16x3'
+    if need_dx and x3 and cin_p == cin and cout_p == cout and cout % 8 == 0:
+        lib = _C.load()
+        planes = workspace(dev, lib.evk_conv2d_split_weight_bytes(ctypes.byref(dk), 1))
+        _C.call('evk_conv2d_split_weight', ctypes.byref(dk), w_ohwi.data_ptr(), 1, planes.data_ptr(), st)
+        acc_ptr = None
+        if accum is not None:
+            accum = as_nhwc(accum, 'conv2d.backward.accum')
+            acc_ptr = accum.data_ptr()
+        dx = empty_nhwc(n, cin, d.H, d.W, dev)
+        sp = timing.span('conv_igemm', cs.flops, cs.abytes)
+        _C.call('evk_conv2d_dgrad_x3', ctypes.byref(dk), dy_ptr, planes.data_ptr(), acc_ptr, dx.data_ptr(), st)
+        if sp is not None:
+            sp.stop()
+    elif need_dx:
         # weights as [cout_p][taps][cin_p]
         if cin_p != cin or cout_p != cout:
             wfull = torch.zeros((cout_p, taps, cin_p), device=dev, dtype=torch.float32)
@@ -217,7 +261,7 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None):
             accum = as_nhwc(accum, 'conv2d.backward.accum')
             acc_ptr = accum.data_ptr()
         dxk = empty_nhwc(n, cin_p, d.H, d.W, dev)
-        sp = timing.span('conv_igemm', cs.flops, cs.abytes)
+        sp = timing.span('conv_igemm_f32', cs.flops, cs.abytes)
         _C.call('evk_conv2d_dgrad', ctypes.byref(dk), dy_ptr, wt.data_ptr(), acc_ptr, dxk.data_ptr(), st)
         if sp is not None:
             sp.stop()
@@ -228,13 +272,14 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None):
             dx = dxk
     if need_dw or need_db:
         lib = _C.load()
-        ws_bytes = lib.evk_conv2d_wgrad_workspace_bytes(ctypes.byref(dk))
+        ws_bytes = (lib.evk_conv2d_wgrad_x3_workspace_bytes if x3 else lib.evk_conv2d_wgrad_workspace_bytes)(
+            ctypes.byref(dk))
         ws = workspace(dev, ws_bytes)
         dwk = torch.empty((cout_p, taps, cin_p), device=dev, dtype=torch.float32)
         dbk = torch.empty((cout_p,), device=dev, dtype=torch.float32) if need_db else None
-        sp = timing.span('conv_wgrad', cs.flops, cs.abytes)
-        _C.call('evk_conv2d_wgrad', ctypes.byref(dk), xk.data_ptr(), dy_ptr, dwk.data_ptr(), _ptr(dbk),
-                ws.data_ptr(), ws_bytes, st)
+        sp = timing.span('conv_wgrad' if x3 else 'conv_wgrad_f32', cs.flops, cs.abytes)
+        _C.call('evk_conv2d_wgrad_x3' if x3 else 'evk_conv2d_wgrad', ctypes.byref(dk), xk.data_ptr(), dy_ptr,
+                dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes, st)
         if sp is not None:
             sp.stop()
         if need_dw:

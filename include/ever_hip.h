@@ -72,6 +72,27 @@ int evk_conv2d_dgrad(const evk_conv_desc* d, const float* dy, const float* wt,
                      float* dx, void* stream);
 int evk_conv2d_pack_dgrad_weight(const evk_conv_desc* d, const float* w, float* wt, void* stream);
 
+/* The same two operations on the bf16 matrix pipe at fp32-grade accuracy ("x3": each fp32 operand is
+ * split exactly into three bf16 terms; six of the nine partial products — everything above 2^-26 of
+ * the product — are accumulated in fp32 by v_mfma_f32_32x32x16_bf16; 2.67x the MFMA rate of the exact
+ * fp32 form).  Same reference call sites as evk_conv2d_fwd / _dgrad.  Requires Cin % 8 == 0 (fwd) /
+ * Cout % 8 == 0 (dgrad).  The weight is pre-split once per optimiser step:
+ *   for_dgrad = 0: planes [3][Cout][Kpad] bf16, K = (ky,kx,ci), Kpad = K rounded up to 32, zero padded;
+ *   for_dgrad = 1: per residue class of the strided data gradient, planes [3][Cin][Kpad_c], K = (jy,jx,co),
+ *                  produced straight from the OHWI parameter (no evk_conv2d_pack_dgrad_weight needed). */
+size_t evk_conv2d_split_weight_bytes(const evk_conv_desc* d, int32_t for_dgrad);
+int evk_conv2d_split_weight(const evk_conv_desc* d, const float* w, int32_t for_dgrad, void* wsplit,
+                            void* stream);
+int evk_conv2d_fwd_x3(const evk_conv_desc* d, const float* x, const void* wsplit, const float* bias,
+                      float* y, uint32_t flags, void* stream);
+int evk_conv2d_dgrad_x3(const evk_conv_desc* d, const float* dy, const void* wsplit_t,
+                        const float* accum, float* dx, void* stream);
+/* weight / bias gradient in the same arithmetic: both operands (dy and im2col(x)) are split in registers
+ * while they are transposed into the pixel-contiguous LDS image the bf16 MFMA needs. */
+size_t evk_conv2d_wgrad_x3_workspace_bytes(const evk_conv_desc* d);
+int evk_conv2d_wgrad_x3(const evk_conv_desc* d, const float* x, const float* dy, float* dw,
+                        float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+
 /* dw[Cout][kh][kw][Cin] = sum_pixels dy (x) im2col(x); dbias[Cout] = sum_pixels dy (dbias may be
  * NULL).  Split over pixel ranges; partials go to `workspace` and are reduced deterministically. */
 size_t evk_conv2d_wgrad_workspace_bytes(const evk_conv_desc* d);

@@ -31,3 +31,12 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     return torch.device('cuda:0')
+
+
+@pytest.fixture(params=['bf16x3', 'f32'])
+def conv_math(request):
+    """Run the test under both convolution arithmetics (split-bf16 MFMA default, exact fp32 MFMA yardstick)."""
+    from ever_amd.hip import functional as HF
+    prev = HF.set_conv_math(request.param)
+    yield request.param
+    HF.set_conv_math(prev)

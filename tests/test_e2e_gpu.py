@@ -60,7 +60,7 @@ def _check_masks(lg, ref, num_classes, what):
 
 
 @pytest.mark.parametrize('name', ['r18_4band_64', 'r50_3band_64', 'r50_3band_128', 'r50_3band_64_c16'])
-def test_farseg_matches_reference_golden(cuda, name):
+def test_farseg_matches_reference_golden(cuda, name, conv_math):
     with open(os.path.join(GOLD, f'e2e_{name}.json')) as f:
         meta = json.load(f)
     gold = np.load(os.path.join(GOLD, f'e2e_{name}.npz'))

@@ -33,11 +33,14 @@ CONV_CASES = [
     (2, 128, 8, 8, 16, 3, 1, 1, 1, True),       # FarSeg-paper classifier 3x3, 16 classes
     (4, 2048, 1, 1, 256, 1, 1, 0, 1, True),     # scene MLP on 1x1 maps
     (1, 512, 9, 7, 520, 3, 1, 1, 1, False),     # Cout not a multiple of the N tile
+    (3, 72, 11, 13, 40, 3, 1, 1, 1, True),      # channels % 8 == 0 only, K = 648 not a multiple of 32 (K padding)
+    (2, 24, 24, 24, 264, 3, 2, 1, 1, False),    # stride-2 residue classes with a ragged N tile
+    (2, 64, 16, 8, 64, 3, 1, 1, 1, False),      # Wo % 8 == 0: single-decomposition wgrad gather
 ]
 
 
 @pytest.mark.parametrize('case', CONV_CASES)
-def test_conv2d_fwd_bwd(cuda, case):
+def test_conv2d_fwd_bwd(cuda, case, conv_math):
     from ever_amd.hip import functional as F
     n, cin, h, w, cout, k, s, p, d, bias = case
     g = torch.Generator().manual_seed(1234 + cin + cout + k)
@@ -61,6 +64,37 @@ def test_conv2d_fwd_bwd(cuda, case):
     _close(wg.grad, wr.grad, what='dw')
     if bias:
         _close(bg.grad, br.grad, what='db')
+
+
+def test_conv_split_matches_fp64_as_well_as_fp32_mfma(cuda):
+    """The split-bf16 kernels must be as close to an fp64 evaluation as the exact-fp32 MFMA kernels are
+    (forward, data gradient, weight gradient), on operands with a non-zero mean (no cancellation luck)."""
+    from ever_amd.hip import functional as F
+    g = torch.Generator().manual_seed(99)
+    n, cin, h, w, cout, k = 2, 256, 24, 24, 192, 3
+    x = torch.randn(n, cin, h, w, generator=g) + 0.5
+    wt = (torch.randn(cout, cin, k, k, generator=g) + 0.1) / (cin * k * k) ** 0.5
+    gy = torch.randn(n, cout, h, w, generator=g) + 0.25
+    x64, w64 = x.double().requires_grad_(), wt.double().requires_grad_()
+    y64 = TF.conv2d(x64, w64, None, padding=1)
+    y64.backward(gy.double())
+    errs = {}
+    for mode in ('f32', 'bf16x3'):
+        prev = F.set_conv_math(mode)
+        try:
+            xg = x.to(cuda).requires_grad_()
+            wg = wt.to(cuda).contiguous(memory_format=torch.channels_last).requires_grad_()
+            yg = F.conv2d(xg, wg, None, padding=1)
+            yg.backward(gy.to(cuda))
+            torch.cuda.synchronize()
+        finally:
+            F.set_conv_math(prev)
+        rel = lambda a, b: ((a.detach().cpu().double() - b).abs().max() / b.abs().max()).item()
+        errs[mode] = (rel(yg, y64.detach()), rel(xg.grad, x64.grad), rel(wg.grad, w64.grad))
+    print('max rel err vs fp64 (y, dx, dw):', errs)
+    for e32, e3 in zip(errs['f32'], errs['bf16x3']):
+        assert e3 <= 2.0 * e32 + 2e-7, errs
+        assert e3 < 5e-6, errs
 
 
 def test_conv2d_relu_epilogue(cuda):
