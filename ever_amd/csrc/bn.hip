@@ -79,9 +79,11 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
   }
 }
 
-// Sum the per-workgroup partials of 32 channels with 8 lanes per channel (coalesced 128-byte rows,
-// fp64), then fold the 8 lanes through LDS.  Returns true on the lane that holds the totals.
-constexpr int kFinCh = 32, kFinLanes = 8;
+// Sum the per-workgroup partials of 8 channels with 32 lanes per channel in fp64 (four independent loads
+// in flight per lane: the chain of up to 2048 partials per channel is latency bound, and a grid of C/8
+// workgroups instead of C/32 spreads it over more CUs), then fold the 32 lanes through LDS in a fixed
+// order.  Returns true on the lane that holds the totals.
+constexpr int kFinCh = 8, kFinLanes = 32;
 __device__ __forceinline__ bool reduce_partials(const float* __restrict__ partial, int nblk, int C, int& c, double& s,
                                                 double& q) {
   __shared__ double red[2][kFinLanes][kFinCh];
@@ -89,11 +91,23 @@ __device__ __forceinline__ bool reduce_partials(const float* __restrict__ partia
   c = blockIdx.x * kFinCh + tc;
   s = 0.0;
   q = 0.0;
-  if (c < C)
-    for (int b = tl; b < nblk; b += kFinLanes) {
-      s += (double)partial[(size_t)b * 2 * C + c];
-      q += (double)partial[(size_t)b * 2 * C + C + c];
+  if (c < C) {
+    const float* ps = partial + c;
+    const size_t st = (size_t)2 * C;
+    int b = tl;
+    for (; b + 3 * kFinLanes < nblk; b += 4 * kFinLanes) {
+      const float s0 = ps[b * st], s1 = ps[(b + kFinLanes) * st], s2 = ps[(b + 2 * kFinLanes) * st],
+                  s3 = ps[(b + 3 * kFinLanes) * st];
+      const float q0 = ps[b * st + C], q1 = ps[(b + kFinLanes) * st + C], q2 = ps[(b + 2 * kFinLanes) * st + C],
+                  q3 = ps[(b + 3 * kFinLanes) * st + C];
+      s += ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
+      q += ((double)q0 + (double)q1) + ((double)q2 + (double)q3);
     }
+    for (; b < nblk; b += kFinLanes) {
+      s += (double)ps[b * st];
+      q += (double)ps[b * st + C];
+    }
+  }
   red[0][tl][tc] = s;
   red[1][tl][tc] = q;
   __syncthreads();

@@ -257,6 +257,10 @@ int launch_igemm_x3(IGemmArgs& a, hipStream_t stream) {
     set_error("conv_igemm_x3: source channels (%d) must be a multiple of 8", a.Cs);
     return EVK_E_UNSUPPORTED;
   }
+  {
+    const int rc = launch_igemm_x3ws(a, stream);  // wave-specialised form for the large layers
+    if (rc != 1) return rc;
+  }
   const int bn = (a.Cd <= 64) ? 64 : 128;
   const long long tn = ceil_div(a.Cd, bn);
   auto tiles = [&](int bm) { return (long long)ceil_div(a.M, bm) * tn; };

@@ -1,0 +1,284 @@
+// Wave-specialised form of the bf16-split implicit-GEMM convolution (arithmetic: conv_igemm_x3.hip).
+//
+// One workgroup = 8 waves on one CU = 2 waves per SIMD with different jobs:
+//   waves 0-3  "matrix" waves: ds_read_b128 fragments + v_mfma_f32_32x32x16_bf16, nothing else.  One per
+//              SIMD, so each owns its SIMD's matrix pipe and issues MFMAs back to back.
+//   waves 4-7  "staging" waves: im2col gather (global -> VGPR), exact 3-way bf16 split (~6 VALU per
+//              element), ds_write_b128 of the three planes, and the pre-split weight planes
+//              global -> VGPR -> LDS.  Their VALU / VMEM / LDS-write instructions issue from a different
+//              wave than the MFMAs, so they fill the matrix pipe's shadow instead of serialising with
+//              it (in the single-role kernel the split is a ~900-cycle MFMA-free phase per step:
+//              measured 56 % matrix-pipe occupancy at 2 workgroups per CU).
+// LDS is a ring of NSTAGE stages; stage s of step kt is written while the matrix waves read step kt's
+// stage, one s_barrier per step for all 8 waves.
+#include "igemm_common.hpp"
+#include "x3_common.hpp"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace evk {
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE>
+__global__ __launch_bounds__(512) void conv_igemm_x3ws_kernel(const IGemmArgs p) {
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int MB = WM / 32, NB = WN / 32;
+  constexpr int AR = BM / 64, BR = BN / 64;
+  constexpr int kStage = 3 * (BM + BN) * kRowBytes;
+  static_assert(WAVES_M * WAVES_N == 4, "4 matrix waves");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = bid % p.tiles_n;
+  const int tile_m = bid / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int nk = p.Kpad / BK3;
+  const int tid = threadIdx.x;
+
+  if (tid >= 256) {
+    // ------------------------------------------------------------------ staging waves
+    const int ptid = tid - 256;
+    const int c4 = ptid & 3;   // 8-float group inside the K step
+    const int rb = ptid >> 2;  // base row 0..63
+
+    int a_y0[AR], a_x0[AR], a_base[AR];
+#pragma unroll
+    for (int j = 0; j < AR; ++j) {
+      const int m = m0 + rb + 64 * j;
+      if (m < p.M) {
+        const int hw = p.Hm * p.Wm;
+        const int n = m / hw;
+        const int rem = m - n * hw;
+        const int gy = rem / p.Wm;
+        const int gx = rem - gy * p.Wm;
+        a_y0[j] = gy * p.ash + p.oy0;
+        a_x0[j] = gx * p.asw + p.ox0;
+        a_base[j] = ((n * p.Hs + a_y0[j]) * p.Ws + a_x0[j]) * p.Cs;
+      } else {
+        a_y0[j] = -(1 << 28);
+        a_x0[j] = 0;
+        a_base[j] = 0;
+      }
+    }
+    int b_off[BR];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+      int co = n0 + rb + 64 * j;
+      co = co < p.Cd ? co : p.Cd - 1;
+      b_off[j] = co * p.Kpad + c4 * 8;
+    }
+    const int plane = p.Cd * p.Kpad;
+    const int cp8 = p.Cs >> 3;
+    int cc, kx, ky;
+    {
+      const int tap = c4 / cp8;
+      cc = c4 - tap * cp8;
+      ky = tap / p.kw;
+      kx = tap - ky * p.kw;
+    }
+
+    // two register sets: the loads of step t+2 are issued before step t+1's registers are consumed, so a
+    // global / L2 round trip has two full steps (~1.5 us) to land (with one set the staging waves sat
+    // in s_waitcnt vmcnt for most of every step and the matrix waves waited for them at the barrier:
+    // measured 209 -> 273 TFLOP/s on 3x3x256 @128^2 when the loads were removed)
+    f32x4 ra[2][AR][2];
+    u32x4 rbv[2][BR][3];
+    uint32_t okmask[2] = {0, 0};
+
+    auto load_tiles = [&](auto SET, int kt) {
+      constexpr int s = decltype(SET)::value;
+      okmask[s] = 0;
+      const bool kvalid = ky < p.kh;
+      const int oy = ky * p.oys, ox = kx * p.oxs;
+      const int tapoff = (oy * p.Ws + ox) * p.Cs + cc * 8;
+#pragma unroll
+      for (int j = 0; j < AR; ++j) {
+        const int sy = a_y0[j] + oy, sx = a_x0[j] + ox;
+        const bool ok = kvalid && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
+        okmask[s] |= ok ? (1u << j) : 0u;
+        const float* src = p.src + (ok ? a_base[j] + tapoff : 0);
+        ra[s][j][0] = *reinterpret_cast<const f32x4*>(src);
+        ra[s][j][1] = *reinterpret_cast<const f32x4*>(src + 4);
+      }
+#pragma unroll
+      for (int j = 0; j < BR; ++j)
+#pragma unroll
+        for (int pt = 0; pt < 3; ++pt)
+          rbv[s][j][pt] = *reinterpret_cast<const u32x4*>(p.wgt3 + (size_t)pt * plane + b_off[j] + kt * BK3);
+      if (cp8 >= 4) {
+        cc += 4;
+        const bool wrap = cc >= cp8;
+        cc = wrap ? cc - cp8 : cc;
+        kx += wrap ? 1 : 0;
+        const bool wrapx = kx == p.kw;
+        kx = wrapx ? 0 : kx;
+        ky += wrapx ? 1 : 0;
+      } else {
+        const int q = (kt + 1) * 4 + c4;
+        const int tap = q / cp8;
+        cc = q - tap * cp8;
+        ky = tap / p.kw;
+        kx = tap - ky * p.kw;
+      }
+    };
+
+    auto store_tiles = [&](auto SET, int stage) {
+      constexpr int s = decltype(SET)::value;
+      unsigned char* Ab = smem3 + stage * kStage;
+      unsigned char* Bb = Ab + 3 * BM * kRowBytes;
+#pragma unroll
+      for (int j = 0; j < AR; ++j) {
+        const int row = rb + 64 * j;
+        const int off = plane_off(row, c4);
+        const bool ok = (okmask[s] >> j) & 1u;
+        u32x4 H, M, L;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const f32x4 v = ra[s][j][e >> 1];
+          const float x0 = ok ? v[2 * (e & 1)] : 0.f, x1 = ok ? v[2 * (e & 1) + 1] : 0.f;
+          uint32_t h, m, l;
+          split2(x0, x1, h, m, l);
+          H[e] = h; M[e] = m; L[e] = l;
+        }
+        *reinterpret_cast<u32x4*>(Ab + off) = H;
+        *reinterpret_cast<u32x4*>(Ab + BM * kRowBytes + off) = M;
+        *reinterpret_cast<u32x4*>(Ab + 2 * BM * kRowBytes + off) = L;
+      }
+#pragma unroll
+      for (int j = 0; j < BR; ++j) {
+        const int off = plane_off(rb + 64 * j, c4);
+#pragma unroll
+        for (int pt = 0; pt < 3; ++pt) *reinterpret_cast<u32x4*>(Bb + pt * BN * kRowBytes + off) = rbv[s][j][pt];
+      }
+    };
+
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    static_assert(NSTAGE == 2, "staging schedule below is written for a two-stage ring");
+    // step t lives in register set t & 1.  Prologue: step 0 -> stage 0, steps 1 and 2 in flight.
+    load_tiles(S0{}, 0);
+    if (1 < nk) load_tiles(S1{}, 1);
+    store_tiles(S0{}, 0);
+    if (2 < nk) load_tiles(S0{}, 2);
+    __syncthreads();
+    // iteration kt: the matrix waves read stage kt & 1; step kt+1 goes to the other stage and its
+    // register set is refilled with step kt+3
+    for (int kt = 0; kt < nk; kt += 2) {
+      if (kt + 1 < nk) {
+        store_tiles(S1{}, 1);
+        if (kt + 3 < nk) load_tiles(S1{}, kt + 3);
+      }
+      __syncthreads();
+      if (kt + 1 < nk) {
+        if (kt + 2 < nk) {
+          store_tiles(S0{}, 0);
+          if (kt + 4 < nk) load_tiles(S0{}, kt + 4);
+        }
+        __syncthreads();
+      }
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- matrix waves
+  // issue arbitration on a SIMD is by priority, then age: the MFMA stream must never queue behind the
+  // staging wave's VALU work
+  __builtin_amdgcn_s_setprio(3);
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int li = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  int fa_off[MB][2], fb_off[NB][2];
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) fa_off[a][kk] = plane_off(wm * WM + a * 32 + li, 2 * kk + lh);
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+      fb_off[b][kk] = 3 * BM * kRowBytes + plane_off(wn * WN + b * 32 + li, 2 * kk + lh);
+
+  bf16x8 fa[2][MB][3], fb[2][NB][3];  // fragment registers, double buffered across the two k-halves
+  auto read_frags = [&](const unsigned char* S, int kk, int slot) {
+#pragma unroll
+    for (int a = 0; a < MB; ++a)
+#pragma unroll
+      for (int pt = 0; pt < 3; ++pt)
+        fa[slot][a][pt] = *reinterpret_cast<const bf16x8*>(S + pt * BM * kRowBytes + fa_off[a][kk]);
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int pt = 0; pt < 3; ++pt)
+        fb[slot][b][pt] = *reinterpret_cast<const bf16x8*>(S + pt * BN * kRowBytes + fb_off[b][kk]);
+  };
+  auto mfmas = [&](int slot) {
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int a = 0; a < MB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[slot][b][kPB[t]], fa[slot][a][kPA[t]], acc[a][b], 0, 0, 0);
+  };
+
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned char* S = smem3 + (kt & 1) * kStage;
+    read_frags(S, 0, 0);
+    read_frags(S, 1, 1);
+    mfmas(0);
+    mfmas(1);
+    __syncthreads();
+  }
+
+  igemm_epilogue<MB, NB, WM, WN>(p, acc, m0, n0, wm, wn, li, lh);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE>
+static int launch_ws(IGemmArgs& a, hipStream_t stream) {
+  a.tiles_m = ceil_div(a.M, BM);
+  a.tiles_n = ceil_div(a.Cd, BN);
+  const size_t lds = (size_t)NSTAGE * 3 * (BM + BN) * kRowBytes;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_x3ws_kernel<BM, BN, WAVES_M, WAVES_N, NSTAGE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const long long nwg = (long long)a.tiles_m * a.tiles_n;
+  if (nwg <= 0 || nwg > 0x7fffffffLL) {
+    set_error("conv_igemm_x3ws: bad grid %lld", nwg);
+    return EVK_E_INVALID;
+  }
+  hipLaunchKernelGGL((conv_igemm_x3ws_kernel<BM, BN, WAVES_M, WAVES_N, NSTAGE>), dim3((unsigned)nwg), dim3(512), lds,
+                     stream, a);
+  return check_launch("conv_igemm_x3ws");
+}
+
+// returns 1 when this form does not apply (caller falls back to the single-role kernel)
+int launch_igemm_x3ws(IGemmArgs& a, hipStream_t stream) {
+  // EVK_X3_WS: 0 never, 1 (default) where measured faster, 2 wherever the tile shapes allow
+  static const int mode = getenv("EVK_X3_WS") ? atoi(getenv("EVK_X3_WS")) : 1;
+  if (mode == 0) return 1;
+  const int bn = (a.Cd <= 64) ? 64 : 128;
+  const long long tn = ceil_div(a.Cd, bn);
+  const long long t128 = (long long)ceil_div(a.M, 128) * tn;
+  if (t128 < 256) return 1;  // cannot fill the chip at one workgroup per CU
+  // One 8-wave workgroup per CU: nothing overlaps a tile's prologue / epilogue, so short reductions
+  // (1x1 convolutions, K <= 512: 2..16 steps) run better as 2-3 single-role workgroups per CU, unless the
+  // grid is below two per CU anyway.  Measured on the FarSeg-R50 layer set (tools/bench_conv_x3.py).
+  if (mode == 1 && a.Kpad < 1024 && t128 >= 512) return 1;
+  if (bn == 128) return launch_ws<128, 128, 2, 2, 2>(a, stream);
+  return launch_ws<128, 64, 2, 2, 2>(a, stream);
+}
+
+}  // namespace evk

@@ -23,6 +23,7 @@ struct IGemmArgs {
   int tiles_m, tiles_n;
   const uint16_t* wgt3;     // split kernel: weights as 3 bf16 planes [3][Cd][Kpad] (Kpad % 32 == 0, zero padded)
   int Kpad;
+  int dbg;                  // dev probes only (EVK_X3_DBG): bit0 staging waves idle in the main loop, bit1 matrix waves skip LDS reads
 };
 
 // XCD-aware tile order: consecutive tile ids (sharing A rows / weights) stay on one XCD's L2.
@@ -83,6 +84,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
 
 int launch_igemm(IGemmArgs& a, hipStream_t stream);
 int launch_igemm_x3(IGemmArgs& a, hipStream_t stream);
+int launch_igemm_x3ws(IGemmArgs& a, hipStream_t stream);  // 1 = not applicable
 
 // One axis of the strided data gradient, for input pixels congruent to c (mod stride):
 // taps k = k0 + j*kstep (j < nt) reach them, from source row  g + o0 + j*ostep.
