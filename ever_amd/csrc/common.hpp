@@ -60,6 +60,12 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
   return (uint32_t)(((uint64_t)__umulhi(n, f.mul) + n) >> f.shift);
 }
 
+// XCD-aware tile order: consecutive tile ids (sharing A rows / weights) stay on one XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 }  // namespace evk

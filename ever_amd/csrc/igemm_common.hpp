@@ -26,12 +26,6 @@ struct IGemmArgs {
   int dbg;                  // dev probes only (EVK_X3_DBG): bit0 staging waves idle in the main loop, bit1 matrix waves skip LDS reads
 };
 
-// XCD-aware tile order: consecutive tile ids (sharing A rows / weights) stay on one XCD's L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-}
-
 // Epilogue shared by both kernels (the C/D fragment layout does not depend on the input dtype).
 template <int MB, int NB, int WM, int WN>
 __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)[MB][NB], int m0, int n0, int wm,

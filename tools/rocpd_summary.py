@@ -28,7 +28,7 @@ def main(db_path, out):
         for n, c, s, a, mn, mx in rows:
             f.write(f'| `{n[:110]}` | {c} | {s / 1e6:.2f} | {a / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} | '
                     f'{100.0 * s / total:.2f} |\n')
-    print(open(out + '.md').read()[:6000])
+    print(f'wrote {out}.md and {out}.csv')
 
 
 if __name__ == '__main__':
