@@ -5,6 +5,7 @@
 // row range is one contiguous span.  Statistics are reduced in two stages (fp32 partials per
 // workgroup, fp64 finalisation) so results do not depend on the launch grid.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace evk {
 
@@ -168,7 +169,7 @@ __global__ void bn_eval_coef_kernel(const float* __restrict__ gamma, const float
 // y = act(x*scale + shift [+ residual]);  scale/shift staged in LDS
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ residual,
                                                        const float* __restrict__ scale_shift, float* __restrict__ y,
-                                                       size_t n4, int C, int relu) {
+                                                       size_t n4, int C, int relu, int unroll) {
   extern __shared__ __attribute__((aligned(16))) float ss[];  // [2][C]
   for (int i = threadIdx.x; i < 2 * C; i += 256) ss[i] = scale_shift[i];
   __syncthreads();
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     }
     return v;
   };
-  for (; i + 3 * S < n4; i += 4 * S) {
+  for (; unroll && i + 3 * S < n4; i += 4 * S) {
     int c1 = cb + dcb; c1 = c1 >= c4 ? c1 - c4 : c1;
     int c2 = c1 + dcb; c2 = c2 >= c4 ? c2 - c4 : c2;
     int c3 = c2 + dcb; c3 = c3 >= c4 ? c3 - c4 : c3;
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ coef,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ dx,
-                                                           size_t n4, int C, int relu) {
+                                                           size_t n4, int C, int relu, int unroll) {
   extern __shared__ __attribute__((aligned(16))) float ss[];  // [7][C]: coef0..2, mean, invstd, sc, sh
   for (int i = threadIdx.x; i < 3 * C; i += 256) ss[i] = coef[i];
   for (int i = threadIdx.x; i < C; i += 256) {
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   };
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   // two elements per trip = 4-6 independent 16-byte loads per lane in flight (see bn_apply_kernel)
-  for (; i + S < n4; i += 2 * S) {
+  for (; unroll && i + S < n4; i += 2 * S) {
     int c1 = cb + dcb; c1 = c1 >= c4 ? c1 - c4 : c1;
     const f32x4 g0 = dy4[i], g1 = dy4[i + S];
     const f32x4 x0 = x4[i], x1 = x4[i + S];
@@ -382,6 +383,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
 }
 
+static int bn_unroll() {
+  static const int u = getenv("EVK_BN_UNROLL") ? atoi(getenv("EVK_BN_UNROLL")) : 1;
+  return u;
+}
 static int stream_grid(size_t n4) {
   size_t b = (n4 + 255) / 256;
   return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
@@ -421,7 +426,7 @@ extern "C" int evk_bn_fwd_train(const float* x, const float* residual, const flo
   if (rc) return rc;
   const size_t n4 = (size_t)rows * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(n4)), dim3(256), 2 * C * sizeof(float), st, x, residual,
-                     scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0);
+                     scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, bn_unroll());
   return check_launch("bn_apply");
 }
 
@@ -442,7 +447,7 @@ extern "C" int evk_bn_fwd_eval(const float* x, const float* residual, const floa
   if (rc) return rc;
   const size_t n4 = (size_t)rows * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(n4)), dim3(256), 2 * C * sizeof(float), st, x, residual,
-                     scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0);
+                     scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, bn_unroll());
   return check_launch("bn_apply");
 }
 
@@ -476,6 +481,6 @@ extern "C" int evk_bn_bwd(const float* dy, const float* x, const float* y, const
   const float* gsrc = d_residual ? d_residual : dy;
   const int relu3 = d_residual ? 0 : relu;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(256), 7 * C * sizeof(float), st, gsrc, x, y,
-                     save_mean, save_invstd, coef, gamma, beta, dx, n4, C, relu3);
+                     save_mean, save_invstd, coef, gamma, beta, dx, n4, C, relu3, bn_unroll());
   return check_launch("bn_bwd_apply");
 }
