@@ -77,6 +77,13 @@ SIGNATURES = {
     'evk_opt_blocks_per_tensor': (c_i32, []),
     'evk_sqnorm_multi': (c_int, [P, P, c_i32, P, c_f32, P, P, P]),
     'evk_sgd_multi': (c_int, [P, P, P, P, c_i32, c_f32, c_f32, c_f32, c_f32, c_i32, c_i32, P, P]),
+    'evk_prob_stats_doubles': (c_i64, [c_i32]),
+    'evk_prob_stats': (c_int, [P, P, c_i64, c_i32, c_i64, P, P]),
+    'evk_prob_stats_bwd': (c_int, [P, P, c_i64, c_i32, c_i64, P, P, P, c_i32, P]),
+    'evk_focal_fwd': (c_int, [P, P, c_i64, c_f32, c_f32, c_i32, c_i32, P, P, P]),
+    'evk_focal_bwd': (c_int, [P, P, c_i64, c_f32, c_f32, c_i32, c_i32, P, P, P]),
+    'evk_confusion_matrix': (c_int, [P, P, c_i64, c_i32, P, P]),
+    'evk_confusion_from_logits': (c_int, [P, P, c_i64, c_i32, c_i32, P, P]),
 }
 
 _lib = None

@@ -15,7 +15,7 @@ from .core.logger import info  # noqa: E402
 from .core.to import to_device, to_tensor  # noqa: E402
 from .interface import (Callback, ConfigurableMixin, ERDataLoader, ERDataset, ERModule,  # noqa: E402
                         LearningRateBase)
-from . import data, module, opt, trainer  # noqa: E402,F401
+from . import api, data, magic, metric, module, opt, trainer  # noqa: E402,F401
 from .core.launcher import Launcher  # noqa: E402
 
 

@@ -108,3 +108,21 @@ class Logger:
                               f'{t:.3f} s/step (data {self._smooth["__data"].value:.3f}), eta {eta / 60:.1f} min')
         for h in self._hooks:
             h(step=step, loss_dict=loss_dict)
+
+
+def get_console_file_logger(name, level, logdir):
+    """Console + file logger (reference ever/core/logger.py `get_console_file_logger`, used by PixelMetric)."""
+    import os
+    import time
+    logger = logging.getLogger(name)
+    logger.setLevel(level)
+    logger.propagate = False
+    if not logger.handlers:
+        fmt = logging.Formatter('%(asctime)s, %(levelname)s:%(name)s:%(message)s', datefmt='%Y-%m-%d %H:%M:%S')
+        ch = logging.StreamHandler()
+        ch.setFormatter(fmt)
+        logger.addHandler(ch)
+        fh = logging.FileHandler(os.path.join(logdir, f'{time.strftime("%Y-%m-%d-%H-%M-%S")}.log'))
+        fh.setFormatter(fmt)
+        logger.addHandler(fh)
+    return logger

@@ -855,3 +855,136 @@ def cross_entropy(y_pred, y_true, ignore_index=255, label_smoothing=0.0):
     y_pred = as_nhwc(y_pred, 'cross_entropy')
     labels = _labels(y_true, y_pred.numel() // y_pred.shape[1], 'cross_entropy')
     return _CeFn.apply(y_pred, labels, int(ignore_index), float(label_smoothing))
+
+
+# ------------------------------------------------------------------ SURVEY §8 f2 / f3 rows
+class _ProbStatsFn(Function):
+    """(tp, sum_p, sum_y) per class over the valid pixels as a float32 [3, C] tensor; backward is the adjoint
+    kernel, so any differentiable function of the statistics (tversky, dice variants) trains through it."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        n, c, h, w = logits.shape
+        lib = _C.load()
+        stats = torch.empty((lib.evk_prob_stats_doubles(c),), device=logits.device, dtype=torch.float64)
+        _C.call('evk_prob_stats', logits.data_ptr(), labels.data_ptr(), n * h * w, c, ignore_index, stats.data_ptr(),
+                _stream())
+        ctx.save_for_backward(logits, labels)
+        ctx.ignore_index = ignore_index
+        return stats[:3 * c].reshape(3, c)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        logits, labels = ctx.saved_tensors
+        n, c, h, w = logits.shape
+        g = g.float().contiguous()
+        d = torch.empty_like(logits)
+        _C.call('evk_prob_stats_bwd', logits.data_ptr(), labels.data_ptr(), n * h * w, c, ctx.ignore_index,
+                g[0].data_ptr(), g[1].data_ptr(), d.data_ptr(), 0, _stream())
+        return d, None, None
+
+
+def prob_stats(y_pred, y_true, ignore_index=255):
+    _require_cuda(y_pred, 'prob_stats')
+    y_pred = as_nhwc(y_pred, 'prob_stats')
+    labels = _labels(y_true, y_pred.numel() // y_pred.shape[1], 'prob_stats')
+    return _ProbStatsFn.apply(y_pred, labels, int(ignore_index))
+
+
+def _all_reduce_sum_differentiable(t):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        import torch.distributed.nn as dist_nn
+        return dist_nn.all_reduce(t)
+    return t
+
+
+def tversky_loss_with_logits(y_pred, y_true, alpha, beta=None, gamma=1.0, smooth_value=1.0, ignore_index=255,
+                             reduction='mean', sync_statistics=True):
+    """reference ever/module/loss.py:78-143: statistics by the HIP kernel, the C-element ratio by autograd."""
+    st = prob_stats(y_pred, y_true, ignore_index)  # float64 [3, C]
+    tp, sp, sy = st[0], st[1], st[2]
+    if isinstance(alpha, (list, tuple)):
+        alpha = torch.as_tensor(alpha, dtype=st.dtype, device=st.device)
+    if beta is None:
+        beta = 1. - alpha
+    fp, fn = sp - tp, sy - tp
+    num, den = tp, tp + alpha * fn + beta * fp
+    if sync_statistics:
+        num, den = _all_reduce_sum_differentiable(num), _all_reduce_sum_differentiable(den)
+    coeff = (num + smooth_value) / (den + smooth_value)
+    loss = ((1. - coeff) ** gamma).float()
+    if reduction == 'mean':
+        return loss.mean()
+    if reduction == 'none':
+        return loss
+    raise ValueError(f'unknown reduction: {reduction}')
+
+
+class _FocalFn(Function):
+    @staticmethod
+    def forward(ctx, logits, target, gamma, alpha, mode, mean):
+        n = logits.numel()
+        stats = torch.empty((1 + 256,), device=logits.device, dtype=torch.float64)
+        loss = torch.empty((), device=logits.device, dtype=torch.float32)
+        _C.call('evk_focal_fwd', logits.data_ptr(), target.data_ptr(), n, gamma, alpha, mode, mean, loss.data_ptr(),
+                stats.data_ptr(), _stream())
+        ctx.save_for_backward(logits, target)
+        ctx.cfg = (gamma, alpha, mode, mean)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        logits, target = ctx.saved_tensors
+        gamma, alpha, mode, mean = ctx.cfg
+        g = g.contiguous().float()
+        d = torch.empty_like(logits)
+        _C.call('evk_focal_bwd', logits.data_ptr(), target.data_ptr(), logits.numel(), gamma, alpha, mode, mean,
+                g.data_ptr(), d.data_ptr(), _stream())
+        return d, None, None, None, None, None
+
+
+def _focal(y_pred, y_true, gamma, alpha, mode, mean, what):
+    _require_cuda(y_pred, what)
+    if y_pred.shape != y_true.shape:
+        raise ValueError(f'{what}: logits {tuple(y_pred.shape)} and targets {tuple(y_true.shape)} must have the same shape')
+    yp = y_pred if y_pred.is_contiguous() or (y_pred.dim() == 4 and is_nhwc(y_pred)) else y_pred.contiguous()
+    # element-wise: any common dense layout works as long as both operands share it
+    yt = y_true.detach().float()
+    if yt.stride() != yp.stride():
+        yt = torch.empty_like(yp).copy_(yt)
+    return _FocalFn.apply(yp, yt, float(gamma), float(alpha), int(mode), int(mean))
+
+
+def focal_loss(y_pred, y_true, gamma=2.0, normalize=False):
+    """reference loss.py:158-176"""
+    return _focal(y_pred, y_true, gamma, -1.0, 2 if normalize else 0, 0 if normalize else 1, 'focal_loss')
+
+
+def sigmoid_focal_loss(y_pred, y_true, alpha=-1, gamma=2, reduction='mean'):
+    """reference loss.py:179-201 (fvcore form)"""
+    if reduction not in ('mean', 'sum'):
+        raise NotImplementedError("sigmoid_focal_loss: reduction must be 'mean' or 'sum' on the HIP path")
+    return _focal(y_pred, y_true, gamma, alpha, 1, 1 if reduction == 'mean' else 0, 'sigmoid_focal_loss')
+
+
+def confusion_matrix_update(cm, y_true, y_pred=None, logits=None):
+    """cm (int64 [C, C], cuda) += counts.  Either integer predictions or NCHW logits (threshold / argmax fused)."""
+    c = cm.shape[0]
+    assert cm.is_cuda and cm.dtype == torch.int64 and cm.is_contiguous() and cm.shape == (c, c)
+    yt = y_true.to(device=cm.device, dtype=torch.int64).contiguous()
+    if logits is not None:
+        _require_cuda(logits, 'confusion_matrix')
+        lg = as_nhwc(logits.detach(), 'confusion_matrix')
+        cl = lg.shape[1]
+        if yt.numel() != lg.numel() // cl:
+            raise ValueError('confusion_matrix: label / logit pixel counts differ')
+        _C.call('evk_confusion_from_logits', lg.data_ptr(), yt.data_ptr(), yt.numel(), cl, c, cm.data_ptr(), _stream())
+    else:
+        yp = y_pred.to(device=cm.device, dtype=torch.int64).contiguous()
+        if yp.numel() != yt.numel():
+            raise ValueError('confusion_matrix: y_true and y_pred sizes differ')
+        _C.call('evk_confusion_matrix', yt.data_ptr(), yp.data_ptr(), yt.numel(), c, cm.data_ptr(), _stream())
+    return cm

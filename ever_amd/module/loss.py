@@ -2,7 +2,8 @@
 from ..hip import functional as HF
 
 __all__ = ['binary_cross_entropy_with_logits', 'dice_loss_with_logits', 'cross_entropy',
-           'label_smoothing_cross_entropy', 'label_smoothing_binary_cross_entropy', 'soft_cross_entropy']
+           'label_smoothing_cross_entropy', 'label_smoothing_binary_cross_entropy', 'soft_cross_entropy',
+           'tversky_loss_with_logits', 'focal_loss', 'sigmoid_focal_loss']
 
 
 def binary_cross_entropy_with_logits(output, target, reduction='mean', ignore_index=255, pos_weight=None):
@@ -40,3 +41,20 @@ def label_smoothing_binary_cross_entropy(output, target, eps=0.1, reduction='mea
 def soft_cross_entropy(input, target):
     """reference loss.py:238-242"""
     return HF.soft_cross_entropy(input, target)
+
+
+def tversky_loss_with_logits(y_pred, y_true, alpha, beta=None, gamma=1.0, smooth_value=1.0, ignore_index=255,
+                             reduction='mean', *, sync_statistics=True):
+    """reference loss.py:78-143"""
+    return HF.tversky_loss_with_logits(y_pred, y_true, alpha, beta, gamma, smooth_value, ignore_index, reduction,
+                                       sync_statistics)
+
+
+def focal_loss(y_pred, y_true, gamma=2.0, normalize=False):
+    """reference loss.py:158-176"""
+    return HF.focal_loss(y_pred, y_true, gamma, normalize)
+
+
+def sigmoid_focal_loss(y_pred, y_true, alpha=-1, gamma=2, reduction='mean'):
+    """reference loss.py:179-201"""
+    return HF.sigmoid_focal_loss(y_pred, y_true, alpha, gamma, reduction)

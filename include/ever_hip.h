@@ -243,6 +243,37 @@ int evk_sgd_multi(float* const* params, const float* const* grads, float* const*
                   float weight_decay, int32_t nesterov, int32_t first_step,
                   const float* clip_coef /* device scalar or NULL */, void* stream);
 
+/* ------------------------------------------------------------------ "next" rows ---- */
+/* Class-probability statistics over the valid pixels: stats[0..C) = tp_c = sum p_c*y_c, [C..2C) = sum p_c,
+ * [2C..3C) = sum y_c  (p = sigmoid for C == 1, softmax otherwise; y one-hot / the 0-1 label).  They are the
+ * sufficient statistics of tversky_loss_with_logits (reference ever/module/loss.py:78-143; the caller
+ * all-reduces them under sync_statistics and forms the ratio), and evk_prob_stats_bwd is their adjoint:
+ * dlogits for any loss L(tp, sp) given g_tp[c] = dL/dtp_c, g_sp[c] = dL/dsp_c (device arrays).
+ * `stats` needs evk_prob_stats_doubles(C) doubles. */
+int64_t evk_prob_stats_doubles(int32_t C);
+int evk_prob_stats(const float* logits, const int64_t* labels, int64_t npix, int32_t C,
+                   int64_t ignore_index, double* stats, void* stream);
+int evk_prob_stats_bwd(const float* logits, const int64_t* labels, int64_t npix, int32_t C,
+                       int64_t ignore_index, const float* g_tp, const float* g_sp, float* dlogits,
+                       int32_t accumulate, void* stream);
+/* Focal losses on float targets of the logits' shape (any layout; n elements).
+ * mode 0: focal_loss(normalize=False), loss.py:158-176 (modulating factor detached);
+ * mode 1: sigmoid_focal_loss, loss.py:179-201 (alpha < 0 disables the alpha weighting);
+ * mode 2: focal_loss(normalize=True) — the normalisation cancels identically: sum of BCE terms.
+ * mean != 0 divides by n.  stats: 1 + 256 doubles. */
+int evk_focal_fwd(const float* logits, const float* target, int64_t n, float gamma, float alpha,
+                  int32_t mode, int32_t mean, float* loss, double* stats, void* stream);
+int evk_focal_bwd(const float* logits, const float* target, int64_t n, float gamma, float alpha,
+                  int32_t mode, int32_t mean, const float* grad_scale, float* dlogits, void* stream);
+/* cm[t*C + p] += #{i : y_true[i] = t, y_pred[i] = p}; pairs with either index outside [0, C) are skipped
+ * (ignore labels).  Replaces the host/scipy.sparse accumulation of ever/metric/confusion_matrix.py:11-24.
+ * The _from_logits form fuses the prediction: threshold 0 for one logit channel (classes {0,1}), first
+ * argmax otherwise; logits are [npix][C_logits] (NHWC). */
+int evk_confusion_matrix(const int64_t* y_true, const int64_t* y_pred, int64_t n, int32_t num_classes,
+                         int64_t* cm, void* stream);
+int evk_confusion_from_logits(const float* logits, const int64_t* y_true, int64_t npix,
+                              int32_t C_logits, int32_t num_classes, int64_t* cm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,8 +35,8 @@ def _install_stubs():
     pt = types.ModuleType('prettytable')
 
     class PrettyTable:
-        def __init__(self, *a, **k):
-            self.field_names, self._rows = [], []
+        def __init__(self, field_names=None, **k):
+            self.field_names, self._rows = list(field_names or []), []
 
         def add_row(self, r):
             self._rows.append(r)
@@ -313,6 +313,79 @@ def launcher_case(er):
     print('[launcher] reference Launcher steps:', records)
 
 
+def next_rows_kats(er):
+    """losses (tversky / focal / sigmoid-focal / OHEM), PixelMetric formulas on a
+    confusion matrix, sliding-window boxes.  Inputs from oracle/portable.py, outputs of the reference."""
+    from oracle import portable
+    from ever.module import loss as L
+    from ever.metric.pixel import PixelMetric
+    from ever.magic.bigimage.sliding_window import sliding_window
+    out, arrays = {}, {}
+    # --- losses on [2, C, 12, 10] logits
+    for c in (1, 4):
+        key = f'next_loss_c{c}'
+        z = torch.from_numpy(portable.uniform(key, (2, c, 12, 10), -3.0, 3.0)).requires_grad_()
+        y = torch.from_numpy(portable.integers(key + '_y', (2, 12, 10), max(c, 2)).astype(np.int64))
+        y[0, :2, :3] = 255
+        for alpha, beta, gamma in ((0.3, None, 1.0), (0.7, 0.5, 2.0)):
+            z.grad = None
+            v = L.tversky_loss_with_logits(z, y, alpha, beta, gamma, smooth_value=1.0, ignore_index=255, sync_statistics=False)
+            v.backward()
+            tag = f'tversky_c{c}_a{alpha}_g{gamma}'
+            out[tag] = float(v)
+            arrays[tag + '_grad'] = z.grad.numpy().copy()
+    zf = torch.from_numpy(portable.uniform('next_focal', (2, 3, 9, 7), -4.0, 4.0)).requires_grad_()
+    yf = torch.from_numpy((portable.uniform01('next_focal_y', 2 * 3 * 9 * 7) > 0.6).astype(np.float32).reshape(2, 3, 9, 7))
+    for normalize in (False, True):
+        zf.grad = None
+        # the reference's normalize branch only broadcasts for already-flat inputs (loss.py:166-174)
+        v = L.focal_loss(zf.reshape(-1), yf.reshape(-1), gamma=2.0, normalize=True) if normalize else L.focal_loss(zf, yf, gamma=2.0)
+        v.backward()
+        out[f'focal_norm{int(normalize)}'] = float(v)
+        arrays[f'focal_norm{int(normalize)}_grad'] = zf.grad.numpy().copy()
+    for alpha, gamma, red in ((-1.0, 2.0, 'mean'), (0.25, 1.5, 'sum')):
+        zf.grad = None
+        v = L.sigmoid_focal_loss(zf, yf, alpha, gamma, red)
+        v.backward()
+        tag = f'sigmoid_focal_a{alpha}_g{gamma}_{red}'
+        out[tag] = float(v)
+        arrays[tag + '_grad'] = zf.grad.numpy().copy()
+    lo = torch.from_numpy(portable.uniform('next_ohem', (3, 50), 0.0, 2.0)).clone()
+    lo[0, :7] = 0.0
+    lo.requires_grad_()
+    v = L.online_hard_example_mining(lo, 0.4)
+    v.backward()
+    out['ohem_0.4'] = float(v)
+    arrays['ohem_0.4_grad'] = lo.grad.numpy().copy()
+    # --- pixel metric
+    for c in (2, 7):
+        yt = portable.integers(f'next_cm_t{c}', (3, 40, 33), c).astype(np.int64)
+        yp = portable.integers(f'next_cm_p{c}', (3, 40, 33), c).astype(np.int64)
+        yp = np.where(portable.uniform01(f'next_cm_m{c}', yt.size).reshape(yt.shape) < 0.6, yt, yp)
+        pm = PixelMetric(c)
+        pm.forward(yt[:2], yp[:2])
+        pm.forward(torch.from_numpy(yt[2:]), torch.from_numpy(yp[2:]))
+        cm = pm.dense_cm
+        tb = pm.summary_all(dense_cm=cm)
+        out[f'metric_c{c}'] = dict(
+            cm=cm.tolist(), iou=PixelMetric.compute_iou_per_class(cm).tolist(),
+            f1=PixelMetric.compute_F_measure_per_class(cm).tolist(),
+            precision=PixelMetric.compute_precision_per_class(cm).tolist(),
+            recall=PixelMetric.compute_recall_per_class(cm).tolist(),
+            oa=float(PixelMetric.compute_overall_accuracy(cm)), kappa=float(PixelMetric.cohen_kappa_score(cm)),
+            table_fields=list(tb.field_names), table_rows=[[x if isinstance(x, str) else float(x) for x in r] for r in tb._rows])
+    # --- sliding window
+    sw = {}
+    for size, k, st in (((1024, 1024), 512, 256), ((610, 340), (256, 128), (200, 100)), ((100, 90), 512, 256),
+                        ((513, 700), 512, 512), ((64, 64), 64, 32)):
+        sw[f'{size}|{k}|{st}'] = sliding_window(size, k, st).tolist()
+    out['sliding_window'] = sw
+    with open(os.path.join(OUT, 'next_kats.json'), 'w') as f:
+        json.dump(out, f)
+    np.savez_compressed(os.path.join(OUT, 'next_kats.npz'), **arrays)
+    print('next-row KATs:', len(out), 'values,', len(arrays), 'arrays')
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     er = import_reference()
@@ -322,8 +395,12 @@ def main():
     if only == 'launcher':
         launcher_case(er)
         return
+    if only == 'next':
+        next_rows_kats(er)
+        return
     op_kats(er)
     block_vectors(er)
+    next_rows_kats(er)
     launcher_case(er)
     e2e_case(er, 'r18_4band_64', 'resnet18', 4, 2, 64)
     e2e_case(er, 'r50_3band_64', 'resnet50', 3, 2, 64)

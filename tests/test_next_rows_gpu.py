@@ -1,0 +1,90 @@
+"""SURVEY §8 f2 / f3 device pieces through the C-ABI against the reference's outputs
+(tests/golden/next_kats.{json,npz}): tversky / focal losses with gradients, GPU confusion matrix."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import portable
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+with open(os.path.join(GOLD, 'next_kats.json')) as f:
+    KATS = json.load(f)
+ARR = np.load(os.path.join(GOLD, 'next_kats.npz'))
+
+
+def _close(a, b, tol=2e-5):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), (np.abs(a - b).max(), np.abs(b).max())
+
+
+@pytest.mark.parametrize('c', [1, 4])
+def test_tversky_matches_reference(cuda, c):
+    from ever_amd.module import loss as L
+    key = f'next_loss_c{c}'
+    y = torch.from_numpy(portable.integers(key + '_y', (2, 12, 10), max(c, 2)).astype(np.int64))
+    y[0, :2, :3] = 255
+    for alpha, beta, gamma in ((0.3, None, 1.0), (0.7, 0.5, 2.0)):
+        z = torch.from_numpy(portable.uniform(key, (2, c, 12, 10), -3.0, 3.0)).to(cuda).requires_grad_()
+        v = L.tversky_loss_with_logits(z, y.to(cuda), alpha, beta, gamma, smooth_value=1.0, ignore_index=255,
+                                       sync_statistics=False)
+        v.backward()
+        tag = f'tversky_c{c}_a{alpha}_g{gamma}'
+        assert abs(v.item() - KATS[tag]) <= 2e-6 * max(1.0, abs(KATS[tag])), (tag, v.item(), KATS[tag])
+        _close(z.grad.cpu().contiguous().numpy(), ARR[tag + '_grad'])
+
+
+def test_focal_losses_match_reference(cuda):
+    from ever_amd.module import loss as L
+    zf = portable.uniform('next_focal', (2, 3, 9, 7), -4.0, 4.0)
+    yf = (portable.uniform01('next_focal_y', 2 * 3 * 9 * 7) > 0.6).astype(np.float32).reshape(2, 3, 9, 7)
+    yt = torch.from_numpy(yf).to(cuda)
+    for normalize in (False, True):
+        z = torch.from_numpy(zf).to(cuda).requires_grad_()
+        v = L.focal_loss(z, yt, gamma=2.0, normalize=normalize)
+        v.backward()
+        tag = f'focal_norm{int(normalize)}'
+        assert abs(v.item() - KATS[tag]) <= 1e-5 * max(1.0, abs(KATS[tag])), (tag, v.item(), KATS[tag])
+        _close(z.grad.cpu().numpy().reshape(-1), ARR[tag + '_grad'].reshape(-1))
+    for alpha, gamma, red in ((-1.0, 2.0, 'mean'), (0.25, 1.5, 'sum')):
+        z = torch.from_numpy(zf).to(cuda).requires_grad_()
+        v = L.sigmoid_focal_loss(z, yt, alpha, gamma, red)
+        v.backward()
+        tag = f'sigmoid_focal_a{alpha}_g{gamma}_{red}'
+        assert abs(v.item() - KATS[tag]) <= 1e-5 * max(1.0, abs(KATS[tag])), (tag, v.item(), KATS[tag])
+        _close(z.grad.cpu().numpy(), ARR[tag + '_grad'])
+
+
+@pytest.mark.parametrize('c', [2, 7])
+def test_gpu_confusion_matrix_is_exact(cuda, c):
+    from ever_amd.metric import PixelMetric
+    yt = portable.integers(f'next_cm_t{c}', (3, 40, 33), c).astype(np.int64)
+    yp = portable.integers(f'next_cm_p{c}', (3, 40, 33), c).astype(np.int64)
+    yp = np.where(portable.uniform01(f'next_cm_m{c}', yt.size).reshape(yt.shape) < 0.6, yt, yp)
+    pm = PixelMetric(c)
+    b0 = pm.forward(torch.from_numpy(yt[:2]).to(cuda), torch.from_numpy(yp[:2]).to(cuda))
+    pm.forward(torch.from_numpy(yt[2:]).to(cuda), torch.from_numpy(yp[2:]).to(cuda))
+    assert pm.dense_cm.tolist() == KATS[f'metric_c{c}']['cm']
+    assert b0.toarray().sum() == 2 * 40 * 33
+    tb = pm.summary_all()
+    assert [float(x) for x in tb.iou(list(range(c)))] == pytest.approx(np.round(KATS[f'metric_c{c}']['iou'], 5).tolist(), abs=1e-6)
+
+
+def test_confusion_from_logits_with_ignore_and_many_classes(cuda):
+    """Fused threshold / argmax counting equals the explicit prediction path; labels outside [0, C) (255) are
+    skipped; a class count beyond the LDS histogram (C*C > 4096) takes the global-atomic path."""
+    from ever_amd.metric import ConfusionMatrix
+    g = torch.Generator().manual_seed(5)
+    for cl, c in ((1, 2), (5, 5), (70, 70)):
+        logits = torch.randn(2, cl, 17, 19, generator=g)
+        y = torch.randint(0, c, (2, 17, 19), generator=g)
+        y[0, :3] = 255
+        pred = (logits[:, 0] > 0).long() if cl == 1 else logits.argmax(1)
+        a, b = ConfusionMatrix(c), ConfusionMatrix(c)
+        a.forward_logits(y.to(cuda), logits.to(cuda))
+        b.forward(y.numpy(), pred.numpy())
+        assert a.dense_cm.tolist() == b.dense_cm.tolist()
+        assert a.dense_cm.sum() == (y != 255).sum().item()
