@@ -84,6 +84,12 @@ SIGNATURES = {
     'evk_focal_bwd': (c_int, [P, P, c_i64, c_f32, c_f32, c_i32, c_i32, P, P, P]),
     'evk_confusion_matrix': (c_int, [P, P, c_i64, c_i32, P, P]),
     'evk_confusion_from_logits': (c_int, [P, P, c_i64, c_i32, c_i32, P, P]),
+    'evk_gn_workspace_bytes': (c_size_t, [c_i32, c_i64, c_i32, c_i32]),
+    'evk_gn_fwd': (c_int, [P, P, P, c_f32, P, P, P, c_i32, c_i64, c_i32, c_i32, c_u32, P, c_size_t, P]),
+    'evk_gn_bwd': (c_int, [P, P, P, P, P, P, P, P, P, c_i32, c_i64, c_i32, c_i32, c_u32, P, c_size_t, P]),
+    'evk_concat_channels': (c_int, [P, P, P, c_i64, c_i32, c_i32, P]),
+    'evk_split_channels': (c_int, [P, P, P, c_i64, c_i32, c_i32, P]),
+    'evk_channel_scale': (c_int, [P, P, P, c_i32, c_i64, c_i32, P]),
 }
 
 _lib = None

@@ -1,0 +1,127 @@
+"""Autograd wrappers of the SURVEY §8 f2 operators: GroupNorm(+ReLU), channel concat, Dropout2d
+(include/ever_hip.h "next rows").  Same conventions as functional.py: logical NCHW, dense NHWC memory, CUDA only."""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _C
+from .functional import _require_cuda, _stream, _ptr, as_nhwc, empty_nhwc, HipPathError
+from .workspace import workspace
+
+__all__ = ['group_norm_act', 'concat_channels', 'dropout2d']
+
+
+class _GroupNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps, relu):
+        n, c, h, w = x.shape
+        dev = x.device
+        lib = _C.load()
+        ws_bytes = lib.evk_gn_workspace_bytes(n, h * w, c, groups)
+        ws = workspace(dev, ws_bytes)
+        y = empty_nhwc(n, c, h, w, dev)
+        mean = torch.empty((n * groups,), device=dev, dtype=torch.float32)
+        rstd = torch.empty((n * groups,), device=dev, dtype=torch.float32)
+        _C.call('evk_gn_fwd', x.data_ptr(), _ptr(weight), _ptr(bias), eps, y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                n, h * w, c, groups, 1 if relu else 0, ws.data_ptr(), ws_bytes, _stream())
+        ctx.save_for_backward(x, weight, mean, rstd, y if relu else None)
+        ctx.cfg = (groups, relu, bias is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, weight, mean, rstd, y = ctx.saved_tensors
+        groups, relu, has_bias = ctx.cfg
+        n, c, h, w = x.shape
+        dev = x.device
+        dy = as_nhwc(dy, 'group_norm.backward')
+        lib = _C.load()
+        ws_bytes = lib.evk_gn_workspace_bytes(n, h * w, c, groups)
+        ws = workspace(dev, ws_bytes)
+        dx = empty_nhwc(n, c, h, w, dev)
+        dg = torch.empty((c,), device=dev, dtype=torch.float32) if weight is not None else None
+        db = torch.empty((c,), device=dev, dtype=torch.float32) if has_bias else None
+        _C.call('evk_gn_bwd', dy.data_ptr(), x.data_ptr(), _ptr(y), _ptr(weight), mean.data_ptr(), rstd.data_ptr(),
+                dx.data_ptr(), _ptr(dg), _ptr(db), n, h * w, c, groups, 1 if relu else 0, ws.data_ptr(), ws_bytes,
+                _stream())
+        return dx, dg, db, None, None, None
+
+
+def group_norm_act(x, num_groups, weight=None, bias=None, eps=1e-5, relu=False):
+    """nn.GroupNorm(+ReLU), reference fs_relation.py:88-116."""
+    _require_cuda(x, 'group_norm')
+    x = as_nhwc(x, 'group_norm')
+    c = x.shape[1]
+    if c % 4 != 0 or c % num_groups != 0:
+        raise HipPathError(f'group_norm: {c} channels must be a multiple of 4 and of num_groups={num_groups}')
+    return _GroupNormFn.apply(x, weight, bias, int(num_groups), float(eps), bool(relu))
+
+
+class _ConcatFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        n, ca, h, w = a.shape
+        cb = b.shape[1]
+        out = empty_nhwc(n, ca + cb, h, w, a.device)
+        _C.call('evk_concat_channels', a.data_ptr(), b.data_ptr(), out.data_ptr(), n * h * w, ca, cb, _stream())
+        ctx.shape = (n, ca, cb, h, w)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        n, ca, cb, h, w = ctx.shape
+        g = as_nhwc(g, 'concat.backward')
+        ga = empty_nhwc(n, ca, h, w, g.device) if ctx.needs_input_grad[0] else None
+        gb = empty_nhwc(n, cb, h, w, g.device) if ctx.needs_input_grad[1] else None
+        if ga is not None or gb is not None:
+            _C.call('evk_split_channels', g.data_ptr(), _ptr(ga), _ptr(gb), n * h * w, ca, cb, _stream())
+        return ga, gb
+
+
+def concat_channels(a, b):
+    """torch.cat([a, b], dim=1), reference fs_relation.py:155."""
+    _require_cuda(a, 'concat')
+    a, b = as_nhwc(a, 'concat'), as_nhwc(b, 'concat')
+    if a.shape[0] != b.shape[0] or a.shape[2:] != b.shape[2:]:
+        raise ValueError(f'concat: shapes {tuple(a.shape)} and {tuple(b.shape)} differ outside the channel axis')
+    if a.shape[1] % 4 or b.shape[1] % 4:
+        raise HipPathError('concat: channel counts must be multiples of 4')
+    return _ConcatFn.apply(a, b)
+
+
+class _ChannelScaleFn(Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        n, c, h, w = x.shape
+        y = empty_nhwc(n, c, h, w, x.device)
+        _C.call('evk_channel_scale', x.data_ptr(), scale.data_ptr(), y.data_ptr(), n, h * w, c, _stream())
+        ctx.save_for_backward(scale)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        scale, = ctx.saved_tensors
+        g = as_nhwc(g, 'dropout2d.backward')
+        n, c, h, w = g.shape
+        dx = empty_nhwc(n, c, h, w, g.device)
+        _C.call('evk_channel_scale', g.data_ptr(), scale.data_ptr(), dx.data_ptr(), n, h * w, c, _stream())
+        return dx, None
+
+
+def dropout2d(x, p=0.5, training=True, mask=None):
+    """nn.Dropout2d: whole channels of a sample are zeroed with probability p and the rest scaled by 1/(1-p)
+    (reference fs_relation.py:104,121).  `mask` ([N, C] of 0/1 keep flags) overrides the random draw."""
+    if not training or p == 0.0:
+        return x
+    _require_cuda(x, 'dropout2d')
+    x = as_nhwc(x, 'dropout2d')
+    n, c = x.shape[:2]
+    if c % 4:
+        raise HipPathError('dropout2d: channel count must be a multiple of 4')
+    if mask is None:
+        mask = torch.bernoulli(torch.full((n, c), 1.0 - p, device=x.device, dtype=torch.float32))
+    scale = (mask.to(device=x.device, dtype=torch.float32) / (1.0 - p)).contiguous()
+    return _ChannelScaleFn.apply(x, scale)

@@ -10,9 +10,9 @@ from ..core import registry
 from ..hip import functional as HF
 from ..interface import ERModule
 from .fpn import FPN, AssymetricDecoder
-from .layers import BatchNorm2d, Conv2d, HipSequential, ReLU
+from .layers import BatchNorm2d, Conv2d, Dropout2d, GroupNorm, HipSequential, ReLU
 
-__all__ = ['FSRelation', 'FarSegHead']
+__all__ = ['FSRelation', 'FSRelationV2', 'FarSegHead']
 
 
 def _mlp(cin, cout):
@@ -44,6 +44,48 @@ class FSRelation(nn.Module):
             scenes = [self.scene_encoder(scene_feature)] * len(contents)
         feats = [enc(f) for enc, f in zip(self.feature_reencoders, features)]
         return [HF.fs_relation(s, c, p) for s, c, p in zip(scenes, contents, feats)]
+
+
+class FSRelationV2(nn.Module):
+    """FarSeg++ relation module (reference fs_relation.py:76-163): GroupNorm scene MLP, relation-weighted
+    re-encoded feature concatenated with the pyramid feature, 1x1 conv-BN-ReLU-Dropout2d projection.
+    Same child names as the reference => same state-dict keys."""
+
+    def __init__(self, scene_embedding_channels, in_channels_list, out_channels, scale_aware_proj=False):
+        super().__init__()
+        self.scale_aware_proj = scale_aware_proj
+
+        def scene_mlp():
+            return HipSequential(Conv2d(scene_embedding_channels, out_channels, 1), GroupNorm(32, out_channels),
+                                 ReLU(True), Conv2d(out_channels, out_channels, 1), GroupNorm(32, out_channels),
+                                 ReLU(True))
+
+        def project():
+            return HipSequential(Conv2d(out_channels * 2, out_channels, 1, bias=False), BatchNorm2d(out_channels),
+                                 ReLU(True), Dropout2d(p=0.1))
+
+        if scale_aware_proj:
+            self.scene_encoder = nn.ModuleList([scene_mlp() for _ in range(len(in_channels_list))])
+            self.project = nn.ModuleList([project() for _ in range(len(in_channels_list))])
+        else:
+            self.scene_encoder = scene_mlp()
+            self.project = project()
+        self.content_encoders = nn.ModuleList([_conv_bn_relu(c, out_channels) for c in in_channels_list])
+        self.feature_reencoders = nn.ModuleList([_conv_bn_relu(c, out_channels) for c in in_channels_list])
+        self.normalizer = nn.Sigmoid()
+
+    def forward(self, scene_feature, features):
+        from ..hip import functional_next as HN
+        contents = [enc(f) for enc, f in zip(self.content_encoders, features)]
+        if self.scale_aware_proj:
+            scenes = [enc(scene_feature) for enc in self.scene_encoder]
+        else:
+            scenes = [self.scene_encoder(scene_feature)] * len(contents)
+        feats = [enc(f) for enc, f in zip(self.feature_reencoders, features)]
+        refined = [HN.concat_channels(HF.fs_relation(s, c, p), o) for s, c, p, o in zip(scenes, contents, feats, features)]
+        if self.scale_aware_proj:
+            return [op(x) for op, x in zip(self.project, refined)]
+        return [self.project(x) for x in refined]
 
 
 @registry.MODEL.register(verbose=False)

@@ -109,6 +109,22 @@ class AdaptiveAvgPool2d(nn.AdaptiveAvgPool2d):
         return HF.global_avg_pool(x)
 
 
+class GroupNorm(nn.GroupNorm):
+    """nn.GroupNorm on evk_gn_fwd / evk_gn_bwd (reference fs_relation.py:88-116); `relu=True` fuses the ReLU."""
+
+    def forward(self, x, relu=False):
+        from ..hip import functional_next as HN
+        return HN.group_norm_act(x, self.num_groups, self.weight, self.bias, self.eps, relu=relu)
+
+
+class Dropout2d(nn.Dropout2d):
+    """nn.Dropout2d: the [N, C] keep-mask is drawn with torch's generator, the scaling is one HIP pass."""
+
+    def forward(self, x):
+        from ..hip import functional_next as HN
+        return HN.dropout2d(x, self.p, self.training)
+
+
 def _unwrap(m):
     # reference ops.Bf16compatible wraps the upsampling module (ever/module/ops.py:152-166); the HIP
     # path is fp32 end to end so the wrapper is transparent.
@@ -126,7 +142,7 @@ def run_sequence(mods, x):
         if isinstance(m, Conv2d) and isinstance(nxt, nn.ReLU):
             x = m(x, relu=True)
             i += 2
-        elif isinstance(m, BatchNorm2d) and isinstance(nxt, nn.ReLU):
+        elif isinstance(m, (BatchNorm2d, GroupNorm)) and isinstance(nxt, nn.ReLU):
             x = m(x, relu=True)
             i += 2
         elif isinstance(m, nn.Identity):
@@ -147,7 +163,7 @@ class HipSequential(nn.Sequential):
 _SWAP = {
     nn.Conv2d: Conv2d, nn.BatchNorm2d: BatchNorm2d, nn.ReLU: ReLU, nn.MaxPool2d: MaxPool2d,
     nn.UpsamplingBilinear2d: UpsamplingBilinear2d, nn.AdaptiveAvgPool2d: AdaptiveAvgPool2d,
-    nn.Sequential: HipSequential,
+    nn.GroupNorm: GroupNorm, nn.Dropout2d: Dropout2d, nn.Sequential: HipSequential,
 }
 
 

@@ -274,6 +274,27 @@ int evk_confusion_matrix(const int64_t* y_true, const int64_t* y_pred, int64_t n
 int evk_confusion_from_logits(const float* logits, const int64_t* y_true, int64_t npix,
                               int32_t C_logits, int32_t num_classes, int64_t* cm, void* stream);
 
+/* nn.GroupNorm(G, C) (+ReLU) on [N, HW, C] — reference fs_relation.py:88-116 (FSRelationV2 scene encoders).
+ * flags bit 0: ReLU fused (backward then needs y).  save_mean / save_rstd: [N*G].  C % 4 == 0, C % G == 0. */
+size_t evk_gn_workspace_bytes(int32_t N, int64_t HW, int32_t C, int32_t G);
+int evk_gn_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y,
+               float* save_mean, float* save_rstd, int32_t N, int64_t HW, int32_t C, int32_t G,
+               uint32_t flags, void* workspace, size_t workspace_bytes, void* stream);
+int evk_gn_bwd(const float* dy, const float* x, const float* y, const float* gamma,
+               const float* save_mean, const float* save_rstd, float* dx, float* dgamma, float* dbeta,
+               int32_t N, int64_t HW, int32_t C, int32_t G, uint32_t flags, void* workspace,
+               size_t workspace_bytes, void* stream);
+/* torch.cat([a, b], dim=1) on NHWC rows and its adjoint (either output of the split may be NULL) —
+ * fs_relation.py:155.  Ca, Cb multiples of 4. */
+int evk_concat_channels(const float* a, const float* b, float* out, int64_t rows, int32_t Ca,
+                        int32_t Cb, void* stream);
+int evk_split_channels(const float* src, float* a, float* b, int64_t rows, int32_t Ca, int32_t Cb,
+                       void* stream);
+/* y[n][hw][c] = x[n][hw][c] * scale[n][c]: nn.Dropout2d with the caller's keep-mask/(1-p) — fs_relation.py:104,
+ * 121; the same call is its backward. */
+int evk_channel_scale(const float* x, const float* scale, float* y, int32_t N, int64_t HW, int32_t C,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -386,6 +386,41 @@ def next_rows_kats(er):
     print('next-row KATs:', len(out), 'values,', len(arrays), 'arrays')
 
 
+def fsrel_v2_case(er):
+    """FSRelationV2 (reference fs_relation.py:76-163) forward + backward with portable weights; Dropout2d is set to
+    p = 0 so that the training-mode run is deterministic (the mask path is tested against its formula)."""
+    from oracle import portable
+    from ever.module.fs_relation import FSRelationV2
+    for sap in (True, False):
+        torch.manual_seed(0)
+        m = FSRelationV2(128, (64, 64, 64, 64), 64, scale_aware_proj=sap)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in portable.fill_state_dict(m.state_dict()).items()})
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout2d):
+                mod.p = 0.0
+        m.train()
+        scene = torch.from_numpy(portable.normalish('fsv2/scene', (2, 128, 1, 1))).requires_grad_()
+        feats = [torch.from_numpy(portable.normalish(f'fsv2/f{i}', (2, 64, s, s))).requires_grad_()
+                 for i, s in enumerate((16, 8, 4, 2))]
+        outs = m(scene, feats)
+        gouts = [torch.from_numpy(portable.normalish(f'fsv2/g{i}', tuple(o.shape))) for i, o in enumerate(outs)]
+        torch.autograd.backward(outs, gouts)
+        arrays = {f'out{i}': o.detach().numpy() for i, o in enumerate(outs)}
+        arrays['dscene'] = scene.grad.numpy()
+        for i, f in enumerate(feats):
+            arrays[f'dfeat{i}'] = f.grad.numpy()
+        for k, p_ in m.named_parameters():
+            arrays['grad/' + k] = p_.grad.numpy()
+        for k, b in m.named_buffers():
+            arrays['buf/' + k] = b.numpy()
+        m.eval()
+        with torch.no_grad():
+            for i, o in enumerate(m(scene, feats)):
+                arrays[f'eval_out{i}'] = o.numpy()
+        np.savez_compressed(os.path.join(OUT, f'fsrel_v2_sap{int(sap)}.npz'), **arrays)
+        print('FSRelationV2 scale_aware_proj =', sap, ':', len(arrays), 'arrays')
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     er = import_reference()
@@ -397,10 +432,12 @@ def main():
         return
     if only == 'next':
         next_rows_kats(er)
+        fsrel_v2_case(er)
         return
     op_kats(er)
     block_vectors(er)
     next_rows_kats(er)
+    fsrel_v2_case(er)
     launcher_case(er)
     e2e_case(er, 'r18_4band_64', 'resnet18', 4, 2, 64)
     e2e_case(er, 'r50_3band_64', 'resnet50', 3, 2, 64)

@@ -88,3 +88,82 @@ def test_confusion_from_logits_with_ignore_and_many_classes(cuda):
         b.forward(y.numpy(), pred.numpy())
         assert a.dense_cm.tolist() == b.dense_cm.tolist()
         assert a.dense_cm.sum() == (y != 255).sum().item()
+
+
+@pytest.mark.parametrize('n,c,h,w,g,relu', [(2, 256, 1, 1, 32, True), (3, 128, 9, 7, 32, False), (2, 48, 33, 20, 4, True),
+                                            (1, 256, 64, 64, 32, True)])
+def test_group_norm_matches_torch(cuda, n, c, h, w, g, relu):
+    from ever_amd.hip import functional_next as HN
+    gen = torch.Generator().manual_seed(n * 1000 + c + h)
+    x = torch.randn(n, c, h, w, generator=gen) * 2 + 0.7
+    wt, b = torch.randn(c, generator=gen), torch.randn(c, generator=gen)
+    gy = torch.randn(n, c, h, w, generator=gen)
+    # fp64 reference: with 8-element groups (the 1x1 scene embedding) 1/std amplifies rounding differences
+    xr, wr, br = x.double().requires_grad_(), wt.double().requires_grad_(), b.double().requires_grad_()
+    yr = torch.nn.functional.group_norm(xr, g, wr, br, 1e-5)
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(gy.double())
+    xg, wg, bg = x.to(cuda).requires_grad_(), wt.to(cuda).requires_grad_(), b.to(cuda).requires_grad_()
+    yg = HN.group_norm_act(xg, g, wg, bg, 1e-5, relu=relu)
+    yg.backward(gy.to(cuda))
+    _close(yg.detach().cpu().contiguous().numpy(), yr.detach().numpy(), 1e-5)
+    _close(xg.grad.cpu().contiguous().numpy(), xr.grad.numpy(), 1e-4)
+    _close(wg.grad.cpu().numpy(), wr.grad.numpy(), 1e-4)
+    _close(bg.grad.cpu().numpy(), br.grad.numpy(), 1e-4)
+
+
+def test_concat_and_dropout2d(cuda):
+    from ever_amd.hip import functional_next as HN
+    gen = torch.Generator().manual_seed(3)
+    a, b = torch.randn(2, 8, 5, 7, generator=gen), torch.randn(2, 12, 5, 7, generator=gen)
+    ag, bg = a.to(cuda).requires_grad_(), b.to(cuda).requires_grad_()
+    out = HN.concat_channels(ag, bg)
+    assert torch.equal(out.detach().cpu(), torch.cat([a, b], 1))
+    gy = torch.randn(2, 20, 5, 7, generator=gen)
+    out.backward(gy.to(cuda))
+    assert torch.equal(ag.grad.cpu(), gy[:, :8]) and torch.equal(bg.grad.cpu(), gy[:, 8:])
+    mask = (torch.rand(2, 8, generator=gen) > 0.3).float()
+    xg = a.to(cuda).requires_grad_()
+    y = HN.dropout2d(xg, 0.25, True, mask=mask)
+    want = a * (mask / 0.75)[:, :, None, None]
+    _close(y.detach().cpu().contiguous().numpy(), want.numpy(), 1e-6)
+    y.backward(torch.ones_like(y))
+    _close(xg.grad.cpu().contiguous().numpy(), ((mask / 0.75)[:, :, None, None]).expand_as(a).numpy(), 1e-6)
+    assert HN.dropout2d(xg, 0.25, False) is xg
+    # the random draw keeps whole channels and rescales the survivors
+    z = HN.dropout2d(torch.ones(4, 64, 3, 3, device=cuda), 0.5, True).cpu()
+    per = z.reshape(4, 64, -1)
+    assert ((per == 0).all(-1) | (per == 2).all(-1)).all() and 0 < (per[:, :, 0] == 0).float().mean() < 1
+
+
+@pytest.mark.parametrize('sap', [True, False])
+def test_fs_relation_v2_matches_reference(cuda, sap, conv_math):
+    from ever_amd.module.fs_relation import FSRelationV2
+    gold = np.load(os.path.join(GOLD, f'fsrel_v2_sap{int(sap)}.npz'))
+    m = FSRelationV2(128, (64, 64, 64, 64), 64, scale_aware_proj=sap)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in portable.fill_state_dict(m.state_dict()).items()})
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout2d):
+            mod.p = 0.0
+    m = m.to(cuda).train()
+    scene = torch.from_numpy(portable.normalish('fsv2/scene', (2, 128, 1, 1))).to(cuda).requires_grad_()
+    feats = [torch.from_numpy(portable.normalish(f'fsv2/f{i}', (2, 64, s, s))).to(cuda).requires_grad_()
+             for i, s in enumerate((16, 8, 4, 2))]
+    outs = m(scene, feats)
+    gouts = [torch.from_numpy(portable.normalish(f'fsv2/g{i}', tuple(o.shape))).to(cuda) for i, o in enumerate(outs)]
+    torch.autograd.backward(outs, gouts)
+    for i, o in enumerate(outs):
+        _close(o.detach().cpu().contiguous().numpy(), gold[f'out{i}'], 1e-4)
+    _close(scene.grad.cpu().contiguous().numpy(), gold['dscene'], 2e-4)
+    for i, f in enumerate(feats):
+        _close(f.grad.cpu().contiguous().numpy(), gold[f'dfeat{i}'], 2e-4)
+    for k, p_ in m.named_parameters():
+        _close(p_.grad.cpu().contiguous().numpy(), gold['grad/' + k], 3e-4)
+    sd = m.state_dict()  # flushes the lazily counted num_batches_tracked
+    for k, _ in m.named_buffers():
+        _close(sd[k].cpu().numpy(), gold['buf/' + k], 1e-5)
+    m.eval()
+    with torch.no_grad():
+        for i, o in enumerate(m(scene, feats)):
+            _close(o.cpu().contiguous().numpy(), gold[f'eval_out{i}'], 1e-4)
