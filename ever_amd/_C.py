@@ -90,6 +90,10 @@ SIGNATURES = {
     'evk_concat_channels': (c_int, [P, P, P, c_i64, c_i32, c_i32, P]),
     'evk_split_channels': (c_int, [P, P, P, c_i64, c_i32, c_i32, P]),
     'evk_channel_scale': (c_int, [P, P, P, c_i32, c_i64, c_i32, P]),
+    'evk_bn_local_stats': (c_int, [P, P, c_i64, c_i32, P, c_size_t, P]),
+    'evk_bn_apply_stats': (c_int, [P, P, P, P, P, P, P, c_i64, c_i32, c_u32, P, c_size_t, P]),
+    'evk_bn_bwd_local_sums': (c_int, [P, P, P, P, P, P, P, P, P, c_i64, c_i32, c_u32, P, c_size_t, P]),
+    'evk_bn_bwd_apply_sums': (c_int, [P, P, P, P, P, P, P, P, P, P, c_i64, c_i32, c_u32, P, c_size_t, P]),
 }
 
 _lib = None

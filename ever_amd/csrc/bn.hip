@@ -484,3 +484,124 @@ extern "C" int evk_bn_bwd(const float* dy, const float* x, const float* y, const
                      save_mean, save_invstd, coef, gamma, beta, dx, n4, C, relu3, bn_unroll());
   return check_launch("bn_bwd_apply");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Staged entry points for synchronized BatchNorm (torch.nn.SyncBatchNorm under
+// `sync_bn=True`, reference ever/trainer/th_ddp_trainer.py): the same kernels as above with the
+// cross-rank exchange left to the caller between the stages (one small all-gather forward, one small
+// all-reduce backward, on torch.distributed / RCCL).
+namespace evk {
+
+// stats[c] = local mean, stats[C + c] = local sum of squared deviations from it (fp64)
+__global__ __launch_bounds__(256) void bn_local_final_kernel(const float* __restrict__ x, const float* __restrict__ partial,
+                                                             int nblk, int C, double rows, double* __restrict__ stats) {
+  int c;
+  double s, q;
+  if (!reduce_partials(partial, nblk, C, c, s, q)) return;
+  const double dm = s / rows;  // mean of (x - pivot)
+  stats[c] = (double)x[c] + dm;
+  double m2 = q - s * dm;
+  stats[C + c] = m2 > 0.0 ? m2 : 0.0;
+}
+__global__ void bn_coef_from_stats_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                          const float* __restrict__ mean, const float* __restrict__ invstd, int C,
+                                          float* __restrict__ scale_shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = (gamma ? gamma[c] : 1.f) * invstd[c];
+  scale_shift[c] = sc;
+  scale_shift[C + c] = (beta ? beta[c] : 0.f) - mean[c] * sc;
+}
+__global__ __launch_bounds__(256) void bn_bwd_sums_final_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                                double* __restrict__ sums) {
+  int c;
+  double s, q;
+  if (!reduce_partials(partial, nblk, C, c, s, q)) return;
+  sums[c] = s;
+  sums[C + c] = q;
+}
+__global__ void bn_bwd_coef_kernel(const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                   const float* __restrict__ mean_g, const float* __restrict__ mean_gx, int C,
+                                   float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  coef[c] = (gamma ? gamma[c] : 1.f) * invstd[c];
+  coef[C + c] = mean_g[c];
+  coef[2 * C + c] = mean_gx[c];
+}
+
+}  // namespace evk
+
+static int bn_stage_check(const char* what, int64_t rows, int32_t C, const void* ws, size_t ws_bytes) {
+  EVK_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 2048, EVK_E_UNSUPPORTED, "%s: rows=%lld C=%d", what, (long long)rows,
+              C);
+  EVK_REQUIRE(ws && ws_bytes >= evk_bn_workspace_bytes(rows, C), EVK_E_WORKSPACE, "%s: workspace too small", what);
+  return EVK_OK;
+}
+
+extern "C" int evk_bn_local_stats(const float* x, double* stats, int64_t rows, int32_t C, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  EVK_REQUIRE(x && stats, EVK_E_INVALID, "bn_local_stats: null pointer");
+  int rc = bn_stage_check("bn_local_stats", rows, C, workspace, workspace_bytes);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const BnPlan pl = bn_plan(rows, C);
+  float* partial = (float*)workspace;
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(pl.nblk), dim3(256), 0, st, x, partial, rows, C, pl.rows_per_blk,
+                     pl.tpc, pl.rl);
+  hipLaunchKernelGGL(bn_local_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, x, (const float*)partial,
+                     pl.nblk, C, (double)rows, stats);
+  return check_launch("bn_local_stats");
+}
+
+extern "C" int evk_bn_apply_stats(const float* x, const float* residual, const float* gamma, const float* beta,
+                                  const float* mean, const float* invstd, float* y, int64_t rows, int32_t C,
+                                  uint32_t flags, void* workspace, size_t workspace_bytes, void* stream) {
+  EVK_REQUIRE(x && y && mean && invstd, EVK_E_INVALID, "bn_apply_stats: null pointer");
+  int rc = bn_stage_check("bn_apply_stats", rows, C, workspace, workspace_bytes);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  float* scale_shift = (float*)workspace;
+  hipLaunchKernelGGL(bn_coef_from_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, st, gamma, beta, mean, invstd, C,
+                     scale_shift);
+  const size_t n4 = (size_t)rows * C / 4;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(n4)), dim3(256), 2 * C * sizeof(float), st, x, residual,
+                     (const float*)scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, bn_unroll());
+  return check_launch("bn_apply_stats");
+}
+
+extern "C" int evk_bn_bwd_local_sums(const float* dy, const float* x, const float* y, const float* gamma,
+                                     const float* beta, const float* mean, const float* invstd, float* d_residual,
+                                     double* sums, int64_t rows, int32_t C, uint32_t flags, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  EVK_REQUIRE(dy && x && mean && invstd && sums, EVK_E_INVALID, "bn_bwd_local_sums: null pointer");
+  const int relu = (flags & EVK_BN_RELU) ? (y ? 1 : 2) : 0;
+  EVK_REQUIRE(relu != 2 || !d_residual, EVK_E_INVALID, "bn_bwd_local_sums: a residual branch needs y for the ReLU mask");
+  int rc = bn_stage_check("bn_bwd_local_sums", rows, C, workspace, workspace_bytes);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const BnPlan pl = bn_plan(rows, C);
+  float* partial = (float*)workspace;
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(pl.nblk), dim3(256), 0, st, dy, x, y, mean, invstd, gamma, beta,
+                     d_residual, partial, rows, C, pl.rows_per_blk, pl.tpc, pl.rl, relu);
+  hipLaunchKernelGGL(bn_bwd_sums_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, (const float*)partial,
+                     pl.nblk, C, sums);
+  return check_launch("bn_bwd_local_sums");
+}
+
+extern "C" int evk_bn_bwd_apply_sums(const float* dy, const float* x, const float* y, const float* gamma,
+                                     const float* beta, const float* mean, const float* invstd, const float* mean_g,
+                                     const float* mean_gx, float* dx, int64_t rows, int32_t C, uint32_t flags,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  EVK_REQUIRE(dy && x && mean && invstd && mean_g && mean_gx && dx, EVK_E_INVALID, "bn_bwd_apply_sums: null pointer");
+  const int relu = (flags & EVK_BN_RELU) ? (y ? 1 : 2) : 0;
+  int rc = bn_stage_check("bn_bwd_apply_sums", rows, C, workspace, workspace_bytes);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  float* coef = (float*)workspace;
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, st, gamma, invstd, mean_g, mean_gx, C, coef);
+  const size_t n4 = (size_t)rows * C / 4;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(256), 7 * C * sizeof(float), st, dy, x, y, mean,
+                     invstd, (const float*)coef, gamma, beta, dx, n4, C, relu, bn_unroll());
+  return check_launch("bn_bwd_apply_sums");
+}

@@ -142,7 +142,7 @@ def run_sequence(mods, x):
         if isinstance(m, Conv2d) and isinstance(nxt, nn.ReLU):
             x = m(x, relu=True)
             i += 2
-        elif isinstance(m, (BatchNorm2d, GroupNorm)) and isinstance(nxt, nn.ReLU):
+        elif isinstance(m, (BatchNorm2d, GroupNorm, nn.SyncBatchNorm)) and isinstance(nxt, nn.ReLU):
             x = m(x, relu=True)
             i += 2
         elif isinstance(m, nn.Identity):

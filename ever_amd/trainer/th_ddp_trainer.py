@@ -28,8 +28,10 @@ class THDDPTrainer(trainer.Trainer):
     def make_model(self, model_fn=None):
         model = super().make_model(model_fn=model_fn)
         if self.config.train.get('sync_bn', False):
-            raise NotImplementedError('sync_bn: SyncBatchNorm has no HIP kernel yet (SURVEY §8 f2); BN statistics '
-                                      'stay per GPU as in the reference default')
+            if not self._cuda:
+                raise NotImplementedError('sync_bn needs the GPU path (staged HIP BatchNorm + RCCL)')
+            from ..module.sync_bn import convert_sync_batchnorm
+            model = convert_sync_batchnorm(model)  # reference: nn.SyncBatchNorm.convert_sync_batchnorm
         model = model.to(self.device)
         ddp_kwargs = dict(find_unused_parameters=getattr(self.args, 'find_unused_parameters', False),
                           bucket_cap_mb=self.config.train.get('bucket_cap_mb', 64),

@@ -295,6 +295,25 @@ int evk_split_channels(const float* src, float* a, float* b, int64_t rows, int32
 int evk_channel_scale(const float* x, const float* scale, float* y, int32_t N, int64_t HW, int32_t C,
                       void* stream);
 
+/* Synchronized BatchNorm in stages (torch.nn.SyncBatchNorm under the trainer's `sync_bn`, reference
+ * ever/trainer/th_ddp_trainer.py + SURVEY §8 C5): the exchange between the stages is the caller's
+ * (torch.distributed over RCCL): forward all-gather of `stats` (local mean, local sum of squared deviations,
+ * fp64 [2C]) + the row count; backward all-reduce of `sums` (sum g, sum g*xhat, fp64 [2C]).
+ * Workspace: evk_bn_workspace_bytes(rows, C).  flags / y / d_residual as evk_bn_fwd_train / evk_bn_bwd. */
+int evk_bn_local_stats(const float* x, double* stats, int64_t rows, int32_t C, void* workspace,
+                       size_t workspace_bytes, void* stream);
+int evk_bn_apply_stats(const float* x, const float* residual, const float* gamma, const float* beta,
+                       const float* mean, const float* invstd, float* y, int64_t rows, int32_t C,
+                       uint32_t flags, void* workspace, size_t workspace_bytes, void* stream);
+int evk_bn_bwd_local_sums(const float* dy, const float* x, const float* y, const float* gamma,
+                          const float* beta, const float* mean, const float* invstd, float* d_residual,
+                          double* sums, int64_t rows, int32_t C, uint32_t flags, void* workspace,
+                          size_t workspace_bytes, void* stream);
+int evk_bn_bwd_apply_sums(const float* dy, const float* x, const float* y, const float* gamma,
+                          const float* beta, const float* mean, const float* invstd, const float* mean_g,
+                          const float* mean_gx, float* dx, int64_t rows, int32_t C, uint32_t flags,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,3 +50,52 @@ def test_farseg_under_ddp_rccl_world1(cuda):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_sync_batchnorm_model_under_rccl_world1(cuda):
+    """convert_sync_batchnorm over the whole FarSeg model, through the real collectives (world_size 1 on this
+    box): with one rank SyncBatchNorm must reproduce BatchNorm (same statistics, fp64-merged), including the
+    fused residual / ReLU call sites of the ResNet blocks and the running statistics."""
+    import torch.distributed as dist
+    import ever_amd as er
+    from ever_amd.module.sync_bn import SyncBatchNorm, convert_sync_batchnorm
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29618')
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group(backend='nccl', init_method='env://', rank=0, world_size=1)
+        created = True
+    try:
+        torch.manual_seed(0)
+        widths = (64, 128, 256, 512)
+        cfg = dict(encoder=dict(resnet_type='resnet18', in_channels=4),
+                   head=dict(fpn=dict(in_channels_list=widths, out_channels=256),
+                             fs_relation=dict(scene_embedding_channels=512)))
+        plain = er.module.FarSeg(cfg).to(cuda).train()
+        synced = er.module.FarSeg(cfg)
+        synced.load_state_dict(plain.state_dict())
+        synced = convert_sync_batchnorm(synced).to(cuda).train()
+        assert sum(isinstance(m, SyncBatchNorm) for m in synced.modules()) == sum(
+            isinstance(m, torch.nn.BatchNorm2d) for m in plain.modules())
+        assert list(synced.state_dict().keys()) == list(plain.state_dict().keys())
+        x = torch.randn(2, 4, 128, 128, device=cuda)
+        y = (torch.rand(2, 128, 128, device=cuda) < 0.3).long()
+        la, lb = plain(x, y), synced(x, y)
+        sum(la.values()).backward()
+        sum(lb.values()).backward()
+        for k in la:
+            assert abs(la[k].item() - lb[k].item()) <= 1e-4 * abs(la[k].item()), (k, la[k].item(), lb[k].item())
+        sa, sb = plain.state_dict(), synced.state_dict()
+        for k in sa:
+            if 'running_' in k:
+                assert torch.allclose(sa[k], sb[k], rtol=1e-4, atol=1e-6), k
+            if 'num_batches_tracked' in k:
+                assert int(sa[k]) == int(sb[k]) == 1, k
+        num = den = 0.0
+        for (k, p), (_, q) in zip(plain.named_parameters(), synced.named_parameters()):
+            num += float((p.grad.double() - q.grad.double()).pow(2).sum())
+            den += float(p.grad.double().pow(2).sum())
+        assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5   # fp32 vs fp64-merged statistics, ill-conditioned net
+    finally:
+        if created:
+            dist.destroy_process_group()

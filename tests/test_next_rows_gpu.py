@@ -167,3 +167,86 @@ def test_fs_relation_v2_matches_reference(cuda, sap, conv_math):
     with torch.no_grad():
         for i, o in enumerate(m(scene, feats)):
             _close(o.cpu().contiguous().numpy(), gold[f'eval_out{i}'], 1e-4)
+
+
+@pytest.mark.parametrize('relu,res', [(False, False), (True, False), (True, True)])
+def test_sync_batchnorm_two_virtual_ranks_equal_full_batch_bn(cuda, relu, res):
+    """SyncBatchNorm semantics = plain BatchNorm over the union of the ranks' batches.  Two 'ranks' are the two
+    halves of a batch on one GPU; the collectives are replaced by a hook that feeds each half the other half's
+    local statistics / sums (exactly what all_gather / all_reduce would deliver), everything else is the
+    product path.  Reference: torch BatchNorm2d on the full batch (CPU, fp64)."""
+    from ever_amd.module.sync_bn import SyncBatchNorm
+    gen = torch.Generator().manual_seed(11)
+    c = 32
+    x = torch.randn(6, c, 9, 5, generator=gen) * 1.7 + 0.4
+    x[:2] += 1.5  # make the two halves statistically different
+    r = torch.randn(6, c, 9, 5, generator=gen) if res else None
+    gy = torch.randn(6, c, 9, 5, generator=gen)
+    wt, bs = torch.rand(c, generator=gen) + 0.5, torch.randn(c, generator=gen)
+    ref = torch.nn.BatchNorm2d(c).double()
+    ref.weight.data, ref.bias.data = wt.double(), bs.double()
+    xr = x.double().requires_grad_()
+    rr = r.double().requires_grad_() if res else None
+    yr = ref(xr)
+    if res:
+        yr = yr + rr
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(gy.double())
+
+    halves = [slice(0, 2), slice(2, 6)]  # unequal counts on purpose
+    mods, xs, rs = [], [], []
+    for _ in halves:
+        m = SyncBatchNorm(c).to(cuda)
+        m.weight.data, m.bias.data = wt.to(cuda), bs.to(cuda)
+        mods.append(m.train())
+    # pass 1: each rank's local forward statistics (what all_gather would exchange)
+    local = {}
+
+    def grab(i):
+        def hook(stats, backward=False):
+            local[(i, backward)] = stats.clone()
+            return stats[None] if not backward else stats
+        return hook
+    for i, sl in enumerate(halves):
+        mods[i]._stats_hook = grab(i)
+        xi = x[sl].to(cuda).requires_grad_()
+        ri = r[sl].to(cuda).requires_grad_() if res else None
+        yi = mods[i](xi, residual=ri, relu=relu)
+        yi.backward(gy[sl].to(cuda))   # records this rank's (unsynchronised) backward sums
+    fwd_all = torch.stack([local[(0, False)], local[(1, False)]])
+
+    # pass 2: the synchronised run.  Forward hook returns the gathered statistics; the backward sums depend on the
+    # synchronised statistics, so they are collected in a first synchronised sweep and summed for the second.
+    def synced(i, bwd_total):
+        def hook(stats, backward=False):
+            if not backward:
+                return fwd_all
+            local[(i, 'sb')] = stats.clone()
+            return bwd_total if bwd_total is not None else stats
+        return hook
+    for sweep in range(2):
+        tot = (local[(0, 'sb')] + local[(1, 'sb')]) if sweep == 1 else None
+        outs = []
+        for i, sl in enumerate(halves):
+            m = SyncBatchNorm(c).to(cuda).train()
+            m.weight.data, m.bias.data = wt.to(cuda), bs.to(cuda)
+            m._stats_hook = synced(i, tot)
+            xi = x[sl].to(cuda).requires_grad_()
+            ri = r[sl].to(cuda).requires_grad_() if res else None
+            yi = m(xi, residual=ri, relu=relu)
+            yi.backward(gy[sl].to(cuda))
+            outs.append((m, xi, ri, yi))
+    y = torch.cat([o[3].detach().cpu() for o in outs])
+    dx = torch.cat([o[1].grad.cpu() for o in outs])
+    _close(y.contiguous().numpy(), yr.detach().numpy(), 2e-5)
+    _close(dx.contiguous().numpy(), xr.grad.numpy(), 1e-4)
+    if res:
+        _close(torch.cat([o[2].grad.cpu() for o in outs]).contiguous().numpy(), rr.grad.numpy(), 1e-5)
+    dw = sum(o[0].weight.grad.cpu() for o in outs)  # DDP would sum (average) the local parameter gradients
+    db = sum(o[0].bias.grad.cpu() for o in outs)
+    _close(dw.numpy(), ref.weight.grad.numpy(), 1e-4)
+    _close(db.numpy(), ref.bias.grad.numpy(), 1e-4)
+    for o in outs:  # running statistics use the merged mean / unbiased variance on every rank
+        _close(o[0].running_mean.cpu().numpy(), ref.running_mean.numpy(), 1e-5)
+        _close(o[0].running_var.cpu().numpy(), ref.running_var.numpy(), 1e-5)
