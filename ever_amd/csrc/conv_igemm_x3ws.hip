@@ -277,6 +277,11 @@ int launch_igemm_x3ws(IGemmArgs& a, hipStream_t stream) {
   // (1x1 convolutions, K <= 512: 2..16 steps) run better as 2-3 single-role workgroups per CU, unless the
   // grid is below two per CU anyway.  Measured on the FarSeg-R50 layer set (tools/bench_conv_x3.py).
   if (mode == 1 && a.Kpad < 1024 && t128 >= 512) return 1;
+  // 128x256 tiles where the output is wide enough: the activation split (VALU) and the L2 -> CU bytes per MFMA
+  // drop by half / a fifth
+  static const int wide = getenv("EVK_X3_WIDE") ? atoi(getenv("EVK_X3_WIDE")) : 1;
+  if (wide && a.Cd >= 256 && (long long)ceil_div(a.M, 128) * ceil_div(a.Cd, 256) >= 256)
+    return launch_ws<128, 256, 2, 2, 2>(a, stream);
   if (bn == 128) return launch_ws<128, 128, 2, 2, 2>(a, stream);
   return launch_ws<128, 64, 2, 2, 2>(a, stream);
 }
