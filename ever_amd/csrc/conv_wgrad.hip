@@ -242,6 +242,10 @@ WGradPlan plan_wgrad(const evk_conv_desc* d, int x3) {
   const int M = d->N * d->Ho * d->Wo;
   pl.bm = d->Cout <= 64 ? 64 : 128;
   pl.bn = Ktot <= 64 ? 64 : 128;
+  // wide wave-specialised tile (128 x 256, one 8-wave workgroup per CU) when both dimensions are there
+  static const int ws_mode = getenv("EVK_WG_WS") ? atoi(getenv("EVK_WG_WS")) : 1;
+  pl.ws = (x3 && ws_mode && d->Cout >= 128 && Ktot >= 256) ? 1 : 0;
+  if (pl.ws) pl.bn = 256;
   pl.tiles_co = ceil_div(d->Cout, pl.bm);
   pl.tiles_k = ceil_div(Ktot, pl.bn);
   const int tiles = pl.tiles_co * pl.tiles_k;
@@ -252,7 +256,7 @@ WGradPlan plan_wgrad(const evk_conv_desc* d, int x3) {
   static const int min_chunk = getenv("EVK_WG_MINCHUNK") ? atoi(getenv("EVK_WG_MINCHUNK")) : 256;
   const int lds_kb = 2 * BKP * (pl.bm + pl.bn) * 4 / 1024;
   // split kernel: single-buffered 3-plane bf16 stage (48 KB at 128x128), residency set by its VGPRs
-  const int per_cu = x3 ? (pl.bm + pl.bn >= 256 ? 3 : 4)
+  const int per_cu = pl.ws ? 1 : x3 ? (pl.bm + pl.bn >= 256 ? 3 : 4)
                         : (lds_kb >= 64 ? 2 : (lds_kb >= 48 ? 3 : 4));
   const int slots = 256 * per_cu;
   int maxsplit = ceil_div(M, min_chunk);  // at least min_chunk pixels per split

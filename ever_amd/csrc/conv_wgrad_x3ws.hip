@@ -1,0 +1,254 @@
+// Wave-specialised, wide-tile form of the split-MFMA weight gradient (arithmetic and LDS image: see
+// conv_wgrad_x3.hip / conv_igemm_x3.hip).  One 8-wave workgroup per CU computes a 128 (Cout) x 256 (k) tile
+// of dw over its pixel chunk:
+//   waves 0-3  matrix waves, 64 x 128 each (2 x 4 MFMA blocks): fragment reads + v_mfma_f32_32x32x16_bf16;
+//   waves 4-7  staging waves: every thread gathers an 8-pixel x 4-channel micro-block of im2col(x) (256 per
+//              step), threads of waves 4-5 one of dy in addition (128 per step); exact 3-way bf16 split and
+//              the register transpose into the pixel-contiguous planes; two register sets deep, two LDS stages.
+// Against the 128x128 single-role kernel: 25 % fewer operand elements (loads and splits) per MFMA, and the
+// split no longer shares a wave with the MFMA stream.
+#include "wgrad_common.hpp"
+#include "x3_common.hpp"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace evk {
+
+struct WGather {
+  const float* src;
+  int Hs, Ws, Cs, ssh, ssw, offy, offx, coff;
+  bool cvalid;
+};
+
+__device__ __forceinline__ void gather8(const WGradArgs& p, const WGather& g, int m0, int pend, f32x4 (&rv)[8],
+                                        uint32_t& okmask) {
+  okmask = 0;
+  if ((p.Wo & 7) == 0) {
+    const uint32_t mm = (uint32_t)min(m0, p.M - 1);
+    const uint32_t n = fdiv(mm, p.fd_hw);
+    const uint32_t rem = mm - n * p.fd_hw.div;
+    const uint32_t oy = fdiv(rem, p.fd_w);
+    const int ox = (int)(rem - oy * p.fd_w.div);
+    const int sy = (int)oy * g.ssh + g.offy;
+    const bool rowok = g.cvalid && m0 < pend && (unsigned)sy < (unsigned)g.Hs;
+    const int base = ((int)n * g.Hs + sy) * g.Ws * g.Cs + g.coff;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int sx = (ox + j) * g.ssw + g.offx;
+      const bool ok = rowok && (unsigned)sx < (unsigned)g.Ws;
+      okmask |= ok ? (1u << j) : 0u;
+      rv[j] = *reinterpret_cast<const f32x4*>(g.src + (ok ? base + sx * g.Cs : 0));
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int m = m0 + j;
+      const uint32_t mm = (uint32_t)min(m, p.M - 1);
+      const uint32_t n = fdiv(mm, p.fd_hw);
+      const uint32_t rem = mm - n * p.fd_hw.div;
+      const uint32_t oy = fdiv(rem, p.fd_w);
+      const int ox = (int)(rem - oy * p.fd_w.div);
+      const int sy = (int)oy * g.ssh + g.offy, sx = ox * g.ssw + g.offx;
+      const bool ok = g.cvalid && m < pend && (unsigned)sy < (unsigned)g.Hs && (unsigned)sx < (unsigned)g.Ws;
+      okmask |= ok ? (1u << j) : 0u;
+      rv[j] = *reinterpret_cast<const f32x4*>(g.src + (ok ? (((int)n * g.Hs + sy) * g.Ws + sx) * g.Cs + g.coff : 0));
+    }
+  }
+}
+
+// split the micro-block and write channel 4*cq+e to LDS row e*Q + cq, 16-byte chunk pg, of the three planes
+__device__ __forceinline__ void split_store8(f32x4 (&rv)[8], uint32_t okmask, unsigned char* base, int plane_bytes, int Q,
+                                             int cq, int pg) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const bool ok = (okmask >> j) & 1u;
+    rv[j].x = ok ? rv[j].x : 0.f; rv[j].y = ok ? rv[j].y : 0.f;
+    rv[j].z = ok ? rv[j].z : 0.f; rv[j].w = ok ? rv[j].w : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int off = plane_off(e * Q + cq, pg);
+    u32x4 H, M, L;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      uint32_t h, m, l;
+      split2(rv[2 * t][e], rv[2 * t + 1][e], h, m, l);
+      H[t] = h; M[t] = m; L[t] = l;
+    }
+    *reinterpret_cast<u32x4*>(base + off) = H;
+    *reinterpret_cast<u32x4*>(base + plane_bytes + off) = M;
+    *reinterpret_cast<u32x4*>(base + 2 * plane_bytes + off) = L;
+  }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p) {
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int MB = WM / 32, NB = WN / 32;
+  constexpr int QA = BM / 4, QB = BN / 4;
+  constexpr int kStage = 3 * (BM + BN) * kRowBytes;
+  static_assert(QB * 4 == 256 && QA * 4 <= 256, "staging waves: one im2col micro-block per thread, dy on the first ones");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = p.tiles_co * p.tiles_k;
+  const int z = bid / ntile;
+  const int tile = bid - z * ntile;
+  const int tile_k = tile % p.tiles_k;
+  const int tile_co = tile / p.tiles_k;
+  const int co0 = tile_co * BM, k0 = tile_k * BN;
+  const int pbeg = z * p.chunk;
+  const int pend = min(p.M, pbeg + p.chunk);
+  const int nk = (pend - pbeg + BKP - 1) / BKP;
+  const int tid = threadIdx.x;
+
+  if (tid >= 256) {
+    // ------------------------------------------------------------------ staging waves
+    const int ptid = tid - 256;
+    const bool hasA = ptid < QA * 4;  // wave-uniform (QA*4 = 128 = two waves)
+    WGather gb, ga;
+    const int bcq = ptid % QB, bpg = ptid / QB;
+    const int acq = ptid % QA, apg = (ptid / QA) & 3;
+    {
+      gb.src = p.x; gb.Hs = p.H; gb.Ws = p.W; gb.Cs = p.Cin; gb.ssh = p.sh; gb.ssw = p.sw;
+      const int q = (k0 >> 2) + bcq;
+      gb.cvalid = q * 4 < p.Ktot;
+      gb.offy = gb.offx = gb.coff = 0;
+      if (gb.cvalid) {
+        const int tap = q / p.cpt;
+        gb.coff = (q - tap * p.cpt) * 4;
+        const int ky = tap / p.kw, kx = tap - ky * p.kw;
+        gb.offy = ky * p.dh - p.ph;
+        gb.offx = kx * p.dw - p.pw;
+      }
+      ga.src = p.dy; ga.Hs = p.Ho; ga.Ws = p.Wo; ga.Cs = p.Cout; ga.ssh = 1; ga.ssw = 1; ga.offy = 0; ga.offx = 0;
+      ga.coff = co0 + acq * 4;
+      ga.cvalid = hasA && ga.coff < p.Cout;
+    }
+    f32x4 ra[2][8], rb[2][8];
+    uint32_t oka[2] = {0, 0}, okb[2] = {0, 0};
+
+    auto load = [&](auto SET, int kt) {
+      constexpr int s = decltype(SET)::value;
+      const int pix0 = pbeg + kt * BKP;
+      gather8(p, gb, pix0 + bpg * 8, pend, rb[s], okb[s]);
+      if (hasA) gather8(p, ga, pix0 + apg * 8, pend, ra[s], oka[s]);
+    };
+    auto store = [&](auto SET, int stage) {
+      constexpr int s = decltype(SET)::value;
+      unsigned char* Ab = smem3 + stage * kStage;
+      unsigned char* Bb = Ab + 3 * BM * kRowBytes;
+      split_store8(rb[s], okb[s], Bb, BN * kRowBytes, QB, bcq, bpg);
+      if (hasA) split_store8(ra[s], oka[s], Ab, BM * kRowBytes, QA, acq, apg);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    if (nk > 0) {
+      load(S0{}, 0);
+      if (1 < nk) load(S1{}, 1);
+      store(S0{}, 0);
+      if (2 < nk) load(S0{}, 2);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+      if (kt + 1 < nk) {
+        store(S1{}, 1);
+        if (kt + 3 < nk) load(S1{}, kt + 3);
+      }
+      __syncthreads();
+      if (kt + 1 < nk) {
+        if (kt + 2 < nk) {
+          store(S0{}, 0);
+          if (kt + 4 < nk) load(S0{}, kt + 4);
+        }
+        __syncthreads();
+      }
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- matrix waves
+  __builtin_amdgcn_s_setprio(3);
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  int fa_off[MB][2], fb_off[NB][2];
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) fa_off[a][kk] = plane_off(wm * WM + a * 32 + li, 2 * kk + lh);
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) fb_off[b][kk] = 3 * BM * kRowBytes + plane_off(wn * WN + b * 32 + li, 2 * kk + lh);
+
+  auto half_step = [&](const unsigned char* S, int kk) {
+    bf16x8 fa[MB][3], fb[NB][3];
+#pragma unroll
+    for (int a = 0; a < MB; ++a)
+#pragma unroll
+      for (int pt = 0; pt < 3; ++pt)
+        fa[a][pt] = *reinterpret_cast<const bf16x8*>(S + pt * BM * kRowBytes + fa_off[a][kk]);
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int pt = 0; pt < 3; ++pt)
+        fb[b][pt] = *reinterpret_cast<const bf16x8*>(S + pt * BN * kRowBytes + fb_off[b][kk]);
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int a = 0; a < MB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][kPA[t]], fb[b][kPB[t]], acc[a][b], 0, 0, 0);
+  };
+
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned char* S = smem3 + (kt & 1) * kStage;
+    half_step(S, 0);
+    half_step(S, 1);
+    __syncthreads();
+  }
+
+  float* out = p.out + (size_t)z * p.Cout * p.Ktot;
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ra_ = wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int row = co0 + 4 * (ra_ % QA) + ra_ / QA;
+      if (row >= p.Cout) continue;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int rb_ = wn * WN + b * 32 + li;
+        const int col = k0 + 4 * (rb_ % QB) + rb_ / QB;
+        if (col < p.Ktot) out[(size_t)row * p.Ktot + col] = acc[a][b][r];
+      }
+    }
+}
+
+int launch_wgrad_x3ws(const WGradArgs& a, hipStream_t stream) {
+  constexpr int BM = 128, BN = 256;
+  const size_t lds = (size_t)2 * 3 * (BM + BN) * kRowBytes;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x3ws_kernel<BM, BN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_wgrad_x3ws_kernel<BM, BN>), dim3(a.tiles_co * a.tiles_k * a.splitk), dim3(512), lds, stream, a);
+  return check_launch("conv_wgrad_x3ws");
+}
+
+}  // namespace evk
