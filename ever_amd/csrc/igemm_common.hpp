@@ -23,7 +23,6 @@ struct IGemmArgs {
   int tiles_m, tiles_n;
   const uint16_t* wgt3;     // split kernel: weights as 3 bf16 planes [3][Cd][Kpad] (Kpad % 32 == 0, zero padded)
   int Kpad;
-  int dbg;                  // dev probes only (EVK_X3_DBG): bit0 staging waves idle in the main loop, bit1 matrix waves skip LDS reads
 };
 
 // Epilogue shared by both kernels (the C/D fragment layout does not depend on the input dtype).
