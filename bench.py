@@ -42,6 +42,8 @@ def parse():
     p.add_argument('--warmup', type=int, default=5)
     p.add_argument('--batch', type=int, default=BATCH, help='tiles per GPU (default: the BASELINE config)')
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--ddp', choices=['flat', 'torch'], default='flat',
+                   help='gradient exchange under --gpus N>1: ever_amd FlatGradDDP (default) or torch DistributedDataParallel')
     p.add_argument('--conv-math', choices=['bf16x3', 'f32'], default=None,
                    help='convolution arithmetic (default: ever_amd default = bf16x3 split MFMA; f32 = exact fp32 MFMA)')
     p.add_argument('--no-kernel-timer', action='store_true')
@@ -128,6 +130,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
+        # the image exports NCCL_DEBUG=VERSION: RCCL's banner would follow the JSON line on stdout
+        if 'EVK_NCCL_DEBUG' in os.environ:
+            os.environ['NCCL_DEBUG'] = os.environ['EVK_NCCL_DEBUG']
+        else:
+            os.environ.pop('NCCL_DEBUG', None)
         dist.init_process_group(backend='nccl', init_method='env://', rank=rank, world_size=world,
                                 device_id=dev)   # RCCL over xGMI, communicator bound to this rank's GPU
     import ever_amd as er
@@ -143,8 +150,12 @@ def main():
     model = er.module.FarSeg(dict()).to(dev).train()      # R50 encoder + FarSegHead reference defaults
     ddp = model
     if use_ddp:
-        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
-                                                        bucket_cap_mb=64, gradient_as_bucket_view=True)
+        if args.ddp == 'flat':   # the trainer's default exchange: one pack launch + one RCCL all-reduce per 64 MB bucket
+            from ever_amd.trainer.grad_reducer import FlatGradDDP
+            ddp = FlatGradDDP(model, bucket_cap_mb=64)
+        else:
+            ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
+                                                            bucket_cap_mb=64, gradient_as_bucket_view=True)
     opt = er.opt.FusedSGD(model.parameters(), lr=0.007, momentum=0.9, weight_decay=1e-4)
     x, y = make_batch(dev, args.batch, rank)
 
@@ -239,9 +250,13 @@ def main():
                         'avg_call_us': round(hb['seconds'] / hb['launches'] * 1e6, 2)}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(line), flush=True)
+        out_line = json.dumps(line)
     if use_ddp:
-        torch.distributed.destroy_process_group()
+        torch.distributed.destroy_process_group()   # RCCL prints its version banner here: keep the JSON line last
+    if rank == 0:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        print(out_line, flush=True)
 
 
 if __name__ == '__main__':

@@ -94,6 +94,7 @@ SIGNATURES = {
     'evk_bn_apply_stats': (c_int, [P, P, P, P, P, P, P, c_i64, c_i32, c_u32, P, c_size_t, P]),
     'evk_bn_bwd_local_sums': (c_int, [P, P, P, P, P, P, P, P, P, c_i64, c_i32, c_u32, P, c_size_t, P]),
     'evk_bn_bwd_apply_sums': (c_int, [P, P, P, P, P, P, P, P, P, P, c_i64, c_i32, c_u32, P, c_size_t, P]),
+    'evk_pack_multi': (c_int, [P, P, P, c_i32, c_f32, P, P]),
 }
 
 _lib = None

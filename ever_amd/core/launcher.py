@@ -19,7 +19,11 @@ import types
 
 import torch
 from torch.amp import GradScaler, autocast
-from torch.nn.parallel import DistributedDataParallel
+from torch.nn.parallel import DistributedDataParallel as _TorchDDP
+
+from ..trainer.grad_reducer import FlatGradDDP
+
+DistributedDataParallel = (_TorchDDP, FlatGradDDP)  # both wrap the model as `.module`
 
 from ..interface.callback import Callback, EvaluationCallback, SaveCheckpointCallback
 from ..interface.learning_rate import LearningRateBase

@@ -93,3 +93,28 @@ extern "C" int evk_sgd_multi(float* const* params, const float* const* grads, fl
                      clip_coef);
   return check_launch("sgd_multi");
 }
+
+// dst[offsets[t] + i] = srcs[t][i] * scale  (srcs[t] == NULL: zeros) — one launch packs every gradient of a
+// bucket into the flat all-reduce buffer, pre-divided by the world size (replaces the per-parameter
+// copy + div kernels of torch DDP's reducer: 238 launches / 2.3 ms per step on FarSeg-R50).
+namespace evk {
+__global__ __launch_bounds__(256) void pack_multi_kernel(const float* const* __restrict__ srcs,
+                                                         const int64_t* __restrict__ sizes,
+                                                         const int64_t* __restrict__ offsets, float scale,
+                                                         float* __restrict__ dst) {
+  const int t = blockIdx.y;
+  const float* s = srcs[t];
+  float* d = dst + offsets[t];
+  const int64_t n = sizes[t];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    d[i] = s ? s[i] * scale : 0.f;
+}
+}  // namespace evk
+
+extern "C" int evk_pack_multi(const float* const* srcs, const int64_t* sizes, const int64_t* offsets, int32_t ntensors,
+                              float scale, float* dst, void* stream) {
+  EVK_REQUIRE(srcs && sizes && offsets && dst && ntensors > 0, EVK_E_INVALID, "pack_multi: bad argument");
+  hipLaunchKernelGGL(evk::pack_multi_kernel, dim3(evk::kOptBlocksPerTensor, ntensors), dim3(256), 0, (hipStream_t)stream,
+                     srcs, sizes, offsets, scale, dst);
+  return evk::check_launch("pack_multi");
+}

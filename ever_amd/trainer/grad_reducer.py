@@ -1,0 +1,190 @@
+"""Flat-bucket gradient exchange for the data-parallel trainer (the one collective of the hot path, SURVEY §8 e).
+
+torch's DistributedDataParallel reducer copies (and divides) every gradient into its bucket with one kernel per
+parameter: 238 launches / 2.3 ms per step on FarSeg-R50, a fixed 4 % of a 51 ms step.  `FlatGradDDP` keeps DDP's
+behaviour — parameters broadcast from rank 0 at construction, gradients averaged over the ranks, buckets filled in
+reverse registration order and all-reduced while the rest of backward still runs — with ONE pack launch per bucket
+(evk_pack_multi, pre-scaled by 1/world) and no unpack: after the reduction `p.grad` is a view into the bucket, which
+is what the fused optimizer reads.
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): ring collectives are per-link bound, so buckets are large
+(64 MB default => 3 all-reduces of the 129 MB of FarSeg-R50 gradients) rather than DDP's 25 MB default.
+On CPU (gloo, tests) the pack is a torch copy; the product path is the HIP kernel."""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .. import _C
+
+__all__ = ['FlatGradDDP']
+
+
+class _Bucket:
+    __slots__ = ('params', 'offsets', 'numel', 'flat', 'views', 'ready', 'flushed', 'work', 'sizes_dev', 'offsets_dev',
+                 '_keep')
+
+
+class FlatGradDDP(nn.Module):
+    def __init__(self, module, bucket_cap_mb=64, process_group=None, broadcast_buffers=True):
+        super().__init__()
+        self.module = module
+        self.process_group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.broadcast_buffers = broadcast_buffers
+        params = [p for p in module.parameters() if p.requires_grad]
+        if not params:
+            raise ValueError('FlatGradDDP: the module has no trainable parameter')
+        self.device = params[0].device
+        for p in params:
+            if p.dtype != torch.float32 or p.device != self.device:
+                raise ValueError('FlatGradDDP: parameters must be fp32 on one device')
+        self._cuda = self.device.type == 'cuda'
+        # gradients become ready roughly in reverse registration order
+        cap = int(bucket_cap_mb * 1024 * 1024) // 4
+        self.buckets = []
+        cur, cur_n = [], 0
+        for p in reversed(params):
+            if cur and cur_n + p.numel() > cap:
+                self.buckets.append(self._make_bucket(cur))
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        self.buckets.append(self._make_bucket(cur))
+        self._bucket_of = {}
+        for bi, b in enumerate(self.buckets):
+            for pi, p in enumerate(b.params):
+                self._bucket_of[p] = (bi, pi)
+        self._next = 0              # buckets are reduced in order on every rank
+        self._callback_queued = False
+        self._comm_stream = torch.cuda.Stream(device=self.device) if self._cuda else None
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
+        self._sync_initial_state()
+
+    # ------------------------------------------------------------------ construction
+    def _make_bucket(self, params):
+        b = _Bucket()
+        b.params = list(params)
+        b.offsets, off = [], 0
+        for p in b.params:
+            b.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4          # 16-byte aligned slots
+        b.numel = off
+        b.flat = torch.zeros((off,), device=self.device, dtype=torch.float32)
+        # the gradient view of a parameter shares the parameter's memory order (OHWI for conv weights)
+        b.views = [b.flat.as_strided(p.shape, p.stride(), o) for p, o in zip(b.params, b.offsets)]
+        b.ready = [False] * len(b.params)
+        b.flushed = False
+        b.work = None
+        b.sizes_dev = torch.tensor([p.numel() for p in b.params], dtype=torch.int64, device=self.device)
+        b.offsets_dev = torch.tensor(b.offsets, dtype=torch.int64, device=self.device)
+        return b
+
+    def _src(self):
+        return dist.get_global_rank(self.process_group, 0) if self.process_group is not None else 0
+
+    def _sync_initial_state(self):
+        # floating-point buffers (BatchNorm running statistics) are re-homed into ONE flat tensor, so that DDP's
+        # per-forward buffer broadcast is a single collective with no gather / scatter kernels
+        fbufs = [b for b in self.module.buffers() if b.dtype == torch.float32 and b.device == self.device]
+        self._flat_buffers = None
+        if fbufs:
+            total = sum((b.numel() + 3) // 4 * 4 for b in fbufs)
+            flat = torch.zeros((total,), device=self.device, dtype=torch.float32)
+            off = 0
+            with torch.no_grad():
+                for b in fbufs:
+                    v = flat[off:off + b.numel()].view(b.shape)
+                    v.copy_(b)
+                    b.data = v
+                    off += (b.numel() + 3) // 4 * 4
+            self._flat_buffers = flat
+        if self.world == 1:
+            return
+        with torch.no_grad():
+            for t in self.module.parameters():
+                dist.broadcast(t, src=self._src(), group=self.process_group)
+            for b in self.module.buffers():
+                if b.dtype != torch.float32:
+                    dist.broadcast(b, src=self._src(), group=self.process_group)
+            self.sync_buffers()
+
+    def sync_buffers(self):
+        """Rank 0's floating-point buffers to every rank (one collective)."""
+        if self.world > 1 and self._flat_buffers is not None:
+            dist.broadcast(self._flat_buffers, src=self._src(), group=self.process_group)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, *args, **kwargs):
+        if self.broadcast_buffers and self.training:
+            self.sync_buffers()   # DDP default: the forward starts from rank 0's BatchNorm running statistics
+        return self.module(*args, **kwargs)
+
+    # ------------------------------------------------------------------ backward
+    def _on_grad(self, p):
+        if not self._callback_queued:
+            self._callback_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
+        bi, pi = self._bucket_of[p]
+        b = self.buckets[bi]
+        b.ready[pi] = True
+        while self._next < len(self.buckets) and all(self.buckets[self._next].ready):
+            self._flush(self.buckets[self._next])
+            self._next += 1
+
+    def _dense_like_param(self, g, p):
+        if g.shape == p.shape and g.stride() == p.stride():
+            return g
+        out = torch.empty_strided(p.shape, p.stride(), dtype=g.dtype, device=g.device)
+        out.copy_(g)
+        return out
+
+    def _flush(self, b):
+        scale = 1.0 / self.world
+        grads = [None if p.grad is None else self._dense_like_param(p.grad, p) for p in b.params]
+        if self._cuda:
+            ptrs = torch.tensor([0 if g is None else g.data_ptr() for g in grads], dtype=torch.int64)
+            ptrs = ptrs.to(self.device, non_blocking=True)
+            _C.call('evk_pack_multi', ptrs.data_ptr(), b.sizes_dev.data_ptr(), b.offsets_dev.data_ptr(), len(grads),
+                    scale, b.flat.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            b._keep = (grads, ptrs)  # alive until the pack has run
+        else:
+            for g, v in zip(grads, b.views):
+                if g is None:
+                    v.zero_()
+                else:
+                    v.copy_(g).mul_(scale)
+        if self.world > 1:
+            if self._cuda:
+                self._comm_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._comm_stream):
+                    b.work = dist.all_reduce(b.flat, group=self.process_group, async_op=True)
+            else:
+                b.work = dist.all_reduce(b.flat, group=self.process_group, async_op=True)
+        for p, v in zip(b.params, b.views):
+            p.grad = v
+        b.flushed = True
+
+    def _finalize(self):
+        # parameters that received no gradient this step: their buckets are completed with zeros
+        while self._next < len(self.buckets):
+            self._flush(self.buckets[self._next])
+            self._next += 1
+        for b in self.buckets:
+            if b.work is not None:
+                b.work.wait()        # the current stream waits for the collective
+                b.work = None
+            b.ready = [False] * len(b.params)
+            b.flushed = False
+            if self._cuda:
+                b._keep = None
+        if self._cuda and self.world > 1:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+        self._next = 0
+        self._callback_queued = False
+
+    # DDP API surface the trainer / launcher use
+    def state_dict(self, *args, **kwargs):
+        return self.module.state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        return self.module.load_state_dict(*args, **kwargs)

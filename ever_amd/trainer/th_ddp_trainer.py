@@ -39,7 +39,15 @@ class THDDPTrainer(trainer.Trainer):
                           broadcast_buffers=self.config.train.get('broadcast_buffers', True))
         if self._cuda:
             ddp_kwargs.update(device_ids=[self.args.local_rank], output_device=self.args.local_rank)
-        model = nn.parallel.DistributedDataParallel(model, **ddp_kwargs)
+        # `ddp = "flat"` (default): one pack launch per bucket instead of torch DDP's per-parameter copy kernels
+        # (grad_reducer.py); `ddp = "torch"` keeps torch's DistributedDataParallel (needed for
+        # find_unused_parameters graphs that change between steps, or gradient accumulation via no_sync)
+        if self.config.train.get('ddp', 'flat') == 'flat' and not ddp_kwargs['find_unused_parameters']:
+            from .grad_reducer import FlatGradDDP
+            model = FlatGradDDP(model, bucket_cap_mb=ddp_kwargs['bucket_cap_mb'],
+                                broadcast_buffers=ddp_kwargs['broadcast_buffers'])
+        else:
+            model = nn.parallel.DistributedDataParallel(model, **ddp_kwargs)
         return self.torch_compile(model)
 
     def torch_compile(self, model):

@@ -314,6 +314,13 @@ int evk_bn_bwd_apply_sums(const float* dy, const float* x, const float* y, const
                           const float* mean_gx, float* dx, int64_t rows, int32_t C, uint32_t flags,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* dst[offsets[t] + i] = srcs[t][i] * scale for t < ntensors (a NULL source packs zeros): one launch gathers the
+ * gradients of a bucket into the flat RCCL all-reduce buffer, pre-divided by the world size — the gradient
+ * exchange of the DDP trainer (reference ever/trainer/th_ddp_trainer.py: DistributedDataParallel's reducer).
+ * srcs / sizes / offsets are device arrays. */
+int evk_pack_multi(const float* const* srcs, const int64_t* sizes, const int64_t* offsets,
+                   int32_t ntensors, float scale, float* dst, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
