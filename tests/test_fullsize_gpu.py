@@ -1,0 +1,95 @@
+"""Size-independent properties at the BASELINE workload size (FarSeg-R50, 3x512x512, batch 16), where the CPU
+oracle would take minutes per evaluation:
+  * per-sample independence in eval mode (BatchNorm frozen): a tile's logits do not depend on its batch mates;
+  * linearity of the backward pass in the batch: with frozen statistics and a mean-reduced BCE over equally
+    sized halves, grad(batch) = (grad(half A) + grad(half B)) / 2  — exercises every conv forward / data-gradient /
+    weight-gradient launch (tile shapes, split-K plans, wave-specialised kernels) at the sizes bench.py times;
+  * a training step is finite and its BatchNorm statistics match a two-pass fp64 evaluation of the stem output."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(cuda, **loss):
+    import ever_amd as er
+    torch.manual_seed(2333)
+    cfg = dict(loss=loss) if loss else dict()
+    return er.module.FarSeg(cfg).to(cuda)
+
+
+def _batch(cuda, n=16):
+    g = torch.Generator(device='cpu').manual_seed(99)
+    x = torch.randn(n, 3, 512, 512, generator=g).to(cuda)
+    y = (torch.rand(n, 512, 512, generator=g) < 0.3).long()
+    y[:, :8, :8] = 255
+    return x, y.to(cuda)
+
+
+def test_eval_logits_are_per_sample_independent_at_full_size(cuda, conv_math):
+    m = _model(cuda).eval()
+    x, _ = _batch(cuda)
+    with torch.no_grad():
+        full = m(x)                       # sigmoid probabilities [16, 1, 512, 512]
+        alone = m(x[5:6])
+        pair = m(x[4:6])
+    ref = full[5:6]
+    scale = float(ref.abs().max())
+    assert float((alone - ref).abs().max()) <= 1e-5 * scale
+    assert float((pair[1:2] - ref).abs().max()) <= 1e-5 * scale
+
+
+def test_backward_is_linear_in_the_batch_with_frozen_statistics(cuda, conv_math):
+    m = _model(cuda)
+    m.eval()                              # BatchNorm uses running statistics: every sample is independent
+    for p in m.parameters():
+        p.requires_grad_(True)
+    x, y = _batch(cuda)
+
+    def grads(xs, ys):
+        m.zero_grad(set_to_none=True)
+        from ever_amd.hip import functional as HF
+        from ever_amd.module import loss as L
+        logits = m.head(m.en(HF.as_nhwc(xs)))
+        L.binary_cross_entropy_with_logits(logits, ys).backward()
+        return [p.grad.detach().clone() for p in m.parameters()]
+
+    g_all = grads(x, y)
+    g_a = grads(x[:8], y[:8])
+    g_b = grads(x[8:], y[8:])
+    # equal numbers of valid pixels in both halves => the batch mean is the mean of the halves' means
+    assert int((y[:8] != 255).sum()) == int((y[8:] != 255).sum())
+    num = den = 0.0
+    worst = 0.0
+    for ga, gb, gf in zip(g_a, g_b, g_all):
+        comb = 0.5 * (ga.double() + gb.double())
+        d = float((comb - gf.double()).norm())
+        s = float(gf.double().norm())
+        num += d * d
+        den += s * s
+        if s > 1e-8:
+            worst = max(worst, d / s)
+    assert (num / den) ** 0.5 < 2e-5, (num / den) ** 0.5
+    assert worst < 5e-4, worst
+
+
+def test_training_step_at_full_size_is_finite_and_stem_statistics_match_fp64(cuda):
+    import ever_amd as er
+    m = _model(cuda).train()
+    x, y = _batch(cuda)
+    losses = m(x, y)
+    sum(losses.values()).backward()
+    assert all(torch.isfinite(v) for v in losses.values())
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+    # BatchNorm running statistics of the stem after one step = 0.9*init + 0.1*batch statistics of conv1(x)
+    stem_conv, stem_bn = m.en.resnet.conv1, m.en.resnet.bn1
+    with torch.no_grad():
+        from ever_amd.hip import functional as HF
+        z = stem_conv(HF.as_nhwc(x)).double()
+        mean = z.mean((0, 2, 3))
+        var = z.var((0, 2, 3), unbiased=True)
+    sd = m.state_dict()
+    rm = sd['en.resnet.bn1.running_mean'].double()
+    rv = sd['en.resnet.bn1.running_var'].double()
+    assert float((rm - 0.1 * mean).abs().max()) <= 1e-5 * float(mean.abs().max() + 1e-3)
+    assert float((rv - (0.9 + 0.1 * var)).abs().max()) <= 1e-5 * float(var.abs().max() + 1.0)
