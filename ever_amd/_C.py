@@ -95,6 +95,11 @@ SIGNATURES = {
     'evk_bn_bwd_local_sums': (c_int, [P, P, P, P, P, P, P, P, P, c_i64, c_i32, c_u32, P, c_size_t, P]),
     'evk_bn_bwd_apply_sums': (c_int, [P, P, P, P, P, P, P, P, P, P, c_i64, c_i32, c_u32, P, c_size_t, P]),
     'evk_pack_multi': (c_int, [P, P, P, c_i32, c_f32, P, P]),
+    'evk_ce_pixel_fwd': (c_int, [P, P, c_i64, c_i32, c_i64, P, P]),
+    'evk_ce_pixel_bwd': (c_int, [P, P, c_i64, c_i32, c_i64, P, P, P]),
+    'evk_ohem_state_bytes': (c_i64, []),
+    'evk_ohem_fwd': (c_int, [P, c_i64, c_i64, P, P, P]),
+    'evk_ohem_bwd': (c_int, [P, c_i64, P, P, P, P]),
 }
 
 _lib = None

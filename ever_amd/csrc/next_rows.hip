@@ -284,3 +284,201 @@ extern "C" int evk_confusion_from_logits(const float* logits, const int64_t* y_t
                      y_true, npix, C_logits, num_classes, reinterpret_cast<unsigned long long*>(cm));
   return check_launch("confusion_from_logits");
 }
+
+// ---------------------------------------------------------------- per-pixel cross entropy + OHEM
+// F.cross_entropy(reduction='none', ignore_index): loss_i = lse(z_i) - z_i[t_i], 0 on ignored pixels; the
+// backward takes a per-pixel upstream gradient.  online_hard_example_mining (reference loss.py:146-155): mean of
+// the non-zero values among the k = int(keep_ratio * N) largest losses.  The k-th largest value is found exactly by
+// a three-pass radix select on the order-preserving integer image of the floats (11 + 11 + 10 bits); ties at the
+// threshold are admitted through a counter (which of several bit-identical losses is kept is arbitrary, as in
+// torch.topk; the loss value does not depend on it).
+namespace evk {
+
+__global__ __launch_bounds__(256) void ce_pixel_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                       int64_t npix, int C, int64_t ignore, float* __restrict__ loss) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = labels[i];
+    if (t == ignore || t < 0 || t >= C) {
+      loss[i] = 0.f;
+      continue;
+    }
+    const float* z = logits + i * C;
+    float m = z[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, z[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(z[c] - m);
+    loss[i] = (m + logf(s)) - z[t];
+  }
+}
+__global__ __launch_bounds__(256) void ce_pixel_bwd_kernel(const float* __restrict__ logits,
+                                                           const int64_t* __restrict__ labels, int64_t npix, int C,
+                                                           int64_t ignore, const float* __restrict__ gpix,
+                                                           float* __restrict__ dlogits) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = labels[i];
+    float* d = dlogits + i * C;
+    const float g = gpix[i];
+    if (t == ignore || t < 0 || t >= C || g == 0.f) {
+      for (int c = 0; c < C; ++c) d[c] = 0.f;
+      continue;
+    }
+    const float* z = logits + i * C;
+    float m = z[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, z[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(z[c] - m);
+    const float lse = m + logf(s);
+    for (int c = 0; c < C; ++c) d[c] = g * (expf(z[c] - lse) - (t == c ? 1.f : 0.f));
+  }
+}
+
+__device__ __forceinline__ uint32_t ordered_bits(float v) {
+  const uint32_t b = __builtin_bit_cast(uint32_t, v);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);  // monotone: a < b  <=>  ordered(a) < ordered(b)
+}
+// state: [0] prefix value (ordered bits, high part fixed so far)  [1] remaining rank (k-th largest inside the prefix)
+//        [2] count of elements strictly above the threshold       [3] ties admitted so far (backward)
+//        [4..4+2048) histogram
+__global__ __launch_bounds__(256) void ohem_hist_kernel(const float* __restrict__ v, int64_t n, int shift, int bits,
+                                                        uint32_t prefix_mask, unsigned long long* __restrict__ state) {
+  __shared__ unsigned int h[2048];
+  for (int i = threadIdx.x; i < 2048; i += 256) h[i] = 0u;
+  __syncthreads();
+  const uint32_t prefix = (uint32_t)state[0];
+  const uint32_t bmask = (1u << bits) - 1u;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const uint32_t u = ordered_bits(v[i]);
+    if ((u & prefix_mask) == (prefix & prefix_mask)) atomicAdd(&h[(u >> shift) & bmask], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (1 << bits); i += 256)
+    if (h[i]) atomicAdd(&state[4 + i], (unsigned long long)h[i]);
+}
+// walk the histogram from the top: find the bin holding the remaining-rank-th largest element
+__global__ void ohem_pick_kernel(unsigned long long* __restrict__ state, int shift, int bits) {
+  if (threadIdx.x != 0) return;
+  unsigned long long rank = state[1];  // 1-based rank inside the current prefix
+  unsigned long long above = state[2];
+  int b = (1 << bits) - 1;
+  for (; b > 0; --b) {
+    const unsigned long long c = state[4 + b];
+    if (rank <= c) break;
+    rank -= c;
+    above += c;
+  }
+  state[0] = (state[0] | ((unsigned long long)b << shift)) & 0xffffffffull;
+  state[1] = rank;
+  state[2] = above;
+  for (int i = 0; i < (1 << bits); ++i) state[4 + i] = 0ull;
+}
+// sums: [0] sum of kept values, [1] number of kept non-zero values
+__global__ __launch_bounds__(256) void ohem_sum_kernel(const float* __restrict__ v, int64_t n,
+                                                       const unsigned long long* __restrict__ state,
+                                                       double* __restrict__ partial) {
+  __shared__ double red[4];
+  const uint32_t thr = (uint32_t)state[0];
+  double s = 0.0, c = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float x = v[i];
+    if (ordered_bits(x) > thr && x != 0.f) {
+      s += (double)x;
+      c += 1.0;
+    }
+  }
+  const double ts = block_sum(s, red), tc = block_sum(c, red);
+  if (threadIdx.x == 0) {
+    partial[2 + 2 * blockIdx.x] = ts;
+    partial[3 + 2 * blockIdx.x] = tc;
+  }
+}
+__global__ void ohem_finish_kernel(double* __restrict__ partial, int nblk, const unsigned long long* __restrict__ state,
+                                   float* __restrict__ loss) {
+  if (threadIdx.x != 0) return;
+  double s = 0.0, c = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s += partial[2 + 2 * b];
+    c += partial[3 + 2 * b];
+  }
+  const uint32_t thr = (uint32_t)state[0];
+  const uint32_t raw = (thr & 0x80000000u) ? (thr & 0x7fffffffu) : ~thr;
+  const float tv = __builtin_bit_cast(float, raw);
+  const double ties = (double)state[1];  // elements equal to the threshold that belong to the top k
+  if (tv != 0.f) {
+    s += ties * (double)tv;
+    c += ties;
+  }
+  partial[0] = s;
+  partial[1] = c;
+  *loss = (float)(s / c);  // no non-zero value kept: 0/0 = NaN, as the mean of an empty selection
+}
+__global__ __launch_bounds__(256) void ohem_bwd_kernel(const float* __restrict__ v, int64_t n,
+                                                       unsigned long long* __restrict__ state,
+                                                       const double* __restrict__ partial,
+                                                       const float* __restrict__ grad_scale, float* __restrict__ dv) {
+  const uint32_t thr = (uint32_t)state[0];
+  const unsigned long long ties = state[1];
+  const float g = (grad_scale ? *grad_scale : 1.f) / (float)partial[1];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float x = v[i];
+    const uint32_t u = ordered_bits(x);
+    float o = 0.f;
+    if (x != 0.f) {
+      if (u > thr) o = g;
+      else if (u == thr && atomicAdd(&state[3], 1ull) < ties) o = g;
+    }
+    dv[i] = o;
+  }
+}
+
+}  // namespace evk
+
+extern "C" int evk_ce_pixel_fwd(const float* logits, const int64_t* labels, int64_t npix, int32_t C, int64_t ignore_index,
+                                float* loss_pix, void* stream) {
+  EVK_REQUIRE(logits && labels && loss_pix && C >= 2, EVK_E_INVALID, "ce_pixel_fwd: bad argument");
+  const int64_t b = (npix + 255) / 256;
+  hipLaunchKernelGGL(ce_pixel_kernel, dim3((unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b))), dim3(256), 0,
+                     (hipStream_t)stream, logits, labels, npix, C, ignore_index, loss_pix);
+  return check_launch("ce_pixel_fwd");
+}
+extern "C" int evk_ce_pixel_bwd(const float* logits, const int64_t* labels, int64_t npix, int32_t C, int64_t ignore_index,
+                                const float* grad_pix, float* dlogits, void* stream) {
+  EVK_REQUIRE(logits && labels && grad_pix && dlogits && C >= 2, EVK_E_INVALID, "ce_pixel_bwd: bad argument");
+  const int64_t b = (npix + 255) / 256;
+  hipLaunchKernelGGL(ce_pixel_bwd_kernel, dim3((unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b))), dim3(256), 0,
+                     (hipStream_t)stream, logits, labels, npix, C, ignore_index, grad_pix, dlogits);
+  return check_launch("ce_pixel_bwd");
+}
+
+extern "C" int64_t evk_ohem_state_bytes(void) { return (int64_t)((4 + 2048) * 8 + (2 + 2 * kNRBlocks) * 8); }
+
+extern "C" int evk_ohem_fwd(const float* losses, int64_t n, int64_t keep, float* loss, void* state, void* stream) {
+  EVK_REQUIRE(losses && loss && state && n > 0 && keep > 0 && keep <= n, EVK_E_INVALID, "ohem_fwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* s = reinterpret_cast<unsigned long long*>(state);
+  double* partial = reinterpret_cast<double*>(s + 4 + 2048);
+  hipError_t e = hipMemsetAsync(state, 0, (size_t)evk_ohem_state_bytes(), st);
+  if (e != hipSuccess) { set_error("ohem_fwd: memset: %s", hipGetErrorString(e)); return EVK_E_LAUNCH; }
+  e = hipMemcpyAsync(s + 1, &keep, sizeof(keep), hipMemcpyHostToDevice, st);  // rank = k (k-th largest)
+  if (e != hipSuccess) { set_error("ohem_fwd: memcpy: %s", hipGetErrorString(e)); return EVK_E_LAUNCH; }
+  const int nblk = nr_grid(n);
+  const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+  const uint32_t masks[3] = {0u, 0xffe00000u, 0xfffffc00u};
+  for (int p = 0; p < 3; ++p) {
+    hipLaunchKernelGGL(ohem_hist_kernel, dim3(nblk), dim3(256), 0, st, losses, n, shifts[p], bits[p], masks[p], s);
+    hipLaunchKernelGGL(ohem_pick_kernel, dim3(1), dim3(64), 0, st, s, shifts[p], bits[p]);
+  }
+  hipLaunchKernelGGL(ohem_sum_kernel, dim3(nblk), dim3(256), 0, st, losses, n, (const unsigned long long*)s, partial);
+  hipLaunchKernelGGL(ohem_finish_kernel, dim3(1), dim3(64), 0, st, partial, nblk, (const unsigned long long*)s, loss);
+  return check_launch("ohem_fwd");
+}
+
+extern "C" int evk_ohem_bwd(const float* losses, int64_t n, void* state, const float* grad_scale, float* dlosses,
+                            void* stream) {
+  EVK_REQUIRE(losses && state && dlosses && n > 0, EVK_E_INVALID, "ohem_bwd: bad argument");
+  unsigned long long* s = reinterpret_cast<unsigned long long*>(state);
+  const double* partial = reinterpret_cast<const double*>(s + 4 + 2048);
+  const int64_t b = (n + 255) / 256;
+  hipLaunchKernelGGL(ohem_bwd_kernel, dim3((unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b))), dim3(256), 0,
+                     (hipStream_t)stream, losses, n, s, partial, grad_scale, dlosses);
+  return check_launch("ohem_bwd");
+}

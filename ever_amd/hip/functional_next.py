@@ -8,7 +8,7 @@ from .. import _C
 from .functional import _require_cuda, _stream, _ptr, as_nhwc, empty_nhwc, HipPathError
 from .workspace import workspace
 
-__all__ = ['group_norm_act', 'concat_channels', 'dropout2d']
+__all__ = ['group_norm_act', 'concat_channels', 'dropout2d', 'cross_entropy_per_pixel', 'online_hard_example_mining']
 
 
 class _GroupNormFn(Function):
@@ -125,3 +125,70 @@ def dropout2d(x, p=0.5, training=True, mask=None):
         mask = torch.bernoulli(torch.full((n, c), 1.0 - p, device=x.device, dtype=torch.float32))
     scale = (mask.to(device=x.device, dtype=torch.float32) / (1.0 - p)).contiguous()
     return _ChannelScaleFn.apply(x, scale)
+
+
+class _CePixelFn(Function):
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        n, c, h, w = logits.shape
+        out = torch.empty((n, h, w), device=logits.device, dtype=torch.float32)
+        _C.call('evk_ce_pixel_fwd', logits.data_ptr(), labels.data_ptr(), n * h * w, c, ignore_index, out.data_ptr(),
+                _stream())
+        ctx.save_for_backward(logits, labels)
+        ctx.ignore_index = ignore_index
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        logits, labels = ctx.saved_tensors
+        n, c, h, w = logits.shape
+        g = g.contiguous().float()
+        d = torch.empty_like(logits)
+        _C.call('evk_ce_pixel_bwd', logits.data_ptr(), labels.data_ptr(), n * h * w, c, ctx.ignore_index, g.data_ptr(),
+                d.data_ptr(), _stream())
+        return d, None, None
+
+
+def cross_entropy_per_pixel(y_pred, y_true, ignore_index=255):
+    """F.cross_entropy(y_pred, y_true, ignore_index=..., reduction='none') -> [N, H, W]"""
+    _require_cuda(y_pred, 'cross_entropy_per_pixel')
+    y_pred = as_nhwc(y_pred, 'cross_entropy_per_pixel')
+    if y_pred.shape[1] < 2:
+        raise HipPathError('cross_entropy_per_pixel: needs at least 2 classes')
+    yt = y_true.to(torch.int64).contiguous()
+    if yt.numel() != y_pred.numel() // y_pred.shape[1]:
+        raise ValueError('cross_entropy_per_pixel: label / logit pixel counts differ')
+    return _CePixelFn.apply(y_pred, yt, int(ignore_index))
+
+
+class _OhemFn(Function):
+    @staticmethod
+    def forward(ctx, losses, keep):
+        lib = _C.load()
+        state = torch.empty((lib.evk_ohem_state_bytes(),), device=losses.device, dtype=torch.uint8)
+        loss = torch.empty((), device=losses.device, dtype=torch.float32)
+        _C.call('evk_ohem_fwd', losses.data_ptr(), losses.numel(), keep, loss.data_ptr(), state.data_ptr(), _stream())
+        ctx.save_for_backward(losses, state)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        losses, state = ctx.saved_tensors
+        g = g.contiguous().float()
+        d = torch.empty_like(losses)
+        _C.call('evk_ohem_bwd', losses.data_ptr(), losses.numel(), state.data_ptr(), g.data_ptr(), d.data_ptr(), _stream())
+        return d, None
+
+
+def online_hard_example_mining(losses, keep_ratio):
+    """reference ever/module/loss.py:146-155: mean of the non-zero values among the int(keep_ratio * N) largest."""
+    assert 0 < keep_ratio < 1, 'The value of keep_ratio must be from 0 to 1.'
+    if not losses.is_cuda or losses.dtype != torch.float32:
+        raise HipPathError('online_hard_example_mining: fp32 CUDA tensor required')
+    flat = losses.contiguous().view(-1) if losses.is_contiguous() else losses.reshape(-1).contiguous()
+    keep = int(keep_ratio * flat.numel())
+    if keep < 1:
+        raise ValueError('online_hard_example_mining: keep_ratio * numel < 1')
+    return _OhemFn.apply(flat, keep)

@@ -3,7 +3,8 @@ from ..hip import functional as HF
 
 __all__ = ['binary_cross_entropy_with_logits', 'dice_loss_with_logits', 'cross_entropy',
            'label_smoothing_cross_entropy', 'label_smoothing_binary_cross_entropy', 'soft_cross_entropy',
-           'tversky_loss_with_logits', 'focal_loss', 'sigmoid_focal_loss']
+           'tversky_loss_with_logits', 'focal_loss', 'sigmoid_focal_loss', 'online_hard_example_mining',
+           'cross_entropy_per_pixel']
 
 
 def binary_cross_entropy_with_logits(output, target, reduction='mean', ignore_index=255, pos_weight=None):
@@ -58,3 +59,15 @@ def focal_loss(y_pred, y_true, gamma=2.0, normalize=False):
 def sigmoid_focal_loss(y_pred, y_true, alpha=-1, gamma=2, reduction='mean'):
     """reference loss.py:179-201"""
     return HF.sigmoid_focal_loss(y_pred, y_true, alpha, gamma, reduction)
+
+
+def online_hard_example_mining(losses, keep_ratio):
+    """reference loss.py:146-155"""
+    from ..hip import functional_next as HN
+    return HN.online_hard_example_mining(losses, keep_ratio)
+
+
+def cross_entropy_per_pixel(output, target, ignore_index=255):
+    """F.cross_entropy(..., reduction='none'): the per-pixel losses OHEM selects from"""
+    from ..hip import functional_next as HN
+    return HN.cross_entropy_per_pixel(output, target, ignore_index)

@@ -321,6 +321,20 @@ int evk_bn_bwd_apply_sums(const float* dy, const float* x, const float* y, const
 int evk_pack_multi(const float* const* srcs, const int64_t* sizes, const int64_t* offsets,
                    int32_t ntensors, float scale, float* dst, void* stream);
 
+/* F.cross_entropy(reduction='none', ignore_index) per pixel (0 on ignored pixels) and its backward with a per-pixel
+ * upstream gradient — the input of online_hard_example_mining. */
+int evk_ce_pixel_fwd(const float* logits, const int64_t* labels, int64_t npix, int32_t C,
+                     int64_t ignore_index, float* loss_pix, void* stream);
+int evk_ce_pixel_bwd(const float* logits, const int64_t* labels, int64_t npix, int32_t C,
+                     int64_t ignore_index, const float* grad_pix, float* dlogits, void* stream);
+/* online_hard_example_mining (reference loss.py:146-155): loss = mean of the non-zero values among the `keep`
+ * largest of losses[0..n); exact k-th value by a 3-pass radix select.  `state`: evk_ohem_state_bytes() bytes, kept
+ * for the backward (dlosses = grad / #kept on the kept non-zero elements, 0 elsewhere). */
+int64_t evk_ohem_state_bytes(void);
+int evk_ohem_fwd(const float* losses, int64_t n, int64_t keep, float* loss, void* state, void* stream);
+int evk_ohem_bwd(const float* losses, int64_t n, void* state, const float* grad_scale, float* dlosses,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

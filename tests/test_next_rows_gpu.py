@@ -250,3 +250,53 @@ def test_sync_batchnorm_two_virtual_ranks_equal_full_batch_bn(cuda, relu, res):
     for o in outs:  # running statistics use the merged mean / unbiased variance on every rank
         _close(o[0].running_mean.cpu().numpy(), ref.running_mean.numpy(), 1e-5)
         _close(o[0].running_var.cpu().numpy(), ref.running_var.numpy(), 1e-5)
+
+
+def test_ohem_matches_reference_kat_and_torch(cuda):
+    from ever_amd.module import loss as L
+    lo = torch.from_numpy(portable.uniform('next_ohem', (3, 50), 0.0, 2.0)).clone()
+    lo[0, :7] = 0.0
+    x = lo.to(cuda).requires_grad_()
+    v = L.online_hard_example_mining(x, 0.4)
+    v.backward()
+    assert abs(v.item() - KATS['ohem_0.4']) <= 1e-6 * abs(KATS['ohem_0.4'])
+    _close(x.grad.cpu().numpy(), ARR['ohem_0.4_grad'], 1e-6)
+    # larger: zeros inside the kept set, negative values, many exact ties at the threshold
+    g = torch.Generator().manual_seed(4)
+    big = torch.randn(70001, generator=g).abs()
+    big[::3] = 0.0
+    big[1::7] = 0.5                         # ties
+    for ratio in (0.05, 0.5, 0.9):
+        k = int(ratio * big.numel())
+        top = big.topk(k).values
+        want = top[top != 0].mean()
+        xb = big.to(cuda).requires_grad_()
+        got = L.online_hard_example_mining(xb, ratio)
+        got.backward()
+        assert abs(got.item() - want.item()) <= 2e-6 * abs(want.item()), (ratio, got.item(), want.item())
+        gsum = xb.grad.sum().item()
+        assert abs(gsum - 1.0) < 1e-4                                   # the mean's weights sum to one
+        assert int((xb.grad != 0).sum()) == int((top != 0).sum())       # exactly the kept non-zero elements
+        kept_min = float(big[xb.grad.cpu() != 0].min())
+        assert kept_min >= float(top[top != 0].min()) - 1e-7
+
+
+def test_cross_entropy_per_pixel_with_ohem_pipeline(cuda):
+    from ever_amd.module import loss as L
+    g = torch.Generator().manual_seed(8)
+    z = torch.randn(2, 6, 21, 17, generator=g)
+    y = torch.randint(0, 6, (2, 21, 17), generator=g)
+    y[1, :4] = 255
+    zr = z.clone().requires_grad_()
+    ref = torch.nn.functional.cross_entropy(zr, y, ignore_index=255, reduction='none')
+    k = int(0.3 * ref.numel())
+    top = ref.reshape(-1).topk(k).values
+    want = top[top != 0].mean()
+    want.backward()
+    zg = z.to(cuda).requires_grad_()
+    pix = L.cross_entropy_per_pixel(zg, y.to(cuda), ignore_index=255)
+    _close(pix.detach().cpu().numpy(), ref.detach().numpy(), 1e-6)
+    got = L.online_hard_example_mining(pix, 0.3)
+    got.backward()
+    assert abs(got.item() - want.item()) <= 1e-5 * abs(want.item())
+    _close(zg.grad.cpu().contiguous().numpy(), zr.grad.numpy(), 1e-5)
