@@ -36,6 +36,8 @@ SIGNATURES = {
     'evk_conv2d_split_weight': (c_int, [_DP, P, c_i32, P, P]),
     'evk_conv2d_fwd_x3': (c_int, [_DP, P, P, P, P, c_u32, P]),
     'evk_conv2d_dgrad_x3': (c_int, [_DP, P, P, P, P, P]),
+    'evk_conv2d_fwd_res': (c_int, [_DP, P, P, P, P, P, c_u32, P]),
+    'evk_conv2d_fwd_x3_res': (c_int, [_DP, P, P, P, P, P, c_u32, P]),
     'evk_conv2d_wgrad_x3_workspace_bytes': (c_size_t, [_DP]),
     'evk_conv2d_wgrad_x3': (c_int, [_DP, P, P, P, P, P, c_size_t, P]),
     'evk_conv2d_wgrad_workspace_bytes': (c_size_t, [_DP]),

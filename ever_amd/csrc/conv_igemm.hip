@@ -347,12 +347,13 @@ static inline int kpad32(int k) { return (k + 31) & ~31; }
 
 // w3 != nullptr selects the bf16-split kernel (conv_igemm_x3.hip) on pre-split weight planes
 static int conv_fwd_any(const evk_conv_desc* d, const float* x, const float* w, const uint16_t* w3, const float* bias,
-                        float* y, uint32_t flags, void* stream) {
+                        float* y, uint32_t flags, void* stream, const float* residual = nullptr) {
   int rc = check_desc(d);
   if (rc) return rc;
   EVK_REQUIRE(x && (w || w3) && y, EVK_E_INVALID, "conv2d_fwd: null pointer");
   IGemmArgs a{};
-  a.src = x; a.wgt = w; a.wgt3 = w3; a.bias = bias; a.dst = y;
+  EVK_REQUIRE(residual != y, EVK_E_INVALID, "conv2d_fwd: residual must not alias y");
+  a.src = x; a.wgt = w; a.wgt3 = w3; a.bias = bias; a.accum = residual; a.dst = y;
   a.N = d->N; a.Hs = d->H; a.Ws = d->W; a.Cs = d->Cin;
   a.Hm = d->Ho; a.Wm = d->Wo; a.Cd = d->Cout;
   a.kh = d->kh; a.kw = d->kw; a.cpt = d->Cin / 4;
@@ -375,6 +376,18 @@ extern "C" int evk_conv2d_fwd_x3(const evk_conv_desc* d, const float* x, const v
                                  float* y, uint32_t flags, void* stream) {
   EVK_REQUIRE(wsplit, EVK_E_INVALID, "conv2d_fwd_x3: null weight planes");
   return conv_fwd_any(d, x, nullptr, reinterpret_cast<const uint16_t*>(wsplit), bias, y, flags, stream);
+}
+
+// y = act(conv(x, w) + bias + residual): the inference form of a ResNet block's last convolution once its
+// BatchNorm is folded into (w, bias) — reference _resnets.py:95-112 (`out += identity; relu`)
+extern "C" int evk_conv2d_fwd_res(const evk_conv_desc* d, const float* x, const float* w, const float* bias,
+                                  const float* residual, float* y, uint32_t flags, void* stream) {
+  return conv_fwd_any(d, x, w, nullptr, bias, y, flags, stream, residual);
+}
+extern "C" int evk_conv2d_fwd_x3_res(const evk_conv_desc* d, const float* x, const void* wsplit, const float* bias,
+                                     const float* residual, float* y, uint32_t flags, void* stream) {
+  EVK_REQUIRE(wsplit, EVK_E_INVALID, "conv2d_fwd_x3_res: null weight planes");
+  return conv_fwd_any(d, x, nullptr, reinterpret_cast<const uint16_t*>(wsplit), bias, y, flags, stream, residual);
 }
 
 static int conv_dgrad_any(const evk_conv_desc* d, const float* dy, const float* wt, const uint16_t* wt3,

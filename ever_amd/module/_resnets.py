@@ -8,6 +8,7 @@ conv -> [BN+ReLU] -> conv -> [BN+ReLU] -> conv -> [BN + identity add + ReLU].
 import torch.nn as nn
 
 from ..hip import functional as HF
+from .fold import conv_bn
 from .layers import AdaptiveAvgPool2d, BatchNorm2d, Conv2d, HipSequential, MaxPool2d, ReLU
 
 __all__ = ['ResNet', 'BasicBlock', 'Bottleneck', 'resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152',
@@ -27,6 +28,12 @@ def _norm(norm_layer):
     if norm_layer is None or norm_layer is nn.BatchNorm2d or norm_layer is BatchNorm2d:
         return BatchNorm2d
     raise NotImplementedError(f'ever_amd ResNet: norm_layer {norm_layer} has no HIP kernel (BatchNorm2d only)')
+
+
+def _inference(bn):
+    """eval mode without autograd: the blocks take the folded-convolution path (module/fold.py)"""
+    import torch
+    return (not bn.training) and not torch.is_grad_enabled()
 
 
 def _fork(block, x):
@@ -58,6 +65,10 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if _inference(self.bn1):
+            shortcut = x if self.downsample is None else conv_bn(self.downsample[0], self.downsample[1], x)
+            out = conv_bn(self.conv1, self.bn1, x, relu=True)
+            return conv_bn(self.conv2, self.bn2, out, residual=shortcut, relu=True)
         h, shortcut = _fork(self, x)
         out = self.bn1(h, relu=True)
         return self.bn2(self.conv2(out), residual=shortcut, relu=True)
@@ -82,6 +93,11 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if _inference(self.bn1):
+            shortcut = x if self.downsample is None else conv_bn(self.downsample[0], self.downsample[1], x)
+            out = conv_bn(self.conv1, self.bn1, x, relu=True)
+            out = conv_bn(self.conv2, self.bn2, out, relu=True)
+            return conv_bn(self.conv3, self.bn3, out, residual=shortcut, relu=True)
         h, shortcut = _fork(self, x)
         out = self.bn1(h, relu=True)
         out = self.bn2(self.conv2(out), relu=True)
@@ -156,7 +172,7 @@ class ResNet(nn.Module):
     def stem_forward(self, x):
         if self.deep_stem:
             return self.stem(x)
-        return self.bn1(self.conv1(x), relu=True)
+        return conv_bn(self.conv1, self.bn1, x, relu=True)
 
     def forward(self, x):
         x = self.maxpool(self.stem_forward(x))

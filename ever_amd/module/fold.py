@@ -1,0 +1,134 @@
+"""Inference-time folding of BatchNorm into the preceding convolution.
+
+In eval mode BatchNorm is the per-channel affine map y = x * s + t with s = gamma / sqrt(running_var + eps),
+t = beta - running_mean * s, so conv -> BN (-> + identity) (-> ReLU) collapses into ONE convolution with weight
+w * s[:, None, None, None], bias (b_conv * s + t), and the residual add / ReLU in the implicit-GEMM epilogue
+(evk_conv2d_fwd_res / _x3_res): the BatchNorm pass (2|x| of HBM traffic per layer) disappears, and the split
+weight planes of the bf16x3 kernels are computed once instead of per call.  `fold_batchnorm(model)` prepares the
+folded parameters next to the original ones (training is unaffected); the call sites (`conv_bn` in the ResNet
+blocks and the Sequential peephole) use them whenever the BatchNorm is in eval mode."""
+import ctypes
+
+import torch
+
+from .. import _C
+from ..hip import functional as HF
+
+__all__ = ['fold_batchnorm', 'unfold_batchnorm', 'conv_bn']
+
+
+class _Folded(object):
+    __slots__ = ('weight', 'bias', 'planes', 'cin', 'cin_p')
+
+
+def _fold_pair(conv, bn):
+    if not isinstance(bn, torch.nn.BatchNorm2d) or bn.running_mean is None:
+        return None
+    with torch.no_grad():
+        dev = conv.weight.device
+        s = (bn.weight if bn.affine else torch.ones_like(bn.running_mean)) * torch.rsqrt(bn.running_var + bn.eps)
+        t = (bn.bias if bn.affine else torch.zeros_like(bn.running_mean)) - bn.running_mean * s
+        w = HF._weight_ohwi(conv.weight.detach())            # logical OIHW over OHWI memory
+        wf = (w * s.view(-1, 1, 1, 1)).contiguous(memory_format=torch.channels_last)
+        b = t if conv.bias is None else conv.bias.detach() * s + t
+        f = _Folded()
+        cout, cin, kh, kw = wf.shape
+        f.cin, f.cin_p = cin, HF._pad4(cin)
+        if f.cin_p != cin:                                    # 3-band stem: pad the K axis once, here
+            f.weight = HF._pad_last(wf.data_ptr(), cout * kh * kw, cin, f.cin_p, dev).reshape(cout, kh, kw, f.cin_p)
+        else:
+            f.weight = wf
+        f.bias = b.contiguous().float()
+        f.planes = None
+    return f
+
+
+def fold_batchnorm(model):
+    """Attach folded parameters to every Conv2d that is directly followed by a BatchNorm2d at a known call site
+    (ResNet stem / blocks / down-sampling branches, conv-BN neighbours inside Sequential containers) and switch the
+    model to eval mode.  Call again after loading new weights."""
+    from . import _resnets
+    from .layers import Conv2d
+    model.eval()
+    n = 0
+
+    def pair(conv, bn):
+        nonlocal n
+        if isinstance(conv, Conv2d) and isinstance(bn, torch.nn.BatchNorm2d) and not isinstance(bn, torch.nn.SyncBatchNorm):
+            f = _fold_pair(conv, bn)
+            if f is not None:
+                conv._folded, bn._folded_into = f, conv
+                n += 1
+    for m in model.modules():
+        if isinstance(m, _resnets.ResNet) and not m.deep_stem:
+            pair(m.conv1, m.bn1)
+        if isinstance(m, (_resnets.BasicBlock, _resnets.Bottleneck)):
+            pair(m.conv1, m.bn1)
+            pair(m.conv2, m.bn2)
+            if isinstance(m, _resnets.Bottleneck):
+                pair(m.conv3, m.bn3)
+            if m.downsample is not None:
+                pair(m.downsample[0], m.downsample[1])
+        if isinstance(m, torch.nn.Sequential):
+            kids = list(m)
+            for a, b in zip(kids, kids[1:]):
+                if getattr(a, '_folded', None) is None:
+                    pair(a, b)
+    model._folded_pairs = n
+    return model
+
+
+def unfold_batchnorm(model):
+    for m in model.modules():
+        if hasattr(m, '_folded'):
+            del m._folded
+        if hasattr(m, '_folded_into'):
+            del m._folded_into
+    return model
+
+
+def _use_folded(conv, bn):
+    return (not bn.training) and getattr(conv, '_folded', None) is not None and getattr(bn, '_folded_into', None) is conv \
+        and not torch.is_grad_enabled()
+
+
+def conv_bn(conv, bn, x, residual=None, relu=False):
+    """bn(conv(x)) (+ residual) (ReLU): one folded convolution at inference, conv + fused BatchNorm pass otherwise."""
+    if _use_folded(conv, bn):
+        return folded_conv2d(x, conv, residual=residual, relu=relu)
+    return bn(conv(x), residual=residual, relu=relu)
+
+
+def folded_conv2d(x, conv, residual=None, relu=False):
+    f = conv._folded
+    x = HF.as_nhwc(x, 'folded conv')
+    n, cin, h, w = x.shape
+    if cin != f.cin:
+        raise ValueError(f'folded conv: input has {cin} channels, expected {f.cin}')
+    dev, st = x.device, HF._stream()
+    cout, kh, kw = f.weight.shape[0], conv.kernel_size[0], conv.kernel_size[1]
+    if f.cin_p != cin:
+        xk = HF._pad_last(x.data_ptr(), n * h * w, cin, f.cin_p, dev)
+        x_ptr = xk.data_ptr()
+    else:
+        x_ptr = x.data_ptr()
+    d = HF._conv_desc(n, h, w, f.cin_p, cout, kh, kw, HF._pair(conv.stride), HF._pair(conv.padding), HF._pair(conv.dilation))
+    y = HF.empty_nhwc(n, cout, d.Ho, d.Wo, dev)
+    res_ptr = None
+    if residual is not None:
+        residual = HF.as_nhwc(residual, 'folded conv residual')
+        if residual.shape != y.shape:
+            raise ValueError('folded conv: residual shape mismatch')
+        res_ptr = residual.data_ptr()
+    flags = 1 if relu else 0
+    if HF.get_conv_math() == 'bf16x3' and f.cin_p == cin and cin % 8 == 0:
+        if f.planes is None:  # constant at inference: split once
+            lib = _C.load()
+            f.planes = torch.empty((lib.evk_conv2d_split_weight_bytes(ctypes.byref(d), 0),), dtype=torch.uint8, device=dev)
+            _C.call('evk_conv2d_split_weight', ctypes.byref(d), f.weight.data_ptr(), 0, f.planes.data_ptr(), st)
+        _C.call('evk_conv2d_fwd_x3_res', ctypes.byref(d), x_ptr, f.planes.data_ptr(), f.bias.data_ptr(), res_ptr,
+                y.data_ptr(), flags, st)
+    else:
+        _C.call('evk_conv2d_fwd_res', ctypes.byref(d), x_ptr, f.weight.data_ptr(), f.bias.data_ptr(), res_ptr, y.data_ptr(),
+                flags, st)
+    return y

@@ -139,7 +139,14 @@ def run_sequence(mods, x):
     while i < n:
         m = mods[i]
         nxt = mods[i + 1] if i + 1 < n else None
-        if isinstance(m, Conv2d) and isinstance(nxt, nn.ReLU):
+        if isinstance(m, Conv2d) and getattr(m, '_folded', None) is not None and nxt is not None \
+                and getattr(nxt, '_folded_into', None) is m and not nxt.training and not torch.is_grad_enabled():
+            # inference: conv + folded BatchNorm (+ ReLU) in one launch (module/fold.py)
+            from .fold import folded_conv2d
+            relu = i + 2 < n and isinstance(mods[i + 2], nn.ReLU)
+            x = folded_conv2d(x, m, relu=relu)
+            i += 3 if relu else 2
+        elif isinstance(m, Conv2d) and isinstance(nxt, nn.ReLU):
             x = m(x, relu=True)
             i += 2
         elif isinstance(m, (BatchNorm2d, GroupNorm, nn.SyncBatchNorm)) and isinstance(nxt, nn.ReLU):

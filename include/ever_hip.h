@@ -85,6 +85,12 @@ int evk_conv2d_split_weight(const evk_conv_desc* d, const float* w, int32_t for_
                             void* stream);
 int evk_conv2d_fwd_x3(const evk_conv_desc* d, const float* x, const void* wsplit, const float* bias,
                       float* y, uint32_t flags, void* stream);
+/* y = act(conv(x, w) + bias + residual): inference form of a residual block's last convolution with its
+ * BatchNorm folded into (w, bias) — `out += identity; relu` of reference _resnets.py:95-112 in the epilogue. */
+int evk_conv2d_fwd_res(const evk_conv_desc* d, const float* x, const float* w, const float* bias,
+                       const float* residual, float* y, uint32_t flags, void* stream);
+int evk_conv2d_fwd_x3_res(const evk_conv_desc* d, const float* x, const void* wsplit, const float* bias,
+                          const float* residual, float* y, uint32_t flags, void* stream);
 int evk_conv2d_dgrad_x3(const evk_conv_desc* d, const float* dy, const void* wsplit_t,
                         const float* accum, float* dx, void* stream);
 /* weight / bias gradient in the same arithmetic: both operands (dy and im2col(x)) are split in registers

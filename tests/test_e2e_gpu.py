@@ -155,3 +155,31 @@ def test_farseg_matches_oracle_larger_tile(cuda):
     cos = dot / np.sqrt(na * nb)
     print(f'worst per-tensor grad rel L2 err vs fp64 {worst:.2e}; global cosine {cos:.6f}; norm ratio {np.sqrt(na / nb):.5f}')
     assert cos > 0.999 and abs(np.sqrt(na / nb) - 1) < 5e-3
+
+
+def test_folded_batchnorm_inference_matches_unfolded_and_reference(cuda, conv_math):
+    """fold_batchnorm: eval-mode logits of the folded model = the unfolded model's (1e-5: only the place of the
+    per-channel scaling changes) and stay within the 1e-3 contract of the reference's eval golden."""
+    from ever_amd.module.fold import fold_batchnorm
+    name = 'r50_3band_128'
+    with open(os.path.join(GOLD, f'e2e_{name}.json')) as f:
+        meta = json.load(f)
+    gold = np.load(os.path.join(GOLD, f'e2e_{name}.npz'))
+    m = _hip_model(meta, cuda)
+    x, y = portable.synthetic_batch(name, meta['n'], meta['in_channels'], meta['hw'], meta['hw'], meta['num_classes'])
+    x, y = torch.from_numpy(x).to(cuda), torch.from_numpy(y).to(cuda)
+    m.train()
+    sum(m.loss(m.head(m.en(x)), y).values()).backward()     # one step's running statistics, as in the golden
+    m.eval()
+    with torch.no_grad():
+        plain = m.head(m.en(x)).cpu().contiguous().numpy()
+    fold_batchnorm(m)
+    assert m._folded_pairs >= 53 + 8                         # every ResNet-50 BatchNorm + the head's conv-BN pairs
+    with torch.no_grad():
+        folded = m.head(m.en(x)).cpu().contiguous().numpy()
+    assert _rel_err(folded, plain) < 2e-5, _rel_err(folded, plain)
+    assert _rel_err(folded, gold['logits_eval']) < 1e-3
+    _check_masks(folded, gold['logits_eval'], meta['num_classes'], name + ' (folded eval)')
+    m.train()                                                # training is untouched by the folded copies
+    lg = m.head(m.en(x))
+    assert _rel_err(lg.detach().cpu().contiguous().numpy(), gold['logits']) < 5e-2  # second step: statistics moved on
