@@ -21,10 +21,23 @@ def main(db_path, out):
         for n, c, s, a, mn, mx in rows:
             w.writerow([n, c, round(s / 1e3, 1), round(a / 1e3, 2), round(mn / 1e3, 2), round(mx / 1e3, 2),
                         round(100.0 * s / total, 2)])
+    fams = [('conv_igemm (forward + data gradient: conv_igemm_x3ws / conv_igemm_x3 / conv_igemm kernels)', ('conv_igemm',)),
+            ('conv_wgrad (conv_wgrad_x3ws / conv_wgrad_x3 / conv_wgrad kernels)', ('conv_wgrad',)),
+            ('BatchNorm (bn_* kernels)', ('bn_',))]
+    fam_rows = []
+    for label, pats in fams:
+        sel = [r for r in rows if any(p in r[0] for p in pats)]
+        if sel:
+            calls, tot = sum(r[1] for r in sel), sum(r[2] for r in sel)
+            fam_rows.append((label, calls, tot, tot / calls))
     with open(out + '.md', 'w') as f:
         f.write(f'# rocprofv3 --kernel-trace --stats summary\n\nsource: `{db_path}`; {sum(r[1] for r in rows)} '
                 f'dispatches, {total / 1e6:.1f} ms of kernel time over a {(span[1] - span[0]) / 1e6:.1f} ms window\n\n')
-        f.write('| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---:|---:|---:|---:|---:|---:|\n')
+        f.write('Kernel families as bench.py times them with HIP events (its `avg_launch_us` is per launch of the family):\n\n'
+                '| family | launches | total ms | avg us per launch | % |\n|---|---:|---:|---:|---:|\n')
+        for label, calls, tot, avg in fam_rows:
+            f.write(f'| {label} | {calls} | {tot / 1e6:.2f} | {avg / 1e3:.1f} | {100.0 * tot / total:.2f} |\n')
+        f.write('\n| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---:|---:|---:|---:|---:|---:|\n')
         for n, c, s, a, mn, mx in rows:
             f.write(f'| `{n[:110]}` | {c} | {s / 1e6:.2f} | {a / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} | '
                     f'{100.0 * s / total:.2f} |\n')
