@@ -1,0 +1,302 @@
+// 3x3 stride-1 "same" convolution (forward and data gradient) in the split-MFMA arithmetic with an LDS-resident
+// input halo — the im2col gather of conv_igemm_x3*.hip re-reads every input pixel nine times from L2 (once per
+// tap) and splits it nine times; here a workgroup owns an 8 x 16 patch of output pixels (= 128 GEMM rows), loads
+// the 10 x 18 halo of one 16-channel chunk ONCE, splits it once into the three bf16 planes, and forms the nine taps'
+// A fragments by shifted ds_read_b128 from the same LDS image: 6.4x fewer activation bytes from L2 and 6.4x fewer
+// split VALU per MFMA (the two costs that hold the generic kernel at ~195 of the ~290 TFLOP/s its matrix waves
+// reach alone).  Replaces the same reference call sites (3x3 convolutions of _resnets.py:21-29,
+// fpn.py:72-73,165).
+//
+// K order: for each 16-channel chunk c, for each kernel row jy: the three taps jx (one barrier per 3 taps = 72
+// MFMAs per matrix wave).  Weights come pre-split in a layout made for this order, [plane][tap][chunk][Cout][16]
+// (split_weight_halo_kernel; 4 KB contiguous per (plane, tap, chunk) for a 128-row tile).
+// Wave roles as in conv_igemm_x3ws.hip: waves 0-3 MFMA + fragment reads, waves 4-7 staging.
+// LDS: halo [2 stages][3 planes][10 x 32 slots][32 B] (pitch 32 >= 18 so that the 16-lane groups of a ds_read_b128
+// always cover 16 distinct row residues), weights [2 stages][3 taps][3 planes][128 rows][32 B]; 16-byte halves of a
+// 32-byte row are swapped on odd 8-row groups (conflict-free b128 reads for any tap shift).
+#include "igemm_common.hpp"
+#include "x3_common.hpp"
+#include <stdlib.h>
+
+namespace evk {
+
+constexpr int kPH = 8, kPW = 16;               // output patch
+constexpr int kHP = 32;                        // halo row pitch in slots
+constexpr int kHSlots = (kPH + 2) * kHP;       // 320
+constexpr int kHaloPix = (kPH + 2) * (kPW + 2);  // 180 real halo pixels
+constexpr int kCh = 16;                        // channels per chunk = one 32x32x16 k-block
+constexpr int kRB = kCh * 2;                   // bytes per row and plane
+
+__device__ __forceinline__ int half_off(int row, int c16) { return row * kRB + ((c16 ^ ((row >> 3) & 1)) << 4); }
+
+template <int BN>
+__global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p, int tiles_y, int tiles_x) {
+  constexpr int kAStage = 3 * kHSlots * kRB;          // 30720 B
+  constexpr int kBStage = 3 * 3 * BN * kRB;           // 36864 B at BN = 128
+  constexpr int WN = BN / 2, NB = WN / 32, MB = 2;    // matrix waves 2 x 2, 64 rows each
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+  unsigned char* const Abase = smem3;                 // [2][kAStage]
+  unsigned char* const Bbase = smem3 + 2 * kAStage;   // [2][kBStage]
+
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = bid % p.tiles_n;
+  int t = bid / p.tiles_n;
+  const int tx = t % tiles_x;
+  t /= tiles_x;
+  const int ty = t % tiles_y;
+  const int n = t / tiles_y;
+  const int Y0 = ty * kPH, X0 = tx * kPW, n0 = tile_n * BN;
+  const int nchunk = p.Cs / kCh;
+  const int niter = nchunk * 3;
+  const int tid = threadIdx.x;
+
+  if (tid >= 256) {
+    // ------------------------------------------------------------------ staging waves
+    const int ptid = tid - 256;
+    // halo items: (pixel 0..179, float4 q 0..3); three per thread, the last pass partially filled
+    int a_src[3], a_lds[3];
+    bool a_ok[3], a_has[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int e = ptid + 256 * i;
+      a_has[i] = e < kHaloPix * 4;
+      const int pix = a_has[i] ? (e >> 2) : 0, q = e & 3;
+      const int hy = pix / (kPW + 2), hx = pix - hy * (kPW + 2);
+      const int sy = Y0 - 1 + hy, sx = X0 - 1 + hx;
+      a_ok[i] = a_has[i] && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
+      a_src[i] = a_ok[i] ? ((n * p.Hs + sy) * p.Ws + sx) * p.Cs + q * 4 : 0;
+      const int hr = hy * kHP + hx;
+      a_lds[i] = hr * kRB + (((q >> 1) ^ ((hr >> 3) & 1)) << 4) + ((q & 1) << 3);
+    }
+    // weight items: 3 taps x 3 planes x BN rows x 2 halves of 16 B
+    constexpr int kBItems = 3 * 3 * BN * 2;
+    constexpr int BI = (kBItems + 255) / 256;
+    int b_src[BI], b_lds[BI];
+    bool b_has[BI];
+    const size_t tap_stride = (size_t)nchunk * p.Cd * kCh;   // bf16 elements between taps of one plane
+    const size_t plane_stride = 9 * tap_stride;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int e0 = ptid + 256 * i;
+      b_has[i] = e0 < kBItems;
+      const int e = b_has[i] ? e0 : 0;
+      const int half = e & 1, row = (e >> 1) % BN, rest = e / (2 * BN);  // rest = jx * 3 + pt
+      const int pt = rest % 3, jx = rest / 3;
+      int co = n0 + row;
+      co = co < p.Cd ? co : p.Cd - 1;
+      b_src[i] = (int)(pt * plane_stride + (size_t)jx * tap_stride + (size_t)co * kCh + half * 8);
+      b_lds[i] = (jx * 3 + pt) * BN * kRB + half_off(row, half);
+    }
+    f32x4 ra[3];
+    u32x4 rbv[BI];
+    auto load_a = [&](int c) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) ra[i] = *reinterpret_cast<const f32x4*>(p.src + a_src[i] + (a_ok[i] ? c * kCh : 0));
+    };
+    auto store_a = [&](int stage) {
+      unsigned char* A = Abase + stage * kAStage;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        if (!a_has[i]) continue;
+        const f32x4 v = ra[i];
+        const bool ok = a_ok[i];
+        uint32_t h0, m0, l0, h1, m1, l1;
+        split2(ok ? v.x : 0.f, ok ? v.y : 0.f, h0, m0, l0);
+        split2(ok ? v.z : 0.f, ok ? v.w : 0.f, h1, m1, l1);
+        *reinterpret_cast<uint2*>(A + a_lds[i]) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(A + kHSlots * kRB + a_lds[i]) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(A + 2 * kHSlots * kRB + a_lds[i]) = make_uint2(l0, l1);
+      }
+    };
+    // iteration it = 3*c + jy reads taps (jy, 0..2) of chunk c
+    auto load_b = [&](int it) {
+      const int c = it / 3, jy = it - 3 * c;
+      const size_t off = (size_t)(jy * 3) * tap_stride + (size_t)c * p.Cd * kCh;
+#pragma unroll
+      for (int i = 0; i < BI; ++i) rbv[i] = *reinterpret_cast<const u32x4*>(p.wgt3 + off + b_src[i]);
+    };
+    auto store_b = [&](int stage) {
+      unsigned char* B = Bbase + stage * kBStage;
+#pragma unroll
+      for (int i = 0; i < BI; ++i)
+        if (b_has[i]) *reinterpret_cast<u32x4*>(B + b_lds[i]) = rbv[i];
+    };
+
+    load_a(0);
+    load_b(0);
+    store_a(0);
+    store_b(0);
+    if (nchunk > 1) load_a(1);
+    if (niter > 1) load_b(1);
+    __syncthreads();
+    for (int it = 0; it < niter; ++it) {
+      const int c = it / 3, jy = it - 3 * c;
+      if (it + 1 < niter) {
+        store_b((it + 1) & 1);
+        if (it + 2 < niter) load_b(it + 2);
+      }
+      if (jy == 0 && c + 1 < nchunk) store_a((c + 1) & 1);   // the other halo stage was last read in chunk c-1
+      if (jy == 1 && c + 2 < nchunk) load_a(c + 2);
+      __syncthreads();
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- matrix waves
+  __builtin_amdgcn_s_setprio(3);
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  int hb[MB];   // halo slot of the lane's pixel for tap offset (0, 0)
+#pragma unroll
+  for (int a = 0; a < MB; ++a) {
+    const int m = wm * 64 + a * 32 + li;
+    hb[a] = ((m >> 4) + 1) * kHP + (m & 15) + 1;
+  }
+  int fb[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) fb[b] = half_off(wn * WN + b * 32 + li, lh);
+
+  __syncthreads();
+  for (int it = 0; it < niter; ++it) {
+    const int c = it / 3, jy = it - 3 * c;
+    const unsigned char* A = Abase + (c & 1) * kAStage;
+    const unsigned char* B = Bbase + (it & 1) * kBStage;
+    const int dy = p.oy0 + jy * p.oys;
+#pragma unroll
+    for (int jx = 0; jx < 3; ++jx) {
+      const int dx = p.ox0 + jx * p.oxs;
+      bf16x8 fa[MB][3], fbv[NB][3];
+#pragma unroll
+      for (int a = 0; a < MB; ++a) {
+        const int hr = hb[a] + dy * kHP + dx;
+        const int off = half_off(hr, lh);
+#pragma unroll
+        for (int pt = 0; pt < 3; ++pt) fa[a][pt] = *reinterpret_cast<const bf16x8*>(A + pt * kHSlots * kRB + off);
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int pt = 0; pt < 3; ++pt)
+          fbv[b][pt] = *reinterpret_cast<const bf16x8*>(B + (jx * 3 + pt) * BN * kRB + fb[b]);
+#pragma unroll
+      for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+        for (int a = 0; a < MB; ++a)
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fbv[b][kPB[t6]], fa[a][kPA[t6]], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int a = 0; a < MB; ++a) {
+    const int m = wm * 64 + a * 32 + li;
+    const int gy = Y0 + (m >> 4), gx = X0 + (m & 15);
+    const size_t roff = (((size_t)n * p.Hd + (size_t)(gy * p.dsh + p.doy)) * p.Wd + (size_t)(gx * p.dsw + p.dox)) * p.Cd;
+    igemm_store_rows<NB, WN>(p, acc[a], roff, n0, wn, lh);
+  }
+}
+
+// does the halo kernel take this launch?  (also decides the layout evk_conv2d_split_weight produces)
+bool conv3x3_halo_applies(const IGemmArgs& a) {
+  static const int on = getenv("EVK_X3_HALO") ? atoi(getenv("EVK_X3_HALO")) : 1;
+  if (!on) return false;
+  if (a.kh != 3 || a.kw != 3 || a.ash != 1 || a.asw != 1) return false;
+  if (!((a.oys == 1 || a.oys == -1) && a.oy0 == -a.oys && (a.oxs == 1 || a.oxs == -1) && a.ox0 == -a.oxs)) return false;
+  if (a.Hm != a.Hs || a.Wm != a.Ws || (a.Hm % kPH) != 0 || (a.Wm % kPW) != 0) return false;
+  if ((a.Cs % kCh) != 0 || a.Cd < 64 || !a.dense_dst && (a.dsh != 1 || a.dsw != 1)) return false;
+  const long long tiles = (long long)a.N * (a.Hm / kPH) * (a.Wm / kPW) * ceil_div(a.Cd, a.Cd <= 64 ? 64 : 128);
+  return tiles >= 256;
+}
+
+// the same decision from a convolution descriptor (forward, or stride-1 data gradient)
+bool conv_desc_uses_halo(const evk_conv_desc* d, int for_dgrad) {
+  if (d->stride_h != 1 || d->stride_w != 1 || d->dil_h != 1 || d->dil_w != 1 || d->pad_h != 1 || d->pad_w != 1) return false;
+  IGemmArgs a{};
+  a.N = d->N; a.kh = d->kh; a.kw = d->kw; a.ash = 1; a.asw = 1; a.dense_dst = 1; a.dsh = 1; a.dsw = 1;
+  if (!for_dgrad) {
+    a.Hs = d->H; a.Ws = d->W; a.Cs = d->Cin; a.Hm = d->Ho; a.Wm = d->Wo; a.Cd = d->Cout;
+    a.oy0 = -1; a.oys = 1; a.ox0 = -1; a.oxs = 1;
+  } else {
+    a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Cout; a.Hm = d->H; a.Wm = d->W; a.Cd = d->Cin;
+    a.oy0 = 1; a.oys = -1; a.ox0 = 1; a.oxs = -1;
+  }
+  return conv3x3_halo_applies(a);
+}
+
+template <int BN>
+static int launch_halo(IGemmArgs& a, hipStream_t stream) {
+  a.tiles_n = ceil_div(a.Cd, BN);
+  const int tiles_y = a.Hm / kPH, tiles_x = a.Wm / kPW;
+  a.tiles_m = a.N * tiles_y * tiles_x;
+  const size_t lds = (size_t)2 * (3 * kHSlots * kRB) + (size_t)2 * (3 * 3 * BN * kRB);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_x3_kernel<BN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const long long nwg = (long long)a.tiles_m * a.tiles_n;
+  hipLaunchKernelGGL((conv3x3_halo_x3_kernel<BN>), dim3((unsigned)nwg), dim3(512), lds, stream, a, tiles_y, tiles_x);
+  return check_launch("conv3x3_halo_x3");
+}
+
+int launch_conv3x3_halo(IGemmArgs& a, hipStream_t stream) {
+  if (!conv3x3_halo_applies(a)) return 1;
+  return a.Cd <= 64 ? launch_halo<64>(a, stream) : launch_halo<128>(a, stream);
+}
+
+// planes for the halo kernel: out[pt][tap][chunk][row][16] bf16; tap = jy*3 + jx in the kernel's (affine) tap
+// order, which is (ky, kx) for the forward and for the stride-1 data gradient alike (the sign of oys flips the
+// direction, not the index).  rows = Cout (forward: w[row][ky][kx][ci]) or Cin (data gradient: w[co][ky][kx][row]).
+__global__ void split_weight_halo_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int Cout, int Cin,
+                                         int for_dgrad) {
+  const int rows = for_dgrad ? Cin : Cout, K = for_dgrad ? Cout : Cin;   // K = reduction channels
+  const int nchunk = K / kCh;
+  const size_t total = (size_t)9 * nchunk * rows * (kCh / 2);
+  const size_t plane = (size_t)9 * nchunk * rows * kCh;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int k2 = (int)(i % (kCh / 2));
+    size_t r = i / (kCh / 2);
+    const int row = (int)(r % rows);
+    r /= rows;
+    const int ch = (int)(r % nchunk);
+    const int tap = (int)(r / nchunk);
+    const int kc = ch * kCh + 2 * k2;
+    float x0, x1;
+    if (for_dgrad) {
+      x0 = w[((size_t)kc * 9 + tap) * Cin + row];
+      x1 = w[((size_t)(kc + 1) * 9 + tap) * Cin + row];
+    } else {
+      x0 = w[((size_t)row * 9 + tap) * Cin + kc];
+      x1 = w[((size_t)row * 9 + tap) * Cin + kc + 1];
+    }
+    uint32_t h, m, l;
+    split2(x0, x1, h, m, l);
+    uint32_t* o = reinterpret_cast<uint32_t*>(out + (((size_t)tap * nchunk + ch) * rows + row) * kCh + 2 * k2);
+    o[0] = h;
+    o[plane >> 1] = m;
+    o[plane] = l;
+  }
+}
+
+int launch_split_weight_halo(const float* w, uint16_t* out, int Cout, int Cin, int for_dgrad, hipStream_t st) {
+  const int rows = for_dgrad ? Cin : Cout, K = for_dgrad ? Cout : Cin;
+  const size_t total = (size_t)9 * (K / kCh) * rows * (kCh / 2);
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(split_weight_halo_kernel, dim3(blocks), dim3(256), 0, st, w, out, Cout, Cin, for_dgrad);
+  return check_launch("split_weight_halo");
+}
+
+}  // namespace evk

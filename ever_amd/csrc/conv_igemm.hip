@@ -364,6 +364,10 @@ static int conv_fwd_any(const evk_conv_desc* d, const float* x, const float* w, 
   a.Hd = d->Ho; a.Wd = d->Wo; a.dsh = 1; a.dsw = 1; a.dense_dst = 1;
   a.relu = (flags & EVK_CONV_RELU) ? 1 : 0;
   a.Kpad = kpad32(a.Ktot);
+  if (w3) {
+    const int hr = launch_conv3x3_halo(a, (hipStream_t)stream);   // 3x3 'same' convolutions: LDS-halo kernel
+    if (hr != 1) return hr;
+  }
   return w3 ? launch_igemm_x3(a, (hipStream_t)stream) : launch_igemm(a, (hipStream_t)stream);
 }
 
@@ -432,7 +436,8 @@ static int conv_dgrad_any(const evk_conv_desc* d, const float* dy, const float* 
         a.dense_dst = (sh == 1 && sw == 1) ? 1 : 0;
         a.relu = 0;
         a.Kpad = kpad32(a.Ktot);
-        rc = wt3 ? launch_igemm_x3(a, st) : launch_igemm(a, st);
+        rc = wt3 ? launch_conv3x3_halo(a, st) : 1;
+        if (rc == 1) rc = wt3 ? launch_igemm_x3(a, st) : launch_igemm(a, st);
         if (rc) return rc;
       }
       woff += wsize;

@@ -362,6 +362,11 @@ extern "C" int evk_conv2d_split_weight(const evk_conv_desc* d, const float* w, i
               "split_weight: bad stride/dilation");
   hipStream_t st = (hipStream_t)stream;
   uint16_t* out = reinterpret_cast<uint16_t*>(wsplit);
+  // 3x3 'same' convolutions served by the LDS-halo kernel take their planes in that kernel's own order (the
+  // decision is a pure function of the descriptor, so the consumer makes the same one); never larger than the
+  // generic layout.
+  if (d->kh == 3 && d->kw == 3 && conv_desc_uses_halo(d, for_dgrad ? 1 : 0))
+    return launch_split_weight_halo(w, out, d->Cout, d->Cin, for_dgrad ? 1 : 0, st);
   if (!for_dgrad) {
     const int K = d->kh * d->kw * d->Cin, Kp = kpad32(K);
     const size_t total = (size_t)d->Cout * (Kp >> 1);

@@ -25,14 +25,44 @@ struct IGemmArgs {
   int Kpad;
 };
 
-// Epilogue shared by both kernels (the C/D fragment layout does not depend on the input dtype).
+// Store one 32-row block of accumulators whose lane's GEMM row lives at element offset `roff` of dst: bias,
+// residual / accumulate, ReLU, 16-byte stores.  The MFMAs are issued as D = W_tile * X_tile^T, so a lane holds
+// ONE pixel (column lane&31) and, per accumulator quad r4, FOUR consecutive output channels
+// co = 8*r4 + 4*(lane>>5) + {0..3}: one 16-byte store per quad (4x fewer store instructions than the
+// row-per-register layout; the small-K 1x1 convolutions are store-issue bound).
+template <int NB, int WN>
+__device__ __forceinline__ void igemm_store_rows(const IGemmArgs& p, f32x16 (&accrow)[NB], size_t roff, int n0, int wn,
+                                                 int lh) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int col = n0 + wn * WN + b * 32 + 8 * r4 + 4 * lh;
+      f32x4 v = {accrow[b][4 * r4], accrow[b][4 * r4 + 1], accrow[b][4 * r4 + 2], accrow[b][4 * r4 + 3]};
+      if (col + 3 < p.Cd && (p.Cd & 3) == 0) {
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+        if (p.accum) v += *reinterpret_cast<const f32x4*>(p.accum + roff + col);
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<f32x4*>(p.dst + roff + col) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (col + e < p.Cd) {
+            float s = v[e];
+            if (p.bias) s += p.bias[col + e];
+            if (p.accum) s += p.accum[roff + col + e];
+            if (p.relu) s = fmaxf(s, 0.f);
+            p.dst[roff + col + e] = s;
+          }
+      }
+    }
+  }
+}
+
+// Epilogue shared by the row-linear kernels (the C/D fragment layout does not depend on the input dtype).
 template <int MB, int NB, int WM, int WN>
 __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)[MB][NB], int m0, int n0, int wm,
                                                int wn, int li, int lh) {
-  // ---- epilogue.  The MFMAs were issued as D = W_tile * X_tile^T, so a lane holds ONE pixel
-  // (column lane&31) and, per accumulator quad r4, FOUR consecutive output channels
-  // co = 8*r4 + 4*(lane>>5) + {0..3}: one 16-byte store per quad (4x fewer store instructions than
-  // the row-per-register layout; the small-K 1x1 convolutions are store-issue bound).
 #pragma unroll
   for (int a = 0; a < MB; ++a) {
     const int row = m0 + wm * WM + a * 32 + li;
@@ -48,36 +78,16 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
       const int gx = rem - gy * p.Wm;
       roff = (((size_t)n * p.Hd + (size_t)(gy * p.dsh + p.doy)) * p.Wd + (size_t)(gx * p.dsw + p.dox)) * p.Cd;
     }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int col = n0 + wn * WN + b * 32 + 8 * r4 + 4 * lh;
-        f32x4 v = {acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
-        if (col + 3 < p.Cd && (p.Cd & 3) == 0) {
-          if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
-          if (p.accum) v += *reinterpret_cast<const f32x4*>(p.accum + roff + col);
-          if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          *reinterpret_cast<f32x4*>(p.dst + roff + col) = v;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (col + e < p.Cd) {
-              float s = v[e];
-              if (p.bias) s += p.bias[col + e];
-              if (p.accum) s += p.accum[roff + col + e];
-              if (p.relu) s = fmaxf(s, 0.f);
-              p.dst[roff + col + e] = s;
-            }
-        }
-      }
-    }
+    igemm_store_rows<NB, WN>(p, acc[a], roff, n0, wn, lh);
   }
 }
 
 int launch_igemm(IGemmArgs& a, hipStream_t stream);
 int launch_igemm_x3(IGemmArgs& a, hipStream_t stream);
 int launch_igemm_x3ws(IGemmArgs& a, hipStream_t stream);  // 1 = not applicable
+int launch_conv3x3_halo(IGemmArgs& a, hipStream_t stream);  // 1 = not applicable
+bool conv_desc_uses_halo(const evk_conv_desc* d, int for_dgrad);
+int launch_split_weight_halo(const float* w, uint16_t* out, int Cout, int Cin, int for_dgrad, hipStream_t st);
 
 // One axis of the strided data gradient, for input pixels congruent to c (mod stride):
 // taps k = k0 + j*kstep (j < nt) reach them, from source row  g + o0 + j*ostep.

@@ -18,7 +18,7 @@ __all__ = ['fold_batchnorm', 'unfold_batchnorm', 'conv_bn']
 
 
 class _Folded(object):
-    __slots__ = ('weight', 'bias', 'planes', 'cin', 'cin_p')
+    __slots__ = ('weight', 'bias', 'planes', 'planes_key', 'cin', 'cin_p')
 
 
 def _fold_pair(conv, bn):
@@ -40,6 +40,7 @@ def _fold_pair(conv, bn):
             f.weight = wf
         f.bias = b.contiguous().float()
         f.planes = None
+        f.planes_key = None
     return f
 
 
@@ -122,7 +123,10 @@ def folded_conv2d(x, conv, residual=None, relu=False):
         res_ptr = residual.data_ptr()
     flags = 1 if relu else 0
     if HF.get_conv_math() == 'bf16x3' and f.cin_p == cin and cin % 8 == 0:
-        if f.planes is None:  # constant at inference: split once
+        # constant at inference: split once per input geometry (the plane layout follows the kernel the
+        # descriptor selects)
+        if f.planes is None or f.planes_key != (n, h, w):
+            f.planes_key = (n, h, w)
             lib = _C.load()
             f.planes = torch.empty((lib.evk_conv2d_split_weight_bytes(ctypes.byref(d), 0),), dtype=torch.uint8, device=dev)
             _C.call('evk_conv2d_split_weight', ctypes.byref(d), f.weight.data_ptr(), 0, f.planes.data_ptr(), st)
