@@ -20,20 +20,28 @@
 
 namespace evk {
 
-constexpr int kPH = 8, kPW = 16;               // output patch
-constexpr int kHP = 32;                        // halo row pitch in slots
-constexpr int kHSlots = (kPH + 2) * kHP;       // 320
-constexpr int kHaloPix = (kPH + 2) * (kPW + 2);  // 180 real halo pixels
+constexpr int kPW = 16;                        // output patch width; height PH = 8 or 16 (template)
+// halo row pitch in slots: 32 (>= 18, multiple of 16: every 16-lane group of a ds_read_b128 covers 16 distinct row
+// residues) for the 8-row patch; 18 for the 16-row patch, whose halo would not fit twice otherwise (2 of 16 lanes
+// of a read group then share a slot: +1 LDS cycle on a path that is not the bottleneck)
+template <int PH> struct HaloGeom {
+  static constexpr int kHP = PH == 8 ? 32 : 18;
+  static constexpr int kHSlots = (PH + 2) * kHP;
+  static constexpr int kHaloPix = (PH + 2) * (kPW + 2);
+};
 constexpr int kCh = 16;                        // channels per chunk = one 32x32x16 k-block
 constexpr int kRB = kCh * 2;                   // bytes per row and plane
 
 __device__ __forceinline__ int half_off(int row, int c16) { return row * kRB + ((c16 ^ ((row >> 3) & 1)) << 4); }
 
-template <int BN>
+template <int BN, int PH>
 __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p, int tiles_y, int tiles_x) {
-  constexpr int kAStage = 3 * kHSlots * kRB;          // 30720 B
+  constexpr int kPH = PH, kHP = HaloGeom<PH>::kHP, kHSlots = HaloGeom<PH>::kHSlots, kHaloPix = HaloGeom<PH>::kHaloPix;
+  constexpr int kAStage = 3 * kHSlots * kRB;          // 30720 B (PH 8) / 31104 B (PH 16)
   constexpr int kBStage = 3 * 3 * BN * kRB;           // 36864 B at BN = 128
-  constexpr int WN = BN / 2, NB = WN / 32, MB = 2;    // matrix waves 2 x 2, 64 rows each
+  constexpr int WMR = PH * kPW / 2;                   // rows per matrix wave (2 waves along M)
+  constexpr int WN = BN / 2, NB = WN / 32, MB = WMR / 32;
+  constexpr int AI = (kHaloPix * 4 + 255) / 256;      // halo items per staging thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
   unsigned char* const Abase = smem3;                 // [2][kAStage]
   unsigned char* const Bbase = smem3 + 2 * kAStage;   // [2][kBStage]
@@ -54,10 +62,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
     // ------------------------------------------------------------------ staging waves
     const int ptid = tid - 256;
     // halo items: (pixel 0..179, float4 q 0..3); three per thread, the last pass partially filled
-    int a_src[3], a_lds[3];
-    bool a_ok[3], a_has[3];
+    int a_src[AI], a_lds[AI];
+    bool a_ok[AI], a_has[AI];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < AI; ++i) {
       const int e = ptid + 256 * i;
       a_has[i] = e < kHaloPix * 4;
       const int pix = a_has[i] ? (e >> 2) : 0, q = e & 3;
@@ -87,16 +95,16 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
       b_src[i] = (int)(pt * plane_stride + (size_t)jx * tap_stride + (size_t)co * kCh + half * 8);
       b_lds[i] = (jx * 3 + pt) * BN * kRB + half_off(row, half);
     }
-    f32x4 ra[3];
+    f32x4 ra[AI];
     u32x4 rbv[BI];
     auto load_a = [&](int c) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) ra[i] = *reinterpret_cast<const f32x4*>(p.src + a_src[i] + (a_ok[i] ? c * kCh : 0));
+      for (int i = 0; i < AI; ++i) ra[i] = *reinterpret_cast<const f32x4*>(p.src + a_src[i] + (a_ok[i] ? c * kCh : 0));
     };
     auto store_a = [&](int stage) {
       unsigned char* A = Abase + stage * kAStage;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < AI; ++i) {
         if (!a_has[i]) continue;
         const f32x4 v = ra[i];
         const bool ok = a_ok[i];
@@ -159,7 +167,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
   int hb[MB];   // halo slot of the lane's pixel for tap offset (0, 0)
 #pragma unroll
   for (int a = 0; a < MB; ++a) {
-    const int m = wm * 64 + a * 32 + li;
+    const int m = wm * WMR + a * 32 + li;
     hb[a] = ((m >> 4) + 1) * kHP + (m & 15) + 1;
   }
   int fb[NB];
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
 
 #pragma unroll
   for (int a = 0; a < MB; ++a) {
-    const int m = wm * 64 + a * 32 + li;
+    const int m = wm * WMR + a * 32 + li;
     const int gy = Y0 + (m >> 4), gx = X0 + (m & 15);
     const size_t roff = (((size_t)n * p.Hd + (size_t)(gy * p.dsh + p.doy)) * p.Wd + (size_t)(gx * p.dsw + p.dox)) * p.Cd;
     igemm_store_rows<NB, WN>(p, acc[a], roff, n0, wn, lh);
@@ -214,9 +222,9 @@ bool conv3x3_halo_applies(const IGemmArgs& a) {
   if (!on) return false;
   if (a.kh != 3 || a.kw != 3 || a.ash != 1 || a.asw != 1) return false;
   if (!((a.oys == 1 || a.oys == -1) && a.oy0 == -a.oys && (a.oxs == 1 || a.oxs == -1) && a.ox0 == -a.oxs)) return false;
-  if (a.Hm != a.Hs || a.Wm != a.Ws || (a.Hm % kPH) != 0 || (a.Wm % kPW) != 0) return false;
+  if (a.Hm != a.Hs || a.Wm != a.Ws || (a.Hm % 8) != 0 || (a.Wm % kPW) != 0) return false;
   if ((a.Cs % kCh) != 0 || a.Cd < 64 || !a.dense_dst && (a.dsh != 1 || a.dsw != 1)) return false;
-  const long long tiles = (long long)a.N * (a.Hm / kPH) * (a.Wm / kPW) * ceil_div(a.Cd, a.Cd <= 64 ? 64 : 128);
+  const long long tiles = (long long)a.N * (a.Hm / 8) * (a.Wm / kPW) * ceil_div(a.Cd, a.Cd <= 64 ? 64 : 128);
   return tiles >= 256;
 }
 
@@ -235,26 +243,32 @@ bool conv_desc_uses_halo(const evk_conv_desc* d, int for_dgrad) {
   return conv3x3_halo_applies(a);
 }
 
-template <int BN>
+template <int BN, int PH>
 static int launch_halo(IGemmArgs& a, hipStream_t stream) {
   a.tiles_n = ceil_div(a.Cd, BN);
-  const int tiles_y = a.Hm / kPH, tiles_x = a.Wm / kPW;
+  const int tiles_y = a.Hm / PH, tiles_x = a.Wm / kPW;
   a.tiles_m = a.N * tiles_y * tiles_x;
-  const size_t lds = (size_t)2 * (3 * kHSlots * kRB) + (size_t)2 * (3 * 3 * BN * kRB);
+  const size_t lds = (size_t)2 * (3 * HaloGeom<PH>::kHSlots * kRB) + (size_t)2 * (3 * 3 * BN * kRB);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_x3_kernel<BN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_x3_kernel<BN, PH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const long long nwg = (long long)a.tiles_m * a.tiles_n;
-  hipLaunchKernelGGL((conv3x3_halo_x3_kernel<BN>), dim3((unsigned)nwg), dim3(512), lds, stream, a, tiles_y, tiles_x);
+  hipLaunchKernelGGL((conv3x3_halo_x3_kernel<BN, PH>), dim3((unsigned)nwg), dim3(512), lds, stream, a, tiles_y, tiles_x);
   return check_launch("conv3x3_halo_x3");
 }
 
 int launch_conv3x3_halo(IGemmArgs& a, hipStream_t stream) {
   if (!conv3x3_halo_applies(a)) return 1;
-  return a.Cd <= 64 ? launch_halo<64>(a, stream) : launch_halo<128>(a, stream);
+  if (a.Cd <= 64) return launch_halo<64, 8>(a, stream);
+  // 16 x 16 patches (256 GEMM rows) halve the weight bytes per MFMA, the larger share of the staging traffic now;
+  // taken when they still fill the chip
+  static const int tall = getenv("EVK_X3_HALO_TALL") ? atoi(getenv("EVK_X3_HALO_TALL")) : 1;
+  if (tall && (a.Hm % 16) == 0 && (long long)a.N * (a.Hm / 16) * (a.Wm / kPW) * ceil_div(a.Cd, 128) >= 256)
+    return launch_halo<128, 16>(a, stream);
+  return launch_halo<128, 8>(a, stream);
 }
 
 // planes for the halo kernel: out[pt][tap][chunk][row][16] bf16; tap = jy*3 + jx in the kernel's (affine) tap
