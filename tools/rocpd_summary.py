@@ -21,7 +21,7 @@ def main(db_path, out):
         for n, c, s, a, mn, mx in rows:
             w.writerow([n, c, round(s / 1e3, 1), round(a / 1e3, 2), round(mn / 1e3, 2), round(mx / 1e3, 2),
                         round(100.0 * s / total, 2)])
-    fams = [('conv_igemm (forward + data gradient: conv_igemm_x3ws / conv_igemm_x3 / conv_igemm kernels)', ('conv_igemm',)),
+    fams = [('conv_igemm (forward + data gradient: conv3x3_halo_x3 / conv_igemm_x3ws / conv_igemm_x3 / conv_igemm kernels)', ('conv_igemm', 'conv3x3_halo')),
             ('conv_wgrad (conv_wgrad_x3ws / conv_wgrad_x3 / conv_wgrad kernels)', ('conv_wgrad',)),
             ('BatchNorm (bn_* kernels)', ('bn_',))]
     fam_rows = []

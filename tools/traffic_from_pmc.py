@@ -9,7 +9,7 @@ import sqlite3
 import sys
 from collections import defaultdict
 
-FAMILIES = {'conv_igemm': ('conv_igemm',), 'conv_wgrad': ('conv_wgrad',), 'bn': ('bn_',)}
+FAMILIES = {'conv_igemm': ('conv_igemm', 'conv3x3_halo'), 'conv_wgrad': ('conv_wgrad',), 'bn': ('bn_',)}
 
 
 def per_dispatch(db_path, counter):
