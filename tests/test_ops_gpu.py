@@ -36,6 +36,9 @@ CONV_CASES = [
     (3, 72, 11, 13, 40, 3, 1, 1, 1, True),      # channels % 8 == 0 only, K = 648 not a multiple of 32 (K padding)
     (2, 24, 24, 24, 264, 3, 2, 1, 1, False),    # stride-2 residue classes with a ragged N tile
     (2, 64, 16, 8, 64, 3, 1, 1, 1, False),      # Wo % 8 == 0: single-decomposition wgrad gather
+    (2, 64, 128, 128, 64, 3, 1, 1, 1, True),    # LDS-halo 3x3 kernel, 64-wide N tile, 8x16 patches (256 workgroups)
+    (2, 48, 128, 128, 160, 3, 1, 1, 1, False),  # LDS-halo kernel, 8x16 patches, ragged N tile, 3 channel chunks
+    (4, 32, 128, 128, 128, 3, 1, 1, 1, True),   # LDS-halo kernel, 16x16 patches
 ]
 
 
