@@ -244,7 +244,10 @@ WGradPlan plan_wgrad(const evk_conv_desc* d, int x3) {
   pl.bn = Ktot <= 64 ? 64 : 128;
   // wide wave-specialised tile (128 x 256, one 8-wave workgroup per CU) when both dimensions are there
   static const int ws_mode = getenv("EVK_WG_WS") ? atoi(getenv("EVK_WG_WS")) : 1;
-  pl.ws = (x3 && ws_mode && d->Cout >= 128 && Ktot >= 256) ? 1 : 0;
+  // (its gathers are raw buffer loads: 32-bit byte offsets, so both tensors must stay below 2 GiB)
+  const bool fits32 = (long long)d->N * d->H * d->W * d->Cin * 4 < 0x7fffffffLL &&
+                      (long long)d->N * d->Ho * d->Wo * d->Cout * 4 < 0x7fffffffLL;
+  pl.ws = (x3 && ws_mode && d->Cout >= 128 && Ktot >= 256 && fits32) ? 1 : 0;
   if (pl.ws) pl.bn = 256;
   pl.tiles_co = ceil_div(d->Cout, pl.bm);
   pl.tiles_k = ceil_div(Ktot, pl.bn);

@@ -81,6 +81,44 @@ __device__ __forceinline__ void split_store8(f32x4 (&rv)[8], uint32_t okmask, un
   }
 }
 
+// Half micro-block of dy: 8 pixels x 2 channels (8-byte loads, 512 B contiguous per pixel across a wave).  dy is the
+// plain [M][Cout] matrix: no tap, no spatial bound, only the pixel range.  Channel 2*cq+e goes to LDS row e*Q2 + cq.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gather8h(const float* __restrict__ dy, int Cout, int coff, bool cvalid, int m0, int pend,
+                                         f32x2v (&rv)[8], uint32_t& okmask) {
+  okmask = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int m = m0 + j;
+    const bool ok = cvalid && m < pend;
+    okmask |= ok ? (1u << j) : 0u;
+    rv[j] = *reinterpret_cast<const f32x2v*>(dy + (ok ? (size_t)m * Cout + coff : 0));
+  }
+}
+__device__ __forceinline__ void split_store8h(f32x2v (&rv)[8], uint32_t okmask, unsigned char* base, int plane_bytes, int Q2,
+                                              int cq, int pg) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const bool ok = (okmask >> j) & 1u;
+    rv[j].x = ok ? rv[j].x : 0.f;
+    rv[j].y = ok ? rv[j].y : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int off = plane_off(e * Q2 + cq, pg);
+    u32x4 H, M, L;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      uint32_t h, m, l;
+      split2(rv[2 * t][e], rv[2 * t + 1][e], h, m, l);
+      H[t] = h; M[t] = m; L[t] = l;
+    }
+    *reinterpret_cast<u32x4*>(base + off) = H;
+    *reinterpret_cast<u32x4*>(base + plane_bytes + off) = M;
+    *reinterpret_cast<u32x4*>(base + 2 * plane_bytes + off) = L;
+  }
+}
+
 template <int BM, int BN>
 __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p) {
   constexpr int WM = BM / 2, WN = BN / 2;
@@ -106,10 +144,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
   if (tid >= 256) {
     // ------------------------------------------------------------------ staging waves
     const int ptid = tid - 256;
-    const bool hasA = ptid < QA * 4;  // wave-uniform (QA*4 = 128 = two waves)
-    WGather gb, ga;
+    // every staging thread: one im2col micro-block (8 px x 4 ch) + one HALF dy micro-block (8 px x 2 ch) — the
+    // dy tile dealt over all four waves (with whole dy micro-blocks on two waves those two set the pace:
+    // measured 51 % matrix-pipe occupancy, the matrix waves waiting at the barrier)
+    constexpr int QA2 = BM / 2;
+    static_assert(QA2 * 4 == 256, "one half dy micro-block per staging thread");
+    WGather gb;
     const int bcq = ptid % QB, bpg = ptid / QB;
-    const int acq = ptid % QA, apg = (ptid / QA) & 3;
+    const int acq = ptid % QA2, apg = ptid / QA2;
+    const int a_coff = co0 + acq * 2;
+    const bool a_cvalid = a_coff < p.Cout;
     {
       gb.src = p.x; gb.Hs = p.H; gb.Ws = p.W; gb.Cs = p.Cin; gb.ssh = p.sh; gb.ssw = p.sw;
       const int q = (k0 >> 2) + bcq;
@@ -122,25 +166,23 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
         gb.offy = ky * p.dh - p.ph;
         gb.offx = kx * p.dw - p.pw;
       }
-      ga.src = p.dy; ga.Hs = p.Ho; ga.Ws = p.Wo; ga.Cs = p.Cout; ga.ssh = 1; ga.ssw = 1; ga.offy = 0; ga.offx = 0;
-      ga.coff = co0 + acq * 4;
-      ga.cvalid = hasA && ga.coff < p.Cout;
     }
-    f32x4 ra[2][8], rb[2][8];
+    f32x2v ra[2][8];
+    f32x4 rb[2][8];
     uint32_t oka[2] = {0, 0}, okb[2] = {0, 0};
 
     auto load = [&](auto SET, int kt) {
       constexpr int s = decltype(SET)::value;
       const int pix0 = pbeg + kt * BKP;
       gather8(p, gb, pix0 + bpg * 8, pend, rb[s], okb[s]);
-      if (hasA) gather8(p, ga, pix0 + apg * 8, pend, ra[s], oka[s]);
+      gather8h(p.dy, p.Cout, a_coff, a_cvalid, pix0 + apg * 8, pend, ra[s], oka[s]);
     };
     auto store = [&](auto SET, int stage) {
       constexpr int s = decltype(SET)::value;
       unsigned char* Ab = smem3 + stage * kStage;
       unsigned char* Bb = Ab + 3 * BM * kRowBytes;
       split_store8(rb[s], okb[s], Bb, BN * kRowBytes, QB, bcq, bpg);
-      if (hasA) split_store8(ra[s], oka[s], Ab, BM * kRowBytes, QA, acq, apg);
+      split_store8h(ra[s], oka[s], Ab, BM * kRowBytes, QA2, acq, apg);
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
@@ -227,7 +269,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ra_ = wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int row = co0 + 4 * (ra_ % QA) + ra_ / QA;
+      const int row = co0 + 2 * (ra_ % (BM / 2)) + ra_ / (BM / 2);   // inverse of the dy staging permutation
       if (row >= p.Cout) continue;
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
