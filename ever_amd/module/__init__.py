@@ -1,12 +1,13 @@
 from . import loss  # noqa: F401
 from .farseg import FarSeg
 from .fpn import FPN, AssymetricDecoder
-from .fs_relation import FarSegHead, FSRelation
+from .freenet import FreeNet
+from .fs_relation import FarSegHead, FSRelation, FSRelationV2
 from .layers import (AdaptiveAvgPool2d, BatchNorm2d, Conv2d, HipSequential, MaxPool2d, ReLU, UpsamplingBilinear2d,
                      to_hip)
 from .ops import Bf16compatible, ConvBlock, ConvUpsampling
 from .resnet import ResNetEncoder
 
-__all__ = ['ResNetEncoder', 'FPN', 'AssymetricDecoder', 'FSRelation', 'FarSegHead', 'FarSeg', 'ConvBlock',
+__all__ = ['ResNetEncoder', 'FPN', 'AssymetricDecoder', 'FSRelation', 'FSRelationV2', 'FarSegHead', 'FarSeg', 'FreeNet', 'ConvBlock',
            'Bf16compatible', 'ConvUpsampling', 'Conv2d', 'BatchNorm2d', 'ReLU', 'MaxPool2d', 'UpsamplingBilinear2d',
            'AdaptiveAvgPool2d', 'HipSequential', 'to_hip', 'loss']
