@@ -40,7 +40,7 @@ CONV_CASES = [
     (2, 48, 128, 128, 160, 3, 1, 1, 1, False),  # LDS-halo kernel, 8x16 patches, ragged N tile, 3 channel chunks
     (4, 32, 128, 128, 128, 3, 1, 1, 1, True),   # LDS-halo kernel, 16x16 patches
     (3, 32, 72, 256, 64, 3, 1, 1, 1, False),    # LDS-halo kernel, non-square, H % 16 != 0 (8-row patches only)
-    (2, 16, 48, 320, 128, 3, 1, 1, 1, True),    # LDS-halo kernel, one channel chunk, 16-row patches, W = 20 patches
+    (3, 16, 96, 320, 128, 3, 1, 1, 1, True),    # LDS-halo kernel, one channel chunk, 16-row patches, W = 20 patches
 ]
 
 
