@@ -179,20 +179,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGradArgs p) {
 }
 
 // out[i] = sum_z ws[z][i]  (fixed order)
-__global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, size_t n4, int splitk,
-                                     size_t stride4) {
+// `lanes` threads share one 16-byte element: lane l sums the splits z = l, l + lanes, ... (fixed order), the lanes are
+// folded through LDS in index order => the result depends on (splitk, lanes) only, never on timing.  With one thread
+// per element a small weight tensor with many splits (1x1 convolutions on 128^2 maps: 4096 floats x 1024 splits) ran on
+// four workgroups and took 78 us — three times the weight-gradient kernel it follows.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, size_t n4,
+                                                            int splitk, size_t stride4, int lanes) {
+  __shared__ f32x4 red[256];
   const f32x4* w4 = reinterpret_cast<const f32x4*>(ws);
   f32x4* o4 = reinterpret_cast<f32x4*>(out);
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    f32x4 s = w4[i];
-    int z = 1;
-    for (; z + 3 < splitk; z += 4) {  // four independent 16-byte loads in flight, fixed summation order
-      const f32x4 a = w4[(size_t)z * stride4 + i], b = w4[(size_t)(z + 1) * stride4 + i];
-      const f32x4 c = w4[(size_t)(z + 2) * stride4 + i], d = w4[(size_t)(z + 3) * stride4 + i];
-      s += (a + b) + (c + d);
+  const int epb = 256 / lanes;                     // elements per workgroup
+  const int e = threadIdx.x % epb, l = threadIdx.x / epb;
+  for (size_t i0 = (size_t)blockIdx.x * epb; i0 < n4; i0 += (size_t)gridDim.x * epb) {
+    const size_t i = i0 + e;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4) {
+      int z = l;
+      for (; z + 3 * lanes < splitk; z += 4 * lanes) {  // four independent 16-byte loads in flight
+        const f32x4 a = w4[(size_t)z * stride4 + i], b = w4[(size_t)(z + lanes) * stride4 + i];
+        const f32x4 c = w4[(size_t)(z + 2 * lanes) * stride4 + i], d = w4[(size_t)(z + 3 * lanes) * stride4 + i];
+        s += (a + b) + (c + d);
+      }
+      for (; z < splitk; z += lanes) s += w4[(size_t)z * stride4 + i];
     }
-    for (; z < splitk; ++z) s += w4[(size_t)z * stride4 + i];
-    o4[i] = s;
+    if (lanes > 1) {
+      red[threadIdx.x] = s;
+      __syncthreads();
+      if (l == 0 && i < n4) {
+        for (int k = 1; k < lanes; ++k) s += red[k * epb + e];
+        o4[i] = s;
+      }
+      __syncthreads();
+    } else if (i < n4) {
+      o4[i] = s;
+    }
   }
 }
 
@@ -334,9 +354,13 @@ static int conv_wgrad_any(const evk_conv_desc* d, const float* x, const float* d
   if (pl.splitk > 1) {
     const size_t n = (size_t)d->Cout * a.Ktot;  // multiple of 4 since Cin % 4 == 0
     const size_t n4 = n / 4;
-    const int blocks = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
+    // enough threads to fill the chip: lanes per element = smallest power of two with n4 * lanes >= 128 K (<= 64)
+    int lanes = 1;
+    while (lanes < 64 && lanes * 2 <= pl.splitk && n4 * (size_t)lanes < 131072) lanes *= 2;
+    const size_t epb = 256 / lanes;
+    const int blocks = (int)((n4 + epb - 1) / epb > 4096 ? 4096 : (n4 + epb - 1) / epb);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, n4,
-                       pl.splitk, n4);
+                       pl.splitk, n4, lanes);
     rc = check_launch("splitk_reduce");
     if (rc) return rc;
   }
