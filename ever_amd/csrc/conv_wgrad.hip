@@ -242,16 +242,24 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 // 32 channels x 8 partial-lanes per workgroup: coalesced 128-byte rows, fp64, LDS fold
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                            int nblk, int C) {
-  __shared__ double red[8][32];
-  const int tc = threadIdx.x & 31, tl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + tc;
+  // 8 channels x 32 partial-lanes per workgroup, four loads in flight per lane (as the BatchNorm finalisation)
+  __shared__ double red[32][8];
+  const int tc = threadIdx.x & 7, tl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + tc;
   double s = 0.0;
-  if (c < C)
-    for (int b = tl; b < nblk; b += 8) s += (double)partial[(size_t)b * C + c];
+  if (c < C) {
+    int b = tl;
+    for (; b + 96 < nblk; b += 128) {
+      const float a0 = partial[(size_t)b * C + c], a1 = partial[(size_t)(b + 32) * C + c];
+      const float a2 = partial[(size_t)(b + 64) * C + c], a3 = partial[(size_t)(b + 96) * C + c];
+      s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+    }
+    for (; b < nblk; b += 32) s += (double)partial[(size_t)b * C + c];
+  }
   red[tl][tc] = s;
   __syncthreads();
   if (tl == 0 && c < C) {
-    for (int k = 1; k < 8; ++k) s += red[k][tc];
+    for (int k = 1; k < 32; ++k) s += red[k][tc];
     out[c] = (float)s;
   }
 }
@@ -371,7 +379,7 @@ static int conv_wgrad_any(const evk_conv_desc* d, const float* x, const float* d
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, st, dy, (float*)workspace, rows, d->Cout, rpb);
     rc = check_launch("colsum_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((d->Cout + 31) / 32), dim3(256), 0, st, (const float*)workspace,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((d->Cout + 7) / 8), dim3(256), 0, st, (const float*)workspace,
                        dbias, nblk, d->Cout);
     rc = check_launch("colsum_final");
   }
