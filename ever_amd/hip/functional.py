@@ -182,7 +182,10 @@ def _conv_forward(x, weight, bias, stride, padding, dilation, relu):
     cs.flops = 2.0 * n * d.Ho * d.Wo * cout * cin * kh * kw  # algorithmic (un-padded) FLOPs
     # algorithmic bytes: input + output + weights, each touched once
     cs.abytes = 4.0 * (n * h * w * cin + n * d.Ho * d.Wo * cout + cout * cin * kh * kw)
-    if _CONV_MATH == 'bf16x3' and cin_p == cin and cin % 8 == 0:
+    # a handful of GEMM rows (the scene-embedding 1x1 convolutions on 1x1 maps, M = batch): the fp32 path has a
+    # dedicated weight-streaming kernel for M <= 32; an MFMA tile would run K = 2048 serially on two workgroups
+    small_m = n * d.Ho * d.Wo <= 32
+    if _CONV_MATH == 'bf16x3' and cin_p == cin and cin % 8 == 0 and not small_m:
         # weights -> three bf16 planes (transient: they change every optimiser step), then the split-MFMA kernel
         lib = _C.load()
         planes = workspace(dev, lib.evk_conv2d_split_weight_bytes(ctypes.byref(d), 0))

@@ -26,4 +26,4 @@ print(f'conv launches {len(rows)}, total {tot/1e3:.2f} ms')
 cum = 0
 for (f, gf), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
     cum += us
-    print(f'{f:16s} {gf:8.2f} GF x{n:3d}  {us/n:8.1f} us  {gf*n/us*1e-3*1e3:7.1f} TF  share {us/tot*100:5.1f}% cum {cum/tot*100:5.1f}%')
+    print(f'{f:16s} {gf:8.2f} GF x{n:3d}  {us/n:8.1f} us  {gf*n/us*1e-3:7.1f} TF  share {us/tot*100:5.1f}% cum {cum/tot*100:5.1f}%')
