@@ -415,14 +415,23 @@ __global__ __launch_bounds__(256) void relation_bwd_kernel(const float* __restri
   float* o = partial + ((size_t)n * nblk + blockIdx.x) * C;
   for (int c = threadIdx.x; c < C; c += 256) o[c] = (sacc[c] + sacc[C + c]) + (sacc[2 * C + c] + sacc[3 * C + c]);
 }
-__global__ void relation_dscene_final_kernel(const float* __restrict__ partial, float* __restrict__ dscene, int nblk,
-                                             int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// 8 channels x 32 partial-lanes per workgroup (fixed fold order), as the other finalisations: a serial walk over up to
+// 256 partials per thread was 32 us of latency per call
+__global__ __launch_bounds__(256) void relation_dscene_final_kernel(const float* __restrict__ partial,
+                                                                    float* __restrict__ dscene, int nblk, int C) {
+  __shared__ double red[32][8];
+  const int tc = threadIdx.x & 7, tl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + tc;
   const int n = blockIdx.y;
-  if (c >= C) return;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)partial[((size_t)n * nblk + b) * C + c];
-  dscene[(size_t)n * C + c] = (float)s;
+  if (c < C)
+    for (int b = tl; b < nblk; b += 32) s += (double)partial[((size_t)n * nblk + b) * C + c];
+  red[tl][tc] = s;
+  __syncthreads();
+  if (tl == 0 && c < C) {
+    for (int k = 1; k < 32; ++k) s += red[k][tc];
+    dscene[(size_t)n * C + c] = (float)s;
+  }
 }
 
 static int relation_blocks(int HW) {
@@ -602,7 +611,7 @@ extern "C" int evk_relation_bwd(const float* dout, const float* scene, const flo
                      feat, r, dcontent, dfeat, (float*)workspace, HW, C, ppb, nblk);
   int rc = check_launch("relation_bwd");
   if (rc) return rc;
-  hipLaunchKernelGGL(relation_dscene_final_kernel, dim3((C + 255) / 256, N), dim3(256), 0, st,
+  hipLaunchKernelGGL(relation_dscene_final_kernel, dim3((C + 7) / 8, N), dim3(256), 0, st,
                      (const float*)workspace, dscene, nblk, C);
   return check_launch("relation_dscene_final");
 }
