@@ -224,8 +224,9 @@ bool conv3x3_halo_applies(const IGemmArgs& a) {
   if (!((a.oys == 1 || a.oys == -1) && a.oy0 == -a.oys && (a.oxs == 1 || a.oxs == -1) && a.ox0 == -a.oxs)) return false;
   if (a.Hm != a.Hs || a.Wm != a.Ws || (a.Hm % 8) != 0 || (a.Wm % kPW) != 0) return false;
   if ((a.Cs % kCh) != 0 || a.Cd < 64 || !a.dense_dst && (a.dsh != 1 || a.dsw != 1)) return false;
-  const long long tiles = (long long)a.N * (a.Hm / 8) * (a.Wm / kPW) * ceil_div(a.Cd, a.Cd <= 64 ? 64 : 128);
-  return tiles >= 256;
+  // enough workgroups for the 256 CUs, if necessary with the 64-wide N tile
+  const long long patches = (long long)a.N * (a.Hm / 8) * (a.Wm / kPW);
+  return patches * ceil_div(a.Cd, 64) >= 256;
 }
 
 // the same decision from a convolution descriptor (forward, or stride-1 data gradient)
@@ -262,7 +263,8 @@ static int launch_halo(IGemmArgs& a, hipStream_t stream) {
 
 int launch_conv3x3_halo(IGemmArgs& a, hipStream_t stream) {
   if (!conv3x3_halo_applies(a)) return 1;
-  if (a.Cd <= 64) return launch_halo<64, 8>(a, stream);
+  if (a.Cd <= 64 || (long long)a.N * (a.Hm / 8) * (a.Wm / kPW) * ceil_div(a.Cd, 128) < 256)
+    return launch_halo<64, 8>(a, stream);   // small maps (16^2 .. 32^2): 64-wide tiles keep every CU busy
   // 16 x 16 patches (256 GEMM rows) halve the weight bytes per MFMA, the larger share of the staging traffic now;
   // taken when they still fill the chip
   static const int tall = getenv("EVK_X3_HALO_TALL") ? atoi(getenv("EVK_X3_HALO_TALL")) : 1;
