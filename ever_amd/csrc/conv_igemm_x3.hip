@@ -273,7 +273,9 @@ int launch_igemm_x3(IGemmArgs& a, hipStream_t stream) {
       return launch_cfg3<64, 64, 2, 2, 1>(a, stream);
     }
     if (tiles(128) >= 256) return launch_cfg3<128, 128, 2, 2, 1>(a, stream);
-    return launch_cfg3<64, 128, 2, 2, 1>(a, stream);
+    if (tiles(64) >= 256) return launch_cfg3<64, 128, 2, 2, 1>(a, stream);
+    // 16^2 maps (M = 4096 rows at batch 16): 64 x 64 tiles are the only ones that give every CU a workgroup
+    return launch_cfg3<64, 64, 2, 2, 1>(a, stream);
   }
   if (bn == 64) {
     if (tiles(128) >= 256) return launch_cfg3<128, 64, 2, 2, 2>(a, stream);
