@@ -16,14 +16,22 @@ for it in range(3):
     if t: t.__exit__()
     m.zero_grad(set_to_none=True)
 torch.cuda.synchronize()
-rows = [(f, fl, s.elapsed_time(e) * 1e3) for f, fl, nb, s, e in t.records if fl > 0]
-tot = sum(r[2] for r in rows)
+PEAK_TF, PEAK_HBM = 416.7e12, 8.0e12       # bf16x3 matrix-pipe peak (2500/6), HBM3E peak
+rows = [(f, fl, nb, s.elapsed_time(e) * 1e3) for f, fl, nb, s, e in t.records if fl > 0]
+tot = sum(r[3] for r in rows)
 agg = {}
-for f, fl, us in rows:
-    k = (f, round(fl / 1e9, 2))
+for f, fl, nb, us in rows:
+    k = (f, round(fl / 1e9, 3), round(nb / 1e6, 1))
     a = agg.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += us
 print(f'conv launches {len(rows)}, total {tot/1e3:.2f} ms')
-cum = 0
-for (f, gf), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+print('bound = max(flop / 416.7 TF, algorithmic bytes / 8 TB/s) per launch; frac = bound / measured')
+cum, bound_tot = 0, 0.0
+for (f, gf, mb), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
     cum += us
-    print(f'{f:16s} {gf:8.2f} GF x{n:3d}  {us/n:8.1f} us  {gf*n/us*1e-3:7.1f} TF  share {us/tot*100:5.1f}% cum {cum/tot*100:5.1f}%')
+    t_mfma, t_hbm = gf * 1e9 / PEAK_TF * 1e6, mb * 1e6 / PEAK_HBM * 1e6
+    bound = max(t_mfma, t_hbm)
+    bound_tot += bound * n
+    print(f'{f:16s} {gf:8.3f} GF {mb:7.1f} MB x{n:3d}  {us/n:8.1f} us  {gf*n/us*1e3:7.1f} TF  '
+          f'{"hbm " if t_hbm > t_mfma else "mfma"} bound {bound:7.1f} us frac {bound*n/us:4.2f}  '
+          f'share {us/tot*100:5.1f}% cum {cum/tot*100:5.1f}%')
+print(f'sum of per-launch bounds {bound_tot/1e3:.2f} ms = {bound_tot/tot:.2f} of the measured conv time')
