@@ -166,52 +166,38 @@ __global__ void bn_eval_coef_kernel(const float* __restrict__ gamma, const float
   scale_shift[C + c] = b - rm[c] * sc;
 }
 
-// y = act(x*scale + shift [+ residual]);  scale/shift staged in LDS
+// Channel chunk of flat 16-byte element i: (i mod c4) without a per-lane 64-bit division — the workgroup's base
+// goes through the scalar unit, the lane offset (< 256 + c4 <= 768) through an exact float reciprocal.
+__device__ __forceinline__ int chunk_of(size_t blk_base, int c4) {
+  const uint32_t v = (uint32_t)(blk_base % (size_t)c4) + threadIdx.x;
+  const uint32_t q = (uint32_t)((float)v * (1.0f / (float)c4));
+  int r = (int)(v - q * (uint32_t)c4);
+  r = r < 0 ? r + c4 : r;
+  return r >= c4 ? r - c4 : r;
+}
+
+// y = act(x*scale + shift [+ residual]).
+// ONE 16-byte element per thread and a grid of n4/256 workgroups: on the 268 MB maps a 1-read + 1-write stream
+// runs at 6.1 TB/s this way against 4.3 TB/s for 2048 grid-striding workgroups with four loads in flight each
+// (tools/probes/copy_patterns.hip) — the resident workgroups then sweep one contiguous window of HBM in dispatch
+// order instead of 2048 x 4 scattered pages.  scale/shift (2C floats) come from L1/L2, not LDS: staging them
+// per workgroup would cost more than the 4 KB a workgroup streams.
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ residual,
                                                        const float* __restrict__ scale_shift, float* __restrict__ y,
-                                                       size_t n4, int C, int relu, int unroll) {
-  extern __shared__ __attribute__((aligned(16))) float ss[];  // [2][C]
-  for (int i = threadIdx.x; i < 2 * C; i += 256) ss[i] = scale_shift[i];
-  __syncthreads();
+                                                       size_t n4, int C, int relu) {
+  const size_t base = (size_t)blockIdx.x * 256;
+  const size_t i = base + threadIdx.x;
+  if (i >= n4) return;
   const int c4 = C >> 2;
-  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-  const f32x4* r4 = reinterpret_cast<const f32x4*>(residual);
-  f32x4* y4 = reinterpret_cast<f32x4*>(y);
-  const f32x4* sc4 = reinterpret_cast<const f32x4*>(ss);
-  const f32x4* sh4 = reinterpret_cast<const f32x4*>(ss + C);
-  // Four independent 16-byte loads per lane and trip: with one, 8 waves/SIMD x 1 KB keeps only ~8 MB in
-  // flight chip-wide, below latency x bandwidth (measured 3.4 TB/s on the 268 MB maps).  The channel
-  // chunk index advances by a constant per trip (no 64-bit modulo in the loop).
-  const size_t S = (size_t)gridDim.x * 256;
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  int cb = (int)(i % c4);
-  const int dcb = (int)(S % c4);
-  auto fin = [&](f32x4 v, const f32x4* rp) {
-    if (residual) v += *rp;
-    if (relu) {
-      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-    }
-    return v;
-  };
-  for (; unroll && i + 3 * S < n4; i += 4 * S) {
-    int c1 = cb + dcb; c1 = c1 >= c4 ? c1 - c4 : c1;
-    int c2 = c1 + dcb; c2 = c2 >= c4 ? c2 - c4 : c2;
-    int c3 = c2 + dcb; c3 = c3 >= c4 ? c3 - c4 : c3;
-    const f32x4 a0 = x4[i], a1 = x4[i + S], a2 = x4[i + 2 * S], a3 = x4[i + 3 * S];
-    f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0, q3 = q0;
-    if (residual) { q0 = r4[i]; q1 = r4[i + S]; q2 = r4[i + 2 * S]; q3 = r4[i + 3 * S]; }
-    y4[i] = fin(a0 * sc4[cb] + sh4[cb], &q0);
-    y4[i + S] = fin(a1 * sc4[c1] + sh4[c1], &q1);
-    y4[i + 2 * S] = fin(a2 * sc4[c2] + sh4[c2], &q2);
-    y4[i + 3 * S] = fin(a3 * sc4[c3] + sh4[c3], &q3);
-    cb = c3 + dcb; cb = cb >= c4 ? cb - c4 : cb;
+  const int cb = chunk_of(base, c4);
+  const f32x4 sc = reinterpret_cast<const f32x4*>(scale_shift)[cb];
+  const f32x4 sh = reinterpret_cast<const f32x4*>(scale_shift + C)[cb];
+  f32x4 v = reinterpret_cast<const f32x4*>(x)[i] * sc + sh;
+  if (residual) v += reinterpret_cast<const f32x4*>(residual)[i];
+  if (relu) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
   }
-  for (; i < n4; i += S) {
-    f32x4 q0 = {0.f, 0.f, 0.f, 0.f};
-    if (residual) q0 = r4[i];
-    y4[i] = fin(x4[i] * sc4[cb] + sh4[cb], &q0);
-    cb += dcb; cb = cb >= c4 ? cb - c4 : cb;
-  }
+  reinterpret_cast<f32x4*>(y)[i] = v;
 }
 
 // Backward stage 1: g = dy * (y > 0) ; partial[blk][0][C] = sum g, [1][C] = sum g * xhat.
@@ -320,77 +306,45 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
   coef[2 * C + c] = train ? (float)(q * inv_rows) : 0.f;
 }
 
-// dx = coef0 * (g - coef1 - xhat*coef2)
+// dx = coef0 * (g - coef1 - xhat*coef2); one 16-byte element per thread (see bn_apply_kernel), the per-channel
+// vectors read through L1.
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ coef,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ dx,
-                                                           size_t n4, int C, int relu, int unroll) {
-  extern __shared__ __attribute__((aligned(16))) float ss[];  // [7][C]: coef0..2, mean, invstd, sc, sh
-  for (int i = threadIdx.x; i < 3 * C; i += 256) ss[i] = coef[i];
-  for (int i = threadIdx.x; i < C; i += 256) {
-    const float m = mean[i], is_ = invstd[i];
-    ss[3 * C + i] = m;
-    ss[4 * C + i] = is_;
-    const float sc_ = (gamma ? gamma[i] : 1.f) * is_;
-    ss[5 * C + i] = sc_;
-    ss[6 * C + i] = (beta ? beta[i] : 0.f) - m * sc_;
-  }
-  __syncthreads();
-  const f32x4* sc4 = reinterpret_cast<const f32x4*>(ss + 5 * C);
-  const f32x4* sh4 = reinterpret_cast<const f32x4*>(ss + 6 * C);
+                                                           size_t n4, int C, int relu) {
+  const size_t base = (size_t)blockIdx.x * 256;
+  const size_t i = base + threadIdx.x;
+  if (i >= n4) return;
   const int c4 = C >> 2;
-  const f32x4* k0 = reinterpret_cast<const f32x4*>(ss);
-  const f32x4* k1 = reinterpret_cast<const f32x4*>(ss + C);
-  const f32x4* k2 = reinterpret_cast<const f32x4*>(ss + 2 * C);
-  const f32x4* mu = reinterpret_cast<const f32x4*>(ss + 3 * C);
-  const f32x4* is = reinterpret_cast<const f32x4*>(ss + 4 * C);
-  const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
-  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-  const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
-  f32x4* dx4 = reinterpret_cast<f32x4*>(dx);
-  const size_t S = (size_t)gridDim.x * 256;
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  int cb = (int)(i % c4);
-  const int dcb = (int)(S % c4);
-  auto one = [&](f32x4 g, const f32x4 xv, const f32x4 yv, int c) {
-    if (relu) {
-      const f32x4 yy = (relu == 1) ? yv : xv * sc4[c] + sh4[c];
-      g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
-      g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+  const int c = chunk_of(base, c4);
+  const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, z4 = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 k0 = reinterpret_cast<const f32x4*>(coef)[c];
+  const f32x4 k1 = reinterpret_cast<const f32x4*>(coef + C)[c];
+  const f32x4 k2 = reinterpret_cast<const f32x4*>(coef + 2 * C)[c];
+  const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c];
+  const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[c];
+  f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+  const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+  if (relu) {
+    f32x4 yy;
+    if (relu == 1) {
+      yy = reinterpret_cast<const f32x4*>(y)[i];
+    } else {  // the forward's pre-activation, same sc/sh arithmetic as bn_stats_final_kernel
+      const f32x4 sc = (gamma ? reinterpret_cast<const f32x4*>(gamma)[c] : one4) * is;
+      const f32x4 sh = (beta ? reinterpret_cast<const f32x4*>(beta)[c] : z4) - mu * sc;
+      yy = xv * sc + sh;
     }
-    const f32x4 xh = (xv - mu[c]) * is[c];
-    return k0[c] * (g - k1[c] - xh * k2[c]);
-  };
-  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  // two elements per trip = 4-6 independent 16-byte loads per lane in flight (see bn_apply_kernel)
-  for (; unroll && i + S < n4; i += 2 * S) {
-    int c1 = cb + dcb; c1 = c1 >= c4 ? c1 - c4 : c1;
-    const f32x4 g0 = dy4[i], g1 = dy4[i + S];
-    const f32x4 x0 = x4[i], x1 = x4[i + S];
-    f32x4 y0 = z4, y1 = z4;
-    if (relu == 1) { y0 = y4[i]; y1 = y4[i + S]; }
-    dx4[i] = one(g0, x0, y0, cb);
-    dx4[i + S] = one(g1, x1, y1, c1);
-    cb = c1 + dcb; cb = cb >= c4 ? cb - c4 : cb;
+    g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+    g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
   }
-  for (; i < n4; i += S) {
-    const f32x4 y0 = (relu == 1) ? y4[i] : z4;
-    dx4[i] = one(dy4[i], x4[i], y0, cb);
-    cb += dcb; cb = cb >= c4 ? cb - c4 : cb;
-  }
+  const f32x4 xh = (xv - mu) * is;
+  reinterpret_cast<f32x4*>(dx)[i] = k0 * (g - k1 - xh * k2);
 }
 
-static int bn_unroll() {
-  static const int u = getenv("EVK_BN_UNROLL") ? atoi(getenv("EVK_BN_UNROLL")) : 1;
-  return u;
-}
-static int stream_grid(size_t n4) {
-  size_t b = (n4 + 255) / 256;
-  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
-}
+static unsigned oneshot_grid(size_t n4) { return (unsigned)((n4 + 255) / 256); }
 
 }  // namespace evk
 
@@ -425,8 +379,8 @@ extern "C" int evk_bn_fwd_train(const float* x, const float* residual, const flo
   rc = check_launch("bn_stats_final");
   if (rc) return rc;
   const size_t n4 = (size_t)rows * C / 4;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(n4)), dim3(256), 2 * C * sizeof(float), st, x, residual,
-                     scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, bn_unroll());
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, x, residual,
+                     scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0);
   return check_launch("bn_apply");
 }
 
@@ -446,8 +400,8 @@ extern "C" int evk_bn_fwd_eval(const float* x, const float* residual, const floa
   int rc = check_launch("bn_eval_coef");
   if (rc) return rc;
   const size_t n4 = (size_t)rows * C / 4;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(n4)), dim3(256), 2 * C * sizeof(float), st, x, residual,
-                     scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, bn_unroll());
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, x, residual,
+                     scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0);
   return check_launch("bn_apply");
 }
 
@@ -480,8 +434,8 @@ extern "C" int evk_bn_bwd(const float* dy, const float* x, const float* y, const
   // when d_residual holds g already, stage 3 can read it instead of re-masking dy
   const float* gsrc = d_residual ? d_residual : dy;
   const int relu3 = d_residual ? 0 : relu;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(256), 7 * C * sizeof(float), st, gsrc, x, y,
-                     save_mean, save_invstd, coef, gamma, beta, dx, n4, C, relu3, bn_unroll());
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, gsrc, x, y,
+                     save_mean, save_invstd, coef, gamma, beta, dx, n4, C, relu3);
   return check_launch("bn_bwd_apply");
 }
 
@@ -565,8 +519,8 @@ extern "C" int evk_bn_apply_stats(const float* x, const float* residual, const f
   hipLaunchKernelGGL(bn_coef_from_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, st, gamma, beta, mean, invstd, C,
                      scale_shift);
   const size_t n4 = (size_t)rows * C / 4;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(n4)), dim3(256), 2 * C * sizeof(float), st, x, residual,
-                     (const float*)scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, bn_unroll());
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, x, residual,
+                     (const float*)scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0);
   return check_launch("bn_apply_stats");
 }
 
@@ -601,7 +555,7 @@ extern "C" int evk_bn_bwd_apply_sums(const float* dy, const float* x, const floa
   float* coef = (float*)workspace;
   hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, st, gamma, invstd, mean_g, mean_gx, C, coef);
   const size_t n4 = (size_t)rows * C / 4;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(256), 7 * C * sizeof(float), st, dy, x, y, mean,
-                     invstd, (const float*)coef, gamma, beta, dx, n4, C, relu, bn_unroll());
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, dy, x, y, mean,
+                     invstd, (const float*)coef, gamma, beta, dx, n4, C, relu);
   return check_launch("bn_bwd_apply_sums");
 }
