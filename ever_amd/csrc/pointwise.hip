@@ -8,7 +8,10 @@
 
 namespace evk {
 
-static inline int grid_for(size_t n, int per_block = 256, int cap = 4096) {
+// One element per thread (the grid-stride loops below then run once): resident workgroups sweep one contiguous
+// window of HBM in dispatch order, 6.1 TB/s for 1R+1W on 268 MB against 5.1 for 4096 grid-striding workgroups
+// (tools/probes/copy_patterns.hip).
+static inline int grid_for(size_t n, int per_block = 256, int cap = 1 << 24) {
   size_t b = (n + per_block - 1) / per_block;
   return (int)(b > (size_t)cap ? cap : (b < 1 ? 1 : b));
 }

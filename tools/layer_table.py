@@ -35,3 +35,13 @@ for (f, gf, mb), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
           f'{"hbm " if t_hbm > t_mfma else "mfma"} bound {bound:7.1f} us frac {bound*n/us:4.2f}  '
           f'share {us/tot*100:5.1f}% cum {cum/tot*100:5.1f}%')
 print(f'sum of per-launch bounds {bound_tot/1e3:.2f} ms = {bound_tot/tot:.2f} of the measured conv time')
+
+# HBM-bound families: (family, MB) -> launches, us, TB/s against algorithmic bytes
+rows = [(f, nb, s.elapsed_time(e) * 1e3) for f, fl, nb, s, e in t.records if fl == 0 and nb > 0]
+tot = sum(r[2] for r in rows)
+agg = {}
+for f, nb, us in rows:
+    a = agg.setdefault((f, round(nb / 1e6, 1)), [0, 0.0]); a[0] += 1; a[1] += us
+print(f'HBM-bound launches {len(rows)}, total {tot/1e3:.2f} ms (a launch = one C-ABI call, e.g. bn_bwd = partial + final + apply)')
+for (f, mb), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
+    print(f'{f:16s} {mb:8.1f} MB x{n:3d}  {us/n:8.1f} us  {mb*n/us/1e6*1e6:7.2f} TB/s  share {us/tot*100:5.1f}%')
