@@ -20,8 +20,14 @@ class ConvDesc(C.Structure):
         'stride_h', 'stride_w', 'pad_h', 'pad_w', 'dil_h', 'dil_w')]
 
 
+class SplitJob(C.Structure):
+    """Mirror of `evk_split_job` (one weight-plane job of evk_conv2d_split_multi)."""
+    _fields_ = [('w', c_void_p), ('out', c_void_p), ('kind', c_i32), ('arg', c_i32 * 13)]
+
+
 P = c_void_p  # every device pointer and the stream are passed as void*
 _DP = C.POINTER(ConvDesc)
+_JP = C.POINTER(SplitJob)
 
 # name -> (restype, argtypes).  Order and types follow include/ever_hip.h exactly;
 # tests/test_abi.py checks that every symbol the header declares is exported and listed here.
@@ -34,6 +40,10 @@ SIGNATURES = {
     'evk_conv2d_pack_dgrad_weight': (c_int, [_DP, P, P, P]),
     'evk_conv2d_split_weight_bytes': (c_size_t, [_DP, c_i32]),
     'evk_conv2d_split_weight': (c_int, [_DP, P, c_i32, P, P]),
+    'evk_conv2d_split_job_count': (c_i32, [_DP, c_i32]),
+    'evk_conv2d_split_jobs': (c_int, [_DP, P, c_i32, P, _JP, c_i32]),
+    'evk_split_job_pairs': (c_i64, [_JP]),
+    'evk_conv2d_split_multi': (c_int, [P, P, c_i32, P]),
     'evk_conv2d_fwd_x3': (c_int, [_DP, P, P, P, P, c_u32, P]),
     'evk_conv2d_dgrad_x3': (c_int, [_DP, P, P, P, P, P]),
     'evk_conv2d_fwd_res': (c_int, [_DP, P, P, P, P, P, c_u32, P]),

@@ -15,7 +15,7 @@
 // always cover 16 distinct row residues), weights [2 stages][3 taps][3 planes][128 rows][32 B]; 16-byte halves of a
 // 32-byte row are swapped on odd 8-row groups (conflict-free b128 reads for any tap shift).
 #include "igemm_common.hpp"
-#include "x3_common.hpp"
+#include "split_weight.hpp"
 #include <stdlib.h>
 
 namespace evk {
@@ -278,33 +278,9 @@ int launch_conv3x3_halo(IGemmArgs& a, hipStream_t stream) {
 // direction, not the index).  rows = Cout (forward: w[row][ky][kx][ci]) or Cin (data gradient: w[co][ky][kx][row]).
 __global__ void split_weight_halo_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int Cout, int Cin,
                                          int for_dgrad) {
-  const int rows = for_dgrad ? Cin : Cout, K = for_dgrad ? Cout : Cin;   // K = reduction channels
-  const int nchunk = K / kCh;
-  const size_t total = (size_t)9 * nchunk * rows * (kCh / 2);
-  const size_t plane = (size_t)9 * nchunk * rows * kCh;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int k2 = (int)(i % (kCh / 2));
-    size_t r = i / (kCh / 2);
-    const int row = (int)(r % rows);
-    r /= rows;
-    const int ch = (int)(r % nchunk);
-    const int tap = (int)(r / nchunk);
-    const int kc = ch * kCh + 2 * k2;
-    float x0, x1;
-    if (for_dgrad) {
-      x0 = w[((size_t)kc * 9 + tap) * Cin + row];
-      x1 = w[((size_t)(kc + 1) * 9 + tap) * Cin + row];
-    } else {
-      x0 = w[((size_t)row * 9 + tap) * Cin + kc];
-      x1 = w[((size_t)row * 9 + tap) * Cin + kc + 1];
-    }
-    uint32_t h, m, l;
-    split2(x0, x1, h, m, l);
-    uint32_t* o = reinterpret_cast<uint32_t*>(out + (((size_t)tap * nchunk + ch) * rows + row) * kCh + 2 * k2);
-    o[0] = h;
-    o[plane >> 1] = m;
-    o[plane] = l;
-  }
+  static_assert(kHaloCh == kCh, "split_weight.hpp chunk width");
+  split_halo_body(w, out, Cout, Cin, for_dgrad, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
+                  (size_t)gridDim.x * blockDim.x);
 }
 
 int launch_split_weight_halo(const float* w, uint16_t* out, int Cout, int Cin, int for_dgrad, hipStream_t st) {

@@ -17,7 +17,7 @@
 // that the ds_read_b128 fragment reads of a 16-lane group cover 16 distinct 16-byte slots.
 // Fragment: lane l holds row l&31, k = 16*kk + 8*(l>>5) .. +7 (one ds_read_b128) for A and B alike.
 #include "igemm_common.hpp"
-#include "x3_common.hpp"
+#include "split_weight.hpp"
 #include <stdlib.h>
 
 namespace evk {
@@ -289,20 +289,7 @@ int launch_igemm_x3(IGemmArgs& a, hipStream_t stream) {
 // the OHWI parameter.  out[pt][row][Kpad] bf16, zero padded along K.
 __global__ void split_weight_fwd_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int rows, int K,
                                         int Kpad) {
-  const size_t total = (size_t)rows * (Kpad >> 1);
-  const size_t plane = (size_t)rows * Kpad;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int row = (int)(i / (Kpad >> 1));
-    const int k = (int)(i - (size_t)row * (Kpad >> 1)) * 2;
-    const float x0 = k < K ? w[(size_t)row * K + k] : 0.f;
-    const float x1 = k + 1 < K ? w[(size_t)row * K + k + 1] : 0.f;
-    uint32_t h, m, l;
-    split2(x0, x1, h, m, l);
-    uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)row * Kpad + k);
-    o[0] = h;
-    o[plane >> 1] = m;
-    o[plane] = l;
-  }
+  split_fwd_body(w, out, rows, K, Kpad, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
 }
 
 // Data-gradient planes of one residue class: row ci, k = (jy, jx, co) with ky = ky0 + jy*ksy, kx = kx0 + jx*ksx
@@ -310,32 +297,8 @@ __global__ void split_weight_fwd_kernel(const float* __restrict__ w, uint16_t* _
 __global__ void split_weight_dgrad_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int Cout, int kh,
                                           int kw, int Cin, int ky0, int ksy, int nty, int kx0, int ksx, int ntx,
                                           int Kpad) {
-  const int K = nty * ntx * Cout;
-  const size_t total = (size_t)Cin * (Kpad >> 1);
-  const size_t plane = (size_t)Cin * Kpad;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int ci = (int)(i / (Kpad >> 1));
-    const int k = (int)(i - (size_t)ci * (Kpad >> 1)) * 2;
-    float x[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int kk = k + e;
-      if (kk < K) {
-        const int co = kk % Cout;
-        const int t = kk / Cout;
-        const int jx = t % ntx, jy = t / ntx;
-        x[e] = w[(((size_t)co * kh + (ky0 + jy * ksy)) * kw + (kx0 + jx * ksx)) * Cin + ci];
-      } else {
-        x[e] = 0.f;
-      }
-    }
-    uint32_t h, m, l;
-    split2(x[0], x[1], h, m, l);
-    uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)ci * Kpad + k);
-    o[0] = h;
-    o[plane >> 1] = m;
-    o[plane] = l;
-  }
+  split_dgrad_body(w, out, Cout, kh, kw, Cin, ky0, ksy, nty, kx0, ksx, ntx, Kpad,
+                   (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
 }
 
 static inline int kpad32(int k) { return (k + 31) & ~31; }

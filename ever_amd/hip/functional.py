@@ -14,7 +14,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _C
-from . import timing
+from . import timing, weight_planes
 from .workspace import workspace
 
 __all__ = [
@@ -156,7 +156,7 @@ def _weight_ohwi(weight):
 
 class _ConvState:
     """What one convolution's backward needs (kept on the autograd ctx)."""
-    __slots__ = ('desc', 'relu', 'cin', 'has_bias', 'flops', 'abytes', 'w_stride', 'xk', 'w_ohwi', 'y')
+    __slots__ = ('desc', 'relu', 'cin', 'has_bias', 'flops', 'abytes', 'w_stride', 'xk', 'w_ohwi', 'y', 'weight')
 
 
 def _conv_forward(x, weight, bias, stride, padding, dilation, relu):
@@ -186,12 +186,16 @@ def _conv_forward(x, weight, bias, stride, padding, dilation, relu):
     # dedicated weight-streaming kernel for M <= 32; an MFMA tile would run K = 2048 serially on two workgroups
     small_m = n * d.Ho * d.Wo <= 32
     if _CONV_MATH == 'bf16x3' and cin_p == cin and cin % 8 == 0 and not small_m:
-        # weights -> three bf16 planes (transient: they change every optimiser step), then the split-MFMA kernel
-        lib = _C.load()
-        planes = workspace(dev, lib.evk_conv2d_split_weight_bytes(ctypes.byref(d), 0))
-        _C.call('evk_conv2d_split_weight', ctypes.byref(d), w_ptr, 0, planes.data_ptr(), st)
+        # weights -> three bf16 planes, then the split-MFMA kernel.  The planes of every registered weight are
+        # refreshed by one launch per weight update (weight_planes); a weight the cache cannot follow (a transient
+        # re-laid-out copy) is split into the shared workspace on every call.
+        pl_ptr = weight_planes.planes_for(weight, w_ohwi, d, 0, st)
+        if pl_ptr is None:
+            planes = workspace(dev, _C.load().evk_conv2d_split_weight_bytes(ctypes.byref(d), 0))
+            _C.call('evk_conv2d_split_weight', ctypes.byref(d), w_ptr, 0, planes.data_ptr(), st)
+            pl_ptr = planes.data_ptr()
         sp = timing.span('conv_igemm', cs.flops, cs.abytes)
-        _C.call('evk_conv2d_fwd_x3', ctypes.byref(d), x_ptr, planes.data_ptr(), _ptr(bias), y.data_ptr(),
+        _C.call('evk_conv2d_fwd_x3', ctypes.byref(d), x_ptr, pl_ptr, _ptr(bias), y.data_ptr(),
                 1 if relu else 0, st)
     else:
         sp = timing.span('conv_igemm_f32', cs.flops, cs.abytes)
@@ -201,7 +205,7 @@ def _conv_forward(x, weight, bias, stride, padding, dilation, relu):
     cs.desc, cs.relu, cs.cin, cs.has_bias = d, relu, cin, bias is not None
     cs.w_stride = tuple(weight.stride())
     # xk (channel-padded copy when Cin % 4 != 0) is what wgrad reads
-    cs.xk, cs.w_ohwi, cs.y = xk, w_ohwi, (y if relu else None)
+    cs.xk, cs.w_ohwi, cs.y, cs.weight = xk, w_ohwi, (y if relu else None), weight
     return y, cs
 
 
@@ -233,16 +237,18 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None):
     taps = kh * kw
     x3 = _CONV_MATH == 'bf16x3'
     if need_dx and x3 and cin_p == cin and cout_p == cout and cout % 8 == 0:
-        lib = _C.load()
-        planes = workspace(dev, lib.evk_conv2d_split_weight_bytes(ctypes.byref(dk), 1))
-        _C.call('evk_conv2d_split_weight', ctypes.byref(dk), w_ohwi.data_ptr(), 1, planes.data_ptr(), st)
+        pl_ptr = weight_planes.planes_for(cs.weight, w_ohwi, dk, 1, st)
+        if pl_ptr is None:
+            planes = workspace(dev, _C.load().evk_conv2d_split_weight_bytes(ctypes.byref(dk), 1))
+            _C.call('evk_conv2d_split_weight', ctypes.byref(dk), w_ohwi.data_ptr(), 1, planes.data_ptr(), st)
+            pl_ptr = planes.data_ptr()
         acc_ptr = None
         if accum is not None:
             accum = as_nhwc(accum, 'conv2d.backward.accum')
             acc_ptr = accum.data_ptr()
         dx = empty_nhwc(n, cin, d.H, d.W, dev)
         sp = timing.span('conv_igemm', cs.flops, cs.abytes)
-        _C.call('evk_conv2d_dgrad_x3', ctypes.byref(dk), dy_ptr, planes.data_ptr(), acc_ptr, dx.data_ptr(), st)
+        _C.call('evk_conv2d_dgrad_x3', ctypes.byref(dk), dy_ptr, pl_ptr, acc_ptr, dx.data_ptr(), st)
         if sp is not None:
             sp.stop()
     elif need_dx:

@@ -8,6 +8,7 @@ from torch.optim.adamw import AdamW
 from torch.optim.sgd import SGD
 
 from .. import _C
+from ..hip import weight_planes
 from ..core import registry
 
 __all__ = ['FusedSGD']
@@ -72,6 +73,8 @@ class FusedSGD(SGD):
                 sizes.data_ptr(), len(params), float(group['lr']), float(mom), float(group['dampening']),
                 float(group['weight_decay']), 1 if group['nesterov'] else 0, 1 if first else 0,
                 None if self._clip is None else self._clip.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        # the kernel wrote the parameters through raw pointers: autograd's version counters did not move
+        weight_planes.note_weights_changed()
 
     @torch.no_grad()
     def step(self, closure=None):

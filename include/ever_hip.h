@@ -83,6 +83,25 @@ int evk_conv2d_pack_dgrad_weight(const evk_conv_desc* d, const float* w, float* 
 size_t evk_conv2d_split_weight_bytes(const evk_conv_desc* d, int32_t for_dgrad);
 int evk_conv2d_split_weight(const evk_conv_desc* d, const float* w, int32_t for_dgrad, void* wsplit,
                             void* stream);
+/* All weights of a model in ONE launch (the planes change once per optimiser step; one launch per convolution
+ * and direction was 164 launches per FarSeg-R50 step).  evk_conv2d_split_jobs fills (on the HOST) the 1..stride^2
+ * jobs that evk_conv2d_split_weight(d, w, for_dgrad, wsplit) would launch — same layouts, chosen from the
+ * descriptor — and returns their number (negative = error).  The caller sets job.arg[12] = workgroups it gives
+ * the job (about evk_split_job_pairs(job) / 2048, at least 1), builds block_map[nblocks][2] = (job index, block
+ * index inside the job), copies both tables to the device once, and calls evk_conv2d_split_multi after every
+ * weight update.  Replaces nothing in the reference (operand preparation of the split arithmetic). */
+typedef struct evk_split_job {
+  const float* w;   /* OHWI parameter */
+  void* out;        /* start of this job's planes inside the convolution's wsplit buffer */
+  int32_t kind;     /* 0 forward, 1 data gradient (one residue class), 2 LDS-halo 3x3 */
+  int32_t arg[13];  /* layout parameters (opaque); arg[12] = workgroups assigned by the caller */
+} evk_split_job;
+int32_t evk_conv2d_split_job_count(const evk_conv_desc* d, int32_t for_dgrad);
+int evk_conv2d_split_jobs(const evk_conv_desc* d, const float* w, int32_t for_dgrad, void* wsplit,
+                          evk_split_job* jobs /* host */, int32_t max_jobs);
+int64_t evk_split_job_pairs(const evk_split_job* job /* host */);
+int evk_conv2d_split_multi(const evk_split_job* jobs_dev, const int32_t* block_map_dev, int32_t nblocks,
+                           void* stream);
 int evk_conv2d_fwd_x3(const evk_conv_desc* d, const float* x, const void* wsplit, const float* bias,
                       float* y, uint32_t flags, void* stream);
 /* y = act(conv(x, w) + bias + residual): inference form of a residual block's last convolution with its
