@@ -314,6 +314,118 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
   }
 }
 
+// Wide-channel forms (C >= 128): ONE WAVE PER PIXEL, lanes across the 16-byte channel chunks, so that the pixel's
+// index arithmetic is wave-uniform.  The element-per-thread kernels above spend ~100 (forward) to ~1000 (backward)
+// VALU instructions per 16 bytes on it and are VALU-bound on the 256-channel decoder maps (2.9 TB/s).  Uniform
+// arithmetic lands on the scalar unit, ONE per CU: three integer divisions per pixel there were just as slow
+// (124 us for 335 MB), hence the multiply-shift divisions and, in the backward, the candidate weights computed
+// across lanes (one VALU pass for all 12 candidates of an axis) and fetched by v_readlane.
+// Forward: a workgroup owns kTileR x kTileC output pixels, stages the input patch they read in LDS (one global load
+// per input pixel and workgroup) and interpolates out of LDS.  Four global loads per output pixel — even wave-uniform
+// and L2-resident — made the kernel L2->L1 bound: 90 us for the 64^2 -> 128^2 x 256 maps against 38 us for its
+// 268 MB of stores alone (tools/probes/upsample_probe.hip).
+constexpr int kTileR = 4, kTileC = 16;
+__global__ __launch_bounds__(256) void bilinear_fwd_tile_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                int Hi, int Wi, int Ho, int Wo, int C, float sy,
+                                                                float sx, int patch_cols) {
+  extern __shared__ __attribute__((aligned(16))) float patch[];  // [rows][patch_cols][C]
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int n = blockIdx.z, oy0 = blockIdx.y * kTileR, ox0 = blockIdx.x * kTileC;
+  const int oy_last = min(oy0 + kTileR, Ho) - 1, ox_last = min(ox0 + kTileC, Wo) - 1;
+  int ylo, yhi, xlo, xhi, t0;
+  float f0, f1;
+  bl_coord(oy0, sy, Hi, ylo, t0, f0, f1);
+  bl_coord(oy_last, sy, Hi, t0, yhi, f0, f1);
+  bl_coord(ox0, sx, Wi, xlo, t0, f0, f1);
+  bl_coord(ox_last, sx, Wi, t0, xhi, f0, f1);
+  const int pr = yhi - ylo + 1, pc = xhi - xlo + 1;  // pc <= patch_cols by the host's bound
+  const float* b = x + (size_t)n * Hi * Wi * C;
+  for (int q = wave; q < pr * pc; q += 4) {
+    const int r = q / pc, c = q - r * pc;
+    const float* src = b + ((size_t)(ylo + r) * Wi + (xlo + c)) * C;
+    float* dst = patch + (size_t)(r * patch_cols + c) * C;
+    for (int k = lane * 4; k < C; k += 256) *reinterpret_cast<f32x4*>(dst + k) = *reinterpret_cast<const f32x4*>(src + k);
+  }
+  __syncthreads();
+  // wave w: output row oy0 + w (kTileR == 4 waves), all kTileC columns
+  const int oy = oy0 + wave;
+  if (oy > oy_last) return;
+  int y0, y1;
+  float hy0, hy1;
+  bl_coord(oy, sy, Hi, y0, y1, hy0, hy1);
+  const float* r0 = patch + (size_t)(y0 - ylo) * patch_cols * C;
+  const float* r1 = patch + (size_t)(y1 - ylo) * patch_cols * C;
+  float* o = y + (((size_t)n * Ho + oy) * Wo + ox0) * C;
+  for (int j = 0; j <= ox_last - ox0; ++j) {
+    int x0, x1;
+    float wx0, wx1;
+    bl_coord(ox0 + j, sx, Wi, x0, x1, wx0, wx1);
+    const int c0 = (x0 - xlo) * C, c1 = (x1 - xlo) * C;
+    for (int k = lane * 4; k < C; k += 256) {
+      const f32x4 v00 = *reinterpret_cast<const f32x4*>(r0 + c0 + k), v01 = *reinterpret_cast<const f32x4*>(r0 + c1 + k);
+      const f32x4 v10 = *reinterpret_cast<const f32x4*>(r1 + c0 + k), v11 = *reinterpret_cast<const f32x4*>(r1 + c1 + k);
+      *reinterpret_cast<f32x4*>(o + (size_t)j * C + k) = hy0 * (wx0 * v00 + wx1 * v01) + hy1 * (wx0 * v10 + wx1 * v11);
+    }
+  }
+}
+
+// weight with which output coordinate o (one axis) reads input coordinate i; 0 when it does not, or o is out of range
+__device__ __forceinline__ float bl_adjoint_weight(int o, int o_hi, float scale, int in, int i) {
+  int i0, i1;
+  float l0, l1;
+  bl_coord(o, scale, in, i0, i1, l0, l1);
+  float w = 0.f;
+  if (i0 == i) w += l0;
+  if (i1 == i) w += l1;
+  return o <= o_hi ? w : 0.f;
+}
+
+__global__ __launch_bounds__(256) void bilinear_bwd_wave_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                                int npix, FastDiv fdWi, FastDiv fdHi, int Ho, int Wo,
+                                                                int C, float sy, float sx, float isy, float isx) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int pix = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;   // see bilinear_fwd_wave_kernel
+  if (pix >= npix) return;
+  const int Hi = (int)fdHi.div, Wi = (int)fdWi.div;
+  const uint32_t t = fdiv((uint32_t)pix, fdWi), ix = (uint32_t)pix - t * fdWi.div;
+  const uint32_t n = fdiv(t, fdHi), iy = t - n * fdHi.div;
+  int oy_lo = (int)floorf((float)((int)iy - 1) * isy) - 1, oy_hi = (int)ceilf((float)((int)iy + 1) * isy) + 1;
+  int ox_lo = (int)floorf((float)((int)ix - 1) * isx) - 1, ox_hi = (int)ceilf((float)((int)ix + 1) * isx) + 1;
+  oy_lo = max(oy_lo, 0); oy_hi = min(oy_hi, Ho - 1);
+  ox_lo = max(ox_lo, 0); ox_hi = min(ox_hi, Wo - 1);
+  // lane j (mod 16) holds the weight of candidate lo + j on each axis; the candidate range of this kernel's callers
+  // (scale >= 2 up-sampling) is at most 12 wide, wider ranges take the element-per-thread kernel
+  const int j = lane & 15;
+  const float wyv = bl_adjoint_weight(oy_lo + j, oy_hi, sy, Hi, (int)iy);
+  const float wxv = bl_adjoint_weight(ox_lo + j, ox_hi, sx, Wi, (int)ix);
+  uint32_t my = (uint32_t)(__ballot(wyv != 0.f) & 0xffffull);
+  const uint32_t mx = (uint32_t)(__ballot(wxv != 0.f) & 0xffffull);
+  const float* b = dy + (size_t)n * Ho * Wo * C;
+  float* o = dx + (size_t)pix * C;
+  f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  // same candidate order (oy ascending, then ox ascending) and weight arithmetic as bilinear_bwd_kernel
+  while (my) {
+    const int jy = __builtin_ctz(my);
+    my &= my - 1;
+    const float wy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wyv), jy));
+    const float* row = b + (size_t)(oy_lo + jy) * Wo * C;
+    uint32_t m = mx;
+    while (m) {
+      const int jx = __builtin_ctz(m);
+      m &= m - 1;
+      const float wx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wxv), jx));
+      const float w = wy * wx;
+      const float* src = row + (size_t)(ox_lo + jx) * C + lane * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (lane * 4 + 256 * k < C) acc[k] += w * *reinterpret_cast<const f32x4*>(src + 256 * k);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (lane * 4 + 256 * k < C) *reinterpret_cast<f32x4*>(o + lane * 4 + 256 * k) = acc[k];
+}
+
 // ------------------------------------------------------------------------------------------------
 // Global average pool: x [N][HW][C] -> y [N][C].  grid (ceil(c4/tpc), N)
 __global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int HW, int C,
@@ -547,7 +659,20 @@ extern "C" int evk_upsample_bilinear_fwd(const float* x, float* y, int32_t N, in
   EVK_REQUIRE(x && y && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, EVK_E_INVALID,
               "bilinear_fwd: bad argument");
   const float sy = ac_scale(Hi, Ho), sx = ac_scale(Wi, Wo);
-  if (C % 4 == 0)
+  // patch of one kTileR x kTileC output tile: rows/cols <= floor((tile - 1) * scale) + 3 (first i0 .. last i1)
+  const int prow = (int)((kTileR - 1) * sy) + 3, pcol = (int)((kTileC - 1) * sx) + 3;
+  const size_t patch_bytes = (size_t)prow * pcol * C * sizeof(float);
+  if (C % 4 == 0 && C >= 128 && patch_bytes <= 64 * 1024 && N <= 65535 && (Ho + kTileR - 1) / kTileR <= 65535) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bilinear_fwd_tile_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(bilinear_fwd_tile_kernel, dim3((Wo + kTileC - 1) / kTileC, (Ho + kTileR - 1) / kTileR, N),
+                       dim3(256), patch_bytes, (hipStream_t)stream, x, y, Hi, Wi, Ho, Wo, C, sy, sx, pcol);
+  }
+  else if (C % 4 == 0)
     hipLaunchKernelGGL(bilinear_fwd_kernel<4>, dim3(grid_for((size_t)N * Ho * Wo * (C / 4))), dim3(256), 0,
                        (hipStream_t)stream, x, y, N, Hi, Wi, Ho, Wo, C, sy, sx);
   else
@@ -562,7 +687,14 @@ extern "C" int evk_upsample_bilinear_bwd(const float* dy, float* dx, int32_t N, 
   const float sy = ac_scale(Hi, Ho), sx = ac_scale(Wi, Wo);
   // inverse scales for the candidate range; in == 1 => every output maps to input 0
   const float isy = sy > 0.f ? 1.f / sy : (float)Ho, isx = sx > 0.f ? 1.f / sx : (float)Wo;
-  if (C % 4 == 0)
+  const long long npix_i = (long long)N * Hi * Wi;
+  // candidate range per axis: ceil((i+1)/s)+1 - (floor((i-1)/s)-1) + 1 <= 2/s + 5; the wave kernel holds 16 per axis
+  const bool narrow = 2.f * isy + 5.f <= 16.f && 2.f * isx + 5.f <= 16.f && Hi > 1 && Wi > 1;
+  if (C % 4 == 0 && C >= 128 && C <= 1024 && narrow && npix_i < 0x7fffffffLL)
+    hipLaunchKernelGGL(bilinear_bwd_wave_kernel, dim3((unsigned)((npix_i + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       dy, dx, (int)npix_i, make_fastdiv((uint32_t)Wi), make_fastdiv((uint32_t)Hi), Ho, Wo, C, sy, sx,
+                       isy, isx);
+  else if (C % 4 == 0)
     hipLaunchKernelGGL(bilinear_bwd_kernel<4>, dim3(grid_for((size_t)N * Hi * Wi * (C / 4))), dim3(256), 0,
                        (hipStream_t)stream, dy, dx, N, Hi, Wi, Ho, Wo, C, sy, sx, isy, isx);
   else

@@ -196,7 +196,8 @@ def test_nearest2x_add(cuda):
     assert torch.equal(lg.grad.cpu().contiguous(), lr.grad)
 
 
-@pytest.mark.parametrize('c,h,w,s', [(256, 8, 8, 2), (1, 16, 16, 4), (16, 8, 12, 4), (128, 1, 1, 2), (64, 5, 3, 2)])
+@pytest.mark.parametrize('c,h,w,s', [(256, 8, 8, 2), (1, 16, 16, 4), (16, 8, 12, 4), (128, 1, 1, 2), (64, 5, 3, 2),
+                                     (512, 7, 9, 4), (132, 6, 5, 8), (320, 3, 1, 2)])
 def test_bilinear_align_corners(cuda, c, h, w, s):
     from ever_amd.hip import functional as F
     g = torch.Generator().manual_seed(5 + c)
