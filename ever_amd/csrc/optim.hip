@@ -5,7 +5,9 @@
 
 namespace evk {
 
-constexpr int kOptBlocksPerTensor = 32;
+// workgroups per tensor: the 20 largest of FarSeg-R50's 238 parameter tensors hold most of the bytes, and 32
+// workgroups each left the chip under-filled (sgd_multi at 1.9 TB/s); small tensors' surplus workgroups exit at once
+constexpr int kOptBlocksPerTensor = 128;
 
 __global__ __launch_bounds__(256) void sqnorm_multi_kernel(const float* const* __restrict__ grads,
                                                            const int64_t* __restrict__ sizes,
@@ -53,16 +55,39 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(float* const* __restrict
   float* b = bufs ? bufs[t] : nullptr;
   const int64_t n = sizes[t];
   const float cc = clip_coef ? *clip_coef : 1.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    float d = g[i] * cc;
-    const float w = p[i];
-    if (wd != 0.f) d += wd * w;
+  // explicit fused multiply-adds: the 16-byte and the scalar loop must round identically (a DDP replica whose
+  // gradients are bucket views takes the scalar loop where an unwrapped model takes the vector one)
+  auto upd = [&](float gi, float w, float& m) {
+    float d = gi * cc;
+    if (wd != 0.f) d = __fmaf_rn(wd, w, d);
     if (momentum != 0.f) {
-      float m = first_step ? d : momentum * b[i] + (1.f - dampening) * d;
-      b[i] = m;
-      d = nesterov ? d + momentum * m : m;
+      m = first_step ? d : __fmaf_rn(momentum, m, (1.f - dampening) * d);
+      d = nesterov ? __fmaf_rn(momentum, m, d) : m;
     }
-    p[i] = w - lr * d;
+    return __fmaf_rn(-lr, d, w);
+  };
+  // 16-byte main part when the three tensors allow it (gradients may be views into a DDP bucket at any 4-byte offset)
+  const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)b) & 15) == 0;
+  const int64_t n4 = vec ? n >> 2 : 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 w = reinterpret_cast<f32x4*>(p)[i];
+    f32x4 m = {0.f, 0.f, 0.f, 0.f};
+    if (momentum != 0.f && !first_step) m = reinterpret_cast<f32x4*>(b)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float me = m[e];
+      w[e] = upd(gv[e], w[e], me);
+      m[e] = me;
+    }
+    if (momentum != 0.f) reinterpret_cast<f32x4*>(b)[i] = m;
+    reinterpret_cast<f32x4*>(p)[i] = w;
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float m = (momentum != 0.f && !first_step) ? b[i] : 0.f;
+    const float w = upd(g[i], p[i], m);
+    if (momentum != 0.f) b[i] = m;
+    p[i] = w;
   }
 }
 

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 def test_fused_sgd_matches_torch_sgd(cuda):
     import ever_amd as er
     torch.manual_seed(0)
-    shapes = [(64, 4, 7, 7), (64,), (256, 64, 1, 1), (128, 128, 3, 3), (1, 256, 1, 1), (1,)]
+    shapes = [(64, 4, 7, 7), (64,), (256, 64, 1, 1), (128, 128, 3, 3), (1, 256, 1, 1), (1,), (7, 3), (1031,)]
     ps_a = [torch.randn(s, device=cuda).requires_grad_() for s in shapes]
     ps_a = [p.detach().contiguous(memory_format=torch.channels_last).requires_grad_() if p.dim() == 4 else p for p in ps_a]
     ps_b = [p.detach().clone().requires_grad_() for p in ps_a]
@@ -21,9 +21,14 @@ def test_fused_sgd_matches_torch_sgd(cuda):
     oa.er_config = dict(grad_clip=dict(max_norm=0.5, norm_type=2))
     for step in range(3):
         gs = [torch.randn_like(p) for p in ps_a]
-        for p, q, g in zip(ps_a, ps_b, gs):
+        for k, (p, q, g) in enumerate(zip(ps_a, ps_b, gs)):
             p.grad = g.clone()
             q.grad = g.clone()
+            if k == 7:   # a gradient at a 4-byte (not 16-byte) aligned address, as a view into a DDP bucket can be
+                flat = torch.zeros(g.numel() + 1, device=cuda)
+                flat[1:].copy_(g.reshape(-1))
+                p.grad = flat[1:].view_as(g)
+                assert p.grad.data_ptr() % 16 != 0
         oa.fused_clip(max_norm=0.5)
         ref_norm = torch.nn.utils.clip_grad_norm_(ps_b, max_norm=0.5)
         assert abs(oa.last_grad_norm.item() - ref_norm.item()) <= 1e-5 * ref_norm.item()
