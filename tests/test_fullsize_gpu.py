@@ -109,3 +109,46 @@ def test_training_step_at_full_size_is_finite_and_stem_statistics_match_fp64(cud
     rv = sd['en.resnet.bn1.running_var'].double()
     assert float((rm - 0.1 * mean).abs().max()) <= 1e-5 * float(mean.abs().max() + 1e-3)
     assert float((rv - (0.9 + 0.1 * var)).abs().max()) <= 1e-5 * float(var.abs().max() + 1.0)
+
+
+def test_config_c3_size_training_step_and_backward_linearity(cuda):
+    """SURVEY §8 configuration C3's size on one GPU: 4-band 1024x1024 tiles, batch 8 (maps of 256^2 .. 32^2: twice the
+    GEMM rows of the bench workload, the 4-band stem through the channel-padded fp32 path).  A training step is
+    finite, the stem statistics match fp64, and with frozen statistics the backward is linear in the batch."""
+    import ever_amd as er
+    torch.manual_seed(7)
+    m = er.module.FarSeg(dict(encoder=dict(in_channels=4))).to(cuda).train()
+    g = torch.Generator(device='cpu').manual_seed(123)
+    x = torch.randn(8, 4, 1024, 1024, generator=g).to(cuda)
+    y = (torch.rand(8, 1024, 1024, generator=g) < 0.3).long()
+    y[:, :8, :8] = 255
+    y = y.to(cuda)
+    losses = m(x, y)
+    sum(losses.values()).backward()
+    assert all(torch.isfinite(v) for v in losses.values())
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+    with torch.no_grad():
+        from ever_amd.hip import functional as HF
+        z = m.en.resnet.conv1(HF.as_nhwc(x)).double()
+        mean, var = z.mean((0, 2, 3)), z.var((0, 2, 3), unbiased=True)
+        del z
+    sd = m.state_dict()
+    assert float((sd['en.resnet.bn1.running_mean'].double() - 0.1 * mean).abs().max()) <= 1e-5 * float(mean.abs().max() + 1e-3)
+    assert float((sd['en.resnet.bn1.running_var'].double() - (0.9 + 0.1 * var)).abs().max()) <= 1e-5 * float(var.abs().max() + 1.0)
+    # frozen statistics (eval-mode BatchNorm, gradients still flow): grad(batch) = mean of the halves' gradients
+    m.zero_grad(set_to_none=True)
+    m.eval()
+    from ever_amd.module import loss as L
+
+    def grads(xs, ys):
+        m.zero_grad(set_to_none=True)
+        lg = m.head(m.en(xs))
+        L.binary_cross_entropy_with_logits(lg, ys).backward()
+        return [p.grad.double().clone() for p in m.parameters()]
+    full = grads(x, y)
+    ga, gb = grads(x[:4], y[:4]), grads(x[4:], y[4:])
+    num = sum(float(((a + b) / 2 - f).square().sum()) for a, b, f in zip(ga, gb, full))
+    den = sum(float(f.square().sum()) for f in full)
+    rel = (num / den) ** 0.5
+    print(f'C3-size backward linearity: global relative L2 {rel:.2e}')
+    assert rel < 5e-2, rel
