@@ -28,11 +28,16 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws_kernel(const IGemmArgs p)
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
 
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = bid % p.tiles_n;
-  const int tile_m = bid / p.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  // PERSISTENT: workgroup b walks tiles b, b + gridDim.x, ... and treats their K loops as ONE sequence of steps
+  // g = 0 .. G-1 (G = my tiles x nk).  The LDS ring, the register sets and the one-barrier-per-step protocol run on
+  // across tile boundaries, so while the matrix waves store tile t's accumulators the staging waves are already two
+  // steps into tile t+1 — and the two roles' memory instructions are counted by different waves' vmcnt, so the
+  // stores' drain never sits in front of a wait for new loads (which is what made persistent tiles useless in the
+  // single-role kernel).  With gridDim.x == tiles it is the one-tile-per-workgroup kernel it used to be.
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int nk = p.Kpad / BK3;
+  const int G = my_tiles * nk;
   const int tid = threadIdx.x;
 
   if (tid >= 256) {
@@ -42,40 +47,46 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws_kernel(const IGemmArgs p)
     const int rb = ptid >> 2;  // base row 0..63
 
     int a_y0[AR], a_x0[AR], a_base[AR];
-#pragma unroll
-    for (int j = 0; j < AR; ++j) {
-      const int m = m0 + rb + 64 * j;
-      if (m < p.M) {
-        const int hw = p.Hm * p.Wm;
-        const int n = m / hw;
-        const int rem = m - n * hw;
-        const int gy = rem / p.Wm;
-        const int gx = rem - gy * p.Wm;
-        a_y0[j] = gy * p.ash + p.oy0;
-        a_x0[j] = gx * p.asw + p.ox0;
-        a_base[j] = ((n * p.Hs + a_y0[j]) * p.Ws + a_x0[j]) * p.Cs;
-      } else {
-        a_y0[j] = -(1 << 28);
-        a_x0[j] = 0;
-        a_base[j] = 0;
-      }
-    }
     int b_off[BR];
-#pragma unroll
-    for (int j = 0; j < BR; ++j) {
-      int co = n0 + rb + 64 * j;
-      co = co < p.Cd ? co : p.Cd - 1;
-      b_off[j] = co * p.Kpad + c4 * 8;
-    }
     const int plane = p.Cd * p.Kpad;
     const int cp8 = p.Cs >> 3;
-    int cc, kx, ky;
-    {
+    int cc = 0, kx = 0, ky = 0;
+    int lt_tile = 0, lt_kt = 0;  // load cursor: (index among my tiles, K step) of the next load_tiles call
+
+    auto begin_tile = [&](int i) {
+      const int bid = xcd_remap((int)blockIdx.x + i * (int)gridDim.x, ntiles);
+      const int tile_n = bid % p.tiles_n;
+      const int tile_m = bid / p.tiles_n;
+      const int m0 = tile_m * BM, n0 = tile_n * BN;
+#pragma unroll
+      for (int j = 0; j < AR; ++j) {
+        const int m = m0 + rb + 64 * j;
+        if (m < p.M) {
+          const int hw = p.Hm * p.Wm;
+          const int n = m / hw;
+          const int rem = m - n * hw;
+          const int gy = rem / p.Wm;
+          const int gx = rem - gy * p.Wm;
+          a_y0[j] = gy * p.ash + p.oy0;
+          a_x0[j] = gx * p.asw + p.ox0;
+          a_base[j] = ((n * p.Hs + a_y0[j]) * p.Ws + a_x0[j]) * p.Cs;
+        } else {
+          a_y0[j] = -(1 << 28);
+          a_x0[j] = 0;
+          a_base[j] = 0;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < BR; ++j) {
+        int co = n0 + rb + 64 * j;
+        co = co < p.Cd ? co : p.Cd - 1;
+        b_off[j] = co * p.Kpad + c4 * 8;
+      }
       const int tap = c4 / cp8;
       cc = c4 - tap * cp8;
       ky = tap / p.kw;
       kx = tap - ky * p.kw;
-    }
+    };
 
     // two register sets: the loads of step t+2 are issued before step t+1's registers are consumed, so a
     // global / L2 round trip has two full steps (~1.5 us) to land (with one set the staging waves sat
@@ -85,8 +96,10 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws_kernel(const IGemmArgs p)
     u32x4 rbv[2][BR][3];
     uint32_t okmask[2] = {0, 0};
 
-    auto load_tiles = [&](auto SET, int kt) {
+    auto load_tiles = [&](auto SET) {
       constexpr int s = decltype(SET)::value;
+      if (lt_kt == 0) begin_tile(lt_tile);
+      const int kt = lt_kt;
       okmask[s] = 0;
       const bool kvalid = ky < p.kh;
       const int oy = ky * p.oys, ox = kx * p.oxs;
@@ -119,6 +132,10 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws_kernel(const IGemmArgs p)
         cc = q - tap * cp8;
         ky = tap / p.kw;
         kx = tap - ky * p.kw;
+      }
+      if (++lt_kt == nk) {
+        lt_kt = 0;
+        ++lt_tile;
       }
     };
 
@@ -155,24 +172,24 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws_kernel(const IGemmArgs p)
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     static_assert(NSTAGE == 2, "staging schedule below is written for a two-stage ring");
-    // step t lives in register set t & 1.  Prologue: step 0 -> stage 0, steps 1 and 2 in flight.
-    load_tiles(S0{}, 0);
-    if (1 < nk) load_tiles(S1{}, 1);
+    // step g lives in register set g & 1 and LDS stage g & 1.  Prologue: step 0 -> stage 0, steps 1 and 2 in flight.
+    load_tiles(S0{});
+    if (1 < G) load_tiles(S1{});
     store_tiles(S0{}, 0);
-    if (2 < nk) load_tiles(S0{}, 2);
+    if (2 < G) load_tiles(S0{});
     __syncthreads();
-    // iteration kt: the matrix waves read stage kt & 1; step kt+1 goes to the other stage and its
-    // register set is refilled with step kt+3
-    for (int kt = 0; kt < nk; kt += 2) {
-      if (kt + 1 < nk) {
+    // iteration g: the matrix waves read stage g & 1; step g+1 goes to the other stage and its
+    // register set is refilled with step g+3
+    for (int g = 0; g < G; g += 2) {
+      if (g + 1 < G) {
         store_tiles(S1{}, 1);
-        if (kt + 3 < nk) load_tiles(S1{}, kt + 3);
+        if (g + 3 < G) load_tiles(S1{});
       }
       __syncthreads();
-      if (kt + 1 < nk) {
-        if (kt + 2 < nk) {
+      if (g + 1 < G) {
+        if (g + 2 < G) {
           store_tiles(S0{}, 0);
-          if (kt + 4 < nk) load_tiles(S0{}, kt + 4);
+          if (g + 4 < G) load_tiles(S0{});
         }
         __syncthreads();
       }
@@ -189,12 +206,6 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws_kernel(const IGemmArgs p)
   const int li = lane & 31, lh = lane >> 5;
 
   f32x16 acc[MB][NB];
-#pragma unroll
-  for (int a = 0; a < MB; ++a)
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   int fa_off[MB][2], fb_off[NB][2];
 #pragma unroll
@@ -231,16 +242,32 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws_kernel(const IGemmArgs p)
   };
 
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const unsigned char* S = smem3 + (kt & 1) * kStage;
-    read_frags(S, 0, 0);
-    read_frags(S, 1, 1);
-    mfmas(0);
-    mfmas(1);
-    __syncthreads();
+  int g = 0;
+  for (int i = 0; i < my_tiles; ++i) {
+#pragma unroll
+    for (int a = 0; a < MB; ++a)
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    for (int kt = 0; kt < nk; ++kt, ++g) {
+      const unsigned char* S = smem3 + (g & 1) * kStage;
+      read_frags(S, 0, 0);
+      read_frags(S, 1, 1);
+      mfmas(0);
+      mfmas(1);
+      __syncthreads();
+    }
+    const int bid = xcd_remap((int)blockIdx.x + i * (int)gridDim.x, ntiles);
+    igemm_epilogue<MB, NB, WM, WN>(p, acc, (bid / p.tiles_n) * BM, (bid % p.tiles_n) * BN, wm, wn, li, lh);
   }
+}
 
-  igemm_epilogue<MB, NB, WM, WN>(p, acc, m0, n0, wm, wn, li, lh);
+// EVK_X3_WS_PERSIST: 1 (default) persistent workgroups, and the wave-specialised form also for short reductions;
+// 0 = one tile per workgroup, short reductions on the single-role kernel
+static int ws_persist() {
+  static const int v = getenv("EVK_X3_WS_PERSIST") ? atoi(getenv("EVK_X3_WS_PERSIST")) : 1;
+  return v;
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE>
@@ -259,8 +286,10 @@ static int launch_ws(IGemmArgs& a, hipStream_t stream) {
     set_error("conv_igemm_x3ws: bad grid %lld", nwg);
     return EVK_E_INVALID;
   }
-  hipLaunchKernelGGL((conv_igemm_x3ws_kernel<BM, BN, WAVES_M, WAVES_N, NSTAGE>), dim3((unsigned)nwg), dim3(512), lds,
-                     stream, a);
+  // one workgroup per CU (LDS), each walking ceil(tiles / 256) tiles; 256 is a multiple of 8, so a workgroup's
+  // tiles stay on its XCD under the remap
+  const unsigned grid = (ws_persist() && nwg > 256) ? 256u : (unsigned)nwg;
+  hipLaunchKernelGGL((conv_igemm_x3ws_kernel<BM, BN, WAVES_M, WAVES_N, NSTAGE>), dim3(grid), dim3(512), lds, stream, a);
   return check_launch("conv_igemm_x3ws");
 }
 
@@ -276,7 +305,9 @@ int launch_igemm_x3ws(IGemmArgs& a, hipStream_t stream) {
   // One 8-wave workgroup per CU: nothing overlaps a tile's prologue / epilogue, so short reductions
   // (1x1 convolutions, K <= 512: 2..16 steps) run better as 2-3 single-role workgroups per CU, unless the
   // grid is below two per CU anyway.  Measured on the FarSeg-R50 layer set (tools/bench_conv_x3.py).
-  if (mode == 1 && a.Kpad < 1024 && t128 >= 512) return 1;
+  // Persistent workgroups recover part of that (64->256 @128^2: 121 -> 111 us, 256->256: 267 -> 251, 512->256 @64^2:
+  // 106 -> 99; tools/ab_conv1x1.py) except for 64-wide outputs (256->64 @128^2: 80 -> 95 us).
+  if (mode == 1 && a.Kpad < 1024 && t128 >= 512 && (!ws_persist() || a.Cd < 128)) return 1;
   // 128x256 tiles where the output is wide enough: the activation split (VALU) and the L2 -> CU bytes per MFMA
   // drop by half / a fifth
   static const int wide = getenv("EVK_X3_WIDE") ? atoi(getenv("EVK_X3_WIDE")) : 1;
