@@ -48,7 +48,14 @@ def get_conv_math():
     return _CONV_MATH
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream():
+    """Raw handle of the current HIP stream of the current device.  ~250 calls per training step: the raw getter skips
+    the Stream-object construction of torch.cuda.current_stream() (2 ms of host time per step)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -8,9 +8,12 @@ import torch
 _buffers = {}
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def workspace(device, nbytes):
-    key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream(device).cuda_stream)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream)
     buf = _buffers.get(key)
     if buf is None or buf.numel() < nbytes:
         # round up so that a sequence of slightly growing requests does not reallocate each time
