@@ -307,7 +307,9 @@ int launch_igemm_x3ws(IGemmArgs& a, hipStream_t stream) {
   // grid is below two per CU anyway.  Measured on the FarSeg-R50 layer set (tools/bench_conv_x3.py).
   // Persistent workgroups recover part of that (64->256 @128^2: 121 -> 111 us, 256->256: 267 -> 251, 512->256 @64^2:
   // 106 -> 99; tools/ab_conv1x1.py) except for 64-wide outputs (256->64 @128^2: 80 -> 95 us).
-  if (mode == 1 && a.Kpad < 1024 && t128 >= 512 && (!ws_persist() || a.Cd < 128)) return 1;
+  // An accumulate / residual epilogue (one more load per store, in the matrix waves) turns the gain into a loss:
+  // folded-BatchNorm inference 1370 -> 1325 tiles/s.
+  if (mode == 1 && a.Kpad < 1024 && t128 >= 512 && (!ws_persist() || a.Cd < 128 || a.accum)) return 1;
   // 128x256 tiles where the output is wide enough: the activation split (VALU) and the L2 -> CU bytes per MFMA
   // drop by half / a fifth
   static const int wide = getenv("EVK_X3_WIDE") ? atoi(getenv("EVK_X3_WIDE")) : 1;
