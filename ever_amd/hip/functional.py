@@ -344,20 +344,20 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False):
 
 
 class _ConvForkFn(Function):
-    """A residual block's fork: x feeds the main-branch conv AND the shortcut (identity, or the
-    down-sampling 1x1 conv; reference _resnets.py:52-69, 92-112, 188-192).  Seeing both consumers in
-    one autograd node lets the backward fold the sum of the two input gradients into the epilogue of
-    the last data-gradient kernel (dx = dgrad(dy_main) + d_shortcut) instead of a separate add pass
-    over the block input."""
+    """Two consumers of one tensor in ONE autograd node: x feeds conv_main AND a second branch — a residual block's
+    shortcut (identity, or the down-sampling 1x1 conv; reference _resnets.py:52-69, 92-112, 188-192) or a sibling
+    convolution (FS-Relation's content / re-encode pair on each pyramid level, fs_relation.py:41-52, 60-63).  Seeing
+    both consumers lets the backward fold the sum of the two input gradients into the epilogue of the last
+    data-gradient kernel (dx = dgrad(dy_main) + d_other) instead of a separate add pass over x."""
 
     @staticmethod
-    def forward(ctx, x, w_main, w_short, cfg_main, cfg_short):
-        y, cs = _conv_forward(x, w_main, None, *cfg_main, False)
+    def forward(ctx, x, w_main, w_short, b_main, b_short, cfg_main, cfg_short):
+        y, cs = _conv_forward(x, w_main, b_main, *cfg_main, False)
         ctx.cs_main = cs
         if w_short is None:
             ctx.cs_short = None
             return y, x.view_as(x)
-        ys, css = _conv_forward(x, w_short, None, *cfg_short, False)
+        ys, css = _conv_forward(x, w_short, b_short, *cfg_short, False)
         ctx.cs_short = css
         return y, ys
 
@@ -365,31 +365,35 @@ class _ConvForkFn(Function):
     @once_differentiable
     def backward(ctx, dy, dshort):
         need_dx = ctx.needs_input_grad[0]
-        dws = None
+        dws = dbs = None
         acc = None
         if ctx.cs_short is None:
             acc = dshort  # gradient of the identity shortcut
         elif dshort is not None:
-            acc, dws, _ = _conv_backward(ctx.cs_short, dshort, need_dx, ctx.needs_input_grad[2], False)
-        dx, dw, _ = _conv_backward(ctx.cs_main, dy, need_dx, ctx.needs_input_grad[1], False,
-                                   accum=acc if need_dx else None)
-        return dx, dw, dws, None, None
+            acc, dws, dbs = _conv_backward(ctx.cs_short, dshort, need_dx, ctx.needs_input_grad[2],
+                                           ctx.cs_short.has_bias and ctx.needs_input_grad[4])
+        if dy is None:   # only the second branch reached the loss
+            return acc, None, dws, None, dbs, None, None
+        dx, dw, db = _conv_backward(ctx.cs_main, dy, need_dx, ctx.needs_input_grad[1],
+                                    ctx.cs_main.has_bias and ctx.needs_input_grad[3],
+                                    accum=acc if need_dx else None)
+        return dx, dw, dws, db, dbs, None, None
 
 
 def conv2d_fork(x, conv_main, conv_short=None):
-    """(conv_main(x), conv_short(x) or x) with a fused input-gradient sum; both convs bias-free."""
+    """(conv_main(x), conv_short(x) or x) with a fused input-gradient sum."""
     _require_cuda(x, 'conv2d_fork')
     x = as_nhwc(x, 'conv2d_fork')
-    if conv_main.bias is not None or (conv_short is not None and conv_short.bias is not None) or x.shape[1] % 4:
+    if x.shape[1] % 4:
         y = conv2d(x, conv_main.weight, conv_main.bias, conv_main.stride, conv_main.padding, conv_main.dilation)
         s = x if conv_short is None else conv2d(x, conv_short.weight, conv_short.bias, conv_short.stride,
                                                 conv_short.padding, conv_short.dilation)
         return y, s
     cfg_m = (_pair(conv_main.stride), _pair(conv_main.padding), _pair(conv_main.dilation))
     if conv_short is None:
-        return _ConvForkFn.apply(x, conv_main.weight, None, cfg_m, None)
+        return _ConvForkFn.apply(x, conv_main.weight, None, conv_main.bias, None, cfg_m, None)
     cfg_s = (_pair(conv_short.stride), _pair(conv_short.padding), _pair(conv_short.dilation))
-    return _ConvForkFn.apply(x, conv_main.weight, conv_short.weight, cfg_m, cfg_s)
+    return _ConvForkFn.apply(x, conv_main.weight, conv_short.weight, conv_main.bias, conv_short.bias, cfg_m, cfg_s)
 
 
 # ------------------------------------------------------------------------------------ batch norm

@@ -23,6 +23,28 @@ def _conv_bn_relu(cin, cout):
     return HipSequential(Conv2d(cin, cout, 1), BatchNorm2d(cout), ReLU(True))
 
 
+def _content_and_reencoded(content_encoders, feature_reencoders, features):
+    """[content_i(f_i)], [reencode_i(f_i)].  Each pyramid level feeds both 1x1 convolutions: under autograd the pair
+    runs as one node whose backward sums the two input gradients in the second data-gradient's epilogue (no add
+    pass over the 256-channel maps); without autograd (or for foreign layer stacks) the Sequentials run as they are,
+    which keeps the folded-BatchNorm inference path."""
+    import torch
+    from .layers import run_sequence
+    contents, feats = [], []
+    for ce, fr, f in zip(content_encoders, feature_reencoders, features):
+        pairable = (torch.is_grad_enabled() and f.requires_grad and isinstance(ce, nn.Sequential)
+                    and isinstance(fr, nn.Sequential) and len(ce) > 0 and len(fr) > 0
+                    and isinstance(ce[0], Conv2d) and isinstance(fr[0], Conv2d))
+        if pairable:
+            yc, yf = HF.conv2d_fork(f, ce[0], fr[0])
+            contents.append(run_sequence(list(ce)[1:], yc))
+            feats.append(run_sequence(list(fr)[1:], yf))
+        else:
+            contents.append(ce(f))
+            feats.append(fr(f))
+    return contents, feats
+
+
 class FSRelation(nn.Module):
     def __init__(self, scene_embedding_channels, in_channels_list, out_channels, scale_aware_proj=False):
         super().__init__()
@@ -37,12 +59,11 @@ class FSRelation(nn.Module):
         self.normalizer = nn.Sigmoid()  # parameter-free; the sigmoid runs inside the relation kernel
 
     def forward(self, scene_feature, features):
-        contents = [enc(f) for enc, f in zip(self.content_encoders, features)]
+        contents, feats = _content_and_reencoded(self.content_encoders, self.feature_reencoders, features)
         if self.scale_aware_proj:
             scenes = [enc(scene_feature) for enc in self.scene_encoder]
         else:
             scenes = [self.scene_encoder(scene_feature)] * len(contents)
-        feats = [enc(f) for enc, f in zip(self.feature_reencoders, features)]
         return [HF.fs_relation(s, c, p) for s, c, p in zip(scenes, contents, feats)]
 
 
@@ -76,12 +97,11 @@ class FSRelationV2(nn.Module):
 
     def forward(self, scene_feature, features):
         from ..hip import functional_next as HN
-        contents = [enc(f) for enc, f in zip(self.content_encoders, features)]
+        contents, feats = _content_and_reencoded(self.content_encoders, self.feature_reencoders, features)
         if self.scale_aware_proj:
             scenes = [enc(scene_feature) for enc in self.scene_encoder]
         else:
             scenes = [self.scene_encoder(scene_feature)] * len(contents)
-        feats = [enc(f) for enc, f in zip(self.feature_reencoders, features)]
         refined = [HN.concat_channels(HF.fs_relation(s, c, p), o) for s, c, p, o in zip(scenes, contents, feats, features)]
         if self.scale_aware_proj:
             return [op(x) for op, x in zip(self.project, refined)]
