@@ -8,6 +8,8 @@ import ctypes as C
 import os
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libever_hip.so')
+# dev A/B runs on one box: EVK_LIB=<path of another build of the same ABI>
+_LIB_PATH = os.environ.get('EVK_LIB', _LIB_PATH)
 
 c_void_p, c_int, c_i32, c_i64, c_u32, c_f32, c_size_t = (
     C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_uint32, C.c_float, C.c_size_t)
