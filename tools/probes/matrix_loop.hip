@@ -1,0 +1,119 @@
+// dev probe: what the matrix-wave loop of the wave-specialised split-MFMA kernels costs, feature by feature.
+// One 8-wave workgroup per CU; waves 0-3 run the kernel's K-step (two k-halves x [fragment reads, 48 MFMAs]), waves
+// 4-7 stand in for the staging waves.  Prints the fp32-equivalent rate (bf16 TFLOP/s / 6) of a 128 x 256 tile loop.
+//   bit 0: s_barrier per step        bit 1: fragment reads (18 ds_read_b128 per half step and wave)
+//   bit 2: staging waves write LDS (18 ds_write_b128 per thread and step)
+//   bit 3: staging waves run ~400 VALU instructions per thread and step
+//   bit 4: matrix waves at s_setprio 3
+// build: hipcc --offload-arch=gfx950 -O3 -w -o matrix_loop matrix_loop.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kStage = 3 * (128 + 256) * 64;  // bytes
+
+template <int MODE>
+__global__ __launch_bounds__(512) void k_loop(const u32x4* in, float* out, int steps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 2 * kStage / 16; i += 512) reinterpret_cast<u32x4*>(smem)[i] = in[i & 1023];
+  __syncthreads();
+  if (tid >= 256) {
+    const int pt = tid - 256;
+    u32x4 v = in[pt];
+    float f = __builtin_bit_cast(float, v.x);
+    for (int s = 0; s < steps; ++s) {
+      if (MODE & 8) {
+#pragma unroll
+        for (int i = 0; i < 400; ++i) f = __builtin_fmaf(f, 1.0001f, 0.5f);
+        v.y = __builtin_bit_cast(unsigned, f);
+      }
+      if (MODE & 4) {
+        unsigned char* S = smem + ((s + 1) & 1) * kStage;
+#pragma unroll
+        for (int i = 0; i < 18; ++i) *reinterpret_cast<u32x4*>(S + ((i * 256 + pt) * 16) % kStage) = v;
+      }
+      if (MODE & 1) __syncthreads();
+    }
+    if (f == 12345.f) out[0] = f;
+    return;
+  }
+  if (MODE & 16) __builtin_amdgcn_s_setprio(3);
+  const int wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  f32x16 acc[2][4];
+  for (int a = 0; a < 2; ++a) for (int b = 0; b < 4; ++b) for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  bf16x8 fa[2][3], fb[4][3];
+  for (int a = 0; a < 2; ++a) for (int p = 0; p < 3; ++p) fa[a][p] = __builtin_bit_cast(bf16x8, in[(tid + 64 * (a * 3 + p)) & 1023]);
+  for (int b = 0; b < 4; ++b) for (int p = 0; p < 3; ++p) fb[b][p] = __builtin_bit_cast(bf16x8, in[(tid + 64 * (b * 3 + p) + 7) & 1023]);
+  const int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+  for (int s = 0; s < steps; ++s) {
+    const unsigned char* S = smem + (s & 1) * kStage;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      if (MODE & 2) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            const int row = wm * 64 + a * 32 + li;
+            fa[a][p] = *reinterpret_cast<const bf16x8*>(S + p * 128 * 64 + row * 64 + (((2 * kk + lh) ^ ((row >> 2) & 3)) << 4));
+          }
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            const int row = wn * 128 + b * 32 + li;
+            fb[b][p] = *reinterpret_cast<const bf16x8*>(S + 3 * 128 * 64 + p * 256 * 64 + row * 64 + (((2 * kk + lh) ^ ((row >> 2) & 3)) << 4));
+          }
+      }
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA[t]], fb[b][PB[t]], acc[a][b], 0, 0, 0);
+    }
+    if (MODE & 1) __syncthreads();
+  }
+  float s = 0;
+  for (int a = 0; a < 2; ++a) for (int b = 0; b < 4; ++b) for (int r = 0; r < 16; ++r) s += acc[a][b][r];
+  out[blockIdx.x * 256 + tid] = s;
+}
+
+template <int MODE> static void run(const u32x4* din, float* dout) {
+  const int steps = 600;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&k_loop<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStage);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e9, last = 0;
+  for (int i = 0; i < 12; ++i) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k_loop<MODE>, dim3(256), dim3(512), 2 * kStage, 0, din, dout, steps);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&last, e0, e1);
+    if (last < best) best = last;
+  }
+  const double flop = 256.0 * steps * 128 * 256 * 32 * 2;   // fp32-equivalent FLOP of the tile loop
+  printf("mode %2d%s%s%s%s%s: %8.1f us (last %8.1f)  %6.1f TF fp32-equivalent, %.2f us per step\n", MODE, MODE & 1 ? " barrier" : "",
+         MODE & 2 ? " frag-reads" : "", MODE & 4 ? " lds-writes" : "", MODE & 8 ? " valu" : "", MODE & 16 ? " prio" : "",
+         best * 1e3, last * 1e3, flop / (last * 1e-3) / 1e12, last * 1e3 / steps);
+}
+
+int main() {
+  unsigned* h = (unsigned*)malloc(1024 * 16);
+  srand(1);
+  for (int i = 0; i < 4096; ++i) {
+    unsigned lo = ((rand() & 1) << 15) | (0x3f80 - ((rand() & 3) << 7)) | (rand() & 0x7f);
+    unsigned hi = ((rand() & 1) << 15) | (0x3f80 - ((rand() & 3) << 7)) | (rand() & 0x7f);
+    h[i] = (hi << 16) | lo;
+  }
+  u32x4* din; float* dout;
+  hipMalloc(&din, 1024 * 16); hipMalloc(&dout, 256 * 256 * 4);
+  hipMemcpy(din, h, 1024 * 16, hipMemcpyHostToDevice);
+  run<0>(din, dout); run<1>(din, dout); run<2>(din, dout); run<3>(din, dout); run<7>(din, dout); run<11>(din, dout);
+  run<15>(din, dout); run<31>(din, dout); run<19>(din, dout);
+  return 0;
+}
