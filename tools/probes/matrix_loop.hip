@@ -5,10 +5,13 @@
 //   bit 2: staging waves write LDS (18 ds_write_b128 per thread and step)
 //   bit 3: staging waves run ~400 VALU instructions per thread and step
 //   bit 4: matrix waves at s_setprio 3
+//   bit 5: staging waves gather 8 x 16 B + 8 x 8 B per thread and step from global memory (two register sets, loads two
+//          steps ahead) and write THAT data to LDS (bit 2 must be set); bit 6: the same with loads three steps ahead
 // build: hipcc --offload-arch=gfx950 -O3 -w -o matrix_loop matrix_loop.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -16,7 +19,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kStage = 3 * (128 + 256) * 64;  // bytes
 
 template <int MODE>
-__global__ __launch_bounds__(512) void k_loop(const u32x4* in, float* out, int steps) {
+__global__ __launch_bounds__(512) void k_loop(const u32x4* in, float* out, int steps, const float* __restrict__ gx, size_t gmask) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   for (int i = tid; i < 2 * kStage / 16; i += 512) reinterpret_cast<u32x4*>(smem)[i] = in[i & 1023];
@@ -25,11 +28,41 @@ __global__ __launch_bounds__(512) void k_loop(const u32x4* in, float* out, int s
     const int pt = tid - 256;
     u32x4 v = in[pt];
     float f = __builtin_bit_cast(float, v.x);
-    for (int s = 0; s < steps; ++s) {
+    constexpr int DIST = (MODE & 64) ? 3 : 2, NSET = DIST;
+    u32x4 rb[3][8];
+    unsigned long long ra[3][8];
+    // x micro-block: 8 pixels x 4 channels of a [pixel][256] fp32 map; dy half micro-block: 8 pixels x 2 channels of [pixel][128]
+    const int cq = pt & 63, pg = pt >> 6;
+    const size_t wg_base = (size_t)blockIdx.x * 4096 * 256;   // this workgroup's pixel window (wraps inside gmask)
+    auto gload = [&](int set, int s) {   // `set` is a constant at every call site
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const size_t px = (size_t)s * 32 + pg * 8 + j;
+        rb[set][j] = *reinterpret_cast<const u32x4*>(gx + ((wg_base + px * 256 + cq * 4) & gmask));
+        ra[set][j] = *reinterpret_cast<const unsigned long long*>(gx + ((wg_base + (1u << 22) + px * 128 + cq * 2) & gmask));
+      }
+    };
+    if (MODE & 32) {
+      gload(0, 0);
+      gload(1 % NSET, 1);
+      if (DIST == 3) gload(2, 2);
+    }
+    auto body = [&](auto SETC, int s) {
+      constexpr int set = decltype(SETC)::value;   // register set of step s+1, the step being staged now
+      if (MODE & 32) {
+        // consume the set (dependency on its loads), then refill it for step s+1+DIST
+        u32x4 acc4 = rb[set][0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) acc4 ^= rb[set][j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc4.x ^= (unsigned)ra[set][j];
+        v = acc4;
+        gload(set, s + 1 + DIST);
+      }
       if (MODE & 8) {
 #pragma unroll
         for (int i = 0; i < 400; ++i) f = __builtin_fmaf(f, 1.0001f, 0.5f);
-        v.y = __builtin_bit_cast(unsigned, f);
+        v.y ^= __builtin_bit_cast(unsigned, f);
       }
       if (MODE & 4) {
         unsigned char* S = smem + ((s + 1) & 1) * kStage;
@@ -37,6 +70,14 @@ __global__ __launch_bounds__(512) void k_loop(const u32x4* in, float* out, int s
         for (int i = 0; i < 18; ++i) *reinterpret_cast<u32x4*>(S + ((i * 256 + pt) * 16) % kStage) = v;
       }
       if (MODE & 1) __syncthreads();
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>;
+    if (NSET == 2) {
+      for (int s = 0; s < steps; s += 2) { body(C1{}, s); body(C0{}, s + 1); }
+    } else {
+      for (int s = 0; s < steps; s += 3) { body(C1{}, s); body(C2{}, s + 1); body(C0{}, s + 2); }
     }
     if (f == 12345.f) out[0] = f;
     return;
@@ -84,6 +125,7 @@ __global__ __launch_bounds__(512) void k_loop(const u32x4* in, float* out, int s
   out[blockIdx.x * 256 + tid] = s;
 }
 
+static float* g_gx; static size_t g_mask;
 template <int MODE> static void run(const u32x4* din, float* dout) {
   const int steps = 600;
   hipFuncSetAttribute(reinterpret_cast<const void*>(&k_loop<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStage);
@@ -91,14 +133,14 @@ template <int MODE> static void run(const u32x4* din, float* dout) {
   float best = 1e9, last = 0;
   for (int i = 0; i < 12; ++i) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k_loop<MODE>, dim3(256), dim3(512), 2 * kStage, 0, din, dout, steps);
+    hipLaunchKernelGGL(k_loop<MODE>, dim3(256), dim3(512), 2 * kStage, 0, din, dout, steps, g_gx, g_mask);
     hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&last, e0, e1);
     if (last < best) best = last;
   }
   const double flop = 256.0 * steps * 128 * 256 * 32 * 2;   // fp32-equivalent FLOP of the tile loop
-  printf("mode %2d%s%s%s%s%s: %8.1f us (last %8.1f)  %6.1f TF fp32-equivalent, %.2f us per step\n", MODE, MODE & 1 ? " barrier" : "",
-         MODE & 2 ? " frag-reads" : "", MODE & 4 ? " lds-writes" : "", MODE & 8 ? " valu" : "", MODE & 16 ? " prio" : "",
+  printf("mode %3d%s%s%s%s%s%s%s: %8.1f us (last %8.1f)  %6.1f TF fp32-equivalent, %.2f us per step\n", MODE, MODE & 1 ? " barrier" : "",
+         MODE & 2 ? " frag-reads" : "", MODE & 4 ? " lds-writes" : "", MODE & 8 ? " valu" : "", MODE & 16 ? " prio" : "", MODE & 32 ? " gather" : "", MODE & 64 ? "(3 ahead)" : "",
          best * 1e3, last * 1e3, flop / (last * 1e-3) / 1e12, last * 1e3 / steps);
 }
 
@@ -113,7 +155,9 @@ int main() {
   u32x4* din; float* dout;
   hipMalloc(&din, 1024 * 16); hipMalloc(&dout, 256 * 256 * 4);
   hipMemcpy(din, h, 1024 * 16, hipMemcpyHostToDevice);
+  { const size_t n = (size_t)1 << 28; hipMalloc(&g_gx, n * 4); hipMemset(g_gx, 0, n * 4); g_mask = n - 1 - 3; }
   run<0>(din, dout); run<1>(din, dout); run<2>(din, dout); run<3>(din, dout); run<7>(din, dout); run<11>(din, dout);
   run<15>(din, dout); run<31>(din, dout); run<19>(din, dout);
+  run<32 + 7>(din, dout); run<32 + 15>(din, dout); run<32 + 31>(din, dout); run<64 + 32 + 31>(din, dout);
   return 0;
 }
