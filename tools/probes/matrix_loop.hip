@@ -39,7 +39,15 @@ __global__ __launch_bounds__(512) void k_loop(const u32x4* in, float* out, int s
       for (int j = 0; j < 8; ++j) {
         const size_t px = (size_t)s * 32 + pg * 8 + j;
         rb[set][j] = *reinterpret_cast<const u32x4*>(gx + ((wg_base + px * 256 + cq * 4) & gmask));
-        ra[set][j] = *reinterpret_cast<const unsigned long long*>(gx + ((wg_base + (1u << 22) + px * 128 + cq * 2) & gmask));
+        if (MODE & 128) {   // all-16-byte variant: 12 loads per thread instead of 8 + 8 half-width ones
+          if (j < 4) {
+            const u32x4 t = *reinterpret_cast<const u32x4*>(gx + ((wg_base + (1u << 22) + px * 128 + (cq & 31) * 4) & gmask));
+            ra[set][2 * j] = ((unsigned long long)t.y << 32) | t.x;
+            ra[set][2 * j + 1] = ((unsigned long long)t.w << 32) | t.z;
+          }
+        } else {
+          ra[set][j] = *reinterpret_cast<const unsigned long long*>(gx + ((wg_base + (1u << 22) + px * 128 + cq * 2) & gmask));
+        }
       }
     };
     if (MODE & 32) {
@@ -140,7 +148,7 @@ template <int MODE> static void run(const u32x4* din, float* dout) {
   }
   const double flop = 256.0 * steps * 128 * 256 * 32 * 2;   // fp32-equivalent FLOP of the tile loop
   printf("mode %3d%s%s%s%s%s%s%s: %8.1f us (last %8.1f)  %6.1f TF fp32-equivalent, %.2f us per step\n", MODE, MODE & 1 ? " barrier" : "",
-         MODE & 2 ? " frag-reads" : "", MODE & 4 ? " lds-writes" : "", MODE & 8 ? " valu" : "", MODE & 16 ? " prio" : "", MODE & 32 ? " gather" : "", MODE & 64 ? "(3 ahead)" : "",
+         MODE & 2 ? " frag-reads" : "", MODE & 4 ? " lds-writes" : "", MODE & 8 ? " valu" : "", MODE & 16 ? " prio" : "", MODE & 32 ? " gather" : "", MODE & 64 ? "(3 ahead)" : (MODE & 128 ? "(12 x 16 B)" : ""),
          best * 1e3, last * 1e3, flop / (last * 1e-3) / 1e12, last * 1e3 / steps);
 }
 
@@ -158,6 +166,6 @@ int main() {
   { const size_t n = (size_t)1 << 28; hipMalloc(&g_gx, n * 4); hipMemset(g_gx, 0, n * 4); g_mask = n - 1 - 3; }
   run<0>(din, dout); run<1>(din, dout); run<2>(din, dout); run<3>(din, dout); run<7>(din, dout); run<11>(din, dout);
   run<15>(din, dout); run<31>(din, dout); run<19>(din, dout);
-  run<32 + 7>(din, dout); run<32 + 15>(din, dout); run<32 + 31>(din, dout); run<64 + 32 + 31>(din, dout);
+  run<32 + 7>(din, dout); run<32 + 15>(din, dout); run<32 + 31>(din, dout); run<64 + 32 + 31>(din, dout); run<128 + 32 + 15>(din, dout);
   return 0;
 }
