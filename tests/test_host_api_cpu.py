@@ -193,3 +193,50 @@ def test_library_exports_every_declared_symbol():
     assert rc == -2 and b'multiple of 4' in lib.evk_last_error()   # EVK_E_UNSUPPORTED: Cin % 4
     assert lib.evk_bn_fwd_train(None, None, None, None, None, None, 0.1, 1e-5, None, None, None, 4, 4, 0, None, 0, None) == -1
     assert lib.evk_conv2d_wgrad_workspace_bytes(ctypes.byref(_C.ConvDesc(2, 8, 8, 64, 8, 8, 64, 3, 3, 1, 1, 1, 1, 1, 1))) > 0
+
+
+def test_split_job_tables_are_host_side_and_match_the_plane_layouts():
+    """evk_conv2d_split_jobs / _job_count / evk_split_job_pairs run on the host (no launch): job counts, plane offsets
+    and sizes follow the layouts evk_conv2d_split_weight_bytes promises, and the layout signature the plane cache keys on
+    separates geometries whose kernels read different planes (LDS-halo 3x3 vs generic) while merging those that do not."""
+    from ever_amd.hip import weight_planes as wp
+    lib = _C.load()
+
+    def jobs_of(d, for_dgrad):
+        n = lib.evk_conv2d_split_job_count(ctypes.byref(d), for_dgrad)
+        arr = (_C.SplitJob * max(n, 1))()
+        got = lib.evk_conv2d_split_jobs(ctypes.byref(d), 4096, for_dgrad, 1 << 20, arr, n)
+        assert 0 <= got <= n
+        return [arr[i] for i in range(got)], arr
+
+    # 1x1 stride 2 (a ResNet down-sampling shortcut): forward = one job; data gradient = only the residue class that
+    # has a tap produces planes, although the layout reserves room for all four
+    d = _C.ConvDesc(16, 128, 128, 256, 64, 64, 512, 1, 1, 2, 2, 0, 0, 1, 1)
+    f, _keep_f = jobs_of(d, 0)
+    assert len(f) == 1 and f[0].kind == 0 and lib.evk_split_job_pairs(ctypes.byref(f[0])) == 512 * 256 // 2
+    g, _keep_g = jobs_of(d, 1)
+    assert lib.evk_conv2d_split_job_count(ctypes.byref(d), 1) == 4 and len(g) == 1 and g[0].kind == 1
+    assert lib.evk_split_job_pairs(ctypes.byref(g[0])) == 256 * 512 // 2
+    # 3x3 stride 2: four residue classes with 4 / 2 / 2 / 1 taps, laid out back to back inside the plane buffer
+    d = _C.ConvDesc(2, 32, 32, 64, 16, 16, 128, 3, 3, 2, 2, 1, 1, 1, 1)
+    g, _keep = jobs_of(d, 1)
+    assert len(g) == 4
+    offs = [j.out - (1 << 20) for j in g]
+    assert offs == sorted(offs) and offs[0] == 0
+    total = lib.evk_conv2d_split_weight_bytes(ctypes.byref(d), 1)
+    last_bytes = 3 * 64 * g[-1].arg[10] * 2
+    assert offs[-1] + last_bytes == total
+    assert sum(lib.evk_split_job_pairs(ctypes.byref(j)) for j in g) == 64 * 128 * 9 // 2   # K = taps*Cout is a multiple of 32 here
+    # 3x3 'same': big maps take the LDS-halo layout, small grids the generic one -> different cache signatures;
+    # two batch sizes that both take the halo kernel share one
+    big = _C.ConvDesc(16, 128, 128, 256, 128, 128, 256, 3, 3, 1, 1, 1, 1, 1, 1)
+    big2 = _C.ConvDesc(8, 128, 128, 256, 128, 128, 256, 3, 3, 1, 1, 1, 1, 1, 1)
+    tiny = _C.ConvDesc(1, 8, 16, 256, 8, 16, 256, 3, 3, 1, 1, 1, 1, 1, 1)
+    assert jobs_of(big, 0)[0][0].kind == 2 and jobs_of(tiny, 0)[0][0].kind == 0
+    assert wp._layout(big, 0)[0] == wp._layout(big2, 0)[0] != wp._layout(tiny, 0)[0]
+    assert wp._layout(big, 0)[1] == lib.evk_conv2d_split_weight_bytes(ctypes.byref(big), 0)
+    # argument checking
+    arr = (_C.SplitJob * 1)()
+    assert lib.evk_conv2d_split_jobs(ctypes.byref(d), 4096, 1, 1 << 20, arr, 1) == -1   # needs room for 4 jobs
+    assert lib.evk_conv2d_split_multi(None, None, 0, None) == 0
+    assert lib.evk_conv2d_split_multi(None, None, 5, None) == -1
