@@ -1,4 +1,5 @@
 from . import loss  # noqa: F401
+from .changestar import ChangeMixin, ChangeStarFarSeg
 from .farseg import FarSeg
 from .fpn import FPN, AssymetricDecoder
 from .freenet import FreeNet
@@ -8,6 +9,6 @@ from .layers import (AdaptiveAvgPool2d, BatchNorm2d, Conv2d, HipSequential, MaxP
 from .ops import Bf16compatible, ConvBlock, ConvUpsampling
 from .resnet import ResNetEncoder
 
-__all__ = ['ResNetEncoder', 'FPN', 'AssymetricDecoder', 'FSRelation', 'FSRelationV2', 'FarSegHead', 'FarSeg', 'FreeNet', 'ConvBlock',
+__all__ = ['ResNetEncoder', 'FPN', 'AssymetricDecoder', 'FSRelation', 'FSRelationV2', 'FarSegHead', 'FarSeg', 'FreeNet', 'ChangeMixin', 'ChangeStarFarSeg', 'ConvBlock',
            'Bf16compatible', 'ConvUpsampling', 'Conv2d', 'BatchNorm2d', 'ReLU', 'MaxPool2d', 'UpsamplingBilinear2d',
            'AdaptiveAvgPool2d', 'HipSequential', 'to_hip', 'loss']

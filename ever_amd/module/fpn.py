@@ -95,15 +95,18 @@ class AssymetricDecoder(nn.Module):
                 Conv2d(out_channels, num_classes, kernel_size, padding=(kernel_size - 1) // 2),
                 Bf16compatible(UpsamplingBilinear2d(scale_factor=scale_factor)) if scale_factor > 1 else nn.Identity())
 
-    def forward(self, feat_list):
+    def features(self, feat_list):
+        """mean of the per-level decoder outputs, before the classifier (what ChangeStar's ChangeMixin consumes)"""
         inner = [block(feat_list[i]) for i, block in enumerate(self.blocks)]
         if len(inner) == 4:
-            out = HF.mean4(*inner)
-        else:  # generic: running add then scale (same left-to-right association as python sum)
-            out = inner[0]
-            for t in inner[1:]:
-                out = HF.add(out, t)
-            out = _Scale.apply(out, 1.0 / len(inner))
+            return HF.mean4(*inner)
+        out = inner[0]  # generic: running add then scale (same left-to-right association as python sum)
+        for t in inner[1:]:
+            out = HF.add(out, t)
+        return _Scale.apply(out, 1.0 / len(inner))
+
+    def forward(self, feat_list):
+        out = self.features(feat_list)
         if self.cls_cfg:
             out = self.classifier(self.dropout(out))
         return out

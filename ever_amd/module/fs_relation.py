@@ -116,11 +116,17 @@ class FarSegHead(ERModule):
         self.fs_relation = FSRelation(**self.config.fs_relation)
         self.fpn_decoder = AssymetricDecoder(**self.config.fpn_decoder)
 
-    def forward(self, feature_list):
+    def refined(self, feature_list):
         fpn_feats = self.fpn(feature_list)
         scene = HF.global_avg_pool(feature_list[-1])  # GAP of c5 (encoder output), not of P5
-        refined = self.fs_relation(scene, fpn_feats)
-        return self.fpn_decoder(refined)
+        return self.fs_relation(scene, fpn_feats)
+
+    def forward(self, feature_list):
+        return self.fpn_decoder(self.refined(feature_list))
+
+    def features(self, feature_list):
+        """decoder feature map before the classifier (stride out_feat_output_stride)"""
+        return self.fpn_decoder.features(self.refined(feature_list))
 
     def set_default_config(self):
         self.config.update(dict(
