@@ -223,7 +223,7 @@ bool conv3x3_halo_applies(const IGemmArgs& a) {
   if (a.kh != 3 || a.kw != 3 || a.ash != 1 || a.asw != 1) return false;
   if (!((a.oys == 1 || a.oys == -1) && a.oy0 == -a.oys && (a.oxs == 1 || a.oxs == -1) && a.ox0 == -a.oxs)) return false;
   if (a.Hm != a.Hs || a.Wm != a.Ws || (a.Hm % 8) != 0 || (a.Wm % kPW) != 0) return false;
-  if ((a.Cs % kCh) != 0 || a.Cd < 64 || !a.dense_dst && (a.dsh != 1 || a.dsw != 1)) return false;
+  if ((a.Cs % kCh) != 0 || a.Cd < 64 || (!a.dense_dst && (a.dsh != 1 || a.dsw != 1))) return false;
   // enough workgroups for the 256 CUs, if necessary with the 64-wide N tile
   const long long patches = (long long)a.N * (a.Hm / 8) * (a.Wm / kPW);
   return patches * ceil_div(a.Cd, 64) >= 256;

@@ -268,7 +268,6 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restri
 // adjoint in gather form: every input pixel sums the (few) output pixels whose 2x2 footprint
 // contains it, with exactly the forward's weights.  Candidate range per axis:
 // src in (i-1, i+1)  <=>  o in ((i-1)/scale, (i+1)/scale), widened by one for float rounding.
-constexpr int kMaxCand = 12;
 template <int VEC>
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N,
                                                            int Hi, int Wi, int Ho, int Wo, int C, float sy, float sx,
