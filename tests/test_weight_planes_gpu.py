@@ -7,6 +7,16 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _split_arithmetic():
+    """the plane cache belongs to the bf16x3 convolutions: run these tests under it whatever EVK_CONV_MATH says"""
+    from ever_amd.hip import functional as F
+    old = F.get_conv_math()
+    F.set_conv_math('bf16x3')
+    yield
+    F.set_conv_math(old)
+
+
 def _net(dev, seed=0):
     from ever_amd.module.layers import Conv2d
     torch.manual_seed(seed)
