@@ -10,9 +10,15 @@ RCCL gradient all-reduce under DDP, overlapped with backward) + fused SGD update
 BASELINE.json configs[1]: FarSeg ResNet-50 FPN, 3-band 512x512, batch 16 per GPU (weak scaling).
 
 Rank 0 prints ONE JSON line: the contract fields plus
-  roofline     — achieved MFMA rate of the dominant kernel family (conv_igemm: conv forward + data
-                 gradient) = algorithmic FLOPs / HIP-event time of its launches over the timed region,
-                 against the dense fp32-MFMA peak (157.3 TF, v_mfma_f32_32x32x2_f32);
+  roofline     — achieved MFMA rate of the dominant kernel family (conv forward + data gradient:
+                 conv3x3_halo_x3 / conv_igemm_x3ws / conv_igemm_x3 kernels) = algorithmic FLOPs / HIP-event
+                 time of its launches over the timed region, against the peak of the instruction the
+                 default arithmetic issues: dense bf16 MFMA 2500 TF / 6 partial products per fp32 product
+                 = 416.7 TF (157.3 TF, v_mfma_f32_32x32x2_f32, under --conv-math f32);
+  roofline_wgrad / roofline_encoder — the same for the weight-gradient family and for the ResNet-50
+                 encoder's convolutions alone (forward + data gradient + weight gradient of `en.*`:
+                 the stack BASELINE.json's 0.6 target is stated on);
+  roofline_hbm_* — achieved algorithmic GB/s of the BatchNorm and resample/loss families vs 8 TB/s;
   cpu_baseline — the CPU oracle (stock PyTorch port of the reference path) timed on this box's host
                  cores on a bounded sample of the same workload (N=1 only).
 """
@@ -61,13 +67,16 @@ def make_batch(dev, batch, rank):
 
 
 def pmc_traffic(family):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE x2 +
-    WRITE_SIZE, MI355X_MICROARCH.md §HBM; see profiles/r01_traffic.json for the method); None if absent."""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as f:
-            return json.load(f)[family]['hbm_bytes_per_launch']
-    except (OSError, KeyError, ValueError):
-        return None
+    """(HBM bytes per launch, file) of a kernel family from the newest committed rocprofv3 PMC passes (FETCH_SIZE x2 +
+    WRITE_SIZE, MI355X_MICROARCH.md §HBM; profiles/rNN_traffic.json states the method); (None, None) if absent."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')), reverse=True):
+        try:
+            with open(path) as f:
+                return json.load(f)[family]['hbm_bytes_per_launch'], os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def host_cores():
@@ -220,12 +229,14 @@ def main():
             ig = fam.get('conv_igemm' if x3 else 'conv_igemm_f32')
             if ig:
                 ach = ig['flops'] / ig['seconds'] / 1e12
+                traffic, traffic_file = pmc_traffic('conv_igemm')
                 line['roofline'] = {
-                    'bound': 'mfma', 'kernel': ('evk::conv_igemm_x3_kernel' if x3 else 'evk::conv_igemm_kernel') +
-                    ' (conv forward + data-gradient launches)',
+                    'bound': 'mfma',
+                    'kernel': ('evk::conv3x3_halo_x3_kernel / conv_igemm_x3ws_kernel / conv_igemm_x3_kernel' if x3
+                               else 'evk::conv_igemm_kernel') + ' (conv forward + data-gradient launches)',
                     'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'peak_note': peak_note,
-                    'frac': round(ach / peak, 4), 'traffic': pmc_traffic('conv_igemm'),
-                    'traffic_unit': 'HBM bytes per launch (PMC, profiles/r01_traffic.json)',
+                    'frac': round(ach / peak, 4), 'traffic': traffic,
+                    'traffic_unit': f'HBM bytes per launch (PMC, {traffic_file})',
                     'algorithmic_bytes_per_launch': round(ig['bytes'] / ig['launches']),
                     'launches_per_step': ig['launches'] // max(1, sampled), 'sampled_steps': sampled,
                     'avg_launch_us': round(ig['seconds'] / ig['launches'] * 1e6, 2),
@@ -233,11 +244,37 @@ def main():
             wg = fam.get('conv_wgrad' if x3 else 'conv_wgrad_f32')
             if wg:
                 ach = wg['flops'] / wg['seconds'] / 1e12
-                line['roofline_wgrad'] = {'bound': 'mfma', 'kernel': ('evk::conv_wgrad_x3_kernel' if x3 else
-                                                                      'evk::conv_wgrad_kernel') + ' (+split-K reduce)',
+                wtraffic, _ = pmc_traffic('conv_wgrad')
+                line['roofline_wgrad'] = {'bound': 'mfma',
+                                          'kernel': ('evk::conv_wgrad_x3ws_kernel / conv_wgrad_x3_kernel' if x3 else
+                                                     'evk::conv_wgrad_kernel') + ' (+split-K reduce)',
                                           'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-                                          'frac': round(ach / peak, 4),
-                                          'avg_launch_us': round(wg['seconds'] / wg['launches'] * 1e6, 2)}
+                                          'frac': round(ach / peak, 4), 'traffic': wtraffic,
+                                          'algorithmic_bytes_per_launch': round(wg['bytes'] / wg['launches']),
+                                          'launches_per_step': wg['launches'] // max(1, sampled),
+                                          'avg_launch_us': round(wg['seconds'] / wg['launches'] * 1e6, 2),
+                                          'algorithmic_gflop_per_launch': round(wg['flops'] / wg['launches'] / 1e9, 3)}
+            # the ResNet-50 encoder's convolutions alone (BASELINE.json north_star: >= 0.6 x MFMA roofline on this
+            # stack): forward + data gradient + weight gradient of every `en.*` convolution, the 7x7 stem on the
+            # exact-fp32 kernel included, all priced against the default arithmetic's peak
+            enc = [fam.get('encoder/' + k) for k in ('conv_igemm', 'conv_wgrad', 'conv_igemm_f32', 'conv_wgrad_f32')]
+            enc = [e for e in enc if e]
+            if enc:
+                fl, sec = sum(e['flops'] for e in enc), sum(e['seconds'] for e in enc)
+                parts = {}
+                for k in ('conv_igemm', 'conv_wgrad', 'conv_igemm_f32', 'conv_wgrad_f32'):
+                    e = fam.get('encoder/' + k)
+                    if e:
+                        parts[k] = {'tflops': round(e['flops'] / e['seconds'] / 1e12, 2),
+                                    'ms_per_step': round(e['seconds'] / max(1, sampled) * 1e3, 3),
+                                    'gflop_per_step': round(e['flops'] / max(1, sampled) / 1e9, 1)}
+                line['roofline_encoder'] = {
+                    'bound': 'mfma', 'kernel': 'all convolution launches of the ResNet-50 encoder (forward + data gradient '
+                                               '+ weight gradient of en.*)',
+                    'achieved': round(fl / sec / 1e12, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                    'frac': round(fl / sec / 1e12 / peak, 4),
+                    'gflop_per_step': round(fl / max(1, sampled) / 1e9, 1),
+                    'ms_per_step': round(sec / max(1, sampled) * 1e3, 3), 'families': parts}
             for fam_name, label in (('bn', 'evk::bn_* (BatchNorm+residual+ReLU forward/backward passes)'),
                                     ('resample_loss', 'evk::bilinear_fwd/bwd + bce/dice kernels (upsample x2/x4, pixel losses)')):
                 hb = fam.get(fam_name)

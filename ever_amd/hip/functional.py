@@ -162,8 +162,28 @@ def _weight_ohwi(weight):
 
 
 class _ConvState:
-    """What one convolution's backward needs (kept on the autograd ctx)."""
-    __slots__ = ('desc', 'relu', 'cin', 'has_bias', 'flops', 'abytes', 'w_stride', 'xk', 'w_ohwi', 'y', 'weight')
+    """What one convolution's backward needs.  The descriptor and flags stay on the autograd ctx; the tensors
+    (xk, y, weight, w_ohwi) travel through ctx.save_for_backward (`_stash` / `_unstash`), so that the output saved on
+    its own node forms no reference cycle, in-place writes to a saved tensor are caught by the version check, and
+    saved-tensor hooks (activation checkpointing, offloading) see them."""
+    __slots__ = ('desc', 'relu', 'cin', 'has_bias', 'flops', 'abytes', 'w_stride', 'xk', 'w_ohwi', 'y', 'weight',
+                 'w_alias', 'scope')
+
+
+def _stash(states):
+    """Tensors of the given conv states, flattened for save_for_backward; the states keep only metadata."""
+    out = []
+    for cs in states:
+        cs.w_alias = cs.w_ohwi is None or cs.w_ohwi.data_ptr() == cs.weight.data_ptr()
+        out += [cs.xk, cs.y, cs.weight, None if cs.w_alias else cs.w_ohwi]
+        cs.xk = cs.y = cs.weight = cs.w_ohwi = None
+    return out
+
+
+def _unstash(states, saved):
+    for i, cs in enumerate(states):
+        cs.xk, cs.y, cs.weight, w = saved[4 * i:4 * i + 4]
+        cs.w_ohwi = cs.weight.detach() if cs.w_alias else w
 
 
 def _conv_forward(x, weight, bias, stride, padding, dilation, relu):
@@ -186,6 +206,7 @@ def _conv_forward(x, weight, bias, stride, padding, dilation, relu):
     d = _conv_desc(n, h, w, cin_p, cout, kh, kw, stride, padding, dilation)
     y = empty_nhwc(n, cout, d.Ho, d.Wo, dev)
     cs = _ConvState()
+    cs.scope = timing.current_scope()
     cs.flops = 2.0 * n * d.Ho * d.Wo * cout * cin * kh * kw  # algorithmic (un-padded) FLOPs
     # algorithmic bytes: input + output + weights, each touched once
     cs.abytes = 4.0 * (n * h * w * cin + n * d.Ho * d.Wo * cout + cout * cin * kh * kw)
@@ -254,7 +275,7 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None):
             accum = as_nhwc(accum, 'conv2d.backward.accum')
             acc_ptr = accum.data_ptr()
         dx = empty_nhwc(n, cin, d.H, d.W, dev)
-        sp = timing.span('conv_igemm', cs.flops, cs.abytes)
+        sp = timing.span('conv_igemm', cs.flops, cs.abytes, cs.scope)
         _C.call('evk_conv2d_dgrad_x3', ctypes.byref(dk), dy_ptr, pl_ptr, acc_ptr, dx.data_ptr(), st)
         if sp is not None:
             sp.stop()
@@ -277,7 +298,7 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None):
             accum = as_nhwc(accum, 'conv2d.backward.accum')
             acc_ptr = accum.data_ptr()
         dxk = empty_nhwc(n, cin_p, d.H, d.W, dev)
-        sp = timing.span('conv_igemm_f32', cs.flops, cs.abytes)
+        sp = timing.span('conv_igemm_f32', cs.flops, cs.abytes, cs.scope)
         _C.call('evk_conv2d_dgrad', ctypes.byref(dk), dy_ptr, wt.data_ptr(), acc_ptr, dxk.data_ptr(), st)
         if sp is not None:
             sp.stop()
@@ -293,7 +314,7 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None):
         ws = workspace(dev, ws_bytes)
         dwk = torch.empty((cout_p, taps, cin_p), device=dev, dtype=torch.float32)
         dbk = torch.empty((cout_p,), device=dev, dtype=torch.float32) if need_db else None
-        sp = timing.span('conv_wgrad' if x3 else 'conv_wgrad_f32', cs.flops, cs.abytes)
+        sp = timing.span('conv_wgrad' if x3 else 'conv_wgrad_f32', cs.flops, cs.abytes, cs.scope)
         _C.call('evk_conv2d_wgrad_x3' if x3 else 'evk_conv2d_wgrad', ctypes.byref(dk), xk.data_ptr(), dy_ptr,
                 dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes, st)
         if sp is not None:
@@ -326,12 +347,14 @@ class _Conv2dFn(Function):
     def forward(ctx, x, weight, bias, stride, padding, dilation, relu):
         y, cs = _conv_forward(x, weight, bias, stride, padding, dilation, relu)
         ctx.cs = cs
+        ctx.save_for_backward(*_stash([cs]))
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
         cs = ctx.cs
+        _unstash([cs], ctx.saved_tensors)
         dx, dw, db = _conv_backward(cs, dy, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                     cs.has_bias and ctx.needs_input_grad[2])
         return dx, dw, db, None, None, None, None
@@ -356,15 +379,18 @@ class _ConvForkFn(Function):
         ctx.cs_main = cs
         if w_short is None:
             ctx.cs_short = None
+            ctx.save_for_backward(*_stash([cs]))
             return y, x.view_as(x)
         ys, css = _conv_forward(x, w_short, b_short, *cfg_short, False)
         ctx.cs_short = css
+        ctx.save_for_backward(*_stash([cs, css]))
         return y, ys
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy, dshort):
         need_dx = ctx.needs_input_grad[0]
+        _unstash([ctx.cs_main] if ctx.cs_short is None else [ctx.cs_main, ctx.cs_short], ctx.saved_tensors)
         dws = dbs = None
         acc = None
         if ctx.cs_short is None:
@@ -764,6 +790,21 @@ def bce_with_logits(y_pred, y_true, ignore_index=255, label_smoothing=0.0):
     return _BceFn.apply(y_pred, labels, int(ignore_index), float(label_smoothing))
 
 
+_rank_sum_hook = None  # tests: callable(tensor, what) -> world size, summing `tensor` in place over virtual ranks
+
+
+def _sum_over_ranks(t, what):
+    """In-place SUM of a device tensor over the data-parallel ranks (RCCL all-reduce, asynchronous to the host);
+    returns the world size.  `_rank_sum_hook` replaces the collective in single-process tests."""
+    if _rank_sum_hook is not None:
+        return _rank_sum_hook(t, what)
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t)
+        return dist.get_world_size()
+    return 1
+
+
 class _DiceFn(Function):
     @staticmethod
     def forward(ctx, logits, labels, smooth, ignore_index, ignore_channel, sync):
@@ -772,12 +813,9 @@ class _DiceFn(Function):
         stats = _stats_buf(2 * c, logits.device)
         st = _stream()
         _timed_call('resample_loss', (4.0 * c + 8.0) * npix, 'evk_dice_stats', logits.data_ptr(), labels.data_ptr(), npix, c, ignore_index, stats.data_ptr(), st)
-        world = 1
-        if sync:
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                world = dist.get_world_size()
-                dist.all_reduce(stats[:2 * c])  # loss.py:46-48: inter / z summed over ranks before the ratio
+        # loss.py:46-48: inter / z summed over the ranks before the ratio.  The collective is enqueued behind the
+        # statistics kernel and the finishing kernel behind it: the host never waits for it.
+        world = _sum_over_ranks(stats[:2 * c], 'dice_stats') if sync else 1
         loss = torch.empty((), device=logits.device, dtype=torch.float32)
         _C.call('evk_dice_finish', stats.data_ptr(), c, float(smooth), ignore_channel, loss.data_ptr(), st)
         ctx.save_for_backward(logits, labels, stats)
@@ -793,9 +831,8 @@ class _DiceFn(Function):
         g = g.contiguous().float()
         if world > 1:
             # backward of torch.distributed.nn.all_reduce(SUM) is an all_reduce(SUM) of the upstream grads
-            import torch.distributed as dist
             g = g.clone()
-            dist.all_reduce(g)
+            _sum_over_ranks(g, 'dice_grad')
         d = torch.empty_like(logits)
         _timed_call('resample_loss', (8.0 * c + 8.0) * n * h * w, 'evk_dice_bwd', logits.data_ptr(), labels.data_ptr(), n * h * w, c, ignore_index, stats.data_ptr(),
                 smooth, ignore_channel, g.data_ptr(), d.data_ptr(), 0, _stream())

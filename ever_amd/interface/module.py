@@ -77,6 +77,10 @@ class ERModule(nn.Module, ConfigurableMixin):
             grad_info = self.clip_grad(optimizer)
             optimizer.step()
         optimizer.zero_grad()
+        # whatever optimizer ran (a custom one may write through `.data`, which moves no version counter the plane
+        # cache can see): the cached bf16 weight planes of the split-arithmetic convolutions are stale from here on
+        from ..hip import weight_planes
+        weight_planes.note_weights_changed()
         return grad_info
 
     def clip_grad(self, optimizer):

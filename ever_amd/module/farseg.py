@@ -9,24 +9,29 @@ import torch
 
 from ..core import registry
 from ..hip import functional as HF
+from ..hip import timing
 from ..interface import ERModule
 from . import loss as L
-from .fs_relation import FarSegHead
+from .fs_relation import FarSegHead, FarSegPPHead
 from .resnet import ResNetEncoder
 
-__all__ = ['FarSeg']
+__all__ = ['FarSeg', 'FarSegPP']
 
 
 @registry.MODEL.register(verbose=False)
 class FarSeg(ERModule):
+    HEAD = FarSegHead
+
     def __init__(self, config):
         super().__init__(config)
         self.en = ResNetEncoder(self.config.encoder)
-        self.head = FarSegHead(self.config.head)
+        self.head = self.HEAD(self.config.head)
 
     def forward(self, x, y=None):
         x = HF.as_nhwc(x, 'FarSeg input')  # boundary: NCHW image -> NHWC (conv pads channels to 4 itself)
-        logits = self.head(self.en(x))
+        with timing.scope('encoder'):   # bench.py prices the encoder conv stack on its own (north_star target)
+            feats = self.en(x)
+        logits = self.head(feats)
         if self.training:
             if isinstance(y, dict):
                 y = y[self.config.loss.get('label_key', 'cls')]
@@ -56,6 +61,12 @@ class FarSeg(ERModule):
             head=dict(),
             loss=dict(ignore_index=255, bce=True, dice=True),
         ))
+
+
+@registry.MODEL.register(verbose=False)
+class FarSegPP(FarSeg):
+    """FarSeg++ (BASELINE config C3): the FarSeg composition with the FSRelationV2 head."""
+    HEAD = FarSegPPHead
 
 
 def _SigmoidNoGrad(logits):

@@ -18,7 +18,16 @@ __all__ = ['fold_batchnorm', 'unfold_batchnorm', 'conv_bn']
 
 
 class _Folded(object):
-    __slots__ = ('weight', 'bias', 'planes', 'planes_key', 'cin', 'cin_p')
+    __slots__ = ('weight', 'bias', 'planes', 'planes_key', 'cin', 'cin_p', 'stamp')
+
+
+def _stamp(conv, bn):
+    """What the folded copy was derived from: autograd's version counters of the convolution / BatchNorm parameters
+    and running statistics, and the plane-cache epoch (moved by raw-pointer optimiser kernels and by every
+    ERModule.apply_gradients).  A folded pair whose stamp no longer matches is re-derived before use."""
+    from ..hip import weight_planes
+    ts = (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    return tuple(-1 if t is None else (t.data_ptr(), t._version) for t in ts) + (weight_planes._epoch,)
 
 
 def _fold_pair(conv, bn):
@@ -41,6 +50,7 @@ def _fold_pair(conv, bn):
         f.bias = b.contiguous().float()
         f.planes = None
         f.planes_key = None
+        f.stamp = _stamp(conv, bn)
     return f
 
 
@@ -89,8 +99,16 @@ def unfold_batchnorm(model):
 
 
 def _use_folded(conv, bn):
-    return (not bn.training) and getattr(conv, '_folded', None) is not None and getattr(bn, '_folded_into', None) is conv \
-        and not torch.is_grad_enabled()
+    if bn.training or torch.is_grad_enabled() or getattr(conv, '_folded', None) is None \
+            or getattr(bn, '_folded_into', None) is not conv:
+        return False
+    if conv._folded.stamp != _stamp(conv, bn):
+        # trained / fine-tuned / re-loaded since fold_batchnorm(): fold again from the current parameters
+        f = _fold_pair(conv, bn)
+        if f is None:
+            return False
+        conv._folded = f
+    return True
 
 
 def conv_bn(conv, bn, x, residual=None, relu=False):

@@ -12,7 +12,7 @@ from ..interface import ERModule
 from .fpn import FPN, AssymetricDecoder
 from .layers import BatchNorm2d, Conv2d, Dropout2d, GroupNorm, HipSequential, ReLU
 
-__all__ = ['FSRelation', 'FSRelationV2', 'FarSegHead']
+__all__ = ['FSRelation', 'FSRelationV2', 'FarSegHead', 'FarSegPPHead']
 
 
 def _mlp(cin, cout):
@@ -108,12 +108,21 @@ class FSRelationV2(nn.Module):
         return [self.project(x) for x in refined]
 
 
+_RELATIONS = {'v1': FSRelation, 'v2': FSRelationV2}
+
+
 @registry.MODEL.register(verbose=False)
 class FarSegHead(ERModule):
     def __init__(self, config):
         super().__init__(config)
         self.fpn = FPN(**self.config.fpn)
-        self.fs_relation = FSRelation(**self.config.fs_relation)
+        # `relation_version`: 'v1' = FSRelation (reference fs_relation.py:8-73, what the reference FarSegHead builds,
+        # :174); 'v2' = FSRelationV2 (:76-163), the FarSeg++ relation module, which the reference ships without a head
+        # that composes it.  The key lives beside the module's constructor arguments, not inside them.
+        version = str(self.config.get('relation_version', 'v1')).lower()
+        if version not in _RELATIONS:
+            raise ValueError(f"FarSegHead: relation_version must be 'v1' or 'v2', got {version!r}")
+        self.fs_relation = _RELATIONS[version](**self.config.fs_relation)
         self.fpn_decoder = AssymetricDecoder(**self.config.fpn_decoder)
 
     def refined(self, feature_list):
@@ -130,6 +139,7 @@ class FarSegHead(ERModule):
 
     def set_default_config(self):
         self.config.update(dict(
+            relation_version='v1',
             fpn=dict(in_channels_list=(256, 512, 1024, 2048), out_channels=256),
             fs_relation=dict(scene_embedding_channels=2048, in_channels_list=(256, 256, 256, 256), out_channels=256,
                              scale_aware_proj=True),
@@ -137,3 +147,13 @@ class FarSegHead(ERModule):
                              out_feat_output_stride=4,
                              classifier_config=dict(scale_factor=4.0, num_classes=1, kernel_size=1)),
         ))
+
+
+@registry.MODEL.register(verbose=False)
+class FarSegPPHead(FarSegHead):
+    """FarSeg++ head (BASELINE config C3): FPN -> FSRelationV2 -> AssymetricDecoder.  Same state-dict prefixes as
+    FarSegHead (`fpn.`, `fs_relation.` incl. `fs_relation.project.*`, `fpn_decoder.`)."""
+
+    def set_default_config(self):
+        super().set_default_config()
+        self.config.update(dict(relation_version='v2'))

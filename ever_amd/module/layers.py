@@ -132,6 +132,11 @@ def _unwrap(m):
     return inner if inner is not None else m
 
 
+def _fold():
+    from . import fold
+    return fold
+
+
 def run_sequence(mods, x):
     """Run modules in order with peephole fusion: conv->ReLU (epilogue), BN->ReLU (one pass)."""
     mods = [_unwrap(m) for m in mods]
@@ -140,9 +145,9 @@ def run_sequence(mods, x):
         m = mods[i]
         nxt = mods[i + 1] if i + 1 < n else None
         if isinstance(m, Conv2d) and getattr(m, '_folded', None) is not None and nxt is not None \
-                and getattr(nxt, '_folded_into', None) is m and not nxt.training and not torch.is_grad_enabled():
+                and _fold()._use_folded(m, nxt):
             # inference: conv + folded BatchNorm (+ ReLU) in one launch (module/fold.py)
-            from .fold import folded_conv2d
+            folded_conv2d = _fold().folded_conv2d
             relu = i + 2 < n and isinstance(mods[i + 2], nn.ReLU)
             x = folded_conv2d(x, m, relu=relu)
             i += 3 if relu else 2

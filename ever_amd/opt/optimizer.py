@@ -9,6 +9,7 @@ from torch.optim.sgd import SGD
 
 from .. import _C
 from ..hip import weight_planes
+from ..hip.ptr_table import PtrTable as _PtrTable
 from ..core import registry
 
 __all__ = ['FusedSGD']
@@ -19,7 +20,7 @@ class FusedSGD(SGD):
         super().__init__(params, lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay,
                          nesterov=nesterov, **{k: v for k, v in kwargs.items() if k in ('maximize',)})
         self._clip = None          # (max_norm,) set by fused_clip for the next step
-        self._clip_bufs = None
+        self._tabs = {}
         self.last_grad_norm = None
 
     # ERModule.clip_grad calls this instead of torch's clip_grad_norm_ (reference module.py:96-108)
@@ -34,7 +35,11 @@ class FusedSGD(SGD):
         dev = params[0].device
         lib = _C.load()
         nb = lib.evk_opt_blocks_per_tensor()
-        grads, sizes = self._tables([p.grad for p in params], dev)
+        for p in params:
+            if not self._dense(p.grad):
+                p.grad = torch.empty_like(p).copy_(p.grad)
+        grads = self._table('clip_g', [p.grad for p in params], dev)
+        sizes = self._table('clip_n', params, dev, sizes=True)
         partial = torch.empty((nb * len(params),), device=dev, dtype=torch.float64)
         norm = torch.empty((), device=dev, dtype=torch.float32)
         coef = torch.empty((), device=dev, dtype=torch.float32)
@@ -47,28 +52,47 @@ class FusedSGD(SGD):
     def _dense(t):
         return t.is_contiguous() or (t.dim() == 4 and t.permute(0, 2, 3, 1).is_contiguous())
 
-    @classmethod
-    def _tables(cls, tensors, dev):
-        if not all(cls._dense(t) for t in tensors):
-            raise RuntimeError('FusedSGD: parameters / gradients must be dense')
-        ptrs = torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64).to(dev, non_blocking=True)
-        sizes = torch.tensor([t.numel() for t in tensors], dtype=torch.int64).to(dev, non_blocking=True)
-        return ptrs, sizes
+    def _table(self, slot, tensors, dev, sizes=False):
+        """Device array of the tensors' addresses (or element counts).  The arrays live in persistent pinned + device
+        buffers and are re-uploaded only when an address actually changed: parameters, momentum buffers and
+        bucket-view gradients (FlatGradDDP) are stable, so the steady state issues no H2D copy at all, and a changed
+        table goes up from pinned memory without blocking the host (SURVEY §8 e: no per-step host sync)."""
+        vals = [t.numel() for t in tensors] if sizes else [t.data_ptr() for t in tensors]
+        tab = self._tabs.get(slot)
+        if tab is None or tab.n != len(vals) or tab.dev != dev:
+            tab = self._tabs[slot] = _PtrTable(len(vals), dev)
+        return tab.upload(vals)
 
-    def _launch(self, group, params, first):
+    @staticmethod
+    def _same_layout(a, b):
+        """element i of `a` is element i of `b` in memory"""
+        return a.stride() == b.stride() or (a.is_contiguous() and b.is_contiguous()) or (
+            a.dim() == 4 and a.permute(0, 2, 3, 1).is_contiguous() and b.permute(0, 2, 3, 1).is_contiguous())
+
+    def _launch(self, group, params, first, slot):
         dev = params[0].device
         mom = group['momentum']
         for p in params:
-            g = p.grad
-            same_layout = (g.is_contiguous() and p.is_contiguous()) or (
-                p.dim() == 4 and g.permute(0, 2, 3, 1).is_contiguous() and p.permute(0, 2, 3, 1).is_contiguous())
-            if not same_layout:  # element i of the grad must be element i of the parameter in memory
-                p.grad = torch.empty_like(p).copy_(g)
-        pt, sizes = self._tables(params, dev)
-        gt, _ = self._tables([p.grad for p in params], dev)
+            if not self._dense(p):
+                raise RuntimeError('FusedSGD: parameters / gradients must be dense')
+            if not (self._dense(p.grad) and self._same_layout(p.grad, p)):
+                p.grad = torch.empty_like(p).copy_(p.grad)
+        pt = self._table((slot, 'p'), params, dev)
+        sizes = self._table((slot, 'n'), params, dev, sizes=True)
+        gt = self._table((slot, 'g'), [p.grad for p in params], dev)
         bt = None
         if mom != 0:
-            bt, _ = self._tables([self.state[p]['momentum_buffer'] for p in params], dev)
+            bufs = []
+            for p in params:
+                st = self.state[p]
+                buf = st['momentum_buffer']
+                if not (self._dense(buf) and self._same_layout(buf, p)):
+                    # a buffer restored from a reference / torch.optim.SGD checkpoint keeps the checkpoint's strides
+                    # (NCHW-dense) while the convolution weights here are channels_last: re-lay it once, or the kernel
+                    # would pair momentum element i with a different weight element
+                    buf = st['momentum_buffer'] = torch.empty_like(p).copy_(buf)
+                bufs.append(buf)
+            bt = self._table((slot, 'b'), bufs, dev)
         _C.call('evk_sgd_multi', pt.data_ptr(), gt.data_ptr(), None if bt is None else bt.data_ptr(),
                 sizes.data_ptr(), len(params), float(group['lr']), float(mom), float(group['dampening']),
                 float(group['weight_decay']), 1 if group['nesterov'] else 0, 1 if first else 0,
@@ -76,13 +100,20 @@ class FusedSGD(SGD):
         # the kernel wrote the parameters through raw pointers: autograd's version counters did not move
         weight_planes.note_weights_changed()
 
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for p, st in self.state.items():
+            buf = st.get('momentum_buffer')
+            if buf is not None and not (self._dense(buf) and self._same_layout(buf, p)):
+                st['momentum_buffer'] = torch.empty_like(p).copy_(buf)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             params = [p for p in group['params'] if p.grad is not None]
             if not params:
                 continue
@@ -102,9 +133,9 @@ class FusedSGD(SGD):
                 for p in fresh:  # torch: buf = clone(d_p) on first use; the kernel writes it (first_step=1)
                     self.state[p]['momentum_buffer'] = torch.empty_like(p)
             if fresh:
-                self._launch(group, fresh, True)
+                self._launch(group, fresh, True, (gi, 'fresh'))
             if warm:
-                self._launch(group, warm, False)
+                self._launch(group, warm, False, (gi, 'warm'))
         self._clip = None
         return loss
 

@@ -21,7 +21,7 @@ __all__ = ['FlatGradDDP']
 
 class _Bucket:
     __slots__ = ('params', 'offsets', 'numel', 'flat', 'views', 'ready', 'flushed', 'work', 'sizes_dev', 'offsets_dev',
-                 '_keep')
+                 '_keep', 'ptr_table')
 
 
 class FlatGradDDP(nn.Module):
@@ -75,6 +75,7 @@ class FlatGradDDP(nn.Module):
         b.ready = [False] * len(b.params)
         b.flushed = False
         b.work = None
+        b.ptr_table = None
         b.sizes_dev = torch.tensor([p.numel() for p in b.params], dtype=torch.int64, device=self.device)
         b.offsets_dev = torch.tensor(b.offsets, dtype=torch.int64, device=self.device)
         return b
@@ -142,11 +143,15 @@ class FlatGradDDP(nn.Module):
         scale = 1.0 / self.world
         grads = [None if p.grad is None else self._dense_like_param(p.grad, p) for p in b.params]
         if self._cuda:
-            ptrs = torch.tensor([0 if g is None else g.data_ptr() for g in grads], dtype=torch.int64)
-            ptrs = ptrs.to(self.device, non_blocking=True)
+            # addresses go up from a persistent pinned table, and only when one changed (the caching allocator hands
+            # the same blocks back step after step): no pageable H2D copy per bucket on the backward's critical path
+            if b.ptr_table is None:
+                from ..hip.ptr_table import PtrTable
+                b.ptr_table = PtrTable(len(grads), self.device)
+            ptrs = b.ptr_table.upload([0 if g is None else g.data_ptr() for g in grads])
             _C.call('evk_pack_multi', ptrs.data_ptr(), b.sizes_dev.data_ptr(), b.offsets_dev.data_ptr(), len(grads),
                     scale, b.flat.data_ptr(), torch.cuda.current_stream().cuda_stream)
-            b._keep = (grads, ptrs)  # alive until the pack has run
+            b._keep = grads  # alive until the pack has run
         else:
             for g, v in zip(grads, b.views):
                 if g is None:

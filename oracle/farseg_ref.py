@@ -171,6 +171,50 @@ class FSRelationRef(nn.Module):
         return [r * p for r, p in zip(rel, ps)]                                                      # :71
 
 
+class FSRelationV2Ref(nn.Module):
+    """module/fs_relation.py:76-163 (FarSeg++): GroupNorm(32) scene MLP(s), sigmoid relation, re-encoded feature
+    weighted by it and concatenated with the pyramid feature, 1x1 (no bias) -> BN -> ReLU -> Dropout2d(0.1)."""
+
+    def __init__(self, scene_embedding_channels, in_channels_list, out_channels, scale_aware_proj=True, dropout=0.1):
+        super().__init__()
+        self.scale_aware_proj = scale_aware_proj
+
+        def mlp():
+            return nn.Sequential(nn.Conv2d(scene_embedding_channels, out_channels, 1), nn.GroupNorm(32, out_channels),
+                                 nn.ReLU(True), nn.Conv2d(out_channels, out_channels, 1),
+                                 nn.GroupNorm(32, out_channels), nn.ReLU(True))
+
+        def proj():
+            return nn.Sequential(nn.Conv2d(out_channels * 2, out_channels, 1, bias=False), nn.BatchNorm2d(out_channels),
+                                 nn.ReLU(True), nn.Dropout2d(p=dropout))
+
+        def enc(c):
+            return nn.Sequential(nn.Conv2d(c, out_channels, 1), nn.BatchNorm2d(out_channels), nn.ReLU(True))
+
+        # registration order as the reference (:86-120): scene_encoder, project, content_encoders, feature_reencoders
+        if scale_aware_proj:
+            self.scene_encoder = nn.ModuleList([mlp() for _ in in_channels_list])
+            self.project = nn.ModuleList([proj() for _ in in_channels_list])
+        else:
+            self.scene_encoder = mlp()
+            self.project = proj()
+        self.content_encoders = nn.ModuleList([enc(c) for c in in_channels_list])
+        self.feature_reencoders = nn.ModuleList([enc(c) for c in in_channels_list])
+
+    def forward(self, scene, feats):
+        contents = [e(f) for e, f in zip(self.content_encoders, feats)]
+        if self.scale_aware_proj:
+            scenes = [e(scene) for e in self.scene_encoder]
+        else:
+            scenes = [self.scene_encoder(scene)] * len(feats)
+        rel = [torch.sigmoid((s * c).sum(dim=1, keepdim=True)) for s, c in zip(scenes, contents)]   # :143-151
+        ps = [e(f) for e, f in zip(self.feature_reencoders, feats)]
+        refined = [torch.cat([r * p, o], dim=1) for r, p, o in zip(rel, ps, feats)]                 # :155
+        if self.scale_aware_proj:
+            return [op(x) for op, x in zip(self.project, refined)]
+        return [self.project(x) for x in refined]
+
+
 # --------------------------------------------------------------------------- decoder -----------
 class _Wrap(nn.Module):  # key-compatible stand-in for ops.Bf16compatible (module/ops.py:152-166), fp32 no-op
     def __init__(self, m):
@@ -212,10 +256,13 @@ class FarSegHeadRef(nn.Module):
     """module/fs_relation.py:166-206 with its default config."""
 
     def __init__(self, in_channels_list=(256, 512, 1024, 2048), fpn_channels=256, decoder_channels=256,
-                 num_classes=1, classifier_kernel=1):
+                 num_classes=1, classifier_kernel=1, relation_version='v1', dropout=0.1):
         super().__init__()
         self.fpn = FPNRef(in_channels_list, fpn_channels)
-        self.fs_relation = FSRelationRef(in_channels_list[-1], (fpn_channels,) * 4, fpn_channels, True)
+        if relation_version == 'v2':   # FarSeg++ composition: the same head with FSRelationV2 (:76-163)
+            self.fs_relation = FSRelationV2Ref(in_channels_list[-1], (fpn_channels,) * 4, fpn_channels, True, dropout)
+        else:
+            self.fs_relation = FSRelationRef(in_channels_list[-1], (fpn_channels,) * 4, fpn_channels, True)
         self.fpn_decoder = AssymetricDecoderRef(fpn_channels, decoder_channels, classifier_config=dict(
             scale_factor=4.0, num_classes=num_classes, kernel_size=classifier_kernel))
 
@@ -273,11 +320,12 @@ class FarSegRef(nn.Module):
     """encoder + head + loss; state-dict prefixes `en.` / `head.` as ever_amd.module.FarSeg."""
 
     def __init__(self, resnet_type='resnet50', in_channels=3, num_classes=1, decoder_channels=256, classifier_kernel=1,
-                 ignore_index=255):
+                 ignore_index=255, relation_version='v1', dropout=0.1):
         super().__init__()
         self.en = ResNetEncoderRef(resnet_type, in_channels)
         widths = (64, 128, 256, 512) if resnet_type in ('resnet18', 'resnet34') else (256, 512, 1024, 2048)
-        self.head = FarSegHeadRef(widths, 256, decoder_channels, num_classes, classifier_kernel)
+        self.head = FarSegHeadRef(widths, 256, decoder_channels, num_classes, classifier_kernel, relation_version,
+                                  dropout)
         self.num_classes = num_classes
         self.ignore_index = ignore_index
 

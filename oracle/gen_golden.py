@@ -64,18 +64,25 @@ def import_reference():
 
 
 def grad_digest(named_params):
-    """Compact, order-stable summary of a gradient set: L2 norm, sum and 4 strided samples per tensor."""
+    """Compact, order-stable summary of a gradient set: L2 norm, sum, 4 strided samples and the projection on a
+    hash-generated +-1 direction (oracle/portable.py: `sign_vector`) per tensor."""
+    from oracle import portable
     d = {}
     for k, p in named_params:
         g = p.grad.detach().double().reshape(-1)
         idx = np.linspace(0, g.numel() - 1, 4).astype(np.int64)
-        d[k] = [float(g.norm()), float(g.sum())] + [float(g[i]) for i in idx]
+        proj = float((g.numpy() * portable.sign_vector(k, g.numel())).sum())
+        d[k] = [float(g.norm()), float(g.sum())] + [float(g[i]) for i in idx] + [proj]
     return d
 
 
-def build_pair(er, resnet_type, in_channels, num_classes=1, decoder_channels=256, classifier_kernel=1):
+BIAS_KEY = 'head.fpn_decoder.classifier.0.bias'
+
+
+def build_pair(er, resnet_type, in_channels, num_classes=1, decoder_channels=256, classifier_kernel=1,
+               relation_version='v1', classifier_bias=None):
     from ever.module.resnet import ResNetEncoder
-    from ever.module.fs_relation import FarSegHead
+    from ever.module.fs_relation import FarSegHead, FSRelationV2
     from oracle import farseg_ref, portable
     widths = (64, 128, 256, 512) if resnet_type in ('resnet18', 'resnet34') else (256, 512, 1024, 2048)
     en = ResNetEncoder(dict(resnet_type=resnet_type, in_channels=in_channels))
@@ -86,6 +93,14 @@ def build_pair(er, resnet_type, in_channels, num_classes=1, decoder_channels=256
         fpn_decoder=dict(in_channels=256, out_channels=decoder_channels, in_feat_output_strides=(4, 8, 16, 32),
                          out_feat_output_stride=4,
                          classifier_config=dict(scale_factor=4.0, num_classes=num_classes, kernel_size=classifier_kernel))))
+    if relation_version == 'v2':
+        # FarSeg++: the reference ships FSRelationV2 (fs_relation.py:76-163) but no head that composes it; the
+        # composition is FarSegHead.forward (:175-181) with the relation module swapped.  Dropout2d p=0 makes the
+        # training-mode run deterministic (the mask path is tested against its formula in test_next_rows_gpu.py).
+        head.fs_relation = FSRelationV2(widths[-1], (256,) * 4, 256, scale_aware_proj=True)
+        for mod in head.fs_relation.modules():
+            if isinstance(mod, torch.nn.Dropout2d):
+                mod.p = 0.0
 
     class RefModel(torch.nn.Module):
         def __init__(self):
@@ -96,22 +111,47 @@ def build_pair(er, resnet_type, in_channels, num_classes=1, decoder_channels=256
             return self.head(self.en(x))
 
     ref = RefModel()
-    ora = farseg_ref.FarSegRef(resnet_type, in_channels, num_classes, decoder_channels, classifier_kernel)
+    ora = farseg_ref.FarSegRef(resnet_type, in_channels, num_classes, decoder_channels, classifier_kernel,
+                               relation_version=relation_version, dropout=0.0)
     assert list(ref.state_dict().keys()) == list(ora.state_dict().keys()), 'state-dict keys differ'
     filled = portable.fill_state_dict(ora.state_dict())
+    if classifier_bias is not None:
+        filled[BIAS_KEY] = np.asarray(classifier_bias, dtype=np.float32)
     farseg_ref.load_portable_weights(ref, filled)
     farseg_ref.load_portable_weights(ora, filled)
     return ref, ora
 
 
-def e2e_case(er, name, resnet_type, in_channels, n, hw, num_classes=1, decoder_channels=256, classifier_kernel=1):
+def pick_classifier_bias(er, name, x, cfg):
+    """The fixture's classifier bias, moved so that NO pixel of the training-mode prediction sits near its decision
+    boundary (SURVEY §7 'argmax bit-exactness near ties'): the threshold in the widest empty interval of the logits
+    (one class), or the best of 400 hashed per-class bias vectors (several classes).  Returns the bias values."""
+    from oracle import portable
+    ref, _ = build_pair(er, *cfg)
+    ref.train()
+    with torch.no_grad():
+        lg = ref(x).numpy()
+    b0 = ref.state_dict()[BIAS_KEY].numpy().astype(np.float64)
+    if lg.shape[1] == 1:
+        s, half = portable.widest_gap_shift(lg)
+        bias = (b0 + s).astype(np.float32)
+    else:
+        db, gap = portable.widest_gap_bias(lg, name)
+        bias = (b0 + db.astype(np.float64)).astype(np.float32)
+    return bias
+
+
+def e2e_case(er, name, resnet_type, in_channels, n, hw, num_classes=1, decoder_channels=256, classifier_kernel=1,
+             relation_version='v1'):
     import ever.module.loss as rloss
     import torch.nn.functional as F
     from oracle import portable
     torch.manual_seed(0)
-    ref, ora = build_pair(er, resnet_type, in_channels, num_classes, decoder_channels, classifier_kernel)
+    cfg = (resnet_type, in_channels, num_classes, decoder_channels, classifier_kernel, relation_version)
     x_np, y_np = portable.synthetic_batch(name, n, in_channels, hw, hw, num_classes)
     x, y = torch.from_numpy(x_np), torch.from_numpy(y_np)
+    bias = pick_classifier_bias(er, name, x, cfg)
+    ref, ora = build_pair(er, *cfg, classifier_bias=bias)
     ref.train()
     ora.train()
     lg_ref = ref(x)
@@ -135,7 +175,7 @@ def e2e_case(er, name, resnet_type, in_channels, n, hw, num_classes=1, decoder_c
     # fp64 run of the SAME reference modules: measures how far fp32 rounding alone moves each
     # gradient on this input (tiny tiles give 8-sample BatchNorm statistics in layer4, which amplify
     # rounding by ~1e4); the GPU parity test sizes its gradient tolerance from this.
-    ref64, _ = build_pair(er, resnet_type, in_channels, num_classes, decoder_channels, classifier_kernel)
+    ref64, _ = build_pair(er, *cfg, classifier_bias=bias)
     ref64 = ref64.double().train()
     lg64 = ref64(x.double())
     if num_classes == 1:
@@ -146,6 +186,14 @@ def e2e_case(er, name, resnet_type, in_channels, n, hw, num_classes=1, decoder_c
     l64.backward()
     gnorm64 = {k: float(p.grad.norm()) for k, p in ref64.named_parameters()}
     logits_noise = float((lg64.detach() - lg_ref.detach().double()).abs().max() / lg64.detach().abs().max())
+    rng = float(lg_ref.detach().abs().max())
+    margin = portable.mask_margin(lg_ref.detach().numpy())
+    m64 = portable.mask_margin(lg64.detach().numpy())
+    flips64 = int(((lg_ref.detach().numpy() > 0) != (lg64.detach().numpy() > 0)).sum()) if num_classes == 1 else \
+        int((lg_ref.detach().numpy().argmax(1) != lg64.detach().numpy().argmax(1)).sum())
+    print(f'[margin] {name}: smallest decision margin {margin.min() / rng:.2e} of the logit range '
+          f'({int((margin < 1e-3 * rng).sum())} of {margin.size} pixels inside 1e-3; fp64 reference: '
+          f'{m64.min() / rng:.2e}, {flips64} fp32-vs-fp64 mask flips)')
     # eval-mode logits (running statistics after one training step)
     ref.eval()
     with torch.no_grad():
@@ -157,10 +205,12 @@ def e2e_case(er, name, resnet_type, in_channels, n, hw, num_classes=1, decoder_c
                         **{k: np.float64(v.item()) for k, v in losses_ref.items()})
     meta = dict(resnet_type=resnet_type, in_channels=in_channels, n=n, hw=hw, num_classes=num_classes,
                 decoder_channels=decoder_channels, classifier_kernel=classifier_kernel,
+                relation_version=relation_version, classifier_bias=[float(b) for b in bias],
+                min_margin_rel=float(margin.min() / rng), pixels_inside_1e3=int((margin < 1e-3 * rng).sum()),
                 losses={k: float(v.item()) for k, v in losses_ref.items()},
                 grads=grad_digest(ref.named_parameters()), grad_norm_fp64=gnorm64, logits_fp32_vs_fp64=logits_noise,
                 running=bdig,
-                argmax_margin=float(lg_ref.detach().abs().min()) if num_classes == 1 else None)
+                argmax_margin=float(margin.min()))
     with open(os.path.join(OUT, f'e2e_{name}.json'), 'w') as f:
         json.dump(meta, f)
 
@@ -421,6 +471,16 @@ def fsrel_v2_case(er):
         print('FSRelationV2 scale_aware_proj =', sap, ':', len(arrays), 'arrays')
 
 
+E2E_CASES = [
+    ('r18_4band_64', 'resnet18', 4, 2, 64, {}),
+    ('r50_3band_64', 'resnet50', 3, 2, 64, {}),
+    ('r50_3band_128', 'resnet50', 3, 2, 128, {}),
+    ('r50_3band_64_c16', 'resnet50', 3, 2, 64, dict(num_classes=16, decoder_channels=128, classifier_kernel=3)),
+    ('r50_3band_256', 'resnet50', 3, 2, 256, {}),                       # well-conditioned gradients: tight bound
+    ('pp_r50_4band_64', 'resnet50', 4, 2, 64, dict(relation_version='v2')),   # FarSeg++ (config C3's model)
+]
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     er = import_reference()
@@ -429,6 +489,11 @@ def main():
     only = sys.argv[1] if len(sys.argv) > 1 else None
     if only == 'launcher':
         launcher_case(er)
+        return
+    if only == 'e2e':
+        for a in E2E_CASES:
+            if len(sys.argv) < 3 or a[0] in sys.argv[2:]:
+                e2e_case(er, *a[:5], **a[5])
         return
     if only == 'next':
         next_rows_kats(er)
@@ -439,10 +504,8 @@ def main():
     next_rows_kats(er)
     fsrel_v2_case(er)
     launcher_case(er)
-    e2e_case(er, 'r18_4band_64', 'resnet18', 4, 2, 64)
-    e2e_case(er, 'r50_3band_64', 'resnet50', 3, 2, 64)
-    e2e_case(er, 'r50_3band_128', 'resnet50', 3, 2, 128)
-    e2e_case(er, 'r50_3band_64_c16', 'resnet50', 3, 2, 64, num_classes=16, decoder_channels=128, classifier_kernel=3)
+    for a in E2E_CASES:
+        e2e_case(er, *a[:5], **a[5])
     with open(os.path.join(OUT, 'PROVENANCE.json'), 'w') as f:
         json.dump(dict(reference='Z-Zheng/ever', version=er.__version__, torch=torch.__version__,
                        generated_by='oracle/gen_golden.py',

@@ -41,6 +41,11 @@ def normalish(key, shape):
     return ((s - 2.0) * np.sqrt(3.0)).astype(np.float32).reshape(shape)
 
 
+def sign_vector(key, n):
+    """n hash-generated +-1 values (float64): a fixed random direction for gradient projections."""
+    return np.where(uniform01(key + '/sign', n) < 0.5, -1.0, 1.0)
+
+
 def integers(key, shape, hi):
     n = int(np.prod(shape))
     return np.minimum((uniform01(key, n) * hi).astype(np.int64), hi - 1).reshape(shape)
@@ -81,3 +86,42 @@ def synthetic_batch(key, n, c, h, w, num_classes=1, p_fg=0.3, ignore_block=8):
     if ignore_block:
         y[:, :ignore_block, :ignore_block] = 255
     return x, y
+
+
+# ------------------------------------------------------------------ mask-decision margins of a fixture
+def mask_margin(logits):
+    """Per-pixel decision margin of a prediction: |logit| for one channel (threshold 0), top-1 minus top-2 otherwise."""
+    lg = np.asarray(logits, dtype=np.float64)
+    if lg.shape[1] == 1:
+        return np.abs(lg[:, 0])
+    srt = np.sort(lg, axis=1)
+    return srt[:, -1] - srt[:, -2]
+
+
+def widest_gap_shift(logits, window=0.05):
+    """Binary head: the bias shift s with |s| <= window * max|logit| that puts the threshold in the middle of the WIDEST
+    empty interval of the logit values (so that no pixel of the fixture sits near the decision).  A shift of the 1x1
+    classifier's bias moves every logit by s (bilinear weights sum to one).  Returns (s, half-width of the gap)."""
+    v = np.sort(np.asarray(logits, dtype=np.float64).reshape(-1))
+    r = np.abs(v).max()
+    lo, hi = np.searchsorted(v, -window * r), np.searchsorted(v, window * r)
+    seg = v[max(lo - 1, 0):hi + 1]
+    gaps = np.diff(seg)
+    i = int(np.argmax(gaps))
+    mid = 0.5 * (seg[i] + seg[i + 1])
+    return float(-mid), float(0.5 * gaps[i])
+
+
+def widest_gap_bias(logits, key, tries=400, scale=0.03):
+    """Multi-class head: among `tries` hash-generated per-class bias vectors (|b| <= scale * logit range) the one that
+    maximises the smallest top-1 / top-2 gap over the fixture's pixels.  Returns (bias [C] float32, smallest gap)."""
+    lg = np.asarray(logits, dtype=np.float64)
+    c = lg.shape[1]
+    r = np.abs(lg).max()
+    best, best_gap = np.zeros(c, dtype=np.float32), float(mask_margin(lg).min())
+    for t in range(tries):
+        b = uniform(f'{key}/bias{t}', (c,), -scale * r, scale * r)
+        g = float(mask_margin(lg + b.astype(np.float64).reshape(1, c, 1, 1)).min())
+        if g > best_gap:
+            best, best_gap = b, g
+    return best, best_gap

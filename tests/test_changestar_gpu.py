@@ -89,3 +89,47 @@ def test_changestar_training_step_is_finite_and_order_losses_are_symmetric(cuda)
     m.zero_grad(set_to_none=True)
     li = m(xi, dict(change=y['change']))
     assert torch.allclose(li['change12_bce_loss'], li['change21_bce_loss'], rtol=1e-6)
+
+
+def test_config_c4_batch8_training_step_and_order_symmetry(cuda):
+    """BASELINE configuration C4 at its stated per-GPU size: ChangeStar(FarSeg-R50 + ChangeMixin), bitemporal
+    2 x (3 x 512 x 512), BATCH 8, one full training step (forward, six losses, backward, fused SGD).  Properties at
+    that size: every loss / gradient / updated parameter is finite; the semantic losses of the two dates swap when the
+    dates swap (training-mode BatchNorm sees the same 16 images either way); with identical dates the two change
+    orders coincide."""
+    import ever_amd as er
+    torch.manual_seed(13)
+    m = er.module.ChangeStarFarSeg(dict()).to(cuda).train()
+    opt = er.opt.FusedSGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    g = torch.Generator(device='cpu').manual_seed(77)
+    x = torch.randn(8, 6, 512, 512, generator=g).to(cuda)
+    y = dict(cls=(torch.rand(8, 512, 512, generator=g) < 0.3).long().to(cuda),
+             cls2=(torch.rand(8, 512, 512, generator=g) < 0.3).long().to(cuda))
+    y['change'] = (y['cls'] != y['cls2']).long()
+    y['change'][:, :8, :8] = 255
+    losses = m(x, y)
+    assert set(losses) == {'t1_bce_loss', 't1_dice_loss', 't2_bce_loss', 't2_dice_loss', 'change12_bce_loss',
+                           'change21_bce_loss'}
+    sum(losses.values()).backward()
+    assert all(torch.isfinite(v) for v in losses.values())
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    first = {k: float(v) for k, v in losses.items()}
+    m.zero_grad(set_to_none=True)
+    # swapped dates (same weights, same 16 images in the BatchNorm batches, other order along the batch)
+    xs = torch.cat([x[:, 3:], x[:, :3]], dim=1)
+    ys = dict(cls=y['cls2'], cls2=y['cls'], change=y['change'])
+    with torch.no_grad():
+        swapped = {k: float(v) for k, v in m(xs, ys).items()}
+    for a, b in (('t1_bce_loss', 't2_bce_loss'), ('t1_dice_loss', 't2_dice_loss'), ('change12_bce_loss', 'change21_bce_loss')):
+        assert abs(first[a] - swapped[b]) <= 1e-3 * abs(first[a]), (a, first[a], swapped[b])
+        assert abs(first[b] - swapped[a]) <= 1e-3 * abs(first[b]), (b, first[b], swapped[a])
+    # the optimizer step on the first batch's gradients
+    losses = m(x, y)
+    sum(losses.values()).backward()
+    opt.step()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p).all() for p in m.parameters())
+    xi = torch.cat([x[:, :3], x[:, :3]], dim=1)
+    with torch.no_grad():
+        li = m(xi, dict(change=y['change']))
+    assert torch.allclose(li['change12_bce_loss'], li['change21_bce_loss'], rtol=1e-6)

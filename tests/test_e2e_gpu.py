@@ -17,9 +17,10 @@ GOLD = os.path.join(os.path.dirname(__file__), 'golden')
 
 
 def _hip_model(meta, dev):
-    from ever_amd.module import FarSeg
+    from ever_amd.module import FarSeg, FarSegPP
     widths = (64, 128, 256, 512) if meta['resnet_type'] in ('resnet18', 'resnet34') else (256, 512, 1024, 2048)
-    m = FarSeg(dict(
+    cls = FarSegPP if meta.get('relation_version', 'v1') == 'v2' else FarSeg
+    m = cls(dict(
         encoder=dict(resnet_type=meta['resnet_type'], in_channels=meta['in_channels']),
         head=dict(fpn=dict(in_channels_list=widths, out_channels=256),
                   fs_relation=dict(scene_embedding_channels=widths[-1], in_channels_list=(256,) * 4, out_channels=256,
@@ -28,7 +29,12 @@ def _hip_model(meta, dev):
                                    classifier_config=dict(scale_factor=4.0, num_classes=meta['num_classes'],
                                                           kernel_size=meta['classifier_kernel'])))))
     filled = portable.fill_state_dict(m.state_dict())
+    if meta.get('classifier_bias') is not None:   # the fixture's bias: no pixel near a decision boundary (gen_golden.py)
+        filled['head.fpn_decoder.classifier.0.bias'] = np.asarray(meta['classifier_bias'], dtype=np.float32)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in filled.items()}, strict=True)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout2d):
+            mod.p = 0.0                           # as in the golden run (deterministic training-mode forward)
     return m.to(dev)
 
 
@@ -37,11 +43,16 @@ def _rel_err(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-def _check_masks(lg, ref, num_classes, what):
-    """Prediction masks (threshold 0 for one logit channel, argmax otherwise) must be identical on
-    every pixel the reference decides by more than the contract tolerance (1e-3 of the logit range).
-    Pixels inside that tie margin are counted and reported: with random-init weights a few of the
-    ~1e4..1e5 pixels land within 1e-5 of a tie, where fp32 summation order alone decides."""
+def _check_masks(lg, ref, num_classes, what, exact=False):
+    """Prediction masks (threshold 0 for one logit channel, argmax otherwise).
+
+    exact=True (the committed training-mode goldens): BIT-EXACT, zero flipped pixels.  Those fixtures' classifier
+    bias was placed by gen_golden.py in the widest empty interval of the reference's logits, so their smallest
+    decision margin (printed; `min_margin_rel` in the fixture) is far above the kernels' rounding differences.  Any
+    continuous logit field over 1e4..1e5 pixels has tens of pixels inside +-1e-3 of the range, so 'no pixel inside
+    the contract margin' is not attainable by choosing inputs; 'no pixel inside the rounding noise' is, and is pinned.
+    exact=False (eval-mode logits, live-oracle sizes — no margin was engineered): identical on every pixel the
+    reference decides by more than the contract tolerance (1e-3 of the logit range); flips inside are reported."""
     tol = 1e-3 * np.abs(ref).max()
     if num_classes == 1:
         ma, mb = lg > 0, ref > 0
@@ -54,12 +65,24 @@ def _check_masks(lg, ref, num_classes, what):
     assert np.array_equal(ma[decided], mb[decided]), f'{what}: masks differ outside the tie margin'
     flips = int((ma != mb).sum())
     ties = int((~decided).sum())
+    if exact:
+        assert flips == 0, (f'{what}: {flips} mask pixels differ from the reference (smallest reference margin '
+                            f'{margin.min() / np.abs(ref).max():.2e} of the logit range)')
     assert flips <= ties, f'{what}: {flips} mask flips but only {ties} pixels within the tie margin'
     print(f'{what}: masks identical on {int(decided.sum())}/{decided.size} decided pixels; '
-          f'{ties} pixels inside the 1e-3 tie margin, {flips} of them flipped')
+          f'{ties} pixels inside the 1e-3 tie margin, {flips} of them flipped; smallest reference margin '
+          f'{margin.min() / np.abs(ref).max():.2e}, largest logit difference {np.abs(lg - ref).max() / np.abs(ref).max():.2e} '
+          f'of the range')
+    return flips
 
 
-@pytest.mark.parametrize('name', ['r18_4band_64', 'r50_3band_64', 'r50_3band_128', 'r50_3band_64_c16'])
+# per-tensor gradient bounds of the well-conditioned fixture (R50, 2 x 3 x 256 x 256: >= 64-sample BatchNorm statistics
+# everywhere), relative to the tensor's fp64 norm: norm, hashed +-1 projection, sum and the 4 stored samples
+TIGHT = dict(norm=5e-3, proj=2e-2, sample=2e-2)
+
+
+@pytest.mark.parametrize('name', ['r18_4band_64', 'r50_3band_64', 'r50_3band_128', 'r50_3band_64_c16', 'r50_3band_256',
+                                  'pp_r50_4band_64'])
 def test_farseg_matches_reference_golden(cuda, name, conv_math):
     with open(os.path.join(GOLD, f'e2e_{name}.json')) as f:
         meta = json.load(f)
@@ -74,7 +97,9 @@ def test_farseg_matches_reference_golden(cuda, name, conv_math):
     torch.cuda.synchronize()
     lg_np = lg.detach().cpu().contiguous().numpy()
     assert _rel_err(lg_np, gold['logits']) < 1e-3, f'logits rel err {_rel_err(lg_np, gold["logits"]):.2e}'
-    _check_masks(lg_np, gold['logits'], meta['num_classes'], name)
+    # bit-exact wherever the fixture's smallest margin is above the rounding noise (every golden but the 131072-pixel
+    # gradient fixture, whose widest empty interval is only 6e-5 of the range)
+    _check_masks(lg_np, gold['logits'], meta['num_classes'], name, exact=meta['min_margin_rel'] >= 1e-4)
     for k, v in meta['losses'].items():
         assert abs(losses[k].item() - v) <= 1e-3 * abs(v), (k, losses[k].item(), v)
     # Gradients.  The backward of a ReLU / max-pool network is DISCONTINUOUS in its activations: a
@@ -95,6 +120,31 @@ def test_farseg_matches_reference_golden(cuda, name, conv_math):
         if abs(gn - ref64) > tol:
             bad.append((k, gn, ref32, ref64))
     assert not bad, f'{len(bad)} gradient norms off: {bad[:5]}'
+    # the stored samples / sum / projection of every gradient tensor (gen_golden.py:grad_digest), measured against the
+    # tensor's own scale: e = |hip - ref| / (fp64 norm of the tensor).  A wrong layout, a dropped tap or a missing
+    # term shows up as e ~ 1 on the samples and the projection even when the norm happens to agree.
+    worst = dict(norm=0.0, proj=0.0, sample=0.0)
+    for k, p in m.named_parameters():
+        d, ref64 = meta['grads'][k], meta['grad_norm_fp64'][k]
+        if ref64 < 1e-6:
+            continue
+        g = p.grad.detach().double().reshape(-1).cpu()
+        idx = np.linspace(0, g.numel() - 1, 4).astype(np.int64)
+        # samples are single elements: scale by the tensor's RMS * 8 (a sample is one draw of the element distribution)
+        rms = ref64 / np.sqrt(g.numel())
+        e_s = max(abs(float(g[i]) - d[2 + j]) for j, i in enumerate(idx)) / (8 * rms + 1e-12)
+        e_p = abs(float((g.numpy() * portable.sign_vector(k, g.numel())).sum()) - d[6]) / ref64 if len(d) > 6 else 0.0
+        e_n = abs(float(g.norm()) - d[0]) / ref64
+        worst = dict(norm=max(worst['norm'], e_n), proj=max(worst['proj'], e_p), sample=max(worst['sample'], e_s))
+    print(f'{name}: worst per-tensor gradient deviations from the reference digest: {worst} (reference fp32-vs-fp64 '
+          f'norm deviation {case_dev:.1e})')
+    if name == 'r50_3band_256':
+        for kk, bound in TIGHT.items():
+            assert worst[kk] <= bound, f'{name}: gradient {kk} deviation {worst[kk]:.2e} > {bound}'
+    else:
+        # badly conditioned small tiles: samples and projections within the same conditioning-scaled budget as norms
+        lim = max(5e-2, 12.0 * case_dev)
+        assert worst['proj'] <= lim and worst['sample'] <= lim, (worst, lim)
     # running statistics after one step, then eval-mode logits
     sd = m.state_dict()
     for k, (s, nrm) in meta['running'].items():

@@ -111,13 +111,17 @@ def test_training_step_at_full_size_is_finite_and_stem_statistics_match_fp64(cud
     assert float((rv - (0.9 + 0.1 * var)).abs().max()) <= 1e-5 * float(var.abs().max() + 1.0)
 
 
-def test_config_c3_size_training_step_and_backward_linearity(cuda):
-    """SURVEY §8 configuration C3's size on one GPU: 4-band 1024x1024 tiles, batch 8 (maps of 256^2 .. 32^2: twice the
-    GEMM rows of the bench workload, the 4-band stem through the channel-padded fp32 path).  A training step is
-    finite, the stem statistics match fp64, and with frozen statistics the backward is linear in the batch."""
+def test_config_c3_farsegpp_training_step_and_backward_linearity(cuda):
+    """BASELINE configuration C3 on one GPU as stated: FarSeg++ (ResNet-50 + FPN + FSRelationV2 + decoder), 4-band
+    1024x1024 tiles, batch 8 (maps of 256^2 .. 32^2: twice the GEMM rows of the bench workload; the 4-band stem through
+    the channel-padded fp32 path; GroupNorm scene MLPs, channel concat, 512->256 projection, Dropout2d in the relation
+    module).  A training step is finite, the stem statistics match fp64, and with frozen statistics (and Dropout2d off)
+    the backward is linear in the batch."""
     import ever_amd as er
+    from ever_amd.module.fs_relation import FSRelationV2
     torch.manual_seed(7)
-    m = er.module.FarSeg(dict(encoder=dict(in_channels=4))).to(cuda).train()
+    m = er.module.FarSegPP(dict(encoder=dict(in_channels=4))).to(cuda).train()
+    assert isinstance(m.head.fs_relation, FSRelationV2)
     g = torch.Generator(device='cpu').manual_seed(123)
     x = torch.randn(8, 4, 1024, 1024, generator=g).to(cuda)
     y = (torch.rand(8, 1024, 1024, generator=g) < 0.3).long()

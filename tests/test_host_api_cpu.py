@@ -240,3 +240,69 @@ def test_split_job_tables_are_host_side_and_match_the_plane_layouts():
     assert lib.evk_conv2d_split_jobs(ctypes.byref(d), 4096, 1, 1 << 20, arr, 1) == -1   # needs room for 4 jobs
     assert lib.evk_conv2d_split_multi(None, None, 0, None) == 0
     assert lib.evk_conv2d_split_multi(None, None, 5, None) == -1
+
+
+def test_pending_log_total_is_the_sum_of_the_losses_only():
+    """reference launcher.py:203-222: total_loss sums the `*loss` entries; averaged tensors (grad_norm from grad_clip,
+    tensor metrics) and python extras are merged afterwards and never enter the total."""
+    import torch
+    from ever_amd.core.launcher import Launcher
+    lz = Launcher.__new__(Launcher)          # only _start_log / log_info_dict are exercised (no model, no files)
+    out = Launcher.log_info_dict(lz, {'cls_loss': torch.tensor(1.0), 'dice_loss': torch.tensor(0.25),
+                                      'grad_norm': torch.tensor(5.0), 'acc': torch.tensor([0.25, 0.75]), 'n': 3})
+    assert out['total_loss'] == 1.25
+    assert out['cls_loss'] == 1.0 and out['dice_loss'] == 0.25 and out['grad_norm'] == 5.0 and out['acc'] == 0.5
+    assert out['n'] == 3
+
+
+def test_launcher_refuses_amp_flags_for_hip_models(tmp_path):
+    """a9: `--mixed_precision bf16|fp16` must not silently train in fp32 on the HIP path."""
+    import torch
+    import pytest
+    import ever_amd as er
+    from ever_amd.core.launcher import Launcher
+    hip = torch.nn.Sequential(er.module.Conv2d(8, 8, 1))
+    for mp in ('bf16', 'fp16'):
+        with pytest.raises(NotImplementedError, match='mixed_precision'):
+            Launcher(str(tmp_path), hip, None, None, mixed_precision=mp)
+    stock = torch.nn.Sequential(torch.nn.Conv2d(8, 8, 1))       # stock torch models keep the reference's autocast
+    Launcher(str(tmp_path), stock, torch.optim.SGD(stock.parameters(), lr=0.1), None, mixed_precision='bf16')
+
+
+def test_fused_sgd_relays_momentum_buffers_of_a_torch_sgd_checkpoint():
+    """Resuming from a reference / torch.optim.SGD checkpoint: its momentum buffers are NCHW-dense while the HIP
+    convolution weights are channels_last (OHWI memory).  The fused kernel pairs elements by memory offset, so the
+    buffers must be re-laid to the parameter's strides (same logical values)."""
+    import torch
+    import ever_amd as er
+    conv = er.module.Conv2d(3, 5, 3)
+    assert conv.weight.stride() == (27, 1, 9, 3)
+    stock = torch.nn.Conv2d(3, 5, 3)
+    stock.load_state_dict(conv.state_dict())
+    ref_opt = torch.optim.SGD(stock.parameters(), lr=0.1, momentum=0.9)
+    stock(torch.randn(2, 3, 8, 8)).sum().backward()
+    ref_opt.step()
+    state = ref_opt.state_dict()
+    assert state['state'][0]['momentum_buffer'].stride() == (27, 9, 3, 1)
+    opt = er.opt.FusedSGD(conv.parameters(), lr=0.1, momentum=0.9)
+    opt.load_state_dict(state)
+    buf = opt.state[conv.weight]['momentum_buffer']
+    assert buf.stride() == conv.weight.stride()
+    assert torch.equal(buf, state['state'][0]['momentum_buffer'])           # logical values untouched
+    assert torch.equal(opt.state[conv.bias]['momentum_buffer'], state['state'][1]['momentum_buffer'])
+
+
+def test_farsegpp_head_builds_fsrelation_v2_with_reference_keys():
+    import ever_amd as er
+    from ever_amd.module.fs_relation import FSRelation, FSRelationV2
+    assert isinstance(er.module.FarSegHead(dict()).fs_relation, FSRelation)
+    h = er.module.FarSegPPHead(dict())
+    assert isinstance(h.fs_relation, FSRelationV2)
+    assert isinstance(er.module.FarSegHead(dict(relation_version='v2')).fs_relation, FSRelationV2)
+    keys = set(h.state_dict())
+    assert {'fs_relation.project.0.0.weight', 'fs_relation.project.3.1.running_var',
+            'fs_relation.scene_encoder.2.1.weight', 'fs_relation.scene_encoder.0.4.bias'} <= keys
+    from oracle import farseg_ref
+    ora = farseg_ref.FarSegHeadRef(relation_version='v2')
+    assert list(ora.state_dict().keys()) == list(h.state_dict().keys())
+    assert er.registry.MODEL['FarSegPP'] is er.module.FarSegPP

@@ -300,3 +300,54 @@ def test_cross_entropy_per_pixel_with_ohem_pipeline(cuda):
     got.backward()
     assert abs(got.item() - want.item()) <= 1e-5 * abs(want.item())
     _close(zg.grad.cpu().contiguous().numpy(), zr.grad.numpy(), 1e-5)
+
+
+@pytest.mark.parametrize('c', [1, 5])
+def test_dice_statistics_all_reduce_two_virtual_ranks_equal_full_batch(cuda, c):
+    """Cross-rank dice (reference loss.py:20-23,46-48: inter and z are SUMMED over the ranks before the ratio, through an
+    autograd-aware all-reduce).  Two 'ranks' = two unequal parts of one batch on one GPU; the collective is replaced by
+    a hook that adds the other part's statistics / upstream gradients (what all_reduce(SUM) delivers); everything
+    else is the product path.  Each rank must report the dice loss of the UNION, and d loss / d logits of its own
+    pixels times the world size (the backward all-reduce sums the ranks' upstream gradients; DDP then averages)."""
+    from ever_amd.hip import functional as HF
+    from oracle import farseg_ref
+    gen = torch.Generator().manual_seed(5)
+    z = torch.randn(5, c, 12, 10, generator=gen) * 2
+    y = torch.randint(0, max(c, 2), (5, 12, 10), generator=gen)
+    y[0, :3, :4] = 255
+    parts = [slice(0, 2), slice(2, 5)]
+    zr = z.double().requires_grad_()
+    ref = farseg_ref.dice_ref(zr, y)
+    ref.backward()
+    local = {}
+
+    def grab(i):
+        def hook(t, what):
+            local[(i, what)] = t.clone()
+            return 1
+        return hook
+    for i, sl in enumerate(parts):   # pass 1: what each rank would contribute to the forward all-reduce
+        HF._rank_sum_hook = grab(i)
+        try:
+            HF.dice_loss_with_logits(z[sl].to(cuda), y[sl].to(cuda))
+        finally:
+            HF._rank_sum_hook = None
+    total = local[(0, 'dice_stats')] + local[(1, 'dice_stats')]
+
+    def synced(t, what):
+        if what == 'dice_stats':
+            t.copy_(total)
+        else:
+            t.mul_(2.0)              # every rank's upstream gradient is the same scalar: SUM over 2 ranks
+        return 2
+    for i, sl in enumerate(parts):
+        zi = z[sl].to(cuda).requires_grad_()
+        HF._rank_sum_hook = synced
+        try:
+            li = HF.dice_loss_with_logits(zi, y[sl].to(cuda))
+            li.backward()
+        finally:
+            HF._rank_sum_hook = None
+        assert abs(li.item() - ref.item()) <= 1e-6 * abs(ref.item()) + 1e-7, (i, li.item(), ref.item())
+        ga, gb = zi.grad.cpu().contiguous().double().numpy(), 2.0 * zr.grad[sl].numpy()
+        assert np.abs(ga - gb).max() <= 1e-4 * np.abs(gb).max(), (np.abs(ga - gb).max(), np.abs(gb).max())

@@ -11,7 +11,7 @@ import torch
 from oracle import farseg_ref, portable
 
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
-CASES = ['r18_4band_64', 'r50_3band_64', 'r50_3band_128', 'r50_3band_64_c16']
+CASES = ['r18_4band_64', 'r50_3band_64', 'r50_3band_128', 'r50_3band_64_c16', 'pp_r50_4band_64']  # (r50_3band_256: GPU test)
 
 
 def _load(name):
@@ -25,8 +25,10 @@ def test_oracle_matches_reference_golden(name):
     meta, gold = _load(name)
     torch.manual_seed(0)
     m = farseg_ref.FarSegRef(meta['resnet_type'], meta['in_channels'], meta['num_classes'], meta['decoder_channels'],
-                             meta['classifier_kernel'])
-    farseg_ref.load_portable_weights(m, portable.fill_state_dict(m.state_dict()))
+                             meta['classifier_kernel'], relation_version=meta.get('relation_version', 'v1'), dropout=0.0)
+    filled = portable.fill_state_dict(m.state_dict())
+    filled['head.fpn_decoder.classifier.0.bias'] = np.asarray(meta['classifier_bias'], dtype=np.float32)
+    farseg_ref.load_portable_weights(m, filled)
     x, y = portable.synthetic_batch(name, meta['n'], meta['in_channels'], meta['hw'], meta['hw'], meta['num_classes'])
     x, y = torch.from_numpy(x), torch.from_numpy(y)
     m.train()
@@ -34,6 +36,15 @@ def test_oracle_matches_reference_golden(name):
     losses = m.loss_from_logits(lg, y)
     sum(losses.values()).backward()
     np.testing.assert_allclose(lg.detach().numpy(), gold['logits'], rtol=1e-4, atol=1e-5)
+    # the fixture's decision margin (gen_golden.py placed the classifier bias in the widest empty interval): recomputed
+    # from the committed logits, and the oracle's masks equal the reference's bit for bit
+    rng = np.abs(gold['logits']).max()
+    margin = portable.mask_margin(gold['logits'])
+    assert abs(margin.min() / rng - meta['min_margin_rel']) <= 1e-6
+    if meta['num_classes'] == 1:
+        assert np.array_equal(lg.detach().numpy() > 0, gold['logits'] > 0)
+    else:
+        assert np.array_equal(lg.detach().numpy().argmax(1), gold['logits'].argmax(1))
     for k, v in meta['losses'].items():
         assert abs(losses[k].item() - v) <= 1e-5 * max(1.0, abs(v)), k
     for k, p in m.named_parameters():
