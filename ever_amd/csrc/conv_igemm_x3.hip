@@ -258,6 +258,10 @@ int launch_igemm_x3(IGemmArgs& a, hipStream_t stream) {
     return EVK_E_UNSUPPORTED;
   }
   {
+    const int rc = launch_igemm_x3dma(a, stream);  // LDS-DMA form for the one-tap (1x1) convolutions
+    if (rc != 1) return rc;
+  }
+  {
     const int rc = launch_igemm_x3ws(a, stream);  // wave-specialised form for the large layers
     if (rc != 1) return rc;
   }

@@ -85,6 +85,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
 int launch_igemm(IGemmArgs& a, hipStream_t stream);
 int launch_igemm_x3(IGemmArgs& a, hipStream_t stream);
 int launch_igemm_x3ws(IGemmArgs& a, hipStream_t stream);  // 1 = not applicable
+int launch_igemm_x3dma(IGemmArgs& a, hipStream_t stream);  // 1 = not applicable
 int launch_conv3x3_halo(IGemmArgs& a, hipStream_t stream);  // 1 = not applicable
 bool conv_desc_uses_halo(const evk_conv_desc* d, int for_dgrad);
 int launch_split_weight_halo(const float* w, uint16_t* out, int Cout, int Cin, int for_dgrad, hipStream_t st);

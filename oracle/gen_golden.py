@@ -185,6 +185,8 @@ def e2e_case(er, name, resnet_type, in_channels, n, hw, num_classes=1, decoder_c
         l64 = F.cross_entropy(lg64, y, ignore_index=255)
     l64.backward()
     gnorm64 = {k: float(p.grad.norm()) for k, p in ref64.named_parameters()}
+    # the fp64 run's digest as well: how far fp32 rounding alone moves the samples / projection of each tensor
+    digest64 = grad_digest(ref64.named_parameters())
     logits_noise = float((lg64.detach() - lg_ref.detach().double()).abs().max() / lg64.detach().abs().max())
     rng = float(lg_ref.detach().abs().max())
     margin = portable.mask_margin(lg_ref.detach().numpy())
@@ -208,7 +210,7 @@ def e2e_case(er, name, resnet_type, in_channels, n, hw, num_classes=1, decoder_c
                 relation_version=relation_version, classifier_bias=[float(b) for b in bias],
                 min_margin_rel=float(margin.min() / rng), pixels_inside_1e3=int((margin < 1e-3 * rng).sum()),
                 losses={k: float(v.item()) for k, v in losses_ref.items()},
-                grads=grad_digest(ref.named_parameters()), grad_norm_fp64=gnorm64, logits_fp32_vs_fp64=logits_noise,
+                grads=grad_digest(ref.named_parameters()), grad_norm_fp64=gnorm64, grads_fp64=digest64, logits_fp32_vs_fp64=logits_noise,
                 running=bdig,
                 argmax_margin=float(margin.min()))
     with open(os.path.join(OUT, f'e2e_{name}.json'), 'w') as f:

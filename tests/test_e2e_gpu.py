@@ -120,31 +120,34 @@ def test_farseg_matches_reference_golden(cuda, name, conv_math):
         if abs(gn - ref64) > tol:
             bad.append((k, gn, ref32, ref64))
     assert not bad, f'{len(bad)} gradient norms off: {bad[:5]}'
-    # the stored samples / sum / projection of every gradient tensor (gen_golden.py:grad_digest), measured against the
-    # tensor's own scale: e = |hip - ref| / (fp64 norm of the tensor).  A wrong layout, a dropped tap or a missing
-    # term shows up as e ~ 1 on the samples and the projection even when the norm happens to agree.
+    # the stored samples / projection of every gradient tensor (gen_golden.py:grad_digest), measured against the
+    # tensor's own scale: e = |hip - ref32| / (fp64 norm of the tensor).  A wrong layout, a dropped tap or a missing
+    # term shows up as e ~ 1 on the samples and the projection even when the norm happens to agree.  The yardstick is
+    # the SAME quantity between the reference's own fp32 and fp64 runs (grads_fp64): what rounding alone does to it.
     worst = dict(norm=0.0, proj=0.0, sample=0.0)
+    noise = dict(norm=0.0, proj=0.0, sample=0.0)
     for k, p in m.named_parameters():
-        d, ref64 = meta['grads'][k], meta['grad_norm_fp64'][k]
+        d, d64, ref64 = meta['grads'][k], meta['grads_fp64'][k], meta['grad_norm_fp64'][k]
         if ref64 < 1e-6:
             continue
         g = p.grad.detach().double().reshape(-1).cpu()
         idx = np.linspace(0, g.numel() - 1, 4).astype(np.int64)
-        # samples are single elements: scale by the tensor's RMS * 8 (a sample is one draw of the element distribution)
-        rms = ref64 / np.sqrt(g.numel())
-        e_s = max(abs(float(g[i]) - d[2 + j]) for j, i in enumerate(idx)) / (8 * rms + 1e-12)
-        e_p = abs(float((g.numpy() * portable.sign_vector(k, g.numel())).sum()) - d[6]) / ref64 if len(d) > 6 else 0.0
-        e_n = abs(float(g.norm()) - d[0]) / ref64
-        worst = dict(norm=max(worst['norm'], e_n), proj=max(worst['proj'], e_p), sample=max(worst['sample'], e_s))
-    print(f'{name}: worst per-tensor gradient deviations from the reference digest: {worst} (reference fp32-vs-fp64 '
-          f'norm deviation {case_dev:.1e})')
+        rms8 = 8 * ref64 / np.sqrt(g.numel()) + 1e-12    # a sample is one draw of the element distribution
+        dev = dict(norm=abs(float(g.norm()) - d[0]) / ref64,
+                   proj=abs(float((g.numpy() * portable.sign_vector(k, g.numel())).sum()) - d[6]) / ref64,
+                   sample=max(abs(float(g[i]) - d[2 + j]) for j, i in enumerate(idx)) / rms8)
+        own = dict(norm=abs(d[0] - d64[0]) / ref64, proj=abs(d[6] - d64[6]) / ref64,
+                   sample=max(abs(d[2 + j] - d64[2 + j]) for j in range(4)) / rms8)
+        for kk in worst:
+            worst[kk], noise[kk] = max(worst[kk], dev[kk]), max(noise[kk], own[kk])
+    print(f'{name}: worst per-tensor gradient deviation from the reference digest '
+          + ', '.join(f'{kk} {worst[kk]:.1e} (reference fp32-vs-fp64: {noise[kk]:.1e})' for kk in worst))
     if name == 'r50_3band_256':
         for kk, bound in TIGHT.items():
             assert worst[kk] <= bound, f'{name}: gradient {kk} deviation {worst[kk]:.2e} > {bound}'
-    else:
-        # badly conditioned small tiles: samples and projections within the same conditioning-scaled budget as norms
-        lim = max(5e-2, 12.0 * case_dev)
-        assert worst['proj'] <= lim and worst['sample'] <= lim, (worst, lim)
+    for kk in worst:   # every fixture: within a small multiple of what fp32 rounding does to the reference itself
+        lim = max(2e-2, 6.0 * noise[kk])
+        assert worst[kk] <= lim, f'{name}: gradient {kk} deviation {worst[kk]:.2e} > {lim:.2e}'
     # running statistics after one step, then eval-mode logits
     sd = m.state_dict()
     for k, (s, nrm) in meta['running'].items():
