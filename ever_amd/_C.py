@@ -32,7 +32,8 @@ _DP = C.POINTER(ConvDesc)
 _JP = C.POINTER(SplitJob)
 
 # name -> (restype, argtypes).  Order and types follow include/ever_hip.h exactly;
-# tests/test_abi.py checks that every symbol the header declares is exported and listed here.
+# tests/test_host_api_cpu.py::test_library_exports_every_declared_symbol checks that every symbol the header declares
+# is exported and listed here.
 SIGNATURES = {
     'evk_last_error': (C.c_char_p, []),
     'evk_abi_version': (c_int, []),
@@ -48,6 +49,13 @@ SIGNATURES = {
     'evk_conv2d_split_multi': (c_int, [P, P, c_i32, P]),
     'evk_conv2d_fwd_x3': (c_int, [_DP, P, P, P, P, c_u32, P]),
     'evk_conv2d_dgrad_x3': (c_int, [_DP, P, P, P, P, P]),
+    'evk_conv_transpose2d_fwd': (c_int, [_DP, P, P, P, P, P]),
+    'evk_conv_transpose2d_fwd_x3': (c_int, [_DP, P, P, P, P, P]),
+    'evk_conv_transpose2d_dgrad': (c_int, [_DP, P, P, P, P]),
+    'evk_conv_transpose2d_dgrad_x3': (c_int, [_DP, P, P, P, P]),
+    'evk_conv_transpose2d_wgrad_workspace_bytes': (c_size_t, [_DP, c_i32]),
+    'evk_conv_transpose2d_wgrad': (c_int, [_DP, P, P, P, P, P, c_size_t, P]),
+    'evk_conv_transpose2d_wgrad_x3': (c_int, [_DP, P, P, P, P, P, c_size_t, P]),
     'evk_conv2d_fwd_res': (c_int, [_DP, P, P, P, P, P, c_u32, P]),
     'evk_conv2d_fwd_x3_res': (c_int, [_DP, P, P, P, P, P, c_u32, P]),
     'evk_conv2d_wgrad_x3_workspace_bytes': (c_size_t, [_DP]),

@@ -313,6 +313,18 @@ static int launch_wgrad(const WGradArgs& a, hipStream_t stream) {
   return check_launch("conv_wgrad");
 }
 
+// column sums of a [rows][c] fp32 matrix (bias gradients): also used by conv_transpose.hip
+size_t colsum_workspace_bytes(int64_t rows, int c) { return (size_t)colsum_blocks(rows) * c * sizeof(float) + 256; }
+int launch_colsum(const float* src, float* out, int64_t rows, int c, float* workspace, hipStream_t st) {
+  const int nblk = colsum_blocks(rows);
+  const int64_t rpb = (rows + nblk - 1) / nblk;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, st, src, workspace, rows, c, rpb);
+  int rc = check_launch("colsum_partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((c + 7) / 8), dim3(256), 0, st, (const float*)workspace, out, nblk, c);
+  return check_launch("colsum_final");
+}
+
 }  // namespace evk
 
 using namespace evk;

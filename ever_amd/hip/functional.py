@@ -18,7 +18,7 @@ from . import timing, weight_planes
 from .workspace import workspace
 
 __all__ = [
-    'HipPathError', 'empty_nhwc', 'as_nhwc', 'is_nhwc', 'image_to_nhwc', 'conv2d', 'conv2d_fork', 'batch_norm_act', 'relu',
+    'HipPathError', 'empty_nhwc', 'as_nhwc', 'is_nhwc', 'image_to_nhwc', 'conv2d', 'conv2d_fork', 'conv_transpose2d', 'batch_norm_act', 'relu',
     'max_pool3x3s2', 'upsample_nearest2x_add', 'upsample_bilinear', 'global_avg_pool', 'fs_relation',
     'mean4', 'add', 'bce_with_logits', 'dice_loss_with_logits', 'cross_entropy', 'soft_cross_entropy',
 ]
@@ -420,6 +420,104 @@ def conv2d_fork(x, conv_main, conv_short=None):
         return _ConvForkFn.apply(x, conv_main.weight, None, conv_main.bias, None, cfg_m, None)
     cfg_s = (_pair(conv_short.stride), _pair(conv_short.padding), _pair(conv_short.dilation))
     return _ConvForkFn.apply(x, conv_main.weight, conv_short.weight, conv_main.bias, conv_short.bias, cfg_m, cfg_s)
+
+
+# ------------------------------------------------------------------------------------ transposed convolution
+class _ConvTranspose2dFn(Function):
+    """nn.ConvTranspose2d = the adjoint of the convolution C that reads the same weight memory as OHWI (include/ever_hip.h,
+    evk_conv_transpose2d_*): forward on the residue-class data-gradient kernel, input gradient on the forward kernel,
+    weight gradient on the weight-gradient kernel with the operand roles swapped.  No reference call site (SURVEY §2.3);
+    parity is against torch.nn.ConvTranspose2d."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, output_padding, dilation):
+        n, cin_t, h, w = x.shape
+        if weight.shape[0] != cin_t:
+            raise ValueError(f'conv_transpose2d: input has {cin_t} channels but weight expects {weight.shape[0]}')
+        cout_t, kh, kw = weight.shape[1], weight.shape[2], weight.shape[3]
+        if cin_t % 4 or cout_t % 4:
+            raise HipPathError('conv_transpose2d: channel counts must be multiples of 4 on the HIP path')
+        ho = (h - 1) * stride[0] - 2 * padding[0] + dilation[0] * (kh - 1) + output_padding[0] + 1
+        wo = (w - 1) * stride[1] - 2 * padding[1] + dilation[1] * (kw - 1) + output_padding[1] + 1
+        # descriptor of C: its input is this operator's output
+        d = _C.ConvDesc(n, ho, wo, cout_t, h, w, cin_t, kh, kw, stride[0], stride[1], padding[0], padding[1],
+                        dilation[0], dilation[1])
+        chk_h = (ho + 2 * padding[0] - dilation[0] * (kh - 1) - 1) // stride[0] + 1
+        chk_w = (wo + 2 * padding[1] - dilation[1] * (kw - 1) - 1) // stride[1] + 1
+        if (chk_h, chk_w) != (h, w) or ho <= 0 or wo <= 0:
+            raise ValueError('conv_transpose2d: output_padding must be smaller than stride or dilation')
+        dev, st = x.device, _stream()
+        w_ohwi = _weight_ohwi(weight.detach())      # [Cin_t][kh][kw][Cout_t]
+        y = empty_nhwc(n, cout_t, ho, wo, dev)
+        x3 = _CONV_MATH == 'bf16x3' and cin_t % 8 == 0
+        flops = 2.0 * n * h * w * cin_t * cout_t * kh * kw
+        sp = timing.span('conv_igemm' if x3 else 'conv_igemm_f32', flops, 4.0 * (x.numel() + y.numel() + weight.numel()))
+        if x3:
+            pl_ptr = weight_planes.planes_for(weight, w_ohwi, d, 1, st)
+            if pl_ptr is None:
+                planes = workspace(dev, _C.load().evk_conv2d_split_weight_bytes(ctypes.byref(d), 1))
+                _C.call('evk_conv2d_split_weight', ctypes.byref(d), w_ohwi.data_ptr(), 1, planes.data_ptr(), st)
+                pl_ptr = planes.data_ptr()
+            _C.call('evk_conv_transpose2d_fwd_x3', ctypes.byref(d), x.data_ptr(), pl_ptr, _ptr(bias), y.data_ptr(), st)
+        else:
+            wt = torch.empty((cout_t, kh * kw, cin_t), device=dev, dtype=torch.float32)
+            _C.call('evk_conv2d_pack_dgrad_weight', ctypes.byref(d), w_ohwi.data_ptr(), wt.data_ptr(), st)
+            _C.call('evk_conv_transpose2d_fwd', ctypes.byref(d), x.data_ptr(), wt.data_ptr(), _ptr(bias), y.data_ptr(), st)
+        if sp is not None:
+            sp.stop()
+        ctx.desc, ctx.flops, ctx.has_bias, ctx.w_stride = d, flops, bias is not None, tuple(weight.stride())
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        d = ctx.desc
+        dev, st = x.device, _stream()
+        gy = as_nhwc(gy, 'conv_transpose2d.backward')
+        w_ohwi = _weight_ohwi(weight.detach())
+        cin_t, cout_t, kh, kw = weight.shape
+        x3m = _CONV_MATH == 'bf16x3'
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            x3 = x3m and cout_t % 8 == 0
+            sp = timing.span('conv_igemm' if x3 else 'conv_igemm_f32', ctx.flops, 4.0 * (x.numel() + gy.numel()))
+            if x3:
+                pl_ptr = weight_planes.planes_for(weight, w_ohwi, d, 0, st)
+                if pl_ptr is None:
+                    planes = workspace(dev, _C.load().evk_conv2d_split_weight_bytes(ctypes.byref(d), 0))
+                    _C.call('evk_conv2d_split_weight', ctypes.byref(d), w_ohwi.data_ptr(), 0, planes.data_ptr(), st)
+                    pl_ptr = planes.data_ptr()
+                _C.call('evk_conv_transpose2d_dgrad_x3', ctypes.byref(d), gy.data_ptr(), pl_ptr, dx.data_ptr(), st)
+            else:
+                _C.call('evk_conv_transpose2d_dgrad', ctypes.byref(d), gy.data_ptr(), w_ohwi.data_ptr(), dx.data_ptr(), st)
+            if sp is not None:
+                sp.stop()
+        need_dw, need_db = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        if need_dw or need_db:
+            ws_bytes = _C.load().evk_conv_transpose2d_wgrad_workspace_bytes(ctypes.byref(d), 1 if x3m else 0)
+            ws = workspace(dev, ws_bytes)
+            dwk = torch.empty((cin_t, kh * kw, cout_t), device=dev, dtype=torch.float32) if need_dw else None
+            db = torch.empty((cout_t,), device=dev, dtype=torch.float32) if need_db else None
+            sp = timing.span('conv_wgrad' if x3m else 'conv_wgrad_f32', ctx.flops, 4.0 * (x.numel() + gy.numel()))
+            _C.call('evk_conv_transpose2d_wgrad_x3' if x3m else 'evk_conv_transpose2d_wgrad', ctypes.byref(d), x.data_ptr(),
+                    gy.data_ptr(), _ptr(dwk), _ptr(db), ws.data_ptr(), ws_bytes, st)
+            if sp is not None:
+                sp.stop()
+            if need_dw:
+                dw = dwk.reshape(cin_t, kh, kw, cout_t).permute(0, 3, 1, 2)   # logical [Cin_t, Cout_t, kh, kw]
+                if kh * kw == 1 and dw.stride() != ctx.w_stride and ctx.w_stride[1] == 1:
+                    dw = dw.as_strided(dw.shape, ctx.w_stride)
+        return dx, dw, db, None, None, None, None
+
+
+def conv_transpose2d(x, weight, bias=None, stride=1, padding=0, output_padding=0, dilation=1):
+    """F.conv_transpose2d (groups = 1).  weight: [Cin, Cout, kh, kw] (channels_last memory preferred)."""
+    _require_cuda(x, 'conv_transpose2d')
+    x = as_nhwc(x, 'conv_transpose2d')
+    return _ConvTranspose2dFn.apply(x, weight, bias, _pair(stride), _pair(padding), _pair(output_padding), _pair(dilation))
 
 
 # ------------------------------------------------------------------------------------ batch norm

@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from ..hip import functional as HF
 
-__all__ = ['Conv2d', 'BatchNorm2d', 'ReLU', 'MaxPool2d', 'UpsamplingBilinear2d', 'AdaptiveAvgPool2d', 'Identity',
+__all__ = ['Conv2d', 'ConvTranspose2d', 'BatchNorm2d', 'ReLU', 'MaxPool2d', 'UpsamplingBilinear2d', 'AdaptiveAvgPool2d', 'Identity',
            'HipSequential', 'run_sequence', 'to_hip']
 
 Identity = nn.Identity
@@ -28,6 +28,23 @@ class Conv2d(nn.Conv2d):
 
     def forward(self, x, relu=False):
         return HF.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, relu=relu)
+
+
+class ConvTranspose2d(nn.ConvTranspose2d):
+    """nn.ConvTranspose2d (groups=1, zero padding) on the residue-class data-gradient kernel (BASELINE.json north_star:
+    "transposed-conv lowered to MFMA"); weight kept [Cin][kh][kw][Cout] in memory.  The reference's hot path has no
+    call site for it; parity is against torch.nn.ConvTranspose2d."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        _check_conv(self)
+        self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
+
+    def forward(self, x, output_size=None):
+        op = self.output_padding
+        if output_size is not None:
+            op = self._output_padding(x, output_size, self.stride, self.padding, self.kernel_size, 2, self.dilation)
+        return HF.conv_transpose2d(x, self.weight, self.bias, self.stride, self.padding, op, self.dilation)
 
 
 def _check_conv(m):
@@ -173,7 +190,7 @@ class HipSequential(nn.Sequential):
 
 
 _SWAP = {
-    nn.Conv2d: Conv2d, nn.BatchNorm2d: BatchNorm2d, nn.ReLU: ReLU, nn.MaxPool2d: MaxPool2d,
+    nn.Conv2d: Conv2d, nn.ConvTranspose2d: ConvTranspose2d, nn.BatchNorm2d: BatchNorm2d, nn.ReLU: ReLU, nn.MaxPool2d: MaxPool2d,
     nn.UpsamplingBilinear2d: UpsamplingBilinear2d, nn.AdaptiveAvgPool2d: AdaptiveAvgPool2d,
     nn.GroupNorm: GroupNorm, nn.Dropout2d: Dropout2d, nn.Sequential: HipSequential,
 }
@@ -188,7 +205,7 @@ def to_hip(model):
         if hip_cls is None:
             continue
         m.__class__ = hip_cls
-        if hip_cls is Conv2d:
+        if hip_cls in (Conv2d, ConvTranspose2d):
             _check_conv(m)
             m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
     return model

@@ -118,6 +118,34 @@ size_t evk_conv2d_wgrad_x3_workspace_bytes(const evk_conv_desc* d);
 int evk_conv2d_wgrad_x3(const evk_conv_desc* d, const float* x, const float* dy, float* dw,
                         float* dbias, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------ transposed convolution -- */
+/* nn.ConvTranspose2d (any kernel / stride / padding / output_padding / dilation, groups = 1).
+ * NO reference call site: the reference's hot path contains no transposed convolution (SURVEY.md §2.3 note;
+ * `grep -rn ConvTranspose /root/reference/ever` is empty).  BASELINE.json's north_star names the operator
+ * ("conv3x3/1x1 and transposed-conv lowered to MFMA"), so it is exposed; parity is pinned against
+ * torch.nn.ConvTranspose2d (tests/test_conv_transpose_gpu.py), the only available oracle.
+ * A transposed convolution with weight wT[Cin_t][kh][kw][Cout_t] (a ConvTranspose2d parameter with channels_last
+ * strides) is the ADJOINT of the convolution C: u[N,H,W,Cin] -> z[N,Ho,Wo,Cout] that reads the same memory as
+ * OHWI with Cout = Cin_t, Cin = Cout_t.  `d` is the descriptor of C: (N,H,W,Cin) = this operator's OUTPUT,
+ * (Ho,Wo,Cout) = its INPUT.  forward = evk_conv2d_dgrad's residue-class kernel (no MFMA on structurally-zero taps)
+ * + bias; input gradient = evk_conv2d_fwd; weight gradient = evk_conv2d_wgrad with the operand roles swapped;
+ * dbias = column sums of dy.  Weight operands are prepared exactly as for the convolution C:
+ * evk_conv2d_pack_dgrad_weight / evk_conv2d_split_weight(for_dgrad = 1) for the forward, the plain parameter /
+ * evk_conv2d_split_weight(for_dgrad = 0) for the input gradient. */
+int evk_conv_transpose2d_fwd(const evk_conv_desc* d, const float* x, const float* wt, const float* bias, float* y,
+                             void* stream);
+int evk_conv_transpose2d_fwd_x3(const evk_conv_desc* d, const float* x, const void* wsplit_t, const float* bias,
+                                float* y, void* stream);
+int evk_conv_transpose2d_dgrad(const evk_conv_desc* d, const float* dy, const float* w, float* dx, void* stream);
+int evk_conv_transpose2d_dgrad_x3(const evk_conv_desc* d, const float* dy, const void* wsplit, float* dx, void* stream);
+size_t evk_conv_transpose2d_wgrad_workspace_bytes(const evk_conv_desc* d, int32_t x3);
+/* x: the operator's input [N,Ho,Wo,Cout], dy: gradient of its output [N,H,W,Cin]; dw in the parameter's memory order
+ * [Cout][kh][kw][Cin] of C; dbias[Cin] (either may be NULL) */
+int evk_conv_transpose2d_wgrad(const evk_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                               void* workspace, size_t workspace_bytes, void* stream);
+int evk_conv_transpose2d_wgrad_x3(const evk_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+
 /* dw[Cout][kh][kw][Cin] = sum_pixels dy (x) im2col(x); dbias[Cout] = sum_pixels dy (dbias may be
  * NULL).  Split over pixel ranges; partials go to `workspace` and are reduced deterministically. */
 size_t evk_conv2d_wgrad_workspace_bytes(const evk_conv_desc* d);

@@ -76,9 +76,11 @@ def _check_masks(lg, ref, num_classes, what, exact=False):
     return flips
 
 
-# per-tensor gradient bounds of the well-conditioned fixture (R50, 2 x 3 x 256 x 256: >= 64-sample BatchNorm statistics
-# everywhere), relative to the tensor's fp64 norm: norm, hashed +-1 projection, sum and the 4 stored samples
-TIGHT = dict(norm=5e-3, proj=2e-2, sample=2e-2)
+# The 131072-pixel fixture (R50, 2 x 3 x 256 x 256) carries the TIGHT gradient bound: every per-tensor deviation (norm,
+# hashed +-1 projection, the 4 stored samples) within TWICE what fp32 rounding alone does to the reference's own
+# gradients on that input (its fp32-vs-fp64 digest difference: 1.0e-2 / 5.4e-2 / 9e-3 — even at 256^2 the deepest
+# BatchNorms see 8 x 8 maps), plus 2e-3.  The small fixtures use six times their own noise.
+TIGHT_FACTOR, TIGHT_ABS = 2.0, 2e-3
 
 
 @pytest.mark.parametrize('name', ['r18_4band_64', 'r50_3band_64', 'r50_3band_128', 'r50_3band_64_c16', 'r50_3band_256',
@@ -143,8 +145,9 @@ def test_farseg_matches_reference_golden(cuda, name, conv_math):
     print(f'{name}: worst per-tensor gradient deviation from the reference digest '
           + ', '.join(f'{kk} {worst[kk]:.1e} (reference fp32-vs-fp64: {noise[kk]:.1e})' for kk in worst))
     if name == 'r50_3band_256':
-        for kk, bound in TIGHT.items():
-            assert worst[kk] <= bound, f'{name}: gradient {kk} deviation {worst[kk]:.2e} > {bound}'
+        for kk in worst:
+            bound = TIGHT_FACTOR * noise[kk] + TIGHT_ABS
+            assert worst[kk] <= bound, f'{name}: gradient {kk} deviation {worst[kk]:.2e} > {bound:.2e}'
     for kk in worst:   # every fixture: within a small multiple of what fp32 rounding does to the reference itself
         lim = max(2e-2, 6.0 * noise[kk])
         assert worst[kk] <= lim, f'{name}: gradient {kk} deviation {worst[kk]:.2e} > {lim:.2e}'
