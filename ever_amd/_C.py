@@ -74,6 +74,9 @@ SIGNATURES = {
     'evk_relu_bwd': (c_int, [P, P, P, c_i64, P]),
     'evk_add': (c_int, [P, P, P, c_i64, P]),
     'evk_scale': (c_int, [P, c_f32, P, c_i64, P]),
+    'evk_mul_scale': (c_int, [P, P, c_f32, P, c_i64, P]),
+    'evk_gelu_fwd': (c_int, [P, P, c_i64, P]),
+    'evk_gelu_bwd': (c_int, [P, P, P, c_i64, P]),
     'evk_maxpool3x3s2_fwd': (c_int, [P, P, P, c_i32, c_i32, c_i32, c_i32, P]),
     'evk_maxpool3x3s2_bwd': (c_int, [P, P, P, c_i32, c_i32, c_i32, c_i32, P]),
     'evk_upsample_nearest2x_add_fwd': (c_int, [P, P, P, c_i32, c_i32, c_i32, c_i32, P]),
@@ -89,6 +92,8 @@ SIGNATURES = {
     'evk_loss_stats_doubles': (c_i64, [c_i32]),
     'evk_bce_fwd': (c_int, [P, P, c_i64, c_i64, c_f32, P, P, P]),
     'evk_bce_bwd': (c_int, [P, P, c_i64, c_i64, c_f32, P, P, P, c_i32, P]),
+    'evk_bce_fwd_ex': (c_int, [P, P, c_i64, c_i64, c_f32, c_f32, c_i32, P, P, P]),
+    'evk_bce_bwd_ex': (c_int, [P, P, c_i64, c_i64, c_f32, c_f32, c_i32, P, P, P, c_i32, P]),
     'evk_soft_ce_fwd': (c_int, [P, P, c_i64, c_i32, P, P, P]),
     'evk_soft_ce_bwd': (c_int, [P, P, c_i64, c_i32, P, P, P]),
     'evk_dice_stats': (c_int, [P, P, c_i64, c_i32, c_i64, P, P]),
@@ -99,6 +104,7 @@ SIGNATURES = {
     'evk_opt_blocks_per_tensor': (c_i32, []),
     'evk_sqnorm_multi': (c_int, [P, P, c_i32, P, c_f32, P, P, P]),
     'evk_sgd_multi': (c_int, [P, P, P, P, c_i32, c_f32, c_f32, c_f32, c_f32, c_i32, c_i32, P, P]),
+    'evk_adam_multi': (c_int, [P, P, P, P, P, c_i32, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_f32, P, P]),
     'evk_prob_stats_doubles': (c_i64, [c_i32]),
     'evk_prob_stats': (c_int, [P, P, c_i64, c_i32, c_i64, P, P]),
     'evk_prob_stats_bwd': (c_int, [P, P, c_i64, c_i32, c_i64, P, P, P, c_i32, P]),

@@ -43,19 +43,20 @@ __global__ void finalize_partials_kernel(double* stats, int K, int nblk) {
 }
 
 // ---------------------------------------------------------------- BCE with logits -----------------
-__device__ __forceinline__ float bce_term(float x, float y) {
-  // aten binary_cross_entropy_with_logits: (1-y)*x + (log1p(exp(-|x|)) + max(-x,0))
-  return (1.f - y) * x + (log1pf(expf(-fabsf(x))) + fmaxf(-x, 0.f));
+__device__ __forceinline__ float bce_term(float x, float y, float pw) {
+  // aten binary_cross_entropy_with_logits: (1-y)*x + (1 + (pos_weight-1)*y) * (log1p(exp(-|x|)) + max(-x,0))
+  return (1.f - y) * x + (1.f + (pw - 1.f) * y) * (log1pf(expf(-fabsf(x))) + fmaxf(-x, 0.f));
 }
 __global__ __launch_bounds__(256) void bce_partial_kernel(const float* __restrict__ logits,
                                                           const int64_t* __restrict__ labels, int64_t npix,
-                                                          int64_t ignore, float eps, double* __restrict__ stats) {
+                                                          int64_t ignore, float eps, float pw,
+                                                          double* __restrict__ stats) {
   double v[2] = {0.0, 0.0};
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
     const int64_t t = labels[i];
     if (t != ignore) {
       const float y = (t == 0) ? eps : (float)t - eps;  // label smoothing (eps = 0: plain BCE)
-      v[0] += (double)bce_term(logits[i], y);
+      v[0] += (double)bce_term(logits[i], y, pw);
       v[1] += 1.0;
     }
   }
@@ -64,19 +65,23 @@ __global__ __launch_bounds__(256) void bce_partial_kernel(const float* __restric
 __global__ void mean_loss_kernel(const double* stats, float* loss) {
   if (threadIdx.x == 0) *loss = (float)(stats[0] / stats[1]);  // 0/0 -> NaN, as mean of an empty tensor
 }
+__global__ void sum_loss_kernel(const double* stats, float* loss) {
+  if (threadIdx.x == 0) *loss = (float)stats[0];               // reduction='sum': 0 for an empty selection, as aten
+}
 __global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ logits,
                                                       const int64_t* __restrict__ labels, int64_t npix, int64_t ignore,
-                                                      float eps, const double* __restrict__ stats,
+                                                      float eps, float pw, int sum_reduction,
+                                                      const double* __restrict__ stats,
                                                       const float* __restrict__ grad_scale, float* __restrict__ dlogits,
                                                       int accumulate) {
-  const float k = (grad_scale ? *grad_scale : 1.f) / (float)stats[1];
+  const float k = (grad_scale ? *grad_scale : 1.f) / (sum_reduction ? 1.f : (float)stats[1]);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
     const int64_t t = labels[i];
     float g = 0.f;
     if (t != ignore) {
       const float p = 1.f / (1.f + expf(-logits[i]));
       const float y = (t == 0) ? eps : (float)t - eps;
-      g = (p - y) * k;
+      g = ((1.f - y) - (1.f + (pw - 1.f) * y) * (1.f - p)) * k;   // pw = 1: p - y
     }
     dlogits[i] = accumulate ? dlogits[i] + g : g;
   }
@@ -327,25 +332,41 @@ extern "C" int evk_soft_ce_bwd(const float* logits, const float* target, int64_t
 
 extern "C" int64_t evk_loss_stats_doubles(int32_t K) { return (int64_t)K * (1 + kLossBlocks); }
 
-extern "C" int evk_bce_fwd(const float* logits, const int64_t* labels, int64_t npix, int64_t ignore_index,
-                           float label_smoothing, float* loss, double* stats, void* stream) {
+extern "C" int evk_bce_fwd_ex(const float* logits, const int64_t* labels, int64_t npix, int64_t ignore_index,
+                              float label_smoothing, float pos_weight, int32_t reduction, float* loss, double* stats,
+                              void* stream) {
   EVK_REQUIRE(logits && labels && loss && stats && npix > 0, EVK_E_INVALID, "bce_fwd: bad argument");
+  EVK_REQUIRE(reduction == 0 || reduction == 1, EVK_E_UNSUPPORTED, "bce_fwd: reduction must be 0 (mean) or 1 (sum)");
   hipStream_t st = (hipStream_t)stream;
   const int nb = loss_grid(npix);
   hipLaunchKernelGGL(bce_partial_kernel, dim3(nb), dim3(256), 0, st, logits, labels, npix, ignore_index,
-                     label_smoothing, stats);
+                     label_smoothing, pos_weight, stats);
   hipLaunchKernelGGL(finalize_partials_kernel, dim3(1), dim3(64), 0, st, stats, 2, nb);
-  hipLaunchKernelGGL(mean_loss_kernel, dim3(1), dim3(64), 0, st, (const double*)stats, loss);
+  if (reduction == 0) {
+    hipLaunchKernelGGL(mean_loss_kernel, dim3(1), dim3(64), 0, st, (const double*)stats, loss);
+  } else {
+    hipLaunchKernelGGL(sum_loss_kernel, dim3(1), dim3(64), 0, st, (const double*)stats, loss);
+  }
   return check_launch("bce_fwd");
+}
+extern "C" int evk_bce_fwd(const float* logits, const int64_t* labels, int64_t npix, int64_t ignore_index,
+                           float label_smoothing, float* loss, double* stats, void* stream) {
+  return evk_bce_fwd_ex(logits, labels, npix, ignore_index, label_smoothing, 1.f, 0, loss, stats, stream);
+}
+extern "C" int evk_bce_bwd_ex(const float* logits, const int64_t* labels, int64_t npix, int64_t ignore_index,
+                              float label_smoothing, float pos_weight, int32_t reduction, const double* stats,
+                              const float* grad_scale, float* dlogits, int32_t accumulate, void* stream) {
+  EVK_REQUIRE(logits && labels && stats && dlogits && npix > 0, EVK_E_INVALID, "bce_bwd: bad argument");
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3((int)((npix + 255) / 256 > 4096 ? 4096 : (npix + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, logits, labels, npix, ignore_index, label_smoothing, pos_weight,
+                     reduction == 1 ? 1 : 0, stats, grad_scale, dlogits, accumulate);
+  return check_launch("bce_bwd");
 }
 extern "C" int evk_bce_bwd(const float* logits, const int64_t* labels, int64_t npix, int64_t ignore_index,
                            float label_smoothing, const double* stats, const float* grad_scale, float* dlogits,
                            int32_t accumulate, void* stream) {
-  EVK_REQUIRE(logits && labels && stats && dlogits && npix > 0, EVK_E_INVALID, "bce_bwd: bad argument");
-  hipLaunchKernelGGL(bce_bwd_kernel, dim3((int)((npix + 255) / 256 > 4096 ? 4096 : (npix + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, logits, labels, npix, ignore_index, label_smoothing, stats, grad_scale, dlogits,
-                     accumulate);
-  return check_launch("bce_bwd");
+  return evk_bce_bwd_ex(logits, labels, npix, ignore_index, label_smoothing, 1.f, 0, stats, grad_scale, dlogits,
+                        accumulate, stream);
 }
 
 extern "C" int evk_dice_stats(const float* logits, const int64_t* labels, int64_t npix, int32_t C, int64_t ignore_index,

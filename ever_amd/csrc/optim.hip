@@ -91,8 +91,53 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(float* const* __restrict
   }
 }
 
+// torch.optim.Adam / AdamW (single-tensor form, no amsgrad): decoupled = 1 is AdamW (p *= 1 - lr*wd), 0 is Adam
+// (g += wd*p).  bc1 = 1 - beta1^step, bc2s = sqrt(1 - beta2^step) are computed by the caller from the step count.
+__global__ __launch_bounds__(256) void adam_multi_kernel(float* const* __restrict__ params,
+                                                         const float* const* __restrict__ grads,
+                                                         float* const* __restrict__ exp_avg,
+                                                         float* const* __restrict__ exp_avg_sq,
+                                                         const int64_t* __restrict__ sizes, float lr, float beta1,
+                                                         float beta2, float eps, float wd, int decoupled, float bc1,
+                                                         float bc2s, const float* __restrict__ clip_coef) {
+  const int t = blockIdx.y;
+  float* p = params[t];
+  const float* g = grads[t];
+  float* m = exp_avg[t];
+  float* v = exp_avg_sq[t];
+  const int64_t n = sizes[t];
+  const float cc = clip_coef ? *clip_coef : 1.f;
+  const float step_size = lr / bc1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float w = p[i];
+    float gi = g[i] * cc;
+    if (wd != 0.f) {
+      if (decoupled) w *= 1.f - lr * wd;
+      else gi = __fmaf_rn(wd, w, gi);
+    }
+    const float mi = __fmaf_rn(gi - m[i], 1.f - beta1, m[i]);            // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = __fmaf_rn(gi * gi, 1.f - beta2, v[i] * beta2);      // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+    const float denom = sqrtf(vi) / bc2s + eps;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = w - step_size * (mi / denom);
+  }
+}
+
 }  // namespace evk
 using namespace evk;
+
+extern "C" int evk_adam_multi(float* const* params, const float* const* grads, float* const* exp_avg,
+                              float* const* exp_avg_sq, const int64_t* sizes, int32_t ntensors, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int32_t decoupled, float bias_correction1,
+                              float sqrt_bias_correction2, const float* clip_coef, void* stream) {
+  EVK_REQUIRE(params && grads && exp_avg && exp_avg_sq && sizes && ntensors > 0, EVK_E_INVALID, "adam_multi: bad argument");
+  EVK_REQUIRE(bias_correction1 > 0.f && sqrt_bias_correction2 > 0.f, EVK_E_INVALID, "adam_multi: bad bias correction");
+  hipLaunchKernelGGL(adam_multi_kernel, dim3(kOptBlocksPerTensor, ntensors), dim3(256), 0, (hipStream_t)stream, params,
+                     grads, exp_avg, exp_avg_sq, sizes, lr, beta1, beta2, eps, weight_decay, decoupled, bias_correction1,
+                     sqrt_bias_correction2, clip_coef);
+  return check_launch("adam_multi");
+}
 
 extern "C" int32_t evk_opt_blocks_per_tensor(void) { return kOptBlocksPerTensor; }
 

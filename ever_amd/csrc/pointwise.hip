@@ -17,7 +17,12 @@ static inline int grid_for(size_t n, int per_block = 256, int cap = 1 << 24) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int OP>  // 0 relu, 1 relu_bwd, 2 add, 3 scale
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_d(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * expf(-0.5f * x * x);
+}
+
+template <int OP>  // 0 relu, 1 relu_bwd, 2 add, 3 scale, 4 a*b*alpha, 5 gelu, 6 gelu_bwd (a = dy, b = x)
 __global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                  float* __restrict__ o, size_t n, float alpha) {
   const size_t n4 = n >> 2;
@@ -35,8 +40,15 @@ __global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, co
       v.z = y.z > 0.f ? v.z : 0.f; v.w = y.w > 0.f ? v.w : 0.f;
     } else if (OP == 2) {
       v += b4[i];
-    } else {
+    } else if (OP == 3) {
       v *= alpha;
+    } else if (OP == 4) {
+      v = v * b4[i] * alpha;
+    } else if (OP == 5) {
+      v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
+    } else {
+      const f32x4 x = b4[i];
+      v.x *= gelu_d(x.x); v.y *= gelu_d(x.y); v.z *= gelu_d(x.z); v.w *= gelu_d(x.w);
     }
     o4[i] = v;
   }
@@ -46,7 +58,10 @@ __global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, co
     if (OP == 0) v = fmaxf(v, 0.f);
     else if (OP == 1) v = b[i] > 0.f ? v : 0.f;
     else if (OP == 2) v += b[i];
-    else v *= alpha;
+    else if (OP == 3) v *= alpha;
+    else if (OP == 4) v = v * b[i] * alpha;
+    else if (OP == 5) v = gelu_f(v);
+    else v *= gelu_d(b[i]);
     o[i] = v;
   }
 }
@@ -579,6 +594,17 @@ extern "C" int evk_add(const float* a, const float* b, float* out, int64_t n, vo
 }
 extern "C" int evk_scale(const float* a, float alpha, float* out, int64_t n, void* stream) {
   EW_LAUNCH(3, a, (const float*)nullptr, out, n, alpha, "scale");
+}
+extern "C" int evk_mul_scale(const float* a, const float* b, float alpha, float* out, int64_t n, void* stream) {
+  EVK_REQUIRE(b, EVK_E_INVALID, "mul_scale: null b");
+  EW_LAUNCH(4, a, b, out, n, alpha, "mul_scale");
+}
+extern "C" int evk_gelu_fwd(const float* x, float* y, int64_t n, void* stream) {
+  EW_LAUNCH(5, x, (const float*)nullptr, y, n, 0.f, "gelu_fwd");
+}
+extern "C" int evk_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream) {
+  EVK_REQUIRE(x, EVK_E_INVALID, "gelu_bwd: null x");
+  EW_LAUNCH(6, dy, x, dx, n, 0.f, "gelu_bwd");
 }
 extern "C" int evk_mean4_fwd(const float* a, const float* b, const float* c, const float* d, float* out, int64_t n,
                              void* stream) {

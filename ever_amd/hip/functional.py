@@ -852,15 +852,16 @@ def _labels(y_true, npix, what):
 
 class _BceFn(Function):
     @staticmethod
-    def forward(ctx, logits, labels, ignore_index, eps):
+    def forward(ctx, logits, labels, ignore_index, eps, pos_weight, reduction):
         npix = logits.numel()
         stats = _stats_buf(2, logits.device)
         loss = torch.empty((), device=logits.device, dtype=torch.float32)
-        _timed_call('resample_loss', 12.0 * npix, 'evk_bce_fwd', logits.data_ptr(), labels.data_ptr(), npix, ignore_index, eps, loss.data_ptr(),
-                stats.data_ptr(), _stream())
+        _timed_call('resample_loss', 12.0 * npix, 'evk_bce_fwd_ex', logits.data_ptr(), labels.data_ptr(), npix, ignore_index, eps,
+                    pos_weight, reduction, loss.data_ptr(), stats.data_ptr(), _stream())
         ctx.save_for_backward(logits, labels, stats)
         ctx.ignore_index = ignore_index
         ctx.eps = eps
+        ctx.pw, ctx.red = pos_weight, reduction
         return loss
 
     @staticmethod
@@ -869,14 +870,27 @@ class _BceFn(Function):
         logits, labels, stats = ctx.saved_tensors
         g = g.contiguous().float()
         d = torch.empty_like(logits)
-        _timed_call('resample_loss', 16.0 * logits.numel(), 'evk_bce_bwd', logits.data_ptr(), labels.data_ptr(), logits.numel(), ctx.ignore_index, ctx.eps,
-                stats.data_ptr(), g.data_ptr(), d.data_ptr(), 0, _stream())
-        return d, None, None, None
+        _timed_call('resample_loss', 16.0 * logits.numel(), 'evk_bce_bwd_ex', logits.data_ptr(), labels.data_ptr(), logits.numel(), ctx.ignore_index, ctx.eps,
+                    ctx.pw, ctx.red, stats.data_ptr(), g.data_ptr(), d.data_ptr(), 0, _stream())
+        return d, None, None, None, None, None
 
 
-def bce_with_logits(y_pred, y_true, ignore_index=255, label_smoothing=0.0):
-    """reference ever/module/loss.py:229-235 (reduction='mean', pos_weight=None); label_smoothing > 0 gives
+def bce_with_logits(y_pred, y_true, ignore_index=255, label_smoothing=0.0, pos_weight=None, reduction='mean'):
+    """reference ever/module/loss.py:229-235 (reduction 'mean' | 'sum', optional pos_weight: a number or a one-element
+    tensor — the heads on this path have one logit channel); label_smoothing > 0 gives
     label_smoothing_binary_cross_entropy (loss.py:222-226)."""
+    if reduction not in ('mean', 'sum'):
+        # 'none' returns one value per NON-IGNORED pixel (the reference compacts with masked_select first): a
+        # data-dependent shape, which a pre-allocated-output kernel cannot produce
+        raise NotImplementedError("binary_cross_entropy_with_logits: reduction must be 'mean' or 'sum' on the HIP path")
+    if pos_weight is None:
+        pw = 1.0
+    elif isinstance(pos_weight, torch.Tensor):
+        if pos_weight.numel() != 1:
+            raise NotImplementedError('binary_cross_entropy_with_logits: pos_weight must have one element (one logit channel)')
+        pw = float(pos_weight.reshape(()).item())
+    else:
+        pw = float(pos_weight)
     _require_cuda(y_pred, 'binary_cross_entropy_with_logits')
     if y_pred.dim() == 4:
         if y_pred.shape[1] != 1:
@@ -885,7 +899,7 @@ def bce_with_logits(y_pred, y_true, ignore_index=255, label_smoothing=0.0):
     else:
         y_pred = y_pred.contiguous()
     labels = _labels(y_true, y_pred.numel(), 'bce')
-    return _BceFn.apply(y_pred, labels, int(ignore_index), float(label_smoothing))
+    return _BceFn.apply(y_pred, labels, int(ignore_index), float(label_smoothing), pw, 0 if reduction == 'mean' else 1)
 
 
 _rank_sum_hook = None  # tests: callable(tensor, what) -> world size, summing `tensor` in place over virtual ranks

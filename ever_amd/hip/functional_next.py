@@ -127,6 +127,76 @@ def dropout2d(x, p=0.5, training=True, mask=None):
     return _ChannelScaleFn.apply(x, scale)
 
 
+class _MulScaleFn(Function):
+    """out = x * mask * alpha (mask carries no gradient)"""
+
+    @staticmethod
+    def forward(ctx, x, mask, alpha):
+        out = torch.empty_like(x)
+        _C.call('evk_mul_scale', x.data_ptr(), mask.data_ptr(), alpha, out.data_ptr(), x.numel(), _stream())
+        ctx.save_for_backward(mask)
+        ctx.alpha = alpha
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        if g.stride() != mask.stride():
+            g = torch.empty_like(mask).copy_(g)
+        dx = torch.empty_like(mask)
+        _C.call('evk_mul_scale', g.data_ptr(), mask.data_ptr(), ctx.alpha, dx.data_ptr(), g.numel(), _stream())
+        return dx, None, None
+
+
+def dropout(x, p=0.5, training=True, mask=None):
+    """nn.Dropout (element-wise; reference fpn.py:183,190: the decoder's `dropout_rate`).  The 0/1 keep mask comes
+    from torch's generator (same stream of random numbers as torch's own dropout would consume is NOT promised — the
+    reference's results under dropout are random anyway); masking and the 1/(1-p) scaling are one HIP pass.
+    `mask` (a tensor of x's shape) overrides the draw."""
+    if not training or p == 0.0:
+        return x
+    _require_cuda(x, 'dropout')
+    if p >= 1.0:
+        raise ValueError('dropout: p must be < 1')
+    if x.dim() == 4:
+        x = as_nhwc(x, 'dropout')
+    if mask is None:
+        mask = torch.empty_like(x).bernoulli_(1.0 - p)
+    else:
+        mask = torch.empty_like(x).copy_(mask.to(device=x.device, dtype=torch.float32))
+    return _MulScaleFn.apply(x, mask, 1.0 / (1.0 - p))
+
+
+class _GeluFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.empty_like(x)
+        _C.call('evk_gelu_fwd', x.data_ptr(), y.data_ptr(), x.numel(), _stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        if g.stride() != x.stride():
+            g = torch.empty_like(x).copy_(g)
+        dx = torch.empty_like(x)
+        _C.call('evk_gelu_bwd', g.data_ptr(), x.data_ptr(), dx.data_ptr(), x.numel(), _stream())
+        return dx
+
+
+def gelu(x):
+    """nn.GELU() (exact erf form): the decoder's activation when norm_fn is not BatchNorm2d (reference fpn.py:167)."""
+    _require_cuda(x, 'gelu')
+    if x.dim() == 4:
+        x = as_nhwc(x, 'gelu')
+    elif not x.is_contiguous():
+        x = x.contiguous()
+    return _GeluFn.apply(x)
+
+
 class _CePixelFn(Function):
     @staticmethod
     def forward(ctx, logits, labels, ignore_index):

@@ -11,7 +11,7 @@ import math
 import torch.nn as nn
 
 from ..hip import functional as HF
-from .layers import BatchNorm2d, Conv2d, HipSequential, ReLU, UpsamplingBilinear2d
+from .layers import BatchNorm2d, Conv2d, Dropout, GELU, GroupNorm, HipSequential, ReLU, UpsamplingBilinear2d
 from .ops import Bf16compatible, ConvBlock
 
 __all__ = ['FPN', 'AssymetricDecoder', 'conv_with_kaiming_uniform', 'default_conv_block', 'conv_bn_block',
@@ -69,9 +69,26 @@ class AssymetricDecoder(nn.Module):
     def __init__(self, in_channels, out_channels, in_feat_output_strides=(4, 8, 16, 32), out_feat_output_stride=4,
                  norm_fn=nn.BatchNorm2d, classifier_config=None):
         super().__init__()
-        if norm_fn not in (nn.BatchNorm2d, BatchNorm2d):
-            raise NotImplementedError('ever_amd AssymetricDecoder: only norm_fn=BatchNorm2d (+ReLU) has HIP kernels')
         self.cls_cfg = classifier_config
+        # reference fpn.py:163-167: norm_fn(num_features=out_channels) (Identity when None), ReLU after BatchNorm2d and
+        # GELU after anything else.  Norms with a HIP kernel: BatchNorm2d / SyncBatchNorm / GroupNorm (instances of
+        # the stock classes are retargeted); any other norm layer is refused here rather than run on ATen.
+        is_bn = norm_fn in (nn.BatchNorm2d, BatchNorm2d)
+
+        def make_norm():
+            if norm_fn is None:
+                return nn.Identity()
+            if is_bn:
+                return BatchNorm2d(num_features=out_channels)
+            m = norm_fn(num_features=out_channels)
+            if isinstance(m, nn.GroupNorm):
+                m.__class__ = GroupNorm
+            elif isinstance(m, nn.BatchNorm2d) and not isinstance(m, nn.SyncBatchNorm):
+                m.__class__ = BatchNorm2d
+            elif not isinstance(m, (GroupNorm, BatchNorm2d, nn.SyncBatchNorm, nn.Identity)):
+                raise NotImplementedError(f'ever_amd AssymetricDecoder: norm layer {type(m).__name__} has no HIP kernel '
+                                          f'(BatchNorm2d, SyncBatchNorm, GroupNorm and None are implemented)')
+            return m
         self.blocks = nn.ModuleList()
         for os_in in in_feat_output_strides:
             n_up = int(math.log2(int(os_in))) - int(math.log2(int(out_feat_output_stride)))
@@ -79,8 +96,8 @@ class AssymetricDecoder(nn.Module):
             self.blocks.append(HipSequential(*[
                 HipSequential(
                     Conv2d(in_channels if i == 0 else out_channels, out_channels, 3, 1, 1, bias=False),
-                    BatchNorm2d(num_features=out_channels),
-                    ReLU(True),
+                    make_norm(),
+                    ReLU(True) if is_bn else GELU(),
                     Bf16compatible(UpsamplingBilinear2d(scale_factor=2)) if n_up != 0 else nn.Identity(),
                 ) for i in range(n_layers)]))
         if self.cls_cfg:
@@ -88,9 +105,7 @@ class AssymetricDecoder(nn.Module):
             num_classes = classifier_config.get('num_classes', -1)
             kernel_size = classifier_config.get('kernel_size', 1)
             dropout_rate = classifier_config.get('dropout_rate', -1)
-            if dropout_rate > 0:
-                raise NotImplementedError('ever_amd AssymetricDecoder: dropout_rate > 0 has no HIP kernel yet')
-            self.dropout = nn.Identity()
+            self.dropout = Dropout(dropout_rate) if dropout_rate > 0 else nn.Identity()
             self.classifier = HipSequential(
                 Conv2d(out_channels, num_classes, kernel_size, padding=(kernel_size - 1) // 2),
                 Bf16compatible(UpsamplingBilinear2d(scale_factor=scale_factor)) if scale_factor > 1 else nn.Identity())

@@ -13,7 +13,7 @@ import torch.nn as nn
 from ..hip import functional as HF
 
 __all__ = ['Conv2d', 'ConvTranspose2d', 'BatchNorm2d', 'ReLU', 'MaxPool2d', 'UpsamplingBilinear2d', 'AdaptiveAvgPool2d', 'Identity',
-           'HipSequential', 'run_sequence', 'to_hip']
+           'Dropout', 'GELU', 'HipSequential', 'run_sequence', 'to_hip']
 
 Identity = nn.Identity
 
@@ -142,6 +142,22 @@ class Dropout2d(nn.Dropout2d):
         return HN.dropout2d(x, self.p, self.training)
 
 
+class Dropout(nn.Dropout):
+    """nn.Dropout (element-wise): mask from torch's generator, masking + scaling in one HIP pass."""
+
+    def forward(self, x):
+        from ..hip import functional_next as HN
+        return HN.dropout(x, self.p, self.training)
+
+
+class GELU(nn.GELU):
+    def forward(self, x):
+        if self.approximate != 'none':
+            raise NotImplementedError("ever_amd GELU: only the exact (erf) form is implemented")
+        from ..hip import functional_next as HN
+        return HN.gelu(x)
+
+
 def _unwrap(m):
     # reference ops.Bf16compatible wraps the upsampling module (ever/module/ops.py:152-166); the HIP
     # path is fp32 end to end so the wrapper is transparent.
@@ -192,7 +208,7 @@ class HipSequential(nn.Sequential):
 _SWAP = {
     nn.Conv2d: Conv2d, nn.ConvTranspose2d: ConvTranspose2d, nn.BatchNorm2d: BatchNorm2d, nn.ReLU: ReLU, nn.MaxPool2d: MaxPool2d,
     nn.UpsamplingBilinear2d: UpsamplingBilinear2d, nn.AdaptiveAvgPool2d: AdaptiveAvgPool2d,
-    nn.GroupNorm: GroupNorm, nn.Dropout2d: Dropout2d, nn.Sequential: HipSequential,
+    nn.GroupNorm: GroupNorm, nn.Dropout2d: Dropout2d, nn.Dropout: Dropout, nn.GELU: GELU, nn.Sequential: HipSequential,
 }
 
 

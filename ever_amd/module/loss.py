@@ -8,10 +8,8 @@ __all__ = ['binary_cross_entropy_with_logits', 'dice_loss_with_logits', 'cross_e
 
 
 def binary_cross_entropy_with_logits(output, target, reduction='mean', ignore_index=255, pos_weight=None):
-    """reference loss.py:229-235"""
-    if reduction != 'mean' or pos_weight is not None:
-        raise NotImplementedError('ever_amd BCE: only reduction="mean" without pos_weight has a HIP kernel')
-    return HF.bce_with_logits(output, target, ignore_index=ignore_index)
+    """reference loss.py:229-235 (reduction 'mean' | 'sum'; 'none' has a data-dependent shape and raises)"""
+    return HF.bce_with_logits(output, target, ignore_index=ignore_index, pos_weight=pos_weight, reduction=reduction)
 
 
 def dice_loss_with_logits(y_pred, y_true, smooth_value=1.0, ignore_index=255, ignore_channel=-1, *,
@@ -34,9 +32,7 @@ def label_smoothing_cross_entropy(output, target, eps=0.1, reduction='mean', ign
 
 def label_smoothing_binary_cross_entropy(output, target, eps=0.1, reduction='mean', ignore_index=255):
     """reference loss.py:222-226"""
-    if reduction != 'mean':
-        raise NotImplementedError('ever_amd label_smoothing_binary_cross_entropy: only reduction="mean"')
-    return HF.bce_with_logits(output, target, ignore_index=ignore_index, label_smoothing=eps)
+    return HF.bce_with_logits(output, target, ignore_index=ignore_index, label_smoothing=eps, reduction=reduction)
 
 
 def soft_cross_entropy(input, target):

@@ -1,2 +1,2 @@
 from . import learning_rate, optimizer  # noqa: F401  (registers LR / OPT entries)
-from .optimizer import FusedSGD  # noqa: F401
+from .optimizer import FusedAdam, FusedAdamW, FusedSGD  # noqa: F401

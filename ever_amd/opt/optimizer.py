@@ -12,7 +12,7 @@ from ..hip import weight_planes
 from ..hip.ptr_table import PtrTable as _PtrTable
 from ..core import registry
 
-__all__ = ['FusedSGD']
+__all__ = ['FusedSGD', 'FusedAdam', 'FusedAdamW']
 
 
 class FusedSGD(SGD):
@@ -140,7 +140,94 @@ class FusedSGD(SGD):
         return loss
 
 
+class _FusedAdamMixin:
+    """torch.optim.Adam / AdamW semantics and state-dict (step, exp_avg, exp_avg_sq) with the update of all parameters of
+    a group done by ONE HIP launch (evk_adam_multi) and gradient clipping folded into it, when the parameters live on
+    the GPU.  amsgrad / maximize / capturable / CPU parameters take torch's own step."""
+    _decoupled = 0
+
+    def _init_fused(self):
+        self._clip = None
+        self._tabs = {}
+        self.last_grad_norm = None
+
+    fused_clip = FusedSGD.fused_clip
+    _table = FusedSGD._table
+    _dense = staticmethod(FusedSGD._dense)
+    _same_layout = staticmethod(FusedSGD._same_layout)
+
+    def _fused_ok(self, group, params):
+        return (params[0].is_cuda and all(p.dtype == torch.float32 for p in params) and not group.get('amsgrad')
+                and not group.get('maximize') and not group.get('capturable') and not group.get('differentiable')
+                and not isinstance(group['lr'], torch.Tensor))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            params = [p for p in group['params'] if p.grad is not None]
+            if not params:
+                continue
+            if not self._fused_ok(group, params):
+                saved = self.param_groups
+                self.param_groups = [group]
+                try:
+                    super().step()
+                finally:
+                    self.param_groups = saved
+                continue
+            by_step = {}
+            for p in params:
+                st = self.state[p]
+                if len(st) == 0:
+                    st['step'] = torch.tensor(0.0, dtype=torch.float32)
+                    st['exp_avg'] = torch.zeros_like(p)
+                    st['exp_avg_sq'] = torch.zeros_like(p)
+                for k in ('exp_avg', 'exp_avg_sq'):
+                    if not (self._dense(st[k]) and self._same_layout(st[k], p)):
+                        st[k] = torch.empty_like(p).copy_(st[k])       # checkpoint strides -> the parameter's
+                if not (self._dense(p.grad) and self._same_layout(p.grad, p)):
+                    p.grad = torch.empty_like(p).copy_(p.grad)
+                st['step'] += 1
+                by_step.setdefault(float(st['step']), []).append(p)
+            beta1, beta2 = group['betas']
+            for step, ps in by_step.items():
+                dev, slot = ps[0].device, (gi, step if len(by_step) > 1 else 0)
+                pt = self._table((slot, 'p'), ps, dev)
+                nt = self._table((slot, 'n'), ps, dev, sizes=True)
+                gt = self._table((slot, 'g'), [p.grad for p in ps], dev)
+                mt = self._table((slot, 'm'), [self.state[p]['exp_avg'] for p in ps], dev)
+                vt = self._table((slot, 'v'), [self.state[p]['exp_avg_sq'] for p in ps], dev)
+                _C.call('evk_adam_multi', pt.data_ptr(), gt.data_ptr(), mt.data_ptr(), vt.data_ptr(), nt.data_ptr(),
+                        len(ps), float(group['lr']), float(beta1), float(beta2), float(group['eps']),
+                        float(group['weight_decay']), self._decoupled, 1.0 - beta1 ** step,
+                        (1.0 - beta2 ** step) ** 0.5, None if self._clip is None else self._clip.data_ptr(),
+                        torch.cuda.current_stream().cuda_stream)
+            weight_planes.note_weights_changed()
+        self._clip = None
+        return loss
+
+
+class FusedAdam(_FusedAdamMixin, Adam):
+    def __init__(self, params, *args, **kwargs):
+        Adam.__init__(self, params, *args, **kwargs)
+        self._init_fused()
+
+
+class FusedAdamW(_FusedAdamMixin, AdamW):
+    _decoupled = 1
+
+    def __init__(self, params, *args, **kwargs):
+        AdamW.__init__(self, params, *args, **kwargs)
+        self._init_fused()
+
+
 registry.OPT.register('sgd', FusedSGD, verbose=False)
 registry.OPT.register('torch_sgd', SGD, verbose=False)
-registry.OPT.register('adam', Adam, verbose=False)
-registry.OPT.register('adamw', AdamW, verbose=False)
+registry.OPT.register('adam', FusedAdam, verbose=False)
+registry.OPT.register('adamw', FusedAdamW, verbose=False)
+registry.OPT.register('torch_adam', Adam, verbose=False)
+registry.OPT.register('torch_adamw', AdamW, verbose=False)

@@ -195,6 +195,11 @@ int evk_relu_fwd(const float* x, float* y, int64_t n, void* stream);
 int evk_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
 int evk_add(const float* a, const float* b, float* out, int64_t n, void* stream);
 int evk_scale(const float* a, float alpha, float* out, int64_t n, void* stream);
+/* out = a * b * alpha — nn.Dropout(p) with a 0/1 keep mask (fpn.py:183,190 `self.dropout(out_feat)`), alpha = 1/(1-p) */
+int evk_mul_scale(const float* a, const float* b, float alpha, float* out, int64_t n, void* stream);
+/* nn.GELU() (exact, erf form) and its derivative: the decoder's activation when norm_fn is not BatchNorm2d — fpn.py:167 */
+int evk_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
+int evk_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);
 
 /* nn.MaxPool2d(3, 2, 1) — _resnets.py:153.  code: one byte per output element = winning tap
  * ky*3+kx (first maximum in scan order).  x: [N,H,W,C] -> y: [N,Ho,Wo,C], Ho = (H-1)/2+1. */
@@ -255,6 +260,14 @@ int evk_bce_bwd(const float* logits, const int64_t* labels, int64_t npix, int64_
                 float label_smoothing, const double* stats, const float* grad_scale, float* dlogits,
                 int32_t accumulate, void* stream);
 
+/* the same with F.binary_cross_entropy_with_logits' `pos_weight` (one float: the path's heads have one logit channel)
+ * and `reduction` (0 = 'mean', 1 = 'sum') — loss.py:229-235 passes both through */
+int evk_bce_fwd_ex(const float* logits, const int64_t* labels, int64_t npix, int64_t ignore_index,
+                   float label_smoothing, float pos_weight, int32_t reduction, float* loss, double* stats, void* stream);
+int evk_bce_bwd_ex(const float* logits, const int64_t* labels, int64_t npix, int64_t ignore_index,
+                   float label_smoothing, float pos_weight, int32_t reduction, const double* stats,
+                   const float* grad_scale, float* dlogits, int32_t accumulate, void* stream);
+
 /* dice_loss_with_logits — loss.py:40-75.  C==1: p=sigmoid; C>1: p=softmax, one-hot target.
  * stats: double[2*C] = {inter[c], z[c]} (z = sum p + sum y, before smoothing).  In distributed
  * training the caller all-reduces `stats` between evk_dice_stats and evk_dice_finish
@@ -295,6 +308,12 @@ int evk_sgd_multi(float* const* params, const float* const* grads, float* const*
                   const int64_t* sizes, int32_t ntensors, float lr, float momentum, float dampening,
                   float weight_decay, int32_t nesterov, int32_t first_step,
                   const float* clip_coef /* device scalar or NULL */, void* stream);
+/* torch.optim.Adam (decoupled = 0) / AdamW (decoupled = 1) step, no amsgrad — opt/optimizer.py:8-9 registers both.
+ * bias_correction1 = 1 - beta1^step, sqrt_bias_correction2 = sqrt(1 - beta2^step) for the step being taken. */
+int evk_adam_multi(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                   const int64_t* sizes, int32_t ntensors, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int32_t decoupled, float bias_correction1, float sqrt_bias_correction2,
+                   const float* clip_coef /* device scalar or NULL */, void* stream);
 
 /* ------------------------------------------------------------------ "next" rows ---- */
 /* Class-probability statistics over the valid pixels: stats[0..C) = tp_c = sum p_c*y_c, [C..2C) = sum p_c,

@@ -351,3 +351,105 @@ def test_dice_statistics_all_reduce_two_virtual_ranks_equal_full_batch(cuda, c):
         assert abs(li.item() - ref.item()) <= 1e-6 * abs(ref.item()) + 1e-7, (i, li.item(), ref.item())
         ga, gb = zi.grad.cpu().contiguous().double().numpy(), 2.0 * zr.grad[sl].numpy()
         assert np.abs(ga - gb).max() <= 1e-4 * np.abs(gb).max(), (np.abs(ga - gb).max(), np.abs(gb).max())
+
+
+@pytest.mark.parametrize('pw,red', [(None, 'mean'), (2.5, 'mean'), (0.4, 'sum'), (None, 'sum')])
+def test_bce_pos_weight_and_reduction_match_reference_formula(cuda, pw, red):
+    """reference loss.py:229-235: _masked_ignore then F.binary_cross_entropy_with_logits(reduction, pos_weight)."""
+    from ever_amd.module import loss as L
+    gen = torch.Generator().manual_seed(9)
+    z = (torch.randn(3, 1, 17, 12, generator=gen) * 3).requires_grad_()
+    y = (torch.rand(3, 17, 12, generator=gen) < 0.4).long()
+    y[1, :5, :4] = 255
+    valid = y.reshape(-1) != 255
+    ref = torch.nn.functional.binary_cross_entropy_with_logits(
+        z.double().reshape(-1)[valid], y.reshape(-1)[valid].double(), reduction=red,
+        pos_weight=None if pw is None else torch.tensor(pw, dtype=torch.float64))
+    (gr,) = torch.autograd.grad(ref, z)
+    zg = z.detach().to(cuda).requires_grad_()
+    out = L.binary_cross_entropy_with_logits(zg, y.to(cuda), reduction=red, pos_weight=None if pw is None else torch.tensor(pw))
+    out.backward()
+    assert abs(out.item() - ref.item()) <= 2e-6 * abs(ref.item())
+    _close(zg.grad.cpu().numpy(), gr.numpy(), 1e-5)
+    with pytest.raises(NotImplementedError):
+        L.binary_cross_entropy_with_logits(zg, y.to(cuda), reduction='none')
+
+
+def test_gelu_and_dropout_kernels(cuda):
+    from ever_amd.hip import functional_next as HN
+    gen = torch.Generator().manual_seed(10)
+    x = torch.randn(2, 8, 7, 5, generator=gen) * 2
+    g = torch.randn(2, 8, 7, 5, generator=gen)
+    xr = x.double().requires_grad_()
+    yr = torch.nn.functional.gelu(xr)
+    yr.backward(g.double())
+    xg = x.to(cuda).requires_grad_()
+    yg = HN.gelu(xg)
+    yg.backward(g.to(cuda))
+    _close(yg.detach().cpu().numpy(), yr.detach().numpy(), 2e-6)
+    _close(xg.grad.cpu().numpy(), xr.grad.numpy(), 2e-6)
+    # dropout with a given mask = the formula; with a drawn mask: zeros at rate ~p, survivors scaled by 1/(1-p)
+    mask = (torch.rand(2, 8, 7, 5, generator=gen) < 0.7).float()
+    xd = x.to(cuda).requires_grad_()
+    yd = HN.dropout(xd, 0.3, True, mask=mask)
+    yd.backward(g.to(cuda))
+    _close(yd.detach().cpu().numpy(), (x * mask / 0.7).numpy(), 1e-6)
+    _close(xd.grad.cpu().numpy(), (g * mask / 0.7).numpy(), 1e-6)
+    big = torch.ones(4, 16, 64, 64, device=cuda)
+    out = HN.dropout(big, 0.25, True)
+    kept = float((out != 0).float().mean())
+    assert abs(kept - 0.75) < 0.01 and torch.allclose(out[out != 0], torch.tensor(1 / 0.75, device=cuda))
+    assert HN.dropout(big, 0.25, False) is big
+
+
+def test_decoder_with_dropout_groupnorm_gelu_and_no_norm_matches_reference_structure(cuda):
+    """reference fpn.py:144-193 options the FarSeg default does not use: `dropout_rate` > 0 (nn.Dropout before the
+    classifier), norm_fn != BatchNorm2d (the activation becomes GELU) and norm_fn=None.  Same state-dict keys as the
+    stock-torch restatement; with dropout off (eval) the outputs and gradients match it."""
+    import functools
+    import math
+    import torch.nn as nn
+    from ever_amd.module.fpn import AssymetricDecoder
+    from oracle import portable
+
+    def ref_decoder(norm_fn, c_in=32, c_out=32):
+        blocks = nn.ModuleList()
+        for s in (4, 8, 16, 32):
+            n_up = int(math.log2(s)) - 2
+            blocks.append(nn.Sequential(*[nn.Sequential(
+                nn.Conv2d(c_in if i == 0 else c_out, c_out, 3, 1, 1, bias=False),
+                norm_fn(num_features=c_out) if norm_fn is not None else nn.Identity(),
+                nn.ReLU(True) if norm_fn == nn.BatchNorm2d else nn.GELU(),
+                nn.UpsamplingBilinear2d(scale_factor=2) if n_up != 0 else nn.Identity()) for i in range(n_up if n_up else 1)]))
+        cls = nn.Conv2d(c_out, 4, 1)
+        return blocks, cls
+
+    class GN(nn.GroupNorm):
+        def __init__(self, num_features):
+            super().__init__(8, num_features)
+
+    for norm_fn in (GN, None):
+        m = AssymetricDecoder(32, 32, norm_fn=norm_fn,
+                              classifier_config=dict(scale_factor=1, num_classes=4, kernel_size=1, dropout_rate=0.2))
+        blocks, cls = ref_decoder(norm_fn)
+        filled = portable.fill_state_dict(m.state_dict())
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in filled.items()})
+        ref_sd = {k.replace('._inner_module', ''): v for k, v in filled.items()}
+        blocks.load_state_dict({k[len('blocks.'):]: torch.from_numpy(v.copy()) for k, v in ref_sd.items() if k.startswith('blocks.')})
+        cls.load_state_dict({k[len('classifier.0.'):]: torch.from_numpy(v.copy()) for k, v in ref_sd.items() if k.startswith('classifier.0.')})
+        feats = [torch.from_numpy(portable.normalish(f'dec/f{i}', (2, 32, s, s))) for i, s in enumerate((16, 8, 4, 2))]
+        fr = [f.double().requires_grad_() for f in feats]
+        blocks, cls = blocks.double(), cls.double()
+        inner = [b(f) for b, f in zip(blocks, fr)]
+        out_r = cls(sum(inner) / 4)
+        out_r.sum().backward()
+        m = m.to(cuda).eval()      # eval: dropout off, the norms here have no running statistics
+        fg = [f.to(cuda).requires_grad_() for f in feats]
+        out = m(fg)
+        out.sum().backward()
+        _close(out.detach().cpu().contiguous().numpy(), out_r.detach().numpy(), 2e-4)
+        for a, b in zip(fg, fr):
+            _close(a.grad.cpu().contiguous().numpy(), b.grad.numpy(), 5e-4)
+        m.train()
+        o1 = m([f.to(cuda) for f in feats])
+        assert torch.isfinite(o1).all()

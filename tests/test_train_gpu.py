@@ -8,6 +8,53 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize('decoupled', [False, True])
+def test_fused_adam_and_adamw_match_torch(cuda, decoupled):
+    """opt/optimizer.py:8-9 registers 'adam' / 'adamw': one-launch HIP step vs torch.optim.Adam / AdamW over 4 steps
+    (clipping folded in; a parameter that skips a step keeps its own step count), identical state-dict schema, and a
+    resume from the torch optimizer's state dict (NCHW-dense moments re-laid to the channels_last parameters)."""
+    import ever_amd as er
+    torch.manual_seed(1)
+    shapes = [(64, 4, 7, 7), (64,), (256, 64, 1, 1), (32, 32, 3, 3), (1,), (7, 3), (1031,)]
+    ps_a = [torch.randn(s, device=cuda) for s in shapes]
+    ps_a = [(p.contiguous(memory_format=torch.channels_last) if p.dim() == 4 else p).requires_grad_() for p in ps_a]
+    ps_b = [p.detach().clone().contiguous().requires_grad_() for p in ps_a]
+    kw = dict(lr=0.01, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.02)
+    fused, stock = (er.opt.FusedAdamW, torch.optim.AdamW) if decoupled else (er.opt.FusedAdam, torch.optim.Adam)
+    assert er.registry.OPT['adamw' if decoupled else 'adam'] is fused
+    oa, ob = fused(ps_a, **kw), stock(ps_b, **kw)
+    for step in range(4):
+        for k, (p, q) in enumerate(zip(ps_a, ps_b)):
+            if step == 1 and k == 2:
+                p.grad = q.grad = None        # no gradient this step: its step counter falls behind the others
+                continue
+            g = torch.randn_like(q)
+            p.grad, q.grad = g.clone(), g.clone()
+        oa.fused_clip(max_norm=5.0)
+        torch.nn.utils.clip_grad_norm_([q for q in ps_b if q.grad is not None], max_norm=5.0)
+        oa.step()
+        ob.step()
+        for p, q in zip(ps_a, ps_b):
+            assert torch.allclose(p, q, rtol=2e-5, atol=2e-6), (step, p.shape, float((p - q).abs().max()))
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert set(sa['state'][0]) == set(sb['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'}
+    assert float(sa['state'][2]['step']) == float(sb['state'][2]['step']) == 3.0
+    # resume from the stock optimizer's checkpoint
+    oc = fused([p.detach().clone().contiguous(memory_format=torch.channels_last).requires_grad_() if p.dim() == 4
+                else p.detach().clone().requires_grad_() for p in ps_b], **kw)
+    import copy
+    oc.load_state_dict(copy.deepcopy(sb))      # (torch shares same-device state tensors with the dict it loads)
+    pc = [p for g in oc.param_groups for p in g['params']]
+    for p, q in zip(pc, ps_b):
+        g = torch.randn_like(q)
+        p.grad, q.grad = g.clone(), g.clone()
+    oc.step()
+    ob.step()
+    for p, q in zip(pc, ps_b):
+        assert torch.allclose(p, q, rtol=2e-5, atol=2e-6)
+        assert oc.state[p]['exp_avg'].stride() == p.stride()
+
+
 def test_fused_sgd_matches_torch_sgd(cuda):
     import ever_amd as er
     torch.manual_seed(0)
