@@ -62,6 +62,9 @@ SIGNATURES = {
     'evk_conv2d_wgrad_x3': (c_int, [_DP, P, P, P, P, P, c_size_t, P]),
     'evk_conv2d_wgrad_workspace_bytes': (c_size_t, [_DP]),
     'evk_conv2d_wgrad': (c_int, [_DP, P, P, P, P, P, c_size_t, P]),
+    'evk_stem_s2d': (c_int, [P, P, c_i32, c_i32, c_i32, c_i32, c_i32, P]),
+    'evk_stem_s2d_weight': (c_int, [P, P, c_i32, c_i32, P]),
+    'evk_stem_s2d_weight_bwd': (c_int, [P, P, c_i32, c_i32, P]),
     'evk_pad_channels': (c_int, [P, P, c_i64, c_i32, c_i32, P]),
     'evk_unpad_channels': (c_int, [P, P, c_i64, c_i32, c_i32, P]),
     'evk_nchw_to_nhwc': (c_int, [P, P, c_i32, c_i32, c_i32, c_i32, c_i32, P]),

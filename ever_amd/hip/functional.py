@@ -520,6 +520,76 @@ def conv_transpose2d(x, weight, bias=None, stride=1, padding=0, output_padding=0
     return _ConvTranspose2dFn.apply(x, weight, bias, _pair(stride), _pair(padding), _pair(output_padding), _pair(dilation))
 
 
+# ------------------------------------------------------------------------------------ ResNet stem (space-to-depth)
+class _StemConvFn(Function):
+    """conv 7x7 / stride 2 / padding 3 on a 3- or 4-band image (reference _resnets.py:149) as a space-to-depth 4x4
+    convolution with 16 input channels on the split-MFMA kernels (csrc/stem_s2d.hip): the image is re-laid once, the
+    weight on every call (12 KB), the products and their sum are the ones of the 7x7 form.  No gradient to the image."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        n, c, h, w = x.shape
+        cout = weight.shape[0]
+        dev, st = x.device, _stream()
+        nchw = not is_nhwc(x)
+        if nchw and not x.is_contiguous():
+            x = x.contiguous()
+        xs = torch.empty((n, h // 2 + 3, w // 2 + 3, 16), device=dev, dtype=torch.float32)
+        _C.call('evk_stem_s2d', x.data_ptr(), xs.data_ptr(), n, c, h, w, 1 if nchw else 0, st)
+        w7 = _weight_ohwi(weight.detach())                       # [Cout][7][7][C]
+        w4 = torch.empty((cout, 4, 4, 16), device=dev, dtype=torch.float32)
+        _C.call('evk_stem_s2d_weight', w7.data_ptr(), w4.data_ptr(), cout, c, st)
+        d = _C.ConvDesc(n, h // 2 + 3, w // 2 + 3, 16, h // 2, w // 2, cout, 4, 4, 1, 1, 0, 0, 1, 1)
+        planes = workspace(dev, _C.load().evk_conv2d_split_weight_bytes(ctypes.byref(d), 0))
+        _C.call('evk_conv2d_split_weight', ctypes.byref(d), w4.data_ptr(), 0, planes.data_ptr(), st)
+        y = empty_nhwc(n, cout, h // 2, w // 2, dev)
+        flops = 2.0 * n * (h // 2) * (w // 2) * cout * c * 49     # algorithmic: the 7x7 taps, not the 4x4x16 padding
+        nbytes = 4.0 * (x.numel() + y.numel() + weight.numel())
+        sp = timing.span('conv_igemm', flops, nbytes)
+        _C.call('evk_conv2d_fwd_x3', ctypes.byref(d), xs.data_ptr(), planes.data_ptr(), None, y.data_ptr(), 0, st)
+        if sp is not None:
+            sp.stop()
+        ctx.desc, ctx.flops, ctx.nbytes, ctx.cin, ctx.scope = d, flops, nbytes, c, timing.current_scope()
+        ctx.w_stride = tuple(weight.stride())
+        ctx.save_for_backward(xs)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (xs,) = ctx.saved_tensors
+        d, c = ctx.desc, ctx.cin
+        dev, st = xs.device, _stream()
+        dy = as_nhwc(dy, 'stem.backward')
+        lib = _C.load()
+        ws_bytes = lib.evk_conv2d_wgrad_x3_workspace_bytes(ctypes.byref(d))
+        ws = workspace(dev, ws_bytes)
+        dw4 = torch.empty((d.Cout, 4, 4, 16), device=dev, dtype=torch.float32)
+        sp = timing.span('conv_wgrad', ctx.flops, ctx.nbytes, ctx.scope)
+        _C.call('evk_conv2d_wgrad_x3', ctypes.byref(d), xs.data_ptr(), dy.data_ptr(), dw4.data_ptr(), None, ws.data_ptr(),
+                ws_bytes, st)
+        if sp is not None:
+            sp.stop()
+        dw7 = torch.empty((d.Cout, 7, 7, c), device=dev, dtype=torch.float32)
+        _C.call('evk_stem_s2d_weight_bwd', dw4.data_ptr(), dw7.data_ptr(), d.Cout, c, st)
+        return None, dw7.permute(0, 3, 1, 2)                     # logical OIHW over OHWI memory, as the parameter
+
+
+def stem_conv_applicable(x, conv):
+    """True when `conv` is the 7x7 / stride-2 / padding-3 stem on a <= 4-band image that needs no gradient, under the
+    split arithmetic: the cases the space-to-depth form covers."""
+    return (_CONV_MATH == 'bf16x3' and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not x.requires_grad
+            and tuple(conv.kernel_size) == (7, 7) and tuple(conv.stride) == (2, 2) and tuple(conv.padding) == (3, 3)
+            and tuple(conv.dilation) == (1, 1) and conv.bias is None and conv.groups == 1 and x.shape[1] <= 4
+            and conv.out_channels % 8 == 0 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+            and os.environ.get('EVK_STEM_S2D', '1') != '0')
+
+
+def stem_conv7x7s2(x, weight):
+    _require_cuda(x, 'stem_conv7x7s2')
+    return _StemConvFn.apply(x, weight)
+
+
 # ------------------------------------------------------------------------------------ batch norm
 class _BatchNormActFn(Function):
     """BatchNorm2d (+ residual add) (+ ReLU) in one pass.

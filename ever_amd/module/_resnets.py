@@ -8,7 +8,7 @@ conv -> [BN+ReLU] -> conv -> [BN+ReLU] -> conv -> [BN + identity add + ReLU].
 import torch.nn as nn
 
 from ..hip import functional as HF
-from .fold import conv_bn
+from .fold import _use_folded, conv_bn
 from .layers import AdaptiveAvgPool2d, BatchNorm2d, Conv2d, HipSequential, MaxPool2d, ReLU
 
 __all__ = ['ResNet', 'BasicBlock', 'Bottleneck', 'resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152',
@@ -172,6 +172,9 @@ class ResNet(nn.Module):
     def stem_forward(self, x):
         if self.deep_stem:
             return self.stem(x)
+        if HF.stem_conv_applicable(x, self.conv1) and not _use_folded(self.conv1, self.bn1):
+            # 7x7 / stride 2 on a 3- or 4-band image: space-to-depth form on the split-MFMA kernels (csrc/stem_s2d.hip)
+            return self.bn1(HF.stem_conv7x7s2(x, self.conv1.weight), relu=True)
         return conv_bn(self.conv1, self.bn1, x, relu=True)
 
     def forward(self, x):

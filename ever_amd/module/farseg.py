@@ -28,7 +28,7 @@ class FarSeg(ERModule):
         self.head = self.HEAD(self.config.head)
 
     def forward(self, x, y=None):
-        x = HF.as_nhwc(x, 'FarSeg input')  # boundary: NCHW image -> NHWC (conv pads channels to 4 itself)
+        HF._require_cuda(x, 'FarSeg input')   # boundary: the stem takes the NCHW (or NHWC) image as it is
         with timing.scope('encoder'):   # bench.py prices the encoder conv stack on its own (north_star target)
             feats = self.en(x)
         logits = self.head(feats)

@@ -154,6 +154,17 @@ int evk_conv2d_wgrad(const evk_conv_desc* d, const float* x, const float* dy, fl
 
 /* [N,H,W,C] -> [N,H,W,Cp] zero padded (forward) and the adjoint / slice (backward). Also used for
  * OHWI weights with rows = Cout*kh*kw.  C, Cp arbitrary. */
+/* The ResNet stem (conv 7x7 stride 2 padding 3 on a 3- or 4-band image; _resnets.py:149, resnet.py:100-117) as a
+ * space-to-depth 4x4 stride-1 convolution with 16 input channels, so that it runs on the split-MFMA kernels
+ * (evk_conv2d_fwd_x3 / _wgrad_x3 with desc N, H/2+3, W/2+3, 16 -> H/2, W/2, Cout, k 4, stride 1, pad 0):
+ *   evk_stem_s2d:            image [N,H,W,C] (or [N,C,H,W] when src_is_nchw) -> [N][H/2+3][W/2+3][16], zero borders
+ *   evk_stem_s2d_weight:     w7 [Cout][7][7][C] -> w4 [Cout][4][4][16]
+ *   evk_stem_s2d_weight_bwd: dw4 -> dw7 (the adjoint gather)
+ * Same products, same sum; C <= 4, H and W even. */
+int evk_stem_s2d(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t src_is_nchw,
+                 void* stream);
+int evk_stem_s2d_weight(const float* w7, float* w4, int32_t Cout, int32_t C, void* stream);
+int evk_stem_s2d_weight_bwd(const float* dw4, float* dw7, int32_t Cout, int32_t C, void* stream);
 int evk_pad_channels(const float* src, float* dst, int64_t rows, int32_t C, int32_t Cp, void* stream);
 int evk_unpad_channels(const float* src, float* dst, int64_t rows, int32_t Cp, int32_t C, void* stream);
 /* NCHW <-> NHWC(+pad) transposes at the model boundary (image in, logits out). */

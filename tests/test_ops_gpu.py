@@ -394,3 +394,31 @@ def test_cpu_tensor_fails_loudly():
     from ever_amd.hip import functional as F
     with pytest.raises(F.HipPathError):
         F.conv2d(torch.randn(1, 4, 4, 4), torch.randn(4, 4, 1, 1))
+
+
+@pytest.mark.parametrize('c,h,w,nchw', [(3, 64, 48, True), (4, 32, 32, True), (3, 34, 62, False), (1, 16, 16, True)])
+def test_stem_space_to_depth_conv_matches_torch(cuda, c, h, w, nchw):
+    """The 7x7 / stride-2 / padding-3 stem as a space-to-depth 4x4 convolution on the split-MFMA kernels
+    (csrc/stem_s2d.hip) vs torch conv2d on the CPU (fp64): forward and weight gradient, 1..4 bands, NCHW and NHWC
+    images, sizes that are not multiples of the tiles."""
+    from ever_amd.hip import functional as HF
+    import ever_amd as er
+    torch.manual_seed(c * 100 + h)
+    conv = er.module.Conv2d(c, 64, 7, 2, 3, bias=False).to(cuda)
+    x = torch.randn(2, c, h, w)
+    ref = torch.nn.functional.conv2d(x.double(), conv.weight.detach().cpu().double(), None, 2, 3)
+    g = torch.randn_like(ref)
+    wr = conv.weight.detach().cpu().double().requires_grad_()
+    torch.nn.functional.conv2d(x.double(), wr, None, 2, 3).backward(g)
+    xg = x.to(cuda)
+    if not nchw:
+        xg = xg.contiguous(memory_format=torch.channels_last)
+    assert HF.stem_conv_applicable(xg, conv)
+    y = HF.stem_conv7x7s2(xg, conv.weight)
+    y.backward(g.float().to(cuda))
+    assert tuple(y.shape) == tuple(ref.shape)
+    a, b = y.detach().cpu().double(), ref
+    assert float((a - b).abs().max() / b.abs().max()) < 1e-5
+    ga, gb = conv.weight.grad.cpu().double(), wr.grad
+    assert float((ga - gb).abs().max() / gb.abs().max()) < 1e-5
+    assert c == 1 or conv.weight.grad.stride() == conv.weight.stride()
