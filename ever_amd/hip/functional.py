@@ -366,6 +366,47 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False):
     return _Conv2dFn.apply(x, weight, bias, _pair(stride), _pair(padding), _pair(dilation), bool(relu))
 
 
+class GradSlot:
+    """A gradient handed from a LATER consumer of a tensor to an EARLIER one, so that the sum of the two input
+    gradients happens inside a data-gradient kernel's epilogue instead of autograd's own add pass.
+
+    ResNetEncoder's stage output c_i feeds the next stage's first block (a `conv2d_fork` node) AND, later in the
+    forward, the head (FPN lateral).  Backward runs the head first: its gradient w.r.t. c_i is parked here
+    (`_SlotOutFn`), and the fork node — which runs afterwards — feeds it to its first data-gradient launch as `accum`.
+    Safety: a slot is only handed to the head if a fork node CLAIMED it during the forward, and parking a gradient in
+    a slot whose claimant has already run raises instead of dropping the gradient."""
+    __slots__ = ('grad', 'claimed', 'consumed')
+
+    def __init__(self):
+        self.grad, self.claimed, self.consumed = None, False, False
+
+
+class _SlotOutFn(Function):
+    @staticmethod
+    def forward(ctx, x, slot):
+        ctx.slot = slot
+        return x.view_as(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        slot = ctx.slot
+        if slot.consumed or slot.grad is not None:
+            raise RuntimeError('gradient slot: the claiming convolution ran its backward before this gradient arrived '
+                               '(or backward ran twice on one graph); disable with EVK_GRAD_SLOTS=0')
+        slot.grad = as_nhwc(g, 'grad slot')
+        return None, None
+
+
+def slot_output(x, slot):
+    """The view of `x` to hand to the later consumer: its gradient goes to `slot` instead of to autograd's sum."""
+    return _SlotOutFn.apply(x, slot)
+
+
+def grad_slots_enabled():
+    return os.environ.get('EVK_GRAD_SLOTS', '1') != '0'
+
+
 class _ConvForkFn(Function):
     """Two consumers of one tensor in ONE autograd node: x feeds conv_main AND a second branch — a residual block's
     shortcut (identity, or the down-sampling 1x1 conv; reference _resnets.py:52-69, 92-112, 188-192) or a sibling
@@ -374,9 +415,10 @@ class _ConvForkFn(Function):
     data-gradient kernel (dx = dgrad(dy_main) + d_other) instead of a separate add pass over x."""
 
     @staticmethod
-    def forward(ctx, x, w_main, w_short, b_main, b_short, cfg_main, cfg_short):
+    def forward(ctx, x, w_main, w_short, b_main, b_short, cfg_main, cfg_short, slot=None):
         y, cs = _conv_forward(x, w_main, b_main, *cfg_main, False)
         ctx.cs_main = cs
+        ctx.slot = slot
         if w_short is None:
             ctx.cs_short = None
             ctx.save_for_backward(*_stash([cs]))
@@ -393,17 +435,26 @@ class _ConvForkFn(Function):
         _unstash([ctx.cs_main] if ctx.cs_short is None else [ctx.cs_main, ctx.cs_short], ctx.saved_tensors)
         dws = dbs = None
         acc = None
+        slot_g = None
+        if ctx.slot is not None:   # a later consumer's gradient of x, parked by _SlotOutFn (the head ran first)
+            ctx.slot.consumed = True
+            slot_g, ctx.slot.grad = ctx.slot.grad, None
+            if not need_dx:
+                slot_g = None
         if ctx.cs_short is None:
             acc = dshort  # gradient of the identity shortcut
         elif dshort is not None:
             acc, dws, dbs = _conv_backward(ctx.cs_short, dshort, need_dx, ctx.needs_input_grad[2],
-                                           ctx.cs_short.has_bias and ctx.needs_input_grad[4])
+                                           ctx.cs_short.has_bias and ctx.needs_input_grad[4], accum=slot_g)
+            slot_g = None
+        if slot_g is not None:     # the shortcut convolution did not run: plain sum
+            acc = slot_g if acc is None else add(acc, slot_g)
         if dy is None:   # only the second branch reached the loss
-            return acc, None, dws, None, dbs, None, None
+            return acc, None, dws, None, dbs, None, None, None
         dx, dw, db = _conv_backward(ctx.cs_main, dy, need_dx, ctx.needs_input_grad[1],
                                     ctx.cs_main.has_bias and ctx.needs_input_grad[3],
                                     accum=acc if need_dx else None)
-        return dx, dw, dws, db, dbs, None, None
+        return dx, dw, dws, db, dbs, None, None, None
 
 
 def conv2d_fork(x, conv_main, conv_short=None):
@@ -419,7 +470,12 @@ def conv2d_fork(x, conv_main, conv_short=None):
     if conv_short is None:
         return _ConvForkFn.apply(x, conv_main.weight, None, conv_main.bias, None, cfg_m, None)
     cfg_s = (_pair(conv_short.stride), _pair(conv_short.padding), _pair(conv_short.dilation))
-    return _ConvForkFn.apply(x, conv_main.weight, conv_short.weight, conv_main.bias, conv_short.bias, cfg_m, cfg_s)
+    slot = getattr(x, '_evk_grad_slot', None)
+    if slot is not None and not slot.claimed and torch.is_grad_enabled() and x.requires_grad:
+        slot.claimed = True   # this node will add the parked gradient inside its shortcut data-gradient launch
+    else:
+        slot = None
+    return _ConvForkFn.apply(x, conv_main.weight, conv_short.weight, conv_main.bias, conv_short.bias, cfg_m, cfg_s, slot)
 
 
 # ------------------------------------------------------------------------------------ transposed convolution

@@ -7,6 +7,7 @@ kernel lays it out NHWC (channels padded to a multiple of 4 for the 16-byte im2c
 """
 from functools import partial
 
+import torch
 import torch.nn as nn
 from torch.utils import checkpoint as cp
 
@@ -14,6 +15,7 @@ from ..core import logger, registry
 from ..interface import ERModule
 from ..util import param_util
 from . import _resnets
+from ..hip import functional as HF
 from .layers import Conv2d
 
 _logger = logger.get_logger()
@@ -112,13 +114,32 @@ class ResNetEncoder(ERModule):
         r = self.resnet
         x = r.maxpool(r.stem_forward(x))
         wcp = self.config.with_cp
+        # A stage output feeds the next stage AND (later) the caller.  With gradient slots the caller's gradient is
+        # added inside the next stage's first data-gradient launch (hip/functional.py:GradSlot) instead of by an
+        # autograd add pass over the whole map; off under activation checkpointing (the fork nodes are rebuilt then).
+        slots = HF.grad_slots_enabled() and not any(wcp) and torch.is_grad_enabled()
+        outs = []
+
+        def stage(layer, t, use_cp):
+            slot = None
+            if slots and t.requires_grad:
+                slot = HF.GradSlot()
+                t._evk_grad_slot = slot
+            y = self._run_stage(layer, t, use_cp)
+            if slot is not None:
+                del t._evk_grad_slot
+                if slot.claimed:
+                    outs[-1] = HF.slot_output(t, slot)
+            return y
         c2 = self._run_stage(r.layer1, x, wcp[0])    # os 4 : 64 (r18/34) / 256 ch
-        c3 = self._run_stage(r.layer2, c2, wcp[1])   # os 8 : 128 / 512
-        c4 = self._run_stage(r.layer3, c3, wcp[2])   # os 16: 256 / 1024
+        outs.append(c2)
+        c3 = stage(r.layer2, c2, wcp[1])             # os 8 : 128 / 512
+        outs.append(c3)
+        c4 = stage(r.layer3, c3, wcp[2])             # os 16: 256 / 1024
+        outs.append(c4)
         if self.config.include_conv5:
-            c5 = self._run_stage(r.layer4, c4, wcp[3])  # os 32: 512 / 2048
-            return [c2, c3, c4, c5]
-        return [c2, c3, c4]
+            outs.append(stage(r.layer4, c4, wcp[3]))  # os 32: 512 / 2048
+        return outs
 
     def set_default_config(self):
         self.config.update(dict(

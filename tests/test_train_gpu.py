@@ -159,3 +159,43 @@ def test_encoder_options_match_oracle(cuda, opts):
         assert enc.resnet.conv1.weight.grad is None and enc.resnet.layer1[0].conv1.weight.grad is None
         assert enc.resnet.layer2[0].conv1.weight.grad is not None
         assert enc.resnet.layer2[0].bn1.weight.grad is None     # frozen BN
+
+
+def test_gradient_slots_equal_autograd_sum(cuda):
+    """The encoder's stage outputs feed the next stage and the head; with gradient slots the head's gradient is added
+    inside the next stage's first data-gradient launch (no autograd add pass).  Gradients must equal the plain
+    autograd-sum path (EVK_GRAD_SLOTS=0) to rounding, and no ATen add may remain for the c2..c4 fan-out."""
+    import os
+    import ever_amd as er
+    torch.manual_seed(21)
+    m = er.module.FarSeg(dict(encoder=dict(resnet_type='resnet50'))).to(cuda).train()
+    x = torch.randn(2, 3, 128, 128, device=cuda)
+    y = (torch.rand(2, 128, 128, device=cuda) < 0.3).long()
+
+    def grads():
+        m.zero_grad(set_to_none=True)
+        sum(m(x, y).values()).backward()
+        return [p.grad.double().clone() for p in m.parameters()]
+    with_slots = grads()
+    os.environ['EVK_GRAD_SLOTS'] = '0'
+    try:
+        plain = grads()
+    finally:
+        del os.environ['EVK_GRAD_SLOTS']
+    num = sum(float((a - b).square().sum()) for a, b in zip(with_slots, plain))
+    den = sum(float(b.square().sum()) for b in plain)
+    assert (num / den) ** 0.5 < 1e-5, (num / den) ** 0.5     # same sums in another order (BN statistics moved once more)
+    from torch.profiler import profile, ProfilerActivity
+
+    def count_adds():
+        with profile(activities=[ProfilerActivity.CPU]) as prof:
+            grads()
+        return sum(e.count for e in prof.key_averages() if e.key in ('aten::add', 'aten::add_'))
+    n_slots = count_adds()
+    os.environ['EVK_GRAD_SLOTS'] = '0'
+    try:
+        n_plain = count_adds()
+    finally:
+        del os.environ['EVK_GRAD_SLOTS']
+    print(f'aten::add calls per step: {n_plain} with autograd sums, {n_slots} with gradient slots')
+    assert n_slots == n_plain - 3, (n_plain, n_slots)   # c2, c3, c4: one whole-map add pass each, gone
