@@ -33,6 +33,37 @@ struct IGemmArgs {
 template <int NB, int WN>
 __device__ __forceinline__ void igemm_store_rows(const IGemmArgs& p, f32x16 (&accrow)[NB], size_t roff, int n0, int wn,
                                                  int lh) {
+  const bool vec = (p.Cd & 3) == 0 && n0 + wn * WN + NB * 32 <= p.Cd;   // whole block inside the tensor, 16-byte rows
+  if (vec) {
+    // gfx9 has ONE in-order vmcnt for loads and stores: a bias / accumulate load issued after a store is only
+    // satisfied once that store has completed, so "load, add, store" per quad serialises the epilogue on the HBM
+    // write latency.  All loads of the row block first (4 x NB quads, 16 x NB registers), one wait, then the stores.
+    f32x4 add[NB][4];
+    const bool has_b = p.bias != nullptr, has_a = p.accum != nullptr;
+    if (has_b || has_a) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int col = n0 + wn * WN + b * 32 + 8 * r4 + 4 * lh;
+          f32x4 t = {0.f, 0.f, 0.f, 0.f};
+          if (has_b) t = *reinterpret_cast<const f32x4*>(p.bias + col);
+          if (has_a) t += *reinterpret_cast<const f32x4*>(p.accum + roff + col);
+          add[b][r4] = t;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int col = n0 + wn * WN + b * 32 + 8 * r4 + 4 * lh;
+        f32x4 v = {accrow[b][4 * r4], accrow[b][4 * r4 + 1], accrow[b][4 * r4 + 2], accrow[b][4 * r4 + 3]};
+        if (has_b || has_a) v += add[b][r4];
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<f32x4*>(p.dst + roff + col) = v;
+      }
+    return;
+  }
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
 #pragma unroll
