@@ -174,6 +174,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
     auto load = [&](auto SET, int kt) {
       constexpr int s = decltype(SET)::value;
       const int pix0 = pbeg + kt * BKP;
+      if (p.dbg & 1) return;   // ablation: no global loads
       gather8(p, gb, pix0 + bpg * 8, pend, rb[s], okb[s]);
       gather8h(p.dy, p.Cout, a_coff, a_cvalid, pix0 + apg * 8, pend, ra[s], oka[s]);
     };
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
       constexpr int s = decltype(SET)::value;
       unsigned char* Ab = smem3 + stage * kStage;
       unsigned char* Bb = Ab + 3 * BM * kRowBytes;
+      if (p.dbg & 2) return;   // ablation: no split, no LDS writes
       split_store8(rb[s], okb[s], Bb, BN * kRowBytes, QB, bcq, bpg);
       split_store8h(ra[s], oka[s], Ab, BM * kRowBytes, QA2, acq, apg);
     };
@@ -232,7 +234,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) fb_off[b][kk] = 3 * BM * kRowBytes + plane_off(wn * WN + b * 32 + li, 2 * kk + lh);
+    // im2col LDS row e * QB + q holds channel 4q + e of the k range (staging permutation).  Matrix wave wn takes q in
+    // [32 wn, 32 wn + 32) of ALL four e-blocks as its NB = 4 column blocks: lane li then owns the four CONSECUTIVE
+    // k columns 4 (32 wn + li) + {0..3} across its blocks, i.e. one 16-byte store per accumulator row.
+    for (int kk = 0; kk < 2; ++kk) fb_off[b][kk] = 3 * BM * kRowBytes + plane_off(b * QB + wn * 32 + li, 2 * kk + lh);
 
   auto half_step = [&](const unsigned char* S, int kk) {
     bf16x8 fa[MB][3], fb[NB][3];
@@ -258,9 +263,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned char* S = smem3 + (kt & 1) * kStage;
-    half_step(S, 0);
-    half_step(S, 1);
+    if (!(p.dbg & 4)) {      // ablation: no fragment reads / MFMAs
+      half_step(S, 0);
+      half_step(S, 1);
+    }
     __syncthreads();
+  }
+  if (p.dbg & 8) {           // ablation: no stores
+    if (acc[0][0][0] == 12345.f) p.out[0] = 0.f;
+    return;
   }
 
   float* out = p.out + (size_t)z * p.Cout * p.Ktot;
@@ -271,11 +282,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
       const int ra_ = wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       const int row = co0 + 2 * (ra_ % (BM / 2)) + ra_ / (BM / 2);   // inverse of the dy staging permutation
       if (row >= p.Cout) continue;
+      static_assert(NB == 4 && QB == 64, "column blocks = the four channels of a staging micro-block");
+      const int col = k0 + 4 * (wn * 32 + li);
+      if (col + 3 < p.Ktot) {   // Ktot = taps * Cin with Cin % 4 == 0: rows are 16-byte aligned
+        const f32x4 v = {acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+        *reinterpret_cast<f32x4*>(out + (size_t)row * p.Ktot + col) = v;
+      } else {
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int rb_ = wn * WN + b * 32 + li;
-        const int col = k0 + 4 * (rb_ % QB) + rb_ / QB;
-        if (col < p.Ktot) out[(size_t)row * p.Ktot + col] = acc[a][b][r];
+        for (int b = 0; b < NB; ++b)
+          if (col + b < p.Ktot) out[(size_t)row * p.Ktot + col + b] = acc[a][b][r];
       }
     }
 }
@@ -289,7 +304,10 @@ int launch_wgrad_x3ws(const WGradArgs& a, hipStream_t stream) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_x3ws_kernel<BM, BN>), dim3(a.tiles_co * a.tiles_k * a.splitk), dim3(512), lds, stream, a);
+  WGradArgs b = a;
+  static const int dbg = getenv("EVK_WG_DBG") ? atoi(getenv("EVK_WG_DBG")) : 0;
+  b.dbg = dbg;
+  hipLaunchKernelGGL((conv_wgrad_x3ws_kernel<BM, BN>), dim3(a.tiles_co * a.tiles_k * a.splitk), dim3(512), lds, stream, b);
   return check_launch("conv_wgrad_x3ws");
 }
 

@@ -15,6 +15,7 @@ struct WGradArgs {
   int chunk;  // pixels per split (multiple of 32)
   int tiles_co, tiles_k, splitk;
   FastDiv fd_hw, fd_w;
+  int dbg;  // EVK_WG_DBG ablation switches of the wave-specialised kernel (0 in production)
 };
 
 constexpr int BKP = 32;  // pixels per step

@@ -32,7 +32,11 @@ for cnt, h, w, cin, cout, k, s, p in L:
     y = torch.empty(B,ho,wo,cout,device=dev); dx = torch.empty_like(x); wtt = torch.empty(cin,k,k,cout,device=dev)
     ws_b = lib.evk_conv2d_wgrad_workspace_bytes(ctypes.byref(d)); ws = workspace(dev, ws_b)
     gf = 2.0*B*ho*wo*cout*cin*k*k/1e9
-    if which == 'wgrad':
+    if which == 'wgrad_x3':
+        ws_b = lib.evk_conv2d_wgrad_x3_workspace_bytes(ctypes.byref(d)); ws = workspace(dev, ws_b)
+        if cin % 8 or cout % 8: continue
+        t = timeit(lambda: _C.call('evk_conv2d_wgrad_x3', ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), ws_b, st))
+    elif which == 'wgrad':
         t = timeit(lambda: _C.call('evk_conv2d_wgrad', ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), ws_b, st))
     elif which == 'fwd':
         t = timeit(lambda: _C.call('evk_conv2d_fwd', ctypes.byref(d), x.data_ptr(), wt.data_ptr(), None, y.data_ptr(), 0, st))
