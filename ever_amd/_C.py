@@ -48,6 +48,8 @@ SIGNATURES = {
     'evk_split_job_pairs': (c_i64, [_JP]),
     'evk_conv2d_split_multi': (c_int, [P, P, c_i32, P]),
     'evk_conv2d_fwd_x3': (c_int, [_DP, P, P, P, P, c_u32, P]),
+    'evk_conv2d_stats_max_parts': (c_i32, [_DP]),
+    'evk_conv2d_fwd_x3_stats': (c_int, [_DP, P, P, P, P, c_u32, P, c_i32, C.POINTER(c_i32), P]),
     'evk_conv2d_dgrad_x3': (c_int, [_DP, P, P, P, P, P]),
     'evk_conv_transpose2d_fwd': (c_int, [_DP, P, P, P, P, P]),
     'evk_conv_transpose2d_fwd_x3': (c_int, [_DP, P, P, P, P, P]),
@@ -71,6 +73,7 @@ SIGNATURES = {
     'evk_nhwc_to_nchw': (c_int, [P, P, c_i32, c_i32, c_i32, c_i32, c_i32, P]),
     'evk_bn_workspace_bytes': (c_size_t, [c_i64, c_i32]),
     'evk_bn_fwd_train': (c_int, [P, P, P, P, P, P, c_f32, c_f32, P, P, P, c_i64, c_i32, c_u32, P, c_size_t, P]),
+    'evk_bn_fwd_train_parts': (c_int, [P, P, P, P, P, P, c_f32, c_f32, P, P, P, c_i64, c_i32, c_u32, P, c_i32, P, c_size_t, P]),
     'evk_bn_fwd_eval': (c_int, [P, P, P, P, P, P, c_f32, P, P, P, c_i64, c_i32, c_u32, P, c_size_t, P]),
     'evk_bn_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_i64, c_i32, c_u32, c_i32, P, c_size_t, P]),
     'evk_relu_fwd': (c_int, [P, P, c_i64, P]),

@@ -344,6 +344,75 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   reinterpret_cast<f32x4*>(dx)[i] = k0 * (g - k1 - xh * k2);
 }
 
+// Statistics that arrive as per-row-part records (count, mean, M2) from the producing convolution's epilogue
+// (igemm_common.hpp: igemm_store_rows_stats): Chan's pairwise merge in fp64, 32 lanes per channel over a fixed strided
+// subset each, then the 32 lanes folded in index order — the same outputs as bn_stats_final_kernel, no pass over x.
+__global__ __launch_bounds__(256) void bn_parts_final_kernel(const float* __restrict__ parts, int nparts, int C,
+                                                             double rows, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var, float momentum, float eps,
+                                                             float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                             float* __restrict__ scale_shift) {
+  // With a common pivot p (the first record's mean) the merge of all records is three plain sums,
+  //   N = sum n_i,  A = sum n_i (mean_i - p),  B = sum [M2_i + n_i (mean_i - p)^2]:  mean = p + A/N,  M2 = B - A^2/N
+  // (Chan's pairwise formula telescoped; no division inside the loop, no order dependence beyond the fixed one below).
+  __shared__ double red[3][kFinLanes][kFinCh];
+  const int tc = threadIdx.x % kFinCh, tl = threadIdx.x / kFinCh;
+  const int c = blockIdx.x * kFinCh + tc;
+  double N = 0.0, A = 0.0, B = 0.0, piv = 0.0;
+  if (c < C) {
+    const size_t st = (size_t)3 * C;
+    piv = (double)parts[C + c];
+    const float* r = parts + c;
+    int b = tl;
+    for (; b + 3 * kFinLanes < nparts; b += 4 * kFinLanes) {   // four independent records in flight per lane
+      const float* r0 = r + (size_t)b * st;
+      const float* r1 = r0 + (size_t)kFinLanes * st;
+      const float* r2 = r1 + (size_t)kFinLanes * st;
+      const float* r3 = r2 + (size_t)kFinLanes * st;
+      const float n0 = r0[0], m0 = r0[C], q0 = r0[2 * C], n1 = r1[0], m1 = r1[C], q1 = r1[2 * C];
+      const float n2 = r2[0], m2 = r2[C], q2 = r2[2 * C], n3 = r3[0], m3 = r3[C], q3 = r3[2 * C];
+      const double d0 = (double)m0 - piv, d1 = (double)m1 - piv, d2 = (double)m2 - piv, d3 = (double)m3 - piv;
+      N += ((double)n0 + (double)n1) + ((double)n2 + (double)n3);
+      A += ((double)n0 * d0 + (double)n1 * d1) + ((double)n2 * d2 + (double)n3 * d3);
+      B += (((double)q0 + (double)n0 * d0 * d0) + ((double)q1 + (double)n1 * d1 * d1)) +
+           (((double)q2 + (double)n2 * d2 * d2) + ((double)q3 + (double)n3 * d3 * d3));
+    }
+    for (; b < nparts; b += kFinLanes) {
+      const float* r0 = r + (size_t)b * st;
+      const double n0 = (double)r0[0], d0 = (double)r0[C] - piv;
+      N += n0;
+      A += n0 * d0;
+      B += (double)r0[2 * C] + n0 * d0 * d0;
+    }
+  }
+  red[0][tl][tc] = N;
+  red[1][tl][tc] = A;
+  red[2][tl][tc] = B;
+  __syncthreads();
+  if (tl != 0 || c >= C) return;
+  for (int k = 1; k < kFinLanes; ++k) {
+    N += red[0][k][tc];
+    A += red[1][k][tc];
+    B += red[2][k][tc];
+  }
+  const double mean = N > 0.0 ? piv + A / N : 0.0;
+  double var = N > 0.0 ? (B - A * A / N) / N : 0.0;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float meanf = (float)mean;
+  save_mean[c] = meanf;
+  save_invstd[c] = invstd;
+  const double unbias = rows > 1.0 ? rows / (rows - 1.0) : 1.0;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * unbias);
+  const float g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
+  const float sc = g * invstd;
+  scale_shift[c] = sc;
+  scale_shift[C + c] = bb - meanf * sc;
+}
+
 static unsigned oneshot_grid(size_t n4) { return (unsigned)((n4 + 255) / 256); }
 
 }  // namespace evk
@@ -377,6 +446,29 @@ extern "C" int evk_bn_fwd_train(const float* x, const float* residual, const flo
                      1.0 / (double)rows, unbias, gamma, beta, running_mean, running_var, momentum, eps, save_mean,
                      save_invstd, scale_shift);
   rc = check_launch("bn_stats_final");
+  if (rc) return rc;
+  const size_t n4 = (size_t)rows * C / 4;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, x, residual,
+                     scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0);
+  return check_launch("bn_apply");
+}
+
+extern "C" int evk_bn_fwd_train_parts(const float* x, const float* residual, const float* gamma, const float* beta,
+                                      float* running_mean, float* running_var, float momentum, float eps, float* y,
+                                      float* save_mean, float* save_invstd, int64_t rows, int32_t C, uint32_t flags,
+                                      const float* parts, int32_t nparts, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+  EVK_REQUIRE(x && y && save_mean && save_invstd && parts && nparts > 0, EVK_E_INVALID, "bn_fwd_train_parts: bad argument");
+  EVK_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 2048, EVK_E_UNSUPPORTED, "bn_fwd_train_parts: rows=%lld C=%d",
+              (long long)rows, C);
+  EVK_REQUIRE(workspace && workspace_bytes >= evk_bn_workspace_bytes(rows, C), EVK_E_WORKSPACE,
+              "bn_fwd_train_parts: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* scale_shift = (float*)workspace + (size_t)kMaxStatBlocks * 2 * C;
+  hipLaunchKernelGGL(bn_parts_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, parts, nparts, C,
+                     (double)rows, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
+                     scale_shift);
+  int rc = check_launch("bn_parts_final");
   if (rc) return rc;
   const size_t n4 = (size_t)rows * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, x, residual,

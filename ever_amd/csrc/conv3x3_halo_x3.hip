@@ -207,6 +207,23 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
     __syncthreads();
   }
 
+  if (p.bn_part) {
+    // BatchNorm statistics of the output from the epilogue: the loop ended on a barrier of all eight waves and the
+    // staging waves have nothing left to write, so the LDS is free to park the tile (igemm_common.hpp)
+    BnLaneStat st;
+    bn_stat_init(st);
+    float* scratch = reinterpret_cast<float*>(smem3) + (wm * 2 + wn) * 32 * (WN + 4);
+    float* xch = reinterpret_cast<float*>(smem3) + 4 * 32 * (WN + 4);
+#pragma unroll
+    for (int a = 0; a < MB; ++a) {
+      const int m = wm * WMR + a * 32 + li;
+      const int gy = Y0 + (m >> 4), gx = X0 + (m & 15);
+      const size_t roff = (((size_t)n * p.Hd + (size_t)(gy * p.dsh + p.doy)) * p.Wd + (size_t)(gx * p.dsw + p.dox)) * p.Cd;
+      igemm_store_rows_stats<NB, WN>(p, acc[a], roff, n0, wn, li, lh, scratch, st);
+    }
+    bn_part_write<WN, 2>(p, st, (n * tiles_y + ty) * tiles_x + tx, n0, wm, wn, lh * 32 + li, xch);
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < MB; ++a) {
     const int m = wm * WMR + a * 32 + li;
@@ -249,6 +266,7 @@ static int launch_halo(IGemmArgs& a, hipStream_t stream) {
   a.tiles_n = ceil_div(a.Cd, BN);
   const int tiles_y = a.Hm / PH, tiles_x = a.Wm / kPW;
   a.tiles_m = a.N * tiles_y * tiles_x;
+  bn_stats_setup(a, PH * kPW, BN, 2, a.tiles_m);   // two row waves per patch; the ring (>= 100 KB) is the scratch
   const size_t lds = (size_t)2 * (3 * HaloGeom<PH>::kHSlots * kRB) + (size_t)2 * (3 * 3 * BN * kRB);
   static bool attr_set = false;
   if (!attr_set) {

@@ -347,7 +347,8 @@ static inline int kpad32(int k) { return (k + 31) & ~31; }
 
 // w3 != nullptr selects the bf16-split kernel (conv_igemm_x3.hip) on pre-split weight planes
 static int conv_fwd_any(const evk_conv_desc* d, const float* x, const float* w, const uint16_t* w3, const float* bias,
-                        float* y, uint32_t flags, void* stream, const float* residual = nullptr) {
+                        float* y, uint32_t flags, void* stream, const float* residual = nullptr,
+                        float* bn_parts = nullptr, int32_t bn_cap = 0, int32_t* nparts = nullptr) {
   int rc = check_desc(d);
   if (rc) return rc;
   EVK_REQUIRE(x && (w || w3) && y, EVK_E_INVALID, "conv2d_fwd: null pointer");
@@ -364,11 +365,20 @@ static int conv_fwd_any(const evk_conv_desc* d, const float* x, const float* w, 
   a.Hd = d->Ho; a.Wd = d->Wo; a.dsh = 1; a.dsw = 1; a.dense_dst = 1;
   a.relu = (flags & EVK_CONV_RELU) ? 1 : 0;
   a.Kpad = kpad32(a.Ktot);
+  a.bn_want = (bn_parts && w3 && d->Cout % 4 == 0) ? 1 : 0;
+  a.bn_buf = bn_parts;
+  a.bn_cap = bn_cap;
+  if (nparts) *nparts = 0;
   if (w3) {
     const int hr = launch_conv3x3_halo(a, (hipStream_t)stream);   // 3x3 'same' convolutions: LDS-halo kernel
-    if (hr != 1) return hr;
+    if (hr != 1) {
+      if (nparts && hr == EVK_OK) *nparts = a.bn_parts;
+      return hr;
+    }
   }
-  return w3 ? launch_igemm_x3(a, (hipStream_t)stream) : launch_igemm(a, (hipStream_t)stream);
+  const int rc2 = w3 ? launch_igemm_x3(a, (hipStream_t)stream) : launch_igemm(a, (hipStream_t)stream);
+  if (nparts && rc2 == EVK_OK) *nparts = a.bn_parts;
+  return rc2;
 }
 
 extern "C" int evk_conv2d_fwd(const evk_conv_desc* d, const float* x, const float* w, const float* bias,
@@ -380,6 +390,19 @@ extern "C" int evk_conv2d_fwd_x3(const evk_conv_desc* d, const float* x, const v
                                  float* y, uint32_t flags, void* stream) {
   EVK_REQUIRE(wsplit, EVK_E_INVALID, "conv2d_fwd_x3: null weight planes");
   return conv_fwd_any(d, x, nullptr, reinterpret_cast<const uint16_t*>(wsplit), bias, y, flags, stream);
+}
+
+extern "C" int32_t evk_conv2d_stats_max_parts(const evk_conv_desc* d) {
+  if (!d) return 0;
+  // one record per tile of at least 64 rows
+  return (int32_t)(((int64_t)d->N * d->Ho * d->Wo + 63) / 64 + 1);
+}
+extern "C" int evk_conv2d_fwd_x3_stats(const evk_conv_desc* d, const float* x, const void* wsplit, const float* bias,
+                                       float* y, uint32_t flags, float* bn_parts, int32_t bn_capacity, int32_t* nparts,
+                                       void* stream) {
+  EVK_REQUIRE(wsplit && bn_parts && nparts, EVK_E_INVALID, "conv2d_fwd_x3_stats: null pointer");
+  return conv_fwd_any(d, x, nullptr, reinterpret_cast<const uint16_t*>(wsplit), bias, y, flags, stream, nullptr, bn_parts,
+                      bn_capacity, nparts);
 }
 
 // y = act(conv(x, w) + bias + residual): the inference form of a ResNet block's last convolution once its

@@ -223,6 +223,11 @@ __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(const IGemmArgs p) {
     }
   }
 
+  if (p.bn_part) {
+    // every wave is done with the last stage (the loop ends on a barrier): the ring becomes epilogue scratch
+    igemm_epilogue_stats<MB, NB, WM, WN, WAVES_M, WAVES_N>(p, acc, m0, n0, wm, wn, li, lh, reinterpret_cast<float*>(smem3));
+    return;
+  }
   igemm_epilogue<MB, NB, WM, WN>(p, acc, m0, n0, wm, wn, li, lh);
 }
 
@@ -230,7 +235,11 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int NBUF>
 static int launch_cfg3(IGemmArgs& a, hipStream_t stream) {
   a.tiles_m = ceil_div(a.M, BM);
   a.tiles_n = ceil_div(a.Cd, BN);
-  const size_t lds = (size_t)NBUF * 3 * (BM + BN) * kRowBytes;
+  bn_stats_setup(a, BM, BN, WAVES_M, a.tiles_m);
+  size_t lds = (size_t)NBUF * 3 * (BM + BN) * kRowBytes;
+  // statistics epilogue: per-wave scratch + the row waves' exchange area
+  const size_t scratch = ((size_t)4 * 32 * (BN / WAVES_N + 4) + (size_t)3 * BN) * sizeof(float);
+  if (lds < scratch) lds = scratch;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_x3_kernel<BM, BN, WAVES_M, WAVES_N, NBUF>),

@@ -259,6 +259,14 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws_kernel(const IGemmArgs p)
       __syncthreads();
     }
     const int bid = xcd_remap((int)blockIdx.x + i * (int)gridDim.x, ntiles);
+    if (p.bn_part) {
+      // statistics mode is launched one tile per workgroup: the staging waves are done (the epilogue's one barrier
+      // must not meet a staging wave's step barrier, which it would in a persistent workgroup), every matrix wave
+      // has passed the loop's last barrier, and the ring is free to serve as the epilogue's scratch
+      igemm_epilogue_stats<MB, NB, WM, WN, WAVES_M, WAVES_N>(p, acc, (bid / p.tiles_n) * BM, (bid % p.tiles_n) * BN, wm, wn,
+                                                             li, lh, reinterpret_cast<float*>(smem3 + p.bn_scratch_off));
+      continue;
+    }
     igemm_epilogue<MB, NB, WM, WN>(p, acc, (bid / p.tiles_n) * BM, (bid % p.tiles_n) * BN, wm, wn, li, lh);
   }
 }
@@ -274,7 +282,9 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE>
 static int launch_ws(IGemmArgs& a, hipStream_t stream) {
   a.tiles_m = ceil_div(a.M, BM);
   a.tiles_n = ceil_div(a.Cd, BN);
-  const size_t lds = (size_t)NSTAGE * 3 * (BM + BN) * kRowBytes;
+  bn_stats_setup(a, BM, BN, WAVES_M, a.tiles_m);
+  const size_t lds = (size_t)NSTAGE * 3 * (BM + BN) * kRowBytes;   // >= the statistics epilogue's scratch
+  a.bn_scratch_off = 0;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_x3ws_kernel<BM, BN, WAVES_M, WAVES_N, NSTAGE>),
@@ -288,7 +298,9 @@ static int launch_ws(IGemmArgs& a, hipStream_t stream) {
   }
   // one workgroup per CU (LDS), each walking ceil(tiles / 256) tiles; 256 is a multiple of 8, so a workgroup's
   // tiles stay on its XCD under the remap
-  const unsigned grid = (ws_persist() && nwg > 256) ? 256u : (unsigned)nwg;
+  // statistics mode: one tile per workgroup (the epilogue parks the tile in the LDS ring, which a persistent
+  // workgroup's staging waves would already be refilling)
+  const unsigned grid = (ws_persist() && nwg > 256 && !a.bn_part) ? 256u : (unsigned)nwg;
   hipLaunchKernelGGL((conv_igemm_x3ws_kernel<BM, BN, WAVES_M, WAVES_N, NSTAGE>), dim3(grid), dim3(512), lds, stream, a);
   return check_launch("conv_igemm_x3ws");
 }

@@ -23,6 +23,15 @@ struct IGemmArgs {
   int tiles_m, tiles_n;
   const uint16_t* wgt3;     // split kernel: weights as 3 bf16 planes [3][Cd][Kpad] (Kpad % 32 == 0, zero padded)
   int Kpad;
+  // BatchNorm statistics of the OUTPUT from the epilogue (forward convolutions followed by a training-mode BatchNorm):
+  // bn_part[part][3][Cd] = (count, mean, M2 = sum (y - mean)^2) of the rows of row-part `part`; nullptr = off.
+  // Written by igemm_store_rows_stats / bn_part_write; merged (Chan) by evk_bn_fwd_train_parts.
+  float* bn_part;
+  int bn_scratch_off;       // byte offset of the statistics epilogue's LDS scratch (0: it reuses the operand ring)
+  int bn_want;              // host side: statistics requested for this launch (the launcher sets bn_part / bn_parts)
+  int bn_parts;             // host side, out: row-parts written (0 = this launch produced no statistics)
+  float* bn_buf;            // host side: the caller's partial buffer (bn_part is set from it when the kernel supports it)
+  int bn_cap;               // host side: capacity of bn_buf in parts
 };
 
 // Store one 32-row block of accumulators whose lane's GEMM row lives at element offset `roff` of dst: bias,
@@ -111,6 +120,141 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
     }
     igemm_store_rows<NB, WN>(p, acc[a], roff, n0, wn, lh);
   }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Epilogue THROUGH LDS with BatchNorm partial statistics.  A 32-row accumulator block is parked in a wave-private LDS
+// scratch ([32][WN + 4] floats) and read back ROW-contiguously: lane (r, c4) then holds 4 consecutive channels of one
+// pixel, stores them as part of a full output row (2-4 whole rows per store instruction), and — the point — keeps
+// per-lane running sums over the rows it sees for ITS 4 channels: the column statistics need no cross-lane reduction
+// until the very end (one or two Chan merges), where the register-layout epilogue would need a 32-lane reduction per
+// accumulator register (~1300 VALU per wave and tile, more than a short-K tile's MFMA work).
+// Shifted by the lane's first value (pivot): var from sums of (y - pivot) does not cancel when |mean| >> std.
+struct BnLaneStat {
+  float n;
+  f32x4 piv, s, q;
+};
+__device__ __forceinline__ void bn_stat_init(BnLaneStat& st) {
+  st.n = 0.f;
+  st.piv = st.s = st.q = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// roff: element offset of THIS lane's row (row li of the block) in dst, or ~0 when the row is outside the tensor
+template <int NB, int WN>
+__device__ __forceinline__ void igemm_store_rows_stats(const IGemmArgs& p, f32x16 (&accrow)[NB], size_t roff, int n0, int wn,
+                                                       int li, int lh, float* scratch, BnLaneStat& st) {
+  constexpr int P = WN + 4, LPR = WN / 4, RPI = 64 / LPR;
+  static_assert(WN == NB * 32 && (64 % LPR) == 0, "column block layout");
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const f32x4 v = {accrow[b][4 * r4], accrow[b][4 * r4 + 1], accrow[b][4 * r4 + 2], accrow[b][4 * r4 + 3]};
+      *reinterpret_cast<f32x4*>(scratch + li * P + b * 32 + 8 * r4 + 4 * lh) = v;
+    }
+  const int lane = lh * 32 + li;
+  const int rsub = lane / LPR, c4 = (lane % LPR) * 4;
+  const int col = n0 + wn * WN + c4;
+  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + col);
+  const uint32_t ro_lo = (uint32_t)roff, ro_hi = (uint32_t)(roff >> 32);
+#pragma unroll
+  for (int it = 0; it < 32 / RPI; ++it) {
+    const int r = it * RPI + rsub;
+    const size_t ro = ((size_t)(uint32_t)__shfl((int)ro_hi, r, 64) << 32) | (uint32_t)__shfl((int)ro_lo, r, 64);
+    f32x4 v = *reinterpret_cast<const f32x4*>(scratch + r * P + c4) + bias;
+    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (ro != ~(size_t)0) {
+      *reinterpret_cast<f32x4*>(p.dst + ro + col) = v;
+      if (st.n == 0.f) st.piv = v;
+      const f32x4 d = v - st.piv;
+      st.s += d;
+      st.q += d * d;
+      st.n += 1.f;
+    }
+  }
+}
+
+// merge the RPI lanes that share a channel group, then the row waves of the tile (through `xch`, an LDS area of
+// WAVES_N x 3 x WN floats outside every wave's scratch; ONE workgroup barrier — waves that have already ended are not
+// waited for), and write ONE record per tile: bn_part[tile][3][Cd]
+template <int WN, int WAVES_M>
+__device__ __forceinline__ void bn_part_write(const IGemmArgs& p, const BnLaneStat& st, int tile, int n0, int wm, int wn,
+                                              int lane, float* xch) {
+  constexpr int LPR = WN / 4;
+  static_assert(WAVES_M == 1 || WAVES_M == 2, "row waves per tile");
+  float n = st.n;
+  const float inv = n > 0.f ? 1.f / n : 0.f;
+  f32x4 mean = st.piv + st.s * inv;
+  f32x4 m2 = st.q - st.s * st.s * inv;
+  auto merge = [&](float n2, const f32x4& mean2, const f32x4& m22) {
+    const float nt = n + n2;
+    const float w2 = nt > 0.f ? n2 / nt : 0.f;
+    const f32x4 dlt = mean2 - mean;
+    mean += dlt * w2;
+    m2 += m22 + dlt * dlt * (n * w2);
+    n = nt;
+  };
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    const float n2 = __shfl_xor(n, off, 64);
+    f32x4 mean2, m22;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      mean2[e] = __shfl_xor(mean[e], off, 64);
+      m22[e] = __shfl_xor(m2[e], off, 64);
+    }
+    merge(n2, mean2, m22);
+  }
+  if (WAVES_M == 2) {
+    float* x = xch + wn * 3 * WN + lane * 4;
+    if (wm == 1 && lane < LPR) {
+      *reinterpret_cast<f32x4*>(x) = f32x4{n, n, n, n};
+      *reinterpret_cast<f32x4*>(x + WN) = mean;
+      *reinterpret_cast<f32x4*>(x + 2 * WN) = m2;
+    }
+    __syncthreads();
+    if (wm == 1) return;
+    if (lane < LPR) merge(x[0], *reinterpret_cast<const f32x4*>(x + WN), *reinterpret_cast<const f32x4*>(x + 2 * WN));
+  }
+  if (lane < LPR) {
+    const int col = n0 + wn * WN + lane * 4;
+    float* rec = p.bn_part + (size_t)tile * 3 * p.Cd + col;
+    *reinterpret_cast<f32x4*>(rec) = f32x4{n, n, n, n};
+    *reinterpret_cast<f32x4*>(rec + p.Cd) = mean;
+    *reinterpret_cast<f32x4*>(rec + 2 * p.Cd) = m2;
+  }
+}
+
+// the row-linear kernels' epilogue in statistics mode (dense destination, Cd % 4 == 0, whole column blocks).
+// scratch_base: LDS area of (waves x 32 x (WN + 4) + WAVES_N x 3 x WN) floats, free of other use
+template <int MB, int NB, int WM, int WN, int WAVES_M, int WAVES_N>
+__device__ __forceinline__ void igemm_epilogue_stats(const IGemmArgs& p, f32x16 (&acc)[MB][NB], int m0, int n0, int wm, int wn,
+                                                     int li, int lh, float* scratch_base) {
+  BnLaneStat st;
+  bn_stat_init(st);
+  float* scratch = scratch_base + (wm * WAVES_N + wn) * 32 * (WN + 4);
+#pragma unroll
+  for (int a = 0; a < MB; ++a) {
+    const int row = m0 + wm * WM + a * 32 + li;
+    const size_t roff = row < p.M ? (size_t)row * p.Cd : ~(size_t)0;
+    igemm_store_rows_stats<NB, WN>(p, acc[a], roff, n0, wn, li, lh, scratch, st);
+  }
+  bn_part_write<WN, WAVES_M>(p, st, m0 / (WM * WAVES_M), n0, wm, wn, lh * 32 + li,
+                             scratch_base + WAVES_M * WAVES_N * 32 * (WN + 4));
+}
+
+// host: may this launch (tile BM x BN, WAVES_M row waves) write statistics?  sets a.bn_part / a.bn_parts
+inline void bn_stats_setup(IGemmArgs& a, int BM, int BN, int WAVES_M, long long row_tiles) {
+  a.bn_part = nullptr;
+  a.bn_parts = 0;
+  if (!a.bn_want || !a.bn_buf) return;
+  (void)WAVES_M;
+  const long long parts = row_tiles;   // one record per tile (the row waves are merged in the epilogue)
+  if (!a.dense_dst || a.accum || (a.Cd % BN) != 0 || parts > a.bn_cap) return;
+  a.bn_part = a.bn_buf;
+  a.bn_parts = (int)parts;
 }
 
 int launch_igemm(IGemmArgs& a, hipStream_t stream);

@@ -48,6 +48,9 @@ def get_conv_math():
     return _CONV_MATH
 
 
+# BatchNorm statistics from the producing convolution's epilogue (EVK_BN_EPILOGUE=0: BatchNorm's own statistics pass)
+_BN_EPILOGUE = os.environ.get('EVK_BN_EPILOGUE', '1') != '0'
+
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
 
@@ -167,7 +170,7 @@ class _ConvState:
     its own node forms no reference cycle, in-place writes to a saved tensor are caught by the version check, and
     saved-tensor hooks (activation checkpointing, offloading) see them."""
     __slots__ = ('desc', 'relu', 'cin', 'has_bias', 'flops', 'abytes', 'w_stride', 'xk', 'w_ohwi', 'y', 'weight',
-                 'w_alias', 'scope')
+                 'w_alias', 'scope', 'bn_parts')
 
 
 def _stash(states):
@@ -186,8 +189,9 @@ def _unstash(states, saved):
         cs.w_ohwi = cs.weight.detach() if cs.w_alias else w
 
 
-def _conv_forward(x, weight, bias, stride, padding, dilation, relu):
-    """evk_conv2d_fwd on NHWC x / OHWI weight -> (y, _ConvState)."""
+def _conv_forward(x, weight, bias, stride, padding, dilation, relu, want_stats=False):
+    """evk_conv2d_fwd on NHWC x / OHWI weight -> (y, _ConvState).  want_stats: also the BatchNorm partial statistics of
+    y from the epilogue (cs.bn_parts = (records tensor, count) or None when this shape's kernel cannot)."""
     n, cin, h, w = x.shape
     cout, cin_w, kh, kw = weight.shape
     if cin_w != cin:
@@ -213,6 +217,7 @@ def _conv_forward(x, weight, bias, stride, padding, dilation, relu):
     # a handful of GEMM rows (the scene-embedding 1x1 convolutions on 1x1 maps, M = batch): the fp32 path has a
     # dedicated weight-streaming kernel for M <= 32; an MFMA tile would run K = 2048 serially on two workgroups
     small_m = n * d.Ho * d.Wo <= 32
+    bn_parts = None
     if _CONV_MATH == 'bf16x3' and cin_p == cin and cin % 8 == 0 and not small_m:
         # weights -> three bf16 planes, then the split-MFMA kernel.  The planes of every registered weight are
         # refreshed by one launch per weight update (weight_planes); a weight the cache cannot follow (a transient
@@ -223,8 +228,17 @@ def _conv_forward(x, weight, bias, stride, padding, dilation, relu):
             _C.call('evk_conv2d_split_weight', ctypes.byref(d), w_ptr, 0, planes.data_ptr(), st)
             pl_ptr = planes.data_ptr()
         sp = timing.span('conv_igemm', cs.flops, cs.abytes)
-        _C.call('evk_conv2d_fwd_x3', ctypes.byref(d), x_ptr, pl_ptr, _ptr(bias), y.data_ptr(),
-                1 if relu else 0, st)
+        if want_stats and _BN_EPILOGUE and not relu and cout % 4 == 0:
+            cap = int(_C.load().evk_conv2d_stats_max_parts(ctypes.byref(d)))
+            parts = torch.empty((cap * 3 * cout,), device=dev, dtype=torch.float32)
+            nparts = ctypes.c_int32(0)
+            _C.call('evk_conv2d_fwd_x3_stats', ctypes.byref(d), x_ptr, pl_ptr, _ptr(bias), y.data_ptr(), 0,
+                    parts.data_ptr(), cap, ctypes.byref(nparts), st)
+            if nparts.value > 0:
+                bn_parts = (parts, int(nparts.value))
+        else:
+            _C.call('evk_conv2d_fwd_x3', ctypes.byref(d), x_ptr, pl_ptr, _ptr(bias), y.data_ptr(),
+                    1 if relu else 0, st)
     else:
         sp = timing.span('conv_igemm_f32', cs.flops, cs.abytes)
         _C.call('evk_conv2d_fwd', ctypes.byref(d), x_ptr, w_ptr, _ptr(bias), y.data_ptr(), 1 if relu else 0, st)
@@ -234,6 +248,7 @@ def _conv_forward(x, weight, bias, stride, padding, dilation, relu):
     cs.w_stride = tuple(weight.stride())
     # xk (channel-padded copy when Cin % 4 != 0) is what wgrad reads
     cs.xk, cs.w_ohwi, cs.y, cs.weight = xk, w_ohwi, (y if relu else None), weight
+    cs.bn_parts = bn_parts
     return y, cs
 
 
@@ -251,9 +266,12 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None):
         _C.call('evk_relu_bwd', dy.data_ptr(), cs.y.data_ptr(), g.data_ptr(), dy.numel(), st)
         dy = g
     rows_o = n * d.Ho * d.Wo
-    cout_p = _pad4(cout)
+    x3 = _CONV_MATH == 'bf16x3'
+    # narrow heads (classifier Cout = 1..7): pad dy / weight rows — to 8 output channels under the split arithmetic, so
+    # that the data gradient stays on the split-MFMA kernels (its reduction is over taps x Cout), else to 4
+    narrow8 = x3 and cin_p == cin and cout % 8 != 0 and cout < 8 and os.environ.get('EVK_NARROW_X3', '1') != '0'
+    cout_p = 8 if narrow8 else _pad4(cout)
     if cout_p != cout:
-        # narrow heads (classifier Cout=1): pad dy / weight rows to 4 output channels
         dyk = _pad_last(dy.data_ptr(), rows_o, cout, cout_p, dev)
         dy_ptr = dyk.data_ptr()
     else:
@@ -263,12 +281,17 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None):
                      d.dil_h, d.dil_w)
     dx = dw = db = None
     taps = kh * kw
-    x3 = _CONV_MATH == 'bf16x3'
-    if need_dx and x3 and cin_p == cin and cout_p == cout and cout % 8 == 0:
-        pl_ptr = weight_planes.planes_for(cs.weight, w_ohwi, dk, 1, st)
+    if need_dx and x3 and cin_p == cin and (narrow8 or (cout_p == cout and cout % 8 == 0)):
+        if narrow8:     # zero rows appended to the (tiny) weight: a transient copy, split on every call
+            w_src = torch.zeros((cout_p, taps, cin), device=dev, dtype=torch.float32)
+            w_src[:cout].copy_(w_ohwi.permute(0, 2, 3, 1).reshape(cout, taps, cin))
+            pl_ptr = None
+        else:
+            w_src = w_ohwi
+            pl_ptr = weight_planes.planes_for(cs.weight, w_ohwi, dk, 1, st)
         if pl_ptr is None:
             planes = workspace(dev, _C.load().evk_conv2d_split_weight_bytes(ctypes.byref(dk), 1))
-            _C.call('evk_conv2d_split_weight', ctypes.byref(dk), w_ohwi.data_ptr(), 1, planes.data_ptr(), st)
+            _C.call('evk_conv2d_split_weight', ctypes.byref(dk), w_src.data_ptr(), 1, planes.data_ptr(), st)
             pl_ptr = planes.data_ptr()
         acc_ptr = None
         if accum is not None:
@@ -344,10 +367,12 @@ class _Conv2dFn(Function):
     """
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, dilation, relu):
-        y, cs = _conv_forward(x, weight, bias, stride, padding, dilation, relu)
+    def forward(ctx, x, weight, bias, stride, padding, dilation, relu, want_stats=False):
+        y, cs = _conv_forward(x, weight, bias, stride, padding, dilation, relu, want_stats)
         ctx.cs = cs
         ctx.save_for_backward(*_stash([cs]))
+        _BN_HANDOFF[0] = cs.bn_parts      # picked up by conv2d() right after apply (same thread, no autograd in between)
+        cs.bn_parts = None
         return y
 
     @staticmethod
@@ -357,13 +382,29 @@ class _Conv2dFn(Function):
         _unstash([cs], ctx.saved_tensors)
         dx, dw, db = _conv_backward(cs, dy, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                     cs.has_bias and ctx.needs_input_grad[2])
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False):
+_BN_HANDOFF = [None, None]   # statistics records of the convolution(s) that just ran: [main, shortcut]
+
+
+def _attach_parts(y, parts):
+    """BatchNorm partial statistics ride on the tensor object to the BatchNorm that consumes it next."""
+    if parts is not None:
+        y._evk_bn_parts = parts
+    return y
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, bn_stats=False):
+    """bn_stats=True: the caller applies a training-mode BatchNorm to the result next; where the kernel can, the
+    epilogue leaves that BatchNorm's partial statistics on the returned tensor (`_evk_bn_parts`) and
+    batch_norm_act() skips its own statistics pass over it."""
     _require_cuda(x, 'conv2d')
     x = as_nhwc(x, 'conv2d')
-    return _Conv2dFn.apply(x, weight, bias, _pair(stride), _pair(padding), _pair(dilation), bool(relu))
+    _BN_HANDOFF[0] = None
+    y = _Conv2dFn.apply(x, weight, bias, _pair(stride), _pair(padding), _pair(dilation), bool(relu), bool(bn_stats))
+    parts, _BN_HANDOFF[0] = _BN_HANDOFF[0], None
+    return _attach_parts(y, parts)
 
 
 class GradSlot:
@@ -415,16 +456,20 @@ class _ConvForkFn(Function):
     data-gradient kernel (dx = dgrad(dy_main) + d_other) instead of a separate add pass over x."""
 
     @staticmethod
-    def forward(ctx, x, w_main, w_short, b_main, b_short, cfg_main, cfg_short, slot=None):
-        y, cs = _conv_forward(x, w_main, b_main, *cfg_main, False)
+    def forward(ctx, x, w_main, w_short, b_main, b_short, cfg_main, cfg_short, slot=None, want_stats=(False, False)):
+        y, cs = _conv_forward(x, w_main, b_main, *cfg_main, False, want_stats[0])
         ctx.cs_main = cs
         ctx.slot = slot
+        _BN_HANDOFF[0], _BN_HANDOFF[1] = cs.bn_parts, None
+        cs.bn_parts = None
         if w_short is None:
             ctx.cs_short = None
             ctx.save_for_backward(*_stash([cs]))
             return y, x.view_as(x)
-        ys, css = _conv_forward(x, w_short, b_short, *cfg_short, False)
+        ys, css = _conv_forward(x, w_short, b_short, *cfg_short, False, want_stats[1])
         ctx.cs_short = css
+        _BN_HANDOFF[1] = css.bn_parts
+        css.bn_parts = None
         ctx.save_for_backward(*_stash([cs, css]))
         return y, ys
 
@@ -450,15 +495,15 @@ class _ConvForkFn(Function):
         if slot_g is not None:     # the shortcut convolution did not run: plain sum
             acc = slot_g if acc is None else add(acc, slot_g)
         if dy is None:   # only the second branch reached the loss
-            return acc, None, dws, None, dbs, None, None, None
+            return acc, None, dws, None, dbs, None, None, None, None
         dx, dw, db = _conv_backward(ctx.cs_main, dy, need_dx, ctx.needs_input_grad[1],
                                     ctx.cs_main.has_bias and ctx.needs_input_grad[3],
                                     accum=acc if need_dx else None)
-        return dx, dw, dws, db, dbs, None, None, None
+        return dx, dw, dws, db, dbs, None, None, None, None
 
 
-def conv2d_fork(x, conv_main, conv_short=None):
-    """(conv_main(x), conv_short(x) or x) with a fused input-gradient sum."""
+def conv2d_fork(x, conv_main, conv_short=None, bn_stats=(False, False)):
+    """(conv_main(x), conv_short(x) or x) with a fused input-gradient sum.  bn_stats: see conv2d()."""
     _require_cuda(x, 'conv2d_fork')
     x = as_nhwc(x, 'conv2d_fork')
     if x.shape[1] % 4:
@@ -467,15 +512,23 @@ def conv2d_fork(x, conv_main, conv_short=None):
                                                 conv_short.padding, conv_short.dilation)
         return y, s
     cfg_m = (_pair(conv_main.stride), _pair(conv_main.padding), _pair(conv_main.dilation))
+    _BN_HANDOFF[0] = _BN_HANDOFF[1] = None
     if conv_short is None:
-        return _ConvForkFn.apply(x, conv_main.weight, None, conv_main.bias, None, cfg_m, None)
+        y, s = _ConvForkFn.apply(x, conv_main.weight, None, conv_main.bias, None, cfg_m, None, None,
+                                 (bool(bn_stats[0]), False))
+        parts, _BN_HANDOFF[0] = _BN_HANDOFF[0], None
+        return _attach_parts(y, parts), s
     cfg_s = (_pair(conv_short.stride), _pair(conv_short.padding), _pair(conv_short.dilation))
     slot = getattr(x, '_evk_grad_slot', None)
     if slot is not None and not slot.claimed and torch.is_grad_enabled() and x.requires_grad:
         slot.claimed = True   # this node will add the parked gradient inside its shortcut data-gradient launch
     else:
         slot = None
-    return _ConvForkFn.apply(x, conv_main.weight, conv_short.weight, conv_main.bias, conv_short.bias, cfg_m, cfg_s, slot)
+    y, s = _ConvForkFn.apply(x, conv_main.weight, conv_short.weight, conv_main.bias, conv_short.bias, cfg_m, cfg_s, slot,
+                             (bool(bn_stats[0]), bool(bn_stats[1])))
+    pm, ps = _BN_HANDOFF
+    _BN_HANDOFF[0] = _BN_HANDOFF[1] = None
+    return _attach_parts(y, pm), _attach_parts(s, ps)
 
 
 # ------------------------------------------------------------------------------------ transposed convolution
@@ -655,7 +708,7 @@ class _BatchNormActFn(Function):
     """
 
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu, parts=None):
         n, c, h, w = x.shape
         rows = n * h * w
         dev = x.device
@@ -669,7 +722,13 @@ class _BatchNormActFn(Function):
         flags = 1 if relu else 0
         # algorithmic bytes (fp32): statistics read + apply read/write (+ residual read)
         nb = 4.0 * x.numel() * ((3 if training else 2) + (1 if residual is not None else 0))
-        if training:
+        if training and parts is not None:
+            # statistics came with x from the convolution's epilogue: merge the records, apply (2|x| of traffic)
+            _timed_call('bn', nb - 4.0 * x.numel(), 'evk_bn_fwd_train_parts', x.data_ptr(), _ptr(residual), _ptr(weight),
+                        _ptr(bias), _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), y.data_ptr(),
+                        save_mean.data_ptr(), save_invstd.data_ptr(), rows, c, flags, parts[0].data_ptr(), parts[1],
+                        ws.data_ptr(), ws_bytes, st)
+        elif training:
             _timed_call('bn', nb, 'evk_bn_fwd_train', x.data_ptr(), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(running_mean),
                     _ptr(running_var), float(momentum), float(eps), y.data_ptr(), save_mean.data_ptr(),
                     save_invstd.data_ptr(), rows, c, flags, ws.data_ptr(), ws_bytes, st)
@@ -711,7 +770,7 @@ class _BatchNormActFn(Function):
         if ctx.has_res and not need_res:
             dres = None
         return (dx, dres, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentum, eps, residual=None, relu=False):
@@ -722,8 +781,11 @@ def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentu
     if residual is not None:
         residual = as_nhwc(residual, 'batch_norm.residual')
     use_batch_stats = training or running_mean is None
+    parts = getattr(x, '_evk_bn_parts', None) if use_batch_stats else None
+    if parts is not None:
+        del x._evk_bn_parts
     return _BatchNormActFn.apply(x, residual, weight, bias, running_mean, running_var, bool(use_batch_stats),
-                                 0.0 if momentum is None else momentum, eps, bool(relu))
+                                 0.0 if momentum is None else momentum, eps, bool(relu), parts)
 
 
 # ------------------------------------------------------------------------------------ pointwise

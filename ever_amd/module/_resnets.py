@@ -8,7 +8,7 @@ conv -> [BN+ReLU] -> conv -> [BN+ReLU] -> conv -> [BN + identity add + ReLU].
 import torch.nn as nn
 
 from ..hip import functional as HF
-from .fold import _use_folded, conv_bn
+from .fold import _takes_epilogue_stats, _use_folded, conv_bn
 from .layers import AdaptiveAvgPool2d, BatchNorm2d, Conv2d, HipSequential, MaxPool2d, ReLU
 
 __all__ = ['ResNet', 'BasicBlock', 'Bottleneck', 'resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152',
@@ -40,8 +40,9 @@ def _fork(block, x):
     """(conv1(x), shortcut) — the block input feeds both; one autograd node so that the two input
     gradients are summed inside the data-gradient kernel (hip/functional.py:_ConvForkFn)."""
     if block.downsample is None:
-        return HF.conv2d_fork(x, block.conv1)
-    h, s = HF.conv2d_fork(x, block.conv1, block.downsample[0])
+        return HF.conv2d_fork(x, block.conv1, bn_stats=(_takes_epilogue_stats(block.bn1), False))
+    h, s = HF.conv2d_fork(x, block.conv1, block.downsample[0],
+                          bn_stats=(_takes_epilogue_stats(block.bn1), _takes_epilogue_stats(block.downsample[1])))
     return h, block.downsample[1](s)
 
 
@@ -71,7 +72,7 @@ class BasicBlock(nn.Module):
             return conv_bn(self.conv2, self.bn2, out, residual=shortcut, relu=True)
         h, shortcut = _fork(self, x)
         out = self.bn1(h, relu=True)
-        return self.bn2(self.conv2(out), residual=shortcut, relu=True)
+        return conv_bn(self.conv2, self.bn2, out, residual=shortcut, relu=True)
 
 
 class Bottleneck(nn.Module):
@@ -100,8 +101,8 @@ class Bottleneck(nn.Module):
             return conv_bn(self.conv3, self.bn3, out, residual=shortcut, relu=True)
         h, shortcut = _fork(self, x)
         out = self.bn1(h, relu=True)
-        out = self.bn2(self.conv2(out), relu=True)
-        return self.bn3(self.conv3(out), residual=shortcut, relu=True)
+        out = conv_bn(self.conv2, self.bn2, out, relu=True)
+        return conv_bn(self.conv3, self.bn3, out, residual=shortcut, relu=True)
 
 
 class ResNet(nn.Module):

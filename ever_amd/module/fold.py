@@ -111,11 +111,17 @@ def _use_folded(conv, bn):
     return True
 
 
+def _takes_epilogue_stats(bn):
+    """training-mode BatchNorm2d of this package (not SyncBatchNorm: its statistics are exchanged across ranks first)"""
+    from .layers import BatchNorm2d
+    return type(bn) is BatchNorm2d and (bn.training or bn.running_mean is None)
+
+
 def conv_bn(conv, bn, x, residual=None, relu=False):
     """bn(conv(x)) (+ residual) (ReLU): one folded convolution at inference, conv + fused BatchNorm pass otherwise."""
     if _use_folded(conv, bn):
         return folded_conv2d(x, conv, residual=residual, relu=relu)
-    return bn(conv(x), residual=residual, relu=relu)
+    return bn(conv(x, bn_stats=_takes_epilogue_stats(bn)), residual=residual, relu=relu)
 
 
 def folded_conv2d(x, conv, residual=None, relu=False):

@@ -26,8 +26,10 @@ class Conv2d(nn.Conv2d):
         _check_conv(self)
         self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
 
-    def forward(self, x, relu=False):
-        return HF.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, relu=relu)
+    def forward(self, x, relu=False, bn_stats=False):
+        """bn_stats: a training-mode BatchNorm consumes the result next (hip/functional.py:conv2d)"""
+        return HF.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, relu=relu,
+                         bn_stats=bn_stats)
 
 
 class ConvTranspose2d(nn.ConvTranspose2d):
@@ -187,6 +189,9 @@ def run_sequence(mods, x):
         elif isinstance(m, Conv2d) and isinstance(nxt, nn.ReLU):
             x = m(x, relu=True)
             i += 2
+        elif isinstance(m, Conv2d) and type(nxt) is BatchNorm2d and nxt.training:
+            x = m(x, bn_stats=True)     # the BatchNorm that follows takes its statistics from this epilogue
+            i += 1
         elif isinstance(m, (BatchNorm2d, GroupNorm, nn.SyncBatchNorm)) and isinstance(nxt, nn.ReLU):
             x = m(x, relu=True)
             i += 2

@@ -104,6 +104,17 @@ int evk_conv2d_split_multi(const evk_split_job* jobs_dev, const int32_t* block_m
                            void* stream);
 int evk_conv2d_fwd_x3(const evk_conv_desc* d, const float* x, const void* wsplit, const float* bias,
                       float* y, uint32_t flags, void* stream);
+/* Forward convolution that also produces the BatchNorm statistics of its OUTPUT ("stats fusable into
+ * conv epilogue"; reference call sites: every conv -> BatchNorm pair of _resnets.py:95-112, fs_relation.py:39-53,
+ * fpn.py:163-167).  The epilogue parks each 32-row accumulator block in LDS, stores it as whole output rows and keeps
+ * per-lane running (count, mean, M2) of its columns; one record per row-part goes to bn_parts[part][3][Cout].
+ * *nparts (host) receives the number of parts written, 0 when this shape's kernel cannot do it (then the call was a
+ * plain evk_conv2d_fwd_x3 and the caller runs evk_bn_fwd_train).  bn_capacity: parts the buffer holds
+ * (evk_conv2d_stats_max_parts).  evk_bn_fwd_train_parts (below) consumes the records. */
+int32_t evk_conv2d_stats_max_parts(const evk_conv_desc* d);
+int evk_conv2d_fwd_x3_stats(const evk_conv_desc* d, const float* x, const void* wsplit, const float* bias,
+                            float* y, uint32_t flags, float* bn_parts, int32_t bn_capacity, int32_t* nparts /* host */,
+                            void* stream);
 /* y = act(conv(x, w) + bias + residual): inference form of a residual block's last convolution with its
  * BatchNorm folded into (w, bias) — `out += identity; relu` of reference _resnets.py:95-112 in the epilogue. */
 int evk_conv2d_fwd_res(const evk_conv_desc* d, const float* x, const float* w, const float* bias,
@@ -186,6 +197,12 @@ int evk_bn_fwd_train(const float* x, const float* residual, const float* gamma, 
                      float* y, float* save_mean, float* save_invstd, int64_t rows, int32_t C,
                      uint32_t flags, void* workspace, size_t workspace_bytes, void* stream);
 /* Eval forward (running statistics): y = act((x-rm)/sqrt(rv+eps)*gamma+beta [+ residual]). */
+/* evk_bn_fwd_train with the statistics pass replaced by the merge (Chan, fp64, fixed order) of the (count, mean, M2)
+ * records a convolution epilogue wrote (evk_conv2d_fwd_x3_stats): one pass over x less per layer. */
+int evk_bn_fwd_train_parts(const float* x, const float* residual, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps, float* y,
+                           float* save_mean, float* save_invstd, int64_t rows, int32_t C, uint32_t flags,
+                           const float* parts, int32_t nparts, void* workspace, size_t workspace_bytes, void* stream);
 int evk_bn_fwd_eval(const float* x, const float* residual, const float* gamma, const float* beta,
                     const float* running_mean, const float* running_var, float eps, float* y,
                     float* save_mean /* may be NULL */, float* save_invstd /* may be NULL */,

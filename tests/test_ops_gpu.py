@@ -422,3 +422,58 @@ def test_stem_space_to_depth_conv_matches_torch(cuda, c, h, w, nchw):
     ga, gb = conv.weight.grad.cpu().double(), wr.grad
     assert float((ga - gb).abs().max() / gb.abs().max()) < 1e-5
     assert c == 1 or conv.weight.grad.stride() == conv.weight.stride()
+
+
+BN_EPI_CASES = [
+    # n, h, w, cin, cout, k, stride, pad, bias     (kernel families: x3 single-role, wave-specialised 128/256 wide, LDS halo)
+    (2, 32, 32, 64, 64, 1, 1, 0, False), (16, 64, 64, 128, 512, 1, 1, 0, False), (16, 32, 32, 256, 128, 1, 1, 0, True),
+    (4, 64, 64, 64, 64, 3, 1, 1, False), (16, 32, 32, 128, 128, 3, 1, 1, False), (16, 64, 64, 256, 256, 3, 1, 1, False),
+    (8, 64, 64, 128, 256, 3, 2, 1, False), (3, 17, 13, 32, 64, 1, 1, 0, False), (16, 128, 128, 64, 256, 1, 1, 0, False),
+]
+
+
+@pytest.mark.parametrize('case', BN_EPI_CASES)
+def test_batchnorm_statistics_from_the_conv_epilogue(cuda, case):
+    """conv -> training-mode BatchNorm with the statistics taken from the convolution's epilogue records (count, mean,
+    M2 per row-part, merged with Chan's formula) against the same pair with BatchNorm's own statistics pass
+    (EVK_BN_EPILOGUE=0 path): output, saved statistics, running statistics and all gradients; and against torch fp64."""
+    import ever_amd as er
+    from ever_amd.hip import functional as HF
+    n, h, w, cin, cout, k, s, p, bias = case
+    torch.manual_seed(cin + cout + k)
+    conv = er.module.Conv2d(cin, cout, k, s, p, bias=bias).to(cuda)
+    bn_a, bn_b = er.module.BatchNorm2d(cout).to(cuda), er.module.BatchNorm2d(cout).to(cuda)
+    with torch.no_grad():
+        bn_a.weight.uniform_(0.5, 1.5)
+        bn_a.bias.uniform_(-0.3, 0.3)
+        bn_b.load_state_dict(bn_a.state_dict())
+    x = torch.randn(n, cin, h, w, device=cuda) + 0.7          # non-zero mean: exercises the pivot shift
+    g = None
+    outs = []
+    for fused, bn in ((True, bn_a), (False, bn_b)):
+        conv.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_()
+        y = conv(xg, bn_stats=fused)
+        assert (getattr(y, '_evk_bn_parts', None) is not None) == fused or not fused, 'no epilogue statistics produced'
+        if fused:
+            assert getattr(y, '_evk_bn_parts', None) is not None, f'{case}: this shape produced no epilogue statistics'
+        z = bn(y, relu=True)
+        if g is None:
+            g = torch.randn_like(z)
+        z.backward(g)
+        outs.append((z.detach(), xg.grad, conv.weight.grad.clone(), bn.weight.grad, bn.bias.grad,
+                     bn.running_mean.clone(), bn.running_var.clone()))
+    names = ['out', 'dx', 'dw', 'dgamma', 'dbeta', 'running_mean', 'running_var']
+    for nm, a, b in zip(names, outs[0], outs[1]):
+        err = float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-12))
+        assert err < 2e-5, (nm, err)
+    # and against torch (fp64 on the CPU)
+    ref_c = torch.nn.Conv2d(cin, cout, k, s, p, bias=bias).double()
+    ref_c.load_state_dict({kk: v.cpu().double() for kk, v in conv.state_dict().items()})
+    ref_b = torch.nn.BatchNorm2d(cout).double()
+    ref_b.weight.data, ref_b.bias.data = bn_b.weight.detach().cpu().double(), bn_b.bias.detach().cpu().double()
+    zr = torch.relu(ref_b(ref_c(x.cpu().double())))
+    err = float((outs[0][0].cpu().double() - zr).abs().max() / zr.abs().max())
+    assert err < 1e-4, err
+    assert float((outs[0][5].cpu().double() - ref_b.running_mean).abs().max()) < 1e-5
+    assert float((outs[0][6].cpu().double() - ref_b.running_var).abs().max()) < 1e-5 * float(ref_b.running_var.abs().max()) + 1e-6

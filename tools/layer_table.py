@@ -17,7 +17,7 @@ for it in range(3):
     m.zero_grad(set_to_none=True)
 torch.cuda.synchronize()
 PEAK_TF, PEAK_HBM = 416.7e12, 8.0e12       # bf16x3 matrix-pipe peak (2500/6), HBM3E peak
-rows = [(f, fl, nb, s.elapsed_time(e) * 1e3) for f, fl, nb, s, e in t.records if fl > 0]
+rows = [(f, fl, nb, s.elapsed_time(e) * 1e3) for f, fl, nb, s, e, _sc in t.records if fl > 0]
 tot = sum(r[3] for r in rows)
 agg = {}
 for f, fl, nb, us in rows:
@@ -37,7 +37,7 @@ for (f, gf, mb), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
 print(f'sum of per-launch bounds {bound_tot/1e3:.2f} ms = {bound_tot/tot:.2f} of the measured conv time')
 
 # HBM-bound families: (family, MB) -> launches, us, TB/s against algorithmic bytes
-rows = [(f, nb, s.elapsed_time(e) * 1e3) for f, fl, nb, s, e in t.records if fl == 0 and nb > 0]
+rows = [(f, nb, s.elapsed_time(e) * 1e3) for f, fl, nb, s, e, _sc in t.records if fl == 0 and nb > 0]
 tot = sum(r[2] for r in rows)
 agg = {}
 for f, nb, us in rows:
