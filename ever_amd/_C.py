@@ -50,6 +50,9 @@ SIGNATURES = {
     'evk_conv2d_fwd_x3': (c_int, [_DP, P, P, P, P, c_u32, P]),
     'evk_conv2d_stats_max_parts': (c_i32, [_DP]),
     'evk_conv2d_fwd_x3_stats': (c_int, [_DP, P, P, P, P, c_u32, P, c_i32, C.POINTER(c_i32), P]),
+    'evk_conv2d_fwd_bf16': (c_int, [_DP, P, P, P, P, c_u32, P, c_i32, C.POINTER(c_i32), P]),
+    'evk_conv2d_dgrad_bf16': (c_int, [_DP, P, P, P, P, P]),
+    'evk_conv2d_wgrad_bf16': (c_int, [_DP, P, P, P, P, P, c_size_t, P]),
     'evk_conv2d_dgrad_x3': (c_int, [_DP, P, P, P, P, P]),
     'evk_conv_transpose2d_fwd': (c_int, [_DP, P, P, P, P, P]),
     'evk_conv_transpose2d_fwd_x3': (c_int, [_DP, P, P, P, P, P]),

@@ -11,8 +11,8 @@ Differences, all outside the numerics:
     line is actually emitted (`log_interval_step`), so the device queue is not drained every
     iteration (reference launcher.py:211 calls .item() per loss per step);
   * `mixed_precision` defaults to 'fp32' so `Trainer.build_launcher` works (reference defect,
-    SURVEY §0.5); 'bf16' / 'fp16' raise for models built from the HIP layers (fp32-only kernels) instead of
-    silently running fp32, and keep the reference's autocast behaviour for stock torch models.
+    SURVEY §0.5); for models built from the HIP layers 'bf16' selects the plain-bf16 convolution arithmetic
+    (hip/functional.py: conv math 'bf16') and 'fp16' raises; stock torch models keep the reference's autocast.
 """
 import os
 import time
@@ -89,12 +89,18 @@ class Launcher:
             raise ValueError('unrecognized datatype, it should be one of [fp32, fp16, bf16].')
         self._mixed_precision, self._amp = _DTYPES[mixed_precision]
         if self._amp and _has_hip_layers(model):
-            # reference launcher.py:40-80 runs the model under torch.autocast; the gfx950 kernels take fp32 tensors
-            # only and compute convolutions at fp32 grade.  Accepting the flag and silently training in
-            # fp32 would misreport both speed and numerics, so it is refused until a bf16 kernel set exists.
-            raise NotImplementedError(
-                f"mixed_precision='{mixed_precision}' is not implemented on the HIP path (fp32 only: the convolutions "
-                f"already run on the bf16 matrix pipe through an exact 3-term split); use --mixed_precision fp32")
+            # reference launcher.py:40-80 runs the model under torch.autocast.  The HIP path's counterpart of bf16
+            # autocast is its plain-bf16 convolution arithmetic (operands rounded to bf16, one MFMA product, fp32
+            # accumulate; BatchNorm statistics, resampling and losses stay fp32, as the reference keeps them: ops.py:152-166,
+            # fpn.py:96-102); tensors stay fp32, so no torch.autocast region and no GradScaler are involved.
+            # fp16 has no kernel set: refused rather than silently run in another arithmetic.
+            if mixed_precision != 'bf16':
+                raise NotImplementedError(
+                    f"mixed_precision='{mixed_precision}' is not implemented on the HIP path; use fp32 (default: fp32-grade "
+                    f"products on the bf16 matrix pipe) or bf16 (plain bf16 operands)")
+            from ..hip import functional as HF
+            HF.set_conv_math('bf16')
+            self._amp = False
         self._model_dir = model_dir
         self._model = model
         self._optimizer = optimizer

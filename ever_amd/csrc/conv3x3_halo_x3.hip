@@ -34,7 +34,7 @@ constexpr int kRB = kCh * 2;                   // bytes per row and plane
 
 __device__ __forceinline__ int half_off(int row, int c16) { return row * kRB + ((c16 ^ ((row >> 3) & 1)) << 4); }
 
-template <int BN, int PH>
+template <int BN, int PH, int NP>
 __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p, int tiles_y, int tiles_x) {
   constexpr int kPH = PH, kHP = HaloGeom<PH>::kHP, kHSlots = HaloGeom<PH>::kHSlots, kHaloPix = HaloGeom<PH>::kHaloPix;
   constexpr int kAStage = 3 * kHSlots * kRB;          // 30720 B (PH 8) / 31104 B (PH 16)
@@ -90,6 +90,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
       const int e = b_has[i] ? e0 : 0;
       const int half = e & 1, row = (e >> 1) % BN, rest = e / (2 * BN);  // rest = jx * 3 + pt
       const int pt = rest % 3, jx = rest / 3;
+      b_has[i] = b_has[i] && (NP == 3 || pt == 0);   // plain bf16: only the h plane of the weights is staged
       int co = n0 + row;
       co = co < p.Cd ? co : p.Cd - 1;
       b_src[i] = (int)(pt * plane_stride + (size_t)jx * tap_stride + (size_t)co * kCh + half * 8);
@@ -108,12 +109,17 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
         if (!a_has[i]) continue;
         const f32x4 v = ra[i];
         const bool ok = a_ok[i];
-        uint32_t h0, m0, l0, h1, m1, l1;
-        split2(ok ? v.x : 0.f, ok ? v.y : 0.f, h0, m0, l0);
-        split2(ok ? v.z : 0.f, ok ? v.w : 0.f, h1, m1, l1);
-        *reinterpret_cast<uint2*>(A + a_lds[i]) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2*>(A + kHSlots * kRB + a_lds[i]) = make_uint2(m0, m1);
-        *reinterpret_cast<uint2*>(A + 2 * kHSlots * kRB + a_lds[i]) = make_uint2(l0, l1);
+        if (NP == 3) {
+          uint32_t h0, m0, l0, h1, m1, l1;
+          split2(ok ? v.x : 0.f, ok ? v.y : 0.f, h0, m0, l0);
+          split2(ok ? v.z : 0.f, ok ? v.w : 0.f, h1, m1, l1);
+          *reinterpret_cast<uint2*>(A + a_lds[i]) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(A + kHSlots * kRB + a_lds[i]) = make_uint2(m0, m1);
+          *reinterpret_cast<uint2*>(A + 2 * kHSlots * kRB + a_lds[i]) = make_uint2(l0, l1);
+        } else {
+          *reinterpret_cast<uint2*>(A + a_lds[i]) =
+              make_uint2(cvt2(ok ? v.x : 0.f, ok ? v.y : 0.f), cvt2(ok ? v.z : 0.f, ok ? v.w : 0.f));
+        }
       }
     };
     // iteration it = 3*c + jy reads taps (jy, 0..2) of chunk c
@@ -189,20 +195,20 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
         const int hr = hb[a] + dy * kHP + dx;
         const int off = half_off(hr, lh);
 #pragma unroll
-        for (int pt = 0; pt < 3; ++pt) fa[a][pt] = *reinterpret_cast<const bf16x8*>(A + pt * kHSlots * kRB + off);
+        for (int pt = 0; pt < NP; ++pt) fa[a][pt] = *reinterpret_cast<const bf16x8*>(A + pt * kHSlots * kRB + off);
       }
 #pragma unroll
       for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int pt = 0; pt < 3; ++pt)
+        for (int pt = 0; pt < NP; ++pt)
           fbv[b][pt] = *reinterpret_cast<const bf16x8*>(B + (jx * 3 + pt) * BN * kRB + fb[b]);
 #pragma unroll
-      for (int t6 = 0; t6 < 6; ++t6)
+      for (int t6 = 0; t6 < X3Prod<NP>::N; ++t6)
 #pragma unroll
         for (int a = 0; a < MB; ++a)
 #pragma unroll
           for (int b = 0; b < NB; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fbv[b][kPB[t6]], fa[a][kPA[t6]], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fbv[b][x3_pb(NP, t6)], fa[a][x3_pa(NP, t6)], acc[a][b], 0, 0, 0);
     }
     __syncthreads();
   }
@@ -261,8 +267,8 @@ bool conv_desc_uses_halo(const evk_conv_desc* d, int for_dgrad) {
   return conv3x3_halo_applies(a);
 }
 
-template <int BN, int PH>
-static int launch_halo(IGemmArgs& a, hipStream_t stream) {
+template <int BN, int PH, int NP>
+static int launch_halo_np(IGemmArgs& a, hipStream_t stream) {
   a.tiles_n = ceil_div(a.Cd, BN);
   const int tiles_y = a.Hm / PH, tiles_x = a.Wm / kPW;
   a.tiles_m = a.N * tiles_y * tiles_x;
@@ -270,13 +276,18 @@ static int launch_halo(IGemmArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)2 * (3 * HaloGeom<PH>::kHSlots * kRB) + (size_t)2 * (3 * 3 * BN * kRB);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_x3_kernel<BN, PH>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_x3_kernel<BN, PH, NP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const long long nwg = (long long)a.tiles_m * a.tiles_n;
-  hipLaunchKernelGGL((conv3x3_halo_x3_kernel<BN, PH>), dim3((unsigned)nwg), dim3(512), lds, stream, a, tiles_y, tiles_x);
+  hipLaunchKernelGGL((conv3x3_halo_x3_kernel<BN, PH, NP>), dim3((unsigned)nwg), dim3(512), lds, stream, a, tiles_y, tiles_x);
   return check_launch("conv3x3_halo_x3");
+}
+
+template <int BN, int PH>
+static int launch_halo(IGemmArgs& a, hipStream_t stream) {
+  return a.planes == 1 ? launch_halo_np<BN, PH, 1>(a, stream) : launch_halo_np<BN, PH, 3>(a, stream);
 }
 
 int launch_conv3x3_halo(IGemmArgs& a, hipStream_t stream) {

@@ -348,7 +348,7 @@ static inline int kpad32(int k) { return (k + 31) & ~31; }
 // w3 != nullptr selects the bf16-split kernel (conv_igemm_x3.hip) on pre-split weight planes
 static int conv_fwd_any(const evk_conv_desc* d, const float* x, const float* w, const uint16_t* w3, const float* bias,
                         float* y, uint32_t flags, void* stream, const float* residual = nullptr,
-                        float* bn_parts = nullptr, int32_t bn_cap = 0, int32_t* nparts = nullptr) {
+                        float* bn_parts = nullptr, int32_t bn_cap = 0, int32_t* nparts = nullptr, int planes = 3) {
   int rc = check_desc(d);
   if (rc) return rc;
   EVK_REQUIRE(x && (w || w3) && y, EVK_E_INVALID, "conv2d_fwd: null pointer");
@@ -365,6 +365,7 @@ static int conv_fwd_any(const evk_conv_desc* d, const float* x, const float* w, 
   a.Hd = d->Ho; a.Wd = d->Wo; a.dsh = 1; a.dsw = 1; a.dense_dst = 1;
   a.relu = (flags & EVK_CONV_RELU) ? 1 : 0;
   a.Kpad = kpad32(a.Ktot);
+  a.planes = planes;
   a.bn_want = (bn_parts && w3 && d->Cout % 4 == 0) ? 1 : 0;
   a.bn_buf = bn_parts;
   a.bn_cap = bn_cap;
@@ -405,6 +406,15 @@ extern "C" int evk_conv2d_fwd_x3_stats(const evk_conv_desc* d, const float* x, c
                       bn_capacity, nparts);
 }
 
+// Plain bf16 operands (ONE product per operand pair, fp32 accumulate): the counterpart of the reference's
+// `--mixed_precision bf16`.  Same arguments and the same weight-plane buffers as the x3 forms (only plane 0 is read).
+extern "C" int evk_conv2d_fwd_bf16(const evk_conv_desc* d, const float* x, const void* wsplit, const float* bias, float* y,
+                                   uint32_t flags, float* bn_parts, int32_t bn_capacity, int32_t* nparts, void* stream) {
+  EVK_REQUIRE(wsplit, EVK_E_INVALID, "conv2d_fwd_bf16: null weight planes");
+  return conv_fwd_any(d, x, nullptr, reinterpret_cast<const uint16_t*>(wsplit), bias, y, flags, stream, nullptr, bn_parts,
+                      bn_capacity, nparts, 1);
+}
+
 // y = act(conv(x, w) + bias + residual): the inference form of a ResNet block's last convolution once its
 // BatchNorm is folded into (w, bias) — reference _resnets.py:95-112 (`out += identity; relu`)
 extern "C" int evk_conv2d_fwd_res(const evk_conv_desc* d, const float* x, const float* w, const float* bias,
@@ -418,7 +428,7 @@ extern "C" int evk_conv2d_fwd_x3_res(const evk_conv_desc* d, const float* x, con
 }
 
 static int conv_dgrad_any(const evk_conv_desc* d, const float* dy, const float* wt, const uint16_t* wt3,
-                          const float* accum, float* dx, void* stream) {
+                          const float* accum, float* dx, void* stream, int planes = 3) {
   int rc = check_desc(d);
   if (rc) return rc;
   EVK_REQUIRE(dy && (wt || wt3) && dx, EVK_E_INVALID, "conv2d_dgrad: null pointer");
@@ -446,6 +456,7 @@ static int conv_dgrad_any(const evk_conv_desc* d, const float* dy, const float* 
       const size_t wsize = (size_t)d->Cin * py.nt * px.nt * d->Cout;
       if (py.nt > 0 && px.nt > 0 && Hm > 0 && Wm > 0) {
         IGemmArgs a{};
+        a.planes = planes;
         a.src = dy; a.wgt = wt ? wt + woff : nullptr; a.wgt3 = wt3 ? wt3 + woff3 : nullptr;
         a.bias = nullptr; a.accum = accum; a.dst = dx;
         a.N = d->N; a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Cout;
@@ -472,6 +483,12 @@ static int conv_dgrad_any(const evk_conv_desc* d, const float* dy, const float* 
 extern "C" int evk_conv2d_dgrad(const evk_conv_desc* d, const float* dy, const float* wt, const float* accum,
                                 float* dx, void* stream) {
   return conv_dgrad_any(d, dy, wt, nullptr, accum, dx, stream);
+}
+
+extern "C" int evk_conv2d_dgrad_bf16(const evk_conv_desc* d, const float* dy, const void* wsplit_t, const float* accum,
+                                     float* dx, void* stream) {
+  EVK_REQUIRE(wsplit_t, EVK_E_INVALID, "conv2d_dgrad_bf16: null weight planes");
+  return conv_dgrad_any(d, dy, nullptr, reinterpret_cast<const uint16_t*>(wsplit_t), accum, dx, stream, 1);
 }
 
 extern "C" int evk_conv2d_dgrad_x3(const evk_conv_desc* d, const float* dy, const void* wsplit_t, const float* accum,

@@ -22,7 +22,7 @@
 
 namespace evk {
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NBUF>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NBUF, int NP>
 __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(const IGemmArgs p) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MB = WM / 32, NB = WN / 32;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(const IGemmArgs p) {
 #pragma unroll
     for (int j = 0; j < BR; ++j)
 #pragma unroll
-      for (int pt = 0; pt < 3; ++pt)
+      for (int pt = 0; pt < NP; ++pt)
         rbv[j][pt] = *reinterpret_cast<const u32x4*>(p.wgt3 + (size_t)pt * plane + b_off[j] + kt * BK3);
     if (cp8 >= 4) {
       cc += 4;
@@ -132,20 +132,26 @@ __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(const IGemmArgs p) {
       for (int e = 0; e < 4; ++e) {
         const f32x4 v = ra[j][e >> 1];
         const float x0 = ok ? v[2 * (e & 1)] : 0.f, x1 = ok ? v[2 * (e & 1) + 1] : 0.f;
-        uint32_t h, m, l;
-        split2(x0, x1, h, m, l);
-        H[e] = h; M[e] = m; L[e] = l;
+        if (NP == 3) {
+          uint32_t h, m, l;
+          split2(x0, x1, h, m, l);
+          H[e] = h; M[e] = m; L[e] = l;
+        } else {
+          H[e] = cvt2(x0, x1);
+        }
       }
       *reinterpret_cast<u32x4*>(Ab + off) = H;
-      *reinterpret_cast<u32x4*>(Ab + BM * kRowBytes + off) = M;
-      *reinterpret_cast<u32x4*>(Ab + 2 * BM * kRowBytes + off) = L;
+      if (NP == 3) {
+        *reinterpret_cast<u32x4*>(Ab + BM * kRowBytes + off) = M;
+        *reinterpret_cast<u32x4*>(Ab + 2 * BM * kRowBytes + off) = L;
+      }
     }
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
       const int row = rb + 64 * j;
       const int off = row * kRowBytes + ((c4 ^ ((row >> 2) & 3)) << 4);
 #pragma unroll
-      for (int pt = 0; pt < 3; ++pt) *reinterpret_cast<u32x4*>(Bb + pt * BN * kRowBytes + off) = rbv[j][pt];
+      for (int pt = 0; pt < NP; ++pt) *reinterpret_cast<u32x4*>(Bb + pt * BN * kRowBytes + off) = rbv[j][pt];
     }
   };
 
@@ -191,20 +197,20 @@ __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(const IGemmArgs p) {
 #pragma unroll
     for (int a = 0; a < MB; ++a)
 #pragma unroll
-      for (int pt = 0; pt < 3; ++pt)
+      for (int pt = 0; pt < NP; ++pt)
         fa[a][pt] = *reinterpret_cast<const bf16x8*>(Ab + pt * BM * kRowBytes + fa_off[a][kk]);
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
-      for (int pt = 0; pt < 3; ++pt)
+      for (int pt = 0; pt < NP; ++pt)
         fb[b][pt] = *reinterpret_cast<const bf16x8*>(Bb + pt * BN * kRowBytes + fb_off[b][kk]);
 #pragma unroll
-    for (int t = first; t < last; ++t)
+    for (int t = first; t < (NP == 3 ? last : 1); ++t)
 #pragma unroll
       for (int a = 0; a < MB; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b][PB[t]], fa[a][PA[t]], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b][NP == 3 ? PB[t] : 0], fa[a][NP == 3 ? PA[t] : 0], acc[a][b], 0, 0, 0);
   };
 
   for (int kt = 0; kt < nk; ++kt) {
@@ -231,8 +237,8 @@ __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(const IGemmArgs p) {
   igemm_epilogue<MB, NB, WM, WN>(p, acc, m0, n0, wm, wn, li, lh);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NBUF>
-static int launch_cfg3(IGemmArgs& a, hipStream_t stream) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NBUF, int NP>
+static int launch_cfg3_np(IGemmArgs& a, hipStream_t stream) {
   a.tiles_m = ceil_div(a.M, BM);
   a.tiles_n = ceil_div(a.Cd, BN);
   bn_stats_setup(a, BM, BN, WAVES_M, a.tiles_m);
@@ -242,7 +248,7 @@ static int launch_cfg3(IGemmArgs& a, hipStream_t stream) {
   if (lds < scratch) lds = scratch;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_x3_kernel<BM, BN, WAVES_M, WAVES_N, NBUF>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_x3_kernel<BM, BN, WAVES_M, WAVES_N, NBUF, NP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -251,8 +257,14 @@ static int launch_cfg3(IGemmArgs& a, hipStream_t stream) {
     set_error("conv_igemm_x3: bad grid %lld", nwg);
     return EVK_E_INVALID;
   }
-  hipLaunchKernelGGL((conv_igemm_x3_kernel<BM, BN, WAVES_M, WAVES_N, NBUF>), dim3((unsigned)nwg), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((conv_igemm_x3_kernel<BM, BN, WAVES_M, WAVES_N, NBUF, NP>), dim3((unsigned)nwg), dim3(256), lds, stream, a);
   return check_launch("conv_igemm_x3");
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NBUF>
+static int launch_cfg3(IGemmArgs& a, hipStream_t stream) {
+  return a.planes == 1 ? launch_cfg3_np<BM, BN, WAVES_M, WAVES_N, NBUF, 1>(a, stream)
+                       : launch_cfg3_np<BM, BN, WAVES_M, WAVES_N, NBUF, 3>(a, stream);
 }
 
 int launch_igemm_x3(IGemmArgs& a, hipStream_t stream) {

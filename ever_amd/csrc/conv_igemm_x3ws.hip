@@ -18,7 +18,7 @@
 
 namespace evk {
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int NP>
 __global__ __launch_bounds__(512) void conv_igemm_x3ws_kernel(const IGemmArgs p) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MB = WM / 32, NB = WN / 32;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws_kernel(const IGemmArgs p)
 #pragma unroll
       for (int j = 0; j < BR; ++j)
 #pragma unroll
-        for (int pt = 0; pt < 3; ++pt)
+        for (int pt = 0; pt < NP; ++pt)
           rbv[s][j][pt] = *reinterpret_cast<const u32x4*>(p.wgt3 + (size_t)pt * plane + b_off[j] + kt * BK3);
       if (cp8 >= 4) {
         cc += 4;
@@ -153,19 +153,25 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws_kernel(const IGemmArgs p)
         for (int e = 0; e < 4; ++e) {
           const f32x4 v = ra[s][j][e >> 1];
           const float x0 = ok ? v[2 * (e & 1)] : 0.f, x1 = ok ? v[2 * (e & 1) + 1] : 0.f;
-          uint32_t h, m, l;
-          split2(x0, x1, h, m, l);
-          H[e] = h; M[e] = m; L[e] = l;
+          if (NP == 3) {
+            uint32_t h, m, l;
+            split2(x0, x1, h, m, l);
+            H[e] = h; M[e] = m; L[e] = l;
+          } else {
+            H[e] = cvt2(x0, x1);
+          }
         }
         *reinterpret_cast<u32x4*>(Ab + off) = H;
-        *reinterpret_cast<u32x4*>(Ab + BM * kRowBytes + off) = M;
-        *reinterpret_cast<u32x4*>(Ab + 2 * BM * kRowBytes + off) = L;
+        if (NP == 3) {
+          *reinterpret_cast<u32x4*>(Ab + BM * kRowBytes + off) = M;
+          *reinterpret_cast<u32x4*>(Ab + 2 * BM * kRowBytes + off) = L;
+        }
       }
 #pragma unroll
       for (int j = 0; j < BR; ++j) {
         const int off = plane_off(rb + 64 * j, c4);
 #pragma unroll
-        for (int pt = 0; pt < 3; ++pt) *reinterpret_cast<u32x4*>(Bb + pt * BN * kRowBytes + off) = rbv[s][j][pt];
+        for (int pt = 0; pt < NP; ++pt) *reinterpret_cast<u32x4*>(Bb + pt * BN * kRowBytes + off) = rbv[s][j][pt];
       }
     };
 
@@ -223,22 +229,22 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws_kernel(const IGemmArgs p)
 #pragma unroll
     for (int a = 0; a < MB; ++a)
 #pragma unroll
-      for (int pt = 0; pt < 3; ++pt)
+      for (int pt = 0; pt < NP; ++pt)
         fa[slot][a][pt] = *reinterpret_cast<const bf16x8*>(S + pt * BM * kRowBytes + fa_off[a][kk]);
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
-      for (int pt = 0; pt < 3; ++pt)
+      for (int pt = 0; pt < NP; ++pt)
         fb[slot][b][pt] = *reinterpret_cast<const bf16x8*>(S + pt * BN * kRowBytes + fb_off[b][kk]);
   };
   auto mfmas = [&](int slot) {
 #pragma unroll
-    for (int t = 0; t < 6; ++t)
+    for (int t = 0; t < X3Prod<NP>::N; ++t)
 #pragma unroll
       for (int a = 0; a < MB; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[slot][b][kPB[t]], fa[slot][a][kPA[t]], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[slot][b][x3_pb(NP, t)], fa[slot][a][x3_pa(NP, t)], acc[a][b], 0, 0, 0);
   };
 
   __syncthreads();
@@ -278,8 +284,8 @@ static int ws_persist() {
   return v;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE>
-static int launch_ws(IGemmArgs& a, hipStream_t stream) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int NP>
+static int launch_ws_np(IGemmArgs& a, hipStream_t stream) {
   a.tiles_m = ceil_div(a.M, BM);
   a.tiles_n = ceil_div(a.Cd, BN);
   bn_stats_setup(a, BM, BN, WAVES_M, a.tiles_m);
@@ -287,7 +293,7 @@ static int launch_ws(IGemmArgs& a, hipStream_t stream) {
   a.bn_scratch_off = 0;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_x3ws_kernel<BM, BN, WAVES_M, WAVES_N, NSTAGE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_x3ws_kernel<BM, BN, WAVES_M, WAVES_N, NSTAGE, NP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -301,8 +307,14 @@ static int launch_ws(IGemmArgs& a, hipStream_t stream) {
   // statistics mode: one tile per workgroup (the epilogue parks the tile in the LDS ring, which a persistent
   // workgroup's staging waves would already be refilling)
   const unsigned grid = (ws_persist() && nwg > 256 && !a.bn_part) ? 256u : (unsigned)nwg;
-  hipLaunchKernelGGL((conv_igemm_x3ws_kernel<BM, BN, WAVES_M, WAVES_N, NSTAGE>), dim3(grid), dim3(512), lds, stream, a);
+  hipLaunchKernelGGL((conv_igemm_x3ws_kernel<BM, BN, WAVES_M, WAVES_N, NSTAGE, NP>), dim3(grid), dim3(512), lds, stream, a);
   return check_launch("conv_igemm_x3ws");
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE>
+static int launch_ws(IGemmArgs& a, hipStream_t stream) {
+  return a.planes == 1 ? launch_ws_np<BM, BN, WAVES_M, WAVES_N, NSTAGE, 1>(a, stream)
+                       : launch_ws_np<BM, BN, WAVES_M, WAVES_N, NSTAGE, 3>(a, stream);
 }
 
 // returns 1 when this form does not apply (caller falls back to the single-role kernel)

@@ -342,7 +342,7 @@ extern "C" size_t evk_conv2d_wgrad_workspace_bytes(const evk_conv_desc* d) { ret
 extern "C" size_t evk_conv2d_wgrad_x3_workspace_bytes(const evk_conv_desc* d) { return wgrad_ws_bytes(d, 1); }
 
 static int conv_wgrad_any(const evk_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
-                          void* workspace, size_t workspace_bytes, void* stream, int x3) {
+                          void* workspace, size_t workspace_bytes, void* stream, int x3, int planes = 3) {
   EVK_REQUIRE(d && x && dy && dw, EVK_E_INVALID, "conv2d_wgrad: null pointer");
   EVK_REQUIRE(d->Cin % 4 == 0 && d->Cout % 4 == 0, EVK_E_UNSUPPORTED,
               "conv2d_wgrad: Cin=%d and Cout=%d must be multiples of 4", d->Cin, d->Cout);
@@ -354,6 +354,7 @@ static int conv_wgrad_any(const evk_conv_desc* d, const float* x, const float* d
   hipStream_t st = (hipStream_t)stream;
   const WGradPlan pl = plan_wgrad(d, x3);
   WGradArgs a{};
+  a.planes = planes;
   a.x = x; a.dy = dy;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
   a.kh = d->kh; a.kw = d->kw; a.cpt = d->Cin / 4;
@@ -401,6 +402,12 @@ static int conv_wgrad_any(const evk_conv_desc* d, const float* x, const float* d
 extern "C" int evk_conv2d_wgrad(const evk_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
                                 void* workspace, size_t workspace_bytes, void* stream) {
   return conv_wgrad_any(d, x, dy, dw, dbias, workspace, workspace_bytes, stream, 0);
+}
+
+extern "C" int evk_conv2d_wgrad_bf16(const evk_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  EVK_REQUIRE(d && d->Cin % 4 == 0 && d->Cout % 4 == 0, EVK_E_UNSUPPORTED, "conv2d_wgrad_bf16: channels must be multiples of 4");
+  return conv_wgrad_any(d, x, dy, dw, dbias, workspace, workspace_bytes, stream, 1, 1);
 }
 
 extern "C" int evk_conv2d_wgrad_x3(const evk_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,

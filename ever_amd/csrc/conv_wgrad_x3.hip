@@ -21,7 +21,7 @@
 
 namespace evk {
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NP>
 __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const WGradArgs p) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MB = WM / 32, NB = WN / 32;
@@ -129,13 +129,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const WGradArgs p) {
       u32x4 H, M, L;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        uint32_t h, m, l;
-        split2(rv[2 * t][e], rv[2 * t + 1][e], h, m, l);
-        H[t] = h; M[t] = m; L[t] = l;
+        if (NP == 3) {
+          uint32_t h, m, l;
+          split2(rv[2 * t][e], rv[2 * t + 1][e], h, m, l);
+          H[t] = h; M[t] = m; L[t] = l;
+        } else {
+          H[t] = cvt2(rv[2 * t][e], rv[2 * t + 1][e]);
+        }
       }
       *reinterpret_cast<u32x4*>(st_base + off) = H;
-      *reinterpret_cast<u32x4*>(st_base + st_plane + off) = M;
-      *reinterpret_cast<u32x4*>(st_base + 2 * st_plane + off) = L;
+      if (NP == 3) {
+        *reinterpret_cast<u32x4*>(st_base + st_plane + off) = M;
+        *reinterpret_cast<u32x4*>(st_base + 2 * st_plane + off) = L;
+      }
     }
   };
 
@@ -166,20 +172,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const WGradArgs p) {
 #pragma unroll
     for (int a = 0; a < MB; ++a)
 #pragma unroll
-      for (int pt = 0; pt < 3; ++pt)
+      for (int pt = 0; pt < NP; ++pt)
         fa[a][pt] = *reinterpret_cast<const bf16x8*>(Ap + pt * BM * kRowBytes + fa_off[a][kk]);
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
-      for (int pt = 0; pt < 3; ++pt)
+      for (int pt = 0; pt < NP; ++pt)
         fb[b][pt] = *reinterpret_cast<const bf16x8*>(Bp + pt * BN * kRowBytes + fb_off[b][kk]);
 #pragma unroll
-    for (int t = 0; t < 6; ++t)
+    for (int t = 0; t < X3Prod<NP>::N; ++t)
 #pragma unroll
       for (int a = 0; a < MB; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][kPA[t]], fb[b][kPB[t]], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][x3_pa(NP, t)], fb[b][x3_pb(NP, t)], acc[a][b], 0, 0, 0);
   };
 
   const int nk = (pend - pbeg + BKP - 1) / BKP;
@@ -222,8 +228,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const WGradArgs p) {
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 static int launch_one(const WGradArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)3 * (BM + BN) * kRowBytes;
-  hipLaunchKernelGGL((conv_wgrad_x3_kernel<BM, BN, WAVES_M, WAVES_N>), dim3(a.tiles_co * a.tiles_k * a.splitk),
-                     dim3(256), lds, stream, a);
+  if (a.planes == 1) {
+    hipLaunchKernelGGL((conv_wgrad_x3_kernel<BM, BN, WAVES_M, WAVES_N, 1>), dim3(a.tiles_co * a.tiles_k * a.splitk),
+                       dim3(256), lds, stream, a);
+  } else {
+    hipLaunchKernelGGL((conv_wgrad_x3_kernel<BM, BN, WAVES_M, WAVES_N, 3>), dim3(a.tiles_co * a.tiles_k * a.splitk),
+                       dim3(256), lds, stream, a);
+  }
   return check_launch("conv_wgrad_x3");
 }
 

@@ -57,6 +57,7 @@ __device__ __forceinline__ void gather8(const WGradArgs& p, const WGather& g, in
 }
 
 // split the micro-block and write channel 4*cq+e to LDS row e*Q + cq, 16-byte chunk pg, of the three planes
+template <int NP>
 __device__ __forceinline__ void split_store8(f32x4 (&rv)[8], uint32_t okmask, unsigned char* base, int plane_bytes, int Q,
                                              int cq, int pg) {
 #pragma unroll
@@ -71,13 +72,19 @@ __device__ __forceinline__ void split_store8(f32x4 (&rv)[8], uint32_t okmask, un
     u32x4 H, M, L;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      uint32_t h, m, l;
-      split2(rv[2 * t][e], rv[2 * t + 1][e], h, m, l);
-      H[t] = h; M[t] = m; L[t] = l;
+      if (NP == 3) {
+        uint32_t h, m, l;
+        split2(rv[2 * t][e], rv[2 * t + 1][e], h, m, l);
+        H[t] = h; M[t] = m; L[t] = l;
+      } else {
+        H[t] = cvt2(rv[2 * t][e], rv[2 * t + 1][e]);
+      }
     }
     *reinterpret_cast<u32x4*>(base + off) = H;
-    *reinterpret_cast<u32x4*>(base + plane_bytes + off) = M;
-    *reinterpret_cast<u32x4*>(base + 2 * plane_bytes + off) = L;
+    if (NP == 3) {
+      *reinterpret_cast<u32x4*>(base + plane_bytes + off) = M;
+      *reinterpret_cast<u32x4*>(base + 2 * plane_bytes + off) = L;
+    }
   }
 }
 
@@ -95,6 +102,7 @@ __device__ __forceinline__ void gather8h(const float* __restrict__ dy, int Cout,
     rv[j] = *reinterpret_cast<const f32x2v*>(dy + (ok ? (size_t)m * Cout + coff : 0));
   }
 }
+template <int NP>
 __device__ __forceinline__ void split_store8h(f32x2v (&rv)[8], uint32_t okmask, unsigned char* base, int plane_bytes, int Q2,
                                               int cq, int pg) {
 #pragma unroll
@@ -109,17 +117,23 @@ __device__ __forceinline__ void split_store8h(f32x2v (&rv)[8], uint32_t okmask, 
     u32x4 H, M, L;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      uint32_t h, m, l;
-      split2(rv[2 * t][e], rv[2 * t + 1][e], h, m, l);
-      H[t] = h; M[t] = m; L[t] = l;
+      if (NP == 3) {
+        uint32_t h, m, l;
+        split2(rv[2 * t][e], rv[2 * t + 1][e], h, m, l);
+        H[t] = h; M[t] = m; L[t] = l;
+      } else {
+        H[t] = cvt2(rv[2 * t][e], rv[2 * t + 1][e]);
+      }
     }
     *reinterpret_cast<u32x4*>(base + off) = H;
-    *reinterpret_cast<u32x4*>(base + plane_bytes + off) = M;
-    *reinterpret_cast<u32x4*>(base + 2 * plane_bytes + off) = L;
+    if (NP == 3) {
+      *reinterpret_cast<u32x4*>(base + plane_bytes + off) = M;
+      *reinterpret_cast<u32x4*>(base + 2 * plane_bytes + off) = L;
+    }
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NP>
 __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MB = WM / 32, NB = WN / 32;
@@ -183,8 +197,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
       unsigned char* Ab = smem3 + stage * kStage;
       unsigned char* Bb = Ab + 3 * BM * kRowBytes;
       if (p.dbg & 2) return;   // ablation: no split, no LDS writes
-      split_store8(rb[s], okb[s], Bb, BN * kRowBytes, QB, bcq, bpg);
-      split_store8h(ra[s], oka[s], Ab, BM * kRowBytes, QA2, acq, apg);
+      split_store8<NP>(rb[s], okb[s], Bb, BN * kRowBytes, QB, bcq, bpg);
+      split_store8h<NP>(ra[s], oka[s], Ab, BM * kRowBytes, QA2, acq, apg);
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
@@ -244,20 +258,20 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
 #pragma unroll
     for (int a = 0; a < MB; ++a)
 #pragma unroll
-      for (int pt = 0; pt < 3; ++pt)
+      for (int pt = 0; pt < NP; ++pt)
         fa[a][pt] = *reinterpret_cast<const bf16x8*>(S + pt * BM * kRowBytes + fa_off[a][kk]);
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
-      for (int pt = 0; pt < 3; ++pt)
+      for (int pt = 0; pt < NP; ++pt)
         fb[b][pt] = *reinterpret_cast<const bf16x8*>(S + pt * BN * kRowBytes + fb_off[b][kk]);
 #pragma unroll
-    for (int t = 0; t < 6; ++t)
+    for (int t = 0; t < X3Prod<NP>::N; ++t)
 #pragma unroll
       for (int a = 0; a < MB; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][kPA[t]], fb[b][kPB[t]], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][x3_pa(NP, t)], fb[b][x3_pb(NP, t)], acc[a][b], 0, 0, 0);
   };
 
   __syncthreads();
@@ -300,14 +314,20 @@ int launch_wgrad_x3ws(const WGradArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)2 * 3 * (BM + BN) * kRowBytes;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x3ws_kernel<BM, BN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x3ws_kernel<BM, BN, 3>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x3ws_kernel<BM, BN, 1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   WGradArgs b = a;
   static const int dbg = getenv("EVK_WG_DBG") ? atoi(getenv("EVK_WG_DBG")) : 0;
   b.dbg = dbg;
-  hipLaunchKernelGGL((conv_wgrad_x3ws_kernel<BM, BN>), dim3(a.tiles_co * a.tiles_k * a.splitk), dim3(512), lds, stream, b);
+  if (a.planes == 1) {
+    hipLaunchKernelGGL((conv_wgrad_x3ws_kernel<BM, BN, 1>), dim3(a.tiles_co * a.tiles_k * a.splitk), dim3(512), lds, stream, b);
+  } else {
+    hipLaunchKernelGGL((conv_wgrad_x3ws_kernel<BM, BN, 3>), dim3(a.tiles_co * a.tiles_k * a.splitk), dim3(512), lds, stream, b);
+  }
   return check_launch("conv_wgrad_x3ws");
 }
 

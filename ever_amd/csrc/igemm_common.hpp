@@ -23,6 +23,7 @@ struct IGemmArgs {
   int tiles_m, tiles_n;
   const uint16_t* wgt3;     // split kernel: weights as 3 bf16 planes [3][Cd][Kpad] (Kpad % 32 == 0, zero padded)
   int Kpad;
+  int planes;               // 3 (0 means 3): exact split, six products; 1: plain bf16 operands, one product (*_bf16 entry points)
   // BatchNorm statistics of the OUTPUT from the epilogue (forward convolutions followed by a training-mode BatchNorm):
   // bn_part[part][3][Cd] = (count, mean, M2 = sum (y - mean)^2) of the rows of row-part `part`; nullptr = off.
   // Written by igemm_store_rows_stats / bn_part_write; merged (Chan) by evk_bn_fwd_train_parts.

@@ -15,6 +15,7 @@ struct WGradArgs {
   int chunk;  // pixels per split (multiple of 32)
   int tiles_co, tiles_k, splitk;
   FastDiv fd_hw, fd_w;
+  int planes;  // 3 (0 means 3): exact split, six products; 1: plain bf16 operands, one product (evk_conv2d_wgrad_bf16)
   int dbg;  // EVK_WG_DBG ablation switches of the wave-specialised kernel (0 in production)
 };
 

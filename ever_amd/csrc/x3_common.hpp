@@ -28,6 +28,19 @@ __device__ __forceinline__ void split2(float x0, float x1, uint32_t& H, uint32_t
   L = __builtin_bit_cast(uint32_t, __builtin_convertvector(s, bf16x2));
 }
 
+// NP = number of bf16 planes per operand: 3 = the exact split above (six partial products, fp32-grade);
+// 1 = plain bf16 (operands rounded to bf16 once, ONE product, fp32 accumulate): the counterpart of the reference's
+// `--mixed_precision bf16` (launcher.py:40-80), selected by the *_bf16 entry points.  LDS / HBM plane layouts are
+// the same; only plane 0 (h) is produced and read.
+template <int NP> struct X3Prod { static constexpr int N = NP == 3 ? 6 : 1; };
+__device__ __forceinline__ constexpr int x3_pa(int np, int t) { return np == 3 ? kPA[t] : 0; }
+__device__ __forceinline__ constexpr int x3_pb(int np, int t) { return np == 3 ? kPB[t] : 0; }
+// two floats -> packed bf16 pair (round-to-nearest-even), first element in the low half
+__device__ __forceinline__ uint32_t cvt2(float x0, float x1) {
+  const f32x2 v = {x0, x1};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
 // byte offset of 16-byte chunk c16 (0..3) of row `row` inside one plane; the XOR spreads the
 // ds_read_b128 / ds_write_b128 of 16 consecutive rows over 16 distinct 16-byte slots of a 256-byte bank row
 __device__ __forceinline__ int plane_off(int row, int c16) { return row * kRowBytes + ((c16 ^ ((row >> 2) & 3)) << 4); }

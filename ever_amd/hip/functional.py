@@ -33,13 +33,26 @@ class HipPathError(RuntimeError):
 #            six bf16 MFMA partial products (error per product < 2^-24: below one fp32 rounding), on the
 #            v_mfma_f32_32x32x16_bf16 pipe;
 #   'f32'    v_mfma_f32_32x32x2_f32, an exact fmaf chain (the parity yardstick for the split kernels).
+#   'bf16'   plain bf16 operands (rounded once), ONE bf16 MFMA product per operand pair, fp32 accumulate, fp32 tensors:
+#            the counterpart of the reference's `--mixed_precision bf16` (core/launcher.py:40-80).  Opt-in only.
 _CONV_MATH = os.environ.get('EVK_CONV_MATH', 'bf16x3')
+_MATH_MODES = ('bf16x3', 'f32', 'bf16')
+
+
+def _planes_math():
+    """True when the convolutions run on the bf16 matrix pipe from weight planes (exact split or plain bf16)."""
+    return _CONV_MATH in ('bf16x3', 'bf16')
+
+
+def _entry(x3_name):
+    """C-ABI entry point of the current plane arithmetic: evk_*_x3 or its plain-bf16 twin evk_*_bf16."""
+    return x3_name if _CONV_MATH == 'bf16x3' else x3_name.replace('_x3', '_bf16')
 
 
 def set_conv_math(mode):
     global _CONV_MATH
-    if mode not in ('bf16x3', 'f32'):
-        raise ValueError(f"conv math must be 'bf16x3' or 'f32', got {mode!r}")
+    if mode not in _MATH_MODES:
+        raise ValueError(f"conv math must be one of {_MATH_MODES}, got {mode!r}")
     prev, _CONV_MATH = _CONV_MATH, mode
     return prev
 
@@ -218,7 +231,7 @@ def _conv_forward(x, weight, bias, stride, padding, dilation, relu, want_stats=F
     # dedicated weight-streaming kernel for M <= 32; an MFMA tile would run K = 2048 serially on two workgroups
     small_m = n * d.Ho * d.Wo <= 32
     bn_parts = None
-    if _CONV_MATH == 'bf16x3' and cin_p == cin and cin % 8 == 0 and not small_m:
+    if _planes_math() and cin_p == cin and cin % 8 == 0 and not small_m:
         # weights -> three bf16 planes, then the split-MFMA kernel.  The planes of every registered weight are
         # refreshed by one launch per weight update (weight_planes); a weight the cache cannot follow (a transient
         # re-laid-out copy) is split into the shared workspace on every call.
@@ -228,17 +241,22 @@ def _conv_forward(x, weight, bias, stride, padding, dilation, relu, want_stats=F
             _C.call('evk_conv2d_split_weight', ctypes.byref(d), w_ptr, 0, planes.data_ptr(), st)
             pl_ptr = planes.data_ptr()
         sp = timing.span('conv_igemm', cs.flops, cs.abytes)
-        if want_stats and _BN_EPILOGUE and not relu and cout % 4 == 0:
+        stats = want_stats and _BN_EPILOGUE and not relu and cout % 4 == 0
+        parts, cap, nparts = None, 0, ctypes.c_int32(0)
+        if stats:
             cap = int(_C.load().evk_conv2d_stats_max_parts(ctypes.byref(d)))
             parts = torch.empty((cap * 3 * cout,), device=dev, dtype=torch.float32)
-            nparts = ctypes.c_int32(0)
+        if _CONV_MATH == 'bf16':
+            _C.call('evk_conv2d_fwd_bf16', ctypes.byref(d), x_ptr, pl_ptr, _ptr(bias), y.data_ptr(), 1 if relu else 0,
+                    _ptr(parts), cap, ctypes.byref(nparts), st)
+        elif stats:
             _C.call('evk_conv2d_fwd_x3_stats', ctypes.byref(d), x_ptr, pl_ptr, _ptr(bias), y.data_ptr(), 0,
                     parts.data_ptr(), cap, ctypes.byref(nparts), st)
-            if nparts.value > 0:
-                bn_parts = (parts, int(nparts.value))
         else:
             _C.call('evk_conv2d_fwd_x3', ctypes.byref(d), x_ptr, pl_ptr, _ptr(bias), y.data_ptr(),
                     1 if relu else 0, st)
+        if nparts.value > 0:
+            bn_parts = (parts, int(nparts.value))
     else:
         sp = timing.span('conv_igemm_f32', cs.flops, cs.abytes)
         _C.call('evk_conv2d_fwd', ctypes.byref(d), x_ptr, w_ptr, _ptr(bias), y.data_ptr(), 1 if relu else 0, st)
@@ -266,7 +284,7 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None):
         _C.call('evk_relu_bwd', dy.data_ptr(), cs.y.data_ptr(), g.data_ptr(), dy.numel(), st)
         dy = g
     rows_o = n * d.Ho * d.Wo
-    x3 = _CONV_MATH == 'bf16x3'
+    x3 = _planes_math()
     # narrow heads (classifier Cout = 1..7): pad dy / weight rows — to 8 output channels under the split arithmetic, so
     # that the data gradient stays on the split-MFMA kernels (its reduction is over taps x Cout), else to 4
     narrow8 = x3 and cin_p == cin and cout % 8 != 0 and cout < 8 and os.environ.get('EVK_NARROW_X3', '1') != '0'
@@ -299,7 +317,7 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None):
             acc_ptr = accum.data_ptr()
         dx = empty_nhwc(n, cin, d.H, d.W, dev)
         sp = timing.span('conv_igemm', cs.flops, cs.abytes, cs.scope)
-        _C.call('evk_conv2d_dgrad_x3', ctypes.byref(dk), dy_ptr, pl_ptr, acc_ptr, dx.data_ptr(), st)
+        _C.call(_entry('evk_conv2d_dgrad_x3'), ctypes.byref(dk), dy_ptr, pl_ptr, acc_ptr, dx.data_ptr(), st)
         if sp is not None:
             sp.stop()
     elif need_dx:
@@ -338,7 +356,7 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None):
         dwk = torch.empty((cout_p, taps, cin_p), device=dev, dtype=torch.float32)
         dbk = torch.empty((cout_p,), device=dev, dtype=torch.float32) if need_db else None
         sp = timing.span('conv_wgrad' if x3 else 'conv_wgrad_f32', cs.flops, cs.abytes, cs.scope)
-        _C.call('evk_conv2d_wgrad_x3' if x3 else 'evk_conv2d_wgrad', ctypes.byref(dk), xk.data_ptr(), dy_ptr,
+        _C.call(_entry('evk_conv2d_wgrad_x3') if x3 else 'evk_conv2d_wgrad', ctypes.byref(dk), xk.data_ptr(), dy_ptr,
                 dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes, st)
         if sp is not None:
             sp.stop()
@@ -558,7 +576,7 @@ class _ConvTranspose2dFn(Function):
         dev, st = x.device, _stream()
         w_ohwi = _weight_ohwi(weight.detach())      # [Cin_t][kh][kw][Cout_t]
         y = empty_nhwc(n, cout_t, ho, wo, dev)
-        x3 = _CONV_MATH == 'bf16x3' and cin_t % 8 == 0
+        x3 = _planes_math() and cin_t % 8 == 0
         flops = 2.0 * n * h * w * cin_t * cout_t * kh * kw
         sp = timing.span('conv_igemm' if x3 else 'conv_igemm_f32', flops, 4.0 * (x.numel() + y.numel() + weight.numel()))
         if x3:
@@ -587,7 +605,7 @@ class _ConvTranspose2dFn(Function):
         gy = as_nhwc(gy, 'conv_transpose2d.backward')
         w_ohwi = _weight_ohwi(weight.detach())
         cin_t, cout_t, kh, kw = weight.shape
-        x3m = _CONV_MATH == 'bf16x3'
+        x3m = _planes_math()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -655,7 +673,11 @@ class _StemConvFn(Function):
         flops = 2.0 * n * (h // 2) * (w // 2) * cout * c * 49     # algorithmic: the 7x7 taps, not the 4x4x16 padding
         nbytes = 4.0 * (x.numel() + y.numel() + weight.numel())
         sp = timing.span('conv_igemm', flops, nbytes)
-        _C.call('evk_conv2d_fwd_x3', ctypes.byref(d), xs.data_ptr(), planes.data_ptr(), None, y.data_ptr(), 0, st)
+        if _CONV_MATH == 'bf16':
+            _C.call('evk_conv2d_fwd_bf16', ctypes.byref(d), xs.data_ptr(), planes.data_ptr(), None, y.data_ptr(), 0, None, 0,
+                    ctypes.byref(ctypes.c_int32(0)), st)
+        else:
+            _C.call('evk_conv2d_fwd_x3', ctypes.byref(d), xs.data_ptr(), planes.data_ptr(), None, y.data_ptr(), 0, st)
         if sp is not None:
             sp.stop()
         ctx.desc, ctx.flops, ctx.nbytes, ctx.cin, ctx.scope = d, flops, nbytes, c, timing.current_scope()
@@ -675,8 +697,8 @@ class _StemConvFn(Function):
         ws = workspace(dev, ws_bytes)
         dw4 = torch.empty((d.Cout, 4, 4, 16), device=dev, dtype=torch.float32)
         sp = timing.span('conv_wgrad', ctx.flops, ctx.nbytes, ctx.scope)
-        _C.call('evk_conv2d_wgrad_x3', ctypes.byref(d), xs.data_ptr(), dy.data_ptr(), dw4.data_ptr(), None, ws.data_ptr(),
-                ws_bytes, st)
+        _C.call(_entry('evk_conv2d_wgrad_x3'), ctypes.byref(d), xs.data_ptr(), dy.data_ptr(), dw4.data_ptr(), None,
+                ws.data_ptr(), ws_bytes, st)
         if sp is not None:
             sp.stop()
         dw7 = torch.empty((d.Cout, 7, 7, c), device=dev, dtype=torch.float32)
@@ -687,7 +709,7 @@ class _StemConvFn(Function):
 def stem_conv_applicable(x, conv):
     """True when `conv` is the 7x7 / stride-2 / padding-3 stem on a <= 4-band image that needs no gradient, under the
     split arithmetic: the cases the space-to-depth form covers."""
-    return (_CONV_MATH == 'bf16x3' and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not x.requires_grad
+    return (_planes_math() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not x.requires_grad
             and tuple(conv.kernel_size) == (7, 7) and tuple(conv.stride) == (2, 2) and tuple(conv.padding) == (3, 3)
             and tuple(conv.dilation) == (1, 1) and conv.bias is None and conv.groups == 1 and x.shape[1] <= 4
             and conv.out_channels % 8 == 0 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0

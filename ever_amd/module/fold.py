@@ -146,7 +146,7 @@ def folded_conv2d(x, conv, residual=None, relu=False):
             raise ValueError('folded conv: residual shape mismatch')
         res_ptr = residual.data_ptr()
     flags = 1 if relu else 0
-    if HF.get_conv_math() == 'bf16x3' and f.cin_p == cin and cin % 8 == 0:
+    if HF.get_conv_math() in ('bf16x3', 'bf16') and f.cin_p == cin and cin % 8 == 0:
         # constant at inference: split once per input geometry (the plane layout follows the kernel the
         # descriptor selects)
         if f.planes is None or f.planes_key != (n, h, w):

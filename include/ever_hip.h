@@ -115,6 +115,18 @@ int32_t evk_conv2d_stats_max_parts(const evk_conv_desc* d);
 int evk_conv2d_fwd_x3_stats(const evk_conv_desc* d, const float* x, const void* wsplit, const float* bias,
                             float* y, uint32_t flags, float* bn_parts, int32_t bn_capacity, int32_t* nparts /* host */,
                             void* stream);
+/* The reference's optional `--mixed_precision bf16` (core/launcher.py:40-80: the model runs under torch.autocast):
+ * the same three convolution directions with PLAIN bf16 operands — activations and weights rounded to bf16 once, one
+ * v_mfma_f32_32x32x16_bf16 product per operand pair, fp32 accumulate, fp32 tensors in HBM.  Same arguments and the same
+ * weight-plane buffers as the x3 forms (only plane 0, the bf16 rounding of the weight, is read).  evk_conv2d_fwd_bf16
+ * also takes the statistics arguments of evk_conv2d_fwd_x3_stats (bn_parts may be NULL).  Accuracy is that of bf16
+ * inputs (relative 2^-9 per operand): never the default, never the headline benchmark. */
+int evk_conv2d_fwd_bf16(const evk_conv_desc* d, const float* x, const void* wsplit, const float* bias, float* y,
+                        uint32_t flags, float* bn_parts, int32_t bn_capacity, int32_t* nparts /* host */, void* stream);
+int evk_conv2d_dgrad_bf16(const evk_conv_desc* d, const float* dy, const void* wsplit_t, const float* accum, float* dx,
+                          void* stream);
+int evk_conv2d_wgrad_bf16(const evk_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                          void* workspace, size_t workspace_bytes, void* stream);
 /* y = act(conv(x, w) + bias + residual): inference form of a residual block's last convolution with its
  * BatchNorm folded into (w, bias) — `out += identity; relu` of reference _resnets.py:95-112 in the epilogue. */
 int evk_conv2d_fwd_res(const evk_conv_desc* d, const float* x, const float* w, const float* bias,

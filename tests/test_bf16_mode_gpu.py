@@ -1,0 +1,161 @@
+"""Row a9: the plain-bf16 convolution arithmetic (`--mixed_precision bf16`, reference core/launcher.py:40-80 runs the
+model under torch.autocast(bfloat16)).
+
+What is pinned: the kernels round each operand to bf16 ONCE (round-to-nearest-even), multiply exactly on the matrix pipe
+and accumulate in fp32.  So against an fp64 convolution of the SAME rounded operands the result may differ only by the
+fp32 accumulation order (tolerance 3e-5 of the result scale, K up to 4608 terms), and against the unrounded fp32
+reference it must sit at bf16 grade (2^-8 per operand, checked as < 2e-2 of the scale).  Tensors stay fp32; BatchNorm
+statistics, resampling and the losses are untouched by the mode.
+"""
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+ACC_TOL = 3e-5      # fp32 accumulation order, relative to the result's max magnitude
+BF16_GRADE = 2e-2   # distance allowed to the unrounded fp32 convolution
+
+
+def _rb(t):
+    """round to bf16 (RNE), back to fp64"""
+    return t.to(torch.bfloat16).double()
+
+
+def _rel(a, b):
+    a = a.detach().cpu().double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+CASES = [
+    # n, cin, h, w, cout, k, stride, pad, dil, bias
+    (2, 64, 16, 16, 256, 1, 1, 0, 1, True),      # 1x1
+    (2, 256, 16, 16, 128, 1, 2, 0, 1, False),    # 1x1 stride 2 (scatter data gradient)
+    (2, 128, 16, 16, 128, 3, 2, 1, 1, False),    # 3x3 stride 2 (residue classes)
+    (1, 64, 16, 16, 96, 3, 1, 2, 2, False),      # dilation 2
+    (3, 72, 11, 13, 40, 3, 1, 1, 1, True),       # K = 648: K padding
+    (2, 64, 128, 128, 64, 3, 1, 1, 1, True),     # LDS-halo 3x3 kernel
+    (2, 48, 128, 128, 160, 3, 1, 1, 1, False),   # LDS-halo kernel, ragged N tile
+    (2, 256, 64, 64, 256, 3, 1, 1, 1, False),    # wave-specialised forward / 128x256 weight gradient
+    (2, 512, 32, 32, 512, 3, 1, 1, 1, False),    # K = 4608
+    (8, 256, 32, 32, 1024, 1, 1, 0, 1, False),   # bottleneck expansion 1x1
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_conv_bf16_rounds_operands_once(cuda, case):
+    from ever_amd.hip import functional as F
+    n, cin, h, w, cout, k, s, p, d, bias = case
+    g = torch.Generator().manual_seed(4321 + cin + cout + k)
+    x = torch.randn(n, cin, h, w, generator=g) + 0.25
+    wt = (torch.randn(cout, cin, k, k, generator=g) + 0.05) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g) if bias else None
+    conv = lambda xx, ww: TF.conv2d(xx, ww, None, stride=s, padding=p, dilation=d)
+    y_shape = conv(x[:1].double(), wt.double()).shape
+    gy = torch.randn((n,) + tuple(y_shape[1:]), generator=g)
+
+    # oracle: fp64 on the rounded operands.  Each of the three products rounds ITS two operands:
+    # y = conv(bf(x), bf(w)); dx = conv^T(bf(dy), bf(w)); dw = corr(bf(x), bf(dy))
+    y_ref = conv(_rb(x), _rb(wt)) + (b.double().view(1, -1, 1, 1) if bias else 0.0)
+    xa = x.double().requires_grad_()
+    conv(xa, _rb(wt)).backward(_rb(gy))
+    wa = wt.double().requires_grad_()
+    conv(_rb(x), wa).backward(_rb(gy))
+    # yardstick: the unrounded fp64 convolution
+    x64, w64 = x.double().requires_grad_(), wt.double().requires_grad_()
+    y64 = conv(x64, w64) + (b.double().view(1, -1, 1, 1) if bias else 0.0)
+    y64.backward(gy.double())
+
+    prev = F.set_conv_math('bf16')
+    try:
+        xg = x.to(cuda).requires_grad_()
+        wg = wt.to(cuda).contiguous(memory_format=torch.channels_last).requires_grad_()
+        bg = b.to(cuda).requires_grad_() if bias else None
+        yg = F.conv2d(xg, wg, bg, stride=s, padding=p, dilation=d)
+        yg.backward(gy.to(cuda))
+        torch.cuda.synchronize()
+    finally:
+        F.set_conv_math(prev)
+    assert yg.dtype == torch.float32 and xg.grad.dtype == torch.float32
+    errs = {'y': _rel(yg, y_ref.detach()), 'dx': _rel(xg.grad, xa.grad), 'dw': _rel(wg.grad, wa.grad)}
+    grade = {'y': _rel(yg, y64.detach()), 'dx': _rel(xg.grad, x64.grad), 'dw': _rel(wg.grad, w64.grad)}
+    print('vs rounded-operand fp64:', errs, ' vs unrounded fp64:', grade)
+    for kk in errs:
+        assert errs[kk] < ACC_TOL, (kk, errs)
+        assert grade[kk] < BF16_GRADE, (kk, grade)
+    # the mode really is bf16: at least one product is visibly off the fp32 answer
+    assert max(grade.values()) > 1e-4, grade
+    if bias:    # bias gradient = fp32 column sum of the unrounded dy
+        assert _rel(bg.grad, gy.double().sum((0, 2, 3))) < 1e-5
+
+
+def test_bn_statistics_ride_the_bf16_forward(cuda):
+    """conv -> training BatchNorm: the epilogue statistics of the bf16 forward equal the statistics of its own output."""
+    from ever_amd.hip import functional as F
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(4, 64, 32, 32, generator=g) + 0.5).to(cuda)
+    wt = (torch.randn(256, 64, 1, 1, generator=g) / 8).to(cuda).contiguous(memory_format=torch.channels_last)
+    gamma, beta = torch.ones(256, device=cuda), torch.zeros(256, device=cuda)
+    rm, rv = torch.zeros(256, device=cuda), torch.ones(256, device=cuda)
+    prev = F.set_conv_math('bf16')
+    try:
+        y = F.conv2d(x, wt, None, bn_stats=True)
+        took = getattr(y, '_evk_bn_parts', None) is not None
+        z = F.batch_norm_act(y, gamma, beta, rm, rv, training=True, momentum=1.0, eps=1e-5)
+        torch.cuda.synchronize()
+    finally:
+        F.set_conv_math(prev)
+    assert took, 'the bf16 forward did not hand statistics to BatchNorm'
+    yc = y.detach().cpu().double()
+    assert _rel(rm, yc.mean((0, 2, 3))) < 1e-5
+    assert _rel(rv, yc.var((0, 2, 3), unbiased=True)) < 1e-5
+    zc = z.detach().cpu().double()
+    assert abs(zc.mean().item()) < 1e-5 and abs(zc.var(unbiased=False).item() - 1.0) < 1e-3
+
+
+def test_farseg_step_under_launcher_bf16(cuda, tmp_path):
+    """`Launcher(mixed_precision='bf16')` on a HIP model trains in the bf16 arithmetic: same loss as the fp32-grade step
+    to bf16 grade, gradients of the same size, and the same direction where the arithmetic allows a bound: the classifier
+    (one bf16 product from the loss).  Deeper layers are NOT bounded: a randomly initialised R50 with batch statistics on
+    noise images amplifies the 2^-8 operand rounding until the encoder gradients decorrelate (cosine ~0.05), and a CPU
+    emulation that rounds the operands of the reference's convolutions shows the same.  The arithmetic
+    itself is pinned per operator above."""
+    import ever_amd as er
+    from ever_amd.hip import functional as F
+    from ever_amd.core.launcher import Launcher
+
+    def build():
+        torch.manual_seed(5)
+        return er.module.FarSeg(dict(encoder=dict(resnet_type='resnet50'))).to(cuda).train()
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 3, 256, 256, generator=g).to(cuda)
+    y = (torch.rand(4, 256, 256, generator=g) < 0.3).long().to(cuda)
+    losses, flat = {}, {}
+    prev = F.get_conv_math()
+    try:
+        for mode in ('fp32', 'bf16'):
+            F.set_conv_math('bf16x3')
+            m = build()
+            opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9)
+            tl = Launcher(str(tmp_path / mode), m, opt, None, mixed_precision=mode)
+            assert tl.scaler is None and tl._amp is False
+            assert F.get_conv_math() == ('bf16' if mode == 'bf16' else 'bf16x3')
+            total = sum(m(x, y).values())
+            total.backward()
+            torch.cuda.synchronize()
+            gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)).item()
+            assert all(p.dtype == torch.float32 for p in m.parameters())
+            assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+            losses[mode] = (total.item(), gn)
+            flat[mode] = dict(m.named_parameters())['head.fpn_decoder.classifier.0.weight'].grad.double().flatten()
+    finally:
+        F.set_conv_math(prev)
+    cos = (torch.dot(flat['fp32'], flat['bf16']) / (flat['fp32'].norm() * flat['bf16'].norm())).item()
+    print('loss, grad norm:', losses, 'classifier gradient cosine:', cos)
+    l32, g32 = losses['fp32']
+    l16, g16 = losses['bf16']
+    assert l16 != l32, 'bf16 step is bit-identical to the fp32-grade step: the mode did not take effect'
+    assert abs(l16 - l32) <= 2e-2 * abs(l32), losses
+    assert cos > 0.999, (cos, losses)
+    assert 0.7 < g16 / g32 < 1.4, losses

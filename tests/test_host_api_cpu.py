@@ -255,16 +255,23 @@ def test_pending_log_total_is_the_sum_of_the_losses_only():
     assert out['n'] == 3
 
 
-def test_launcher_refuses_amp_flags_for_hip_models(tmp_path):
-    """a9: `--mixed_precision bf16|fp16` must not silently train in fp32 on the HIP path."""
+def test_launcher_amp_flags_for_hip_models(tmp_path):
+    """a9: `--mixed_precision` must not silently train in another arithmetic on the HIP path: bf16 selects the
+    plain-bf16 convolution kernels, fp16 (no kernel set) raises."""
     import torch
     import pytest
     import ever_amd as er
     from ever_amd.core.launcher import Launcher
+    from ever_amd.hip import functional as HF
     hip = torch.nn.Sequential(er.module.Conv2d(8, 8, 1))
-    for mp in ('bf16', 'fp16'):
-        with pytest.raises(NotImplementedError, match='mixed_precision'):
-            Launcher(str(tmp_path), hip, None, None, mixed_precision=mp)
+    with pytest.raises(NotImplementedError, match='mixed_precision'):
+        Launcher(str(tmp_path), hip, None, None, mixed_precision='fp16')
+    prev = HF.get_conv_math()
+    try:   # bf16 = the plain-bf16 convolution arithmetic, no autocast region, no GradScaler
+        lz = Launcher(str(tmp_path), hip, torch.optim.SGD(hip.parameters(), lr=0.1), None, mixed_precision='bf16')
+        assert HF.get_conv_math() == 'bf16' and lz._amp is False and lz.scaler is None
+    finally:
+        HF.set_conv_math(prev)
     stock = torch.nn.Sequential(torch.nn.Conv2d(8, 8, 1))       # stock torch models keep the reference's autocast
     Launcher(str(tmp_path), stock, torch.optim.SGD(stock.parameters(), lr=0.1), None, mixed_precision='bf16')
 
