@@ -429,6 +429,9 @@ BN_EPI_CASES = [
     (2, 32, 32, 64, 64, 1, 1, 0, False), (16, 64, 64, 128, 512, 1, 1, 0, False), (16, 32, 32, 256, 128, 1, 1, 0, True),
     (4, 64, 64, 64, 64, 3, 1, 1, False), (16, 32, 32, 128, 128, 3, 1, 1, False), (16, 64, 64, 256, 256, 3, 1, 1, False),
     (8, 64, 64, 128, 256, 3, 2, 1, False), (3, 17, 13, 32, 64, 1, 1, 0, False), (16, 128, 128, 64, 256, 1, 1, 0, False),
+    # the R18 / 64x64 plumbing configuration: a handful of row tiles, one row tile, strided, fewer rows than a tile
+    (2, 16, 16, 64, 64, 3, 1, 1, False), (2, 8, 8, 128, 128, 3, 1, 1, False), (2, 16, 16, 64, 128, 3, 2, 1, False),
+    (2, 16, 16, 64, 128, 1, 2, 0, False), (2, 6, 6, 64, 64, 3, 1, 1, False),
 ]
 
 
