@@ -222,6 +222,10 @@ def main():
                        else 'fp32 MFMA (exact fmaf chain)',
                        'whole_model_tflops': round(tiles_s * GF_FWD_BWD_PER_TILE / 1e3 / world, 2)},
         }
+        if use_ddp:
+            line['config']['gradient_exchange'] = ('FlatGradDDP: 64 MB buckets, one pack launch + one RCCL all-reduce per bucket'
+                                                   if args.ddp == 'flat' else 'torch DistributedDataParallel') + \
+                (' (world 1, forced by EVK_BENCH_FORCE_DDP)' if world == 1 else '')
         if timer is not None:
             fam = timer.summary()
             x3 = conv_math in ('bf16x3', 'bf16')
