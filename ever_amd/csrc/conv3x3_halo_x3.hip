@@ -17,6 +17,7 @@
 #include "igemm_common.hpp"
 #include "split_weight.hpp"
 #include <stdlib.h>
+#include <string.h>
 
 namespace evk {
 
@@ -292,6 +293,15 @@ static int launch_halo(IGemmArgs& a, hipStream_t stream) {
 
 int launch_conv3x3_halo(IGemmArgs& a, hipStream_t stream) {
   if (!conv3x3_halo_applies(a)) return 1;
+  static const bool tune = getenv("EVK_TUNE") != nullptr;
+  if (tune) {   // tools/autotune_convs.py
+    const char* f = getenv("EVK_X3_HALO_FORCE");
+    if (f && *f) {
+      if (!strcmp(f, "h64x8")) return launch_halo<64, 8>(a, stream);
+      if (!strcmp(f, "h128x8") && a.Cd > 64) return launch_halo<128, 8>(a, stream);
+      if (!strcmp(f, "h128x16") && a.Cd > 64 && (a.Hm % 16) == 0) return launch_halo<128, 16>(a, stream);
+    }
+  }
   if (a.Cd <= 64 || (long long)a.N * (a.Hm / 8) * (a.Wm / kPW) * ceil_div(a.Cd, 128) < 256)
     return launch_halo<64, 8>(a, stream);   // small maps (16^2 .. 32^2): 64-wide tiles keep every CU busy
   // 16 x 16 patches (256 GEMM rows) halve the weight bytes per MFMA, the larger share of the staging traffic now;

@@ -19,6 +19,7 @@
 #include "igemm_common.hpp"
 #include "split_weight.hpp"
 #include <stdlib.h>
+#include <string.h>
 
 namespace evk {
 
@@ -277,6 +278,19 @@ int launch_igemm_x3(IGemmArgs& a, hipStream_t stream) {
   if ((a.Cs & 7) != 0) {
     set_error("conv_igemm_x3: source channels (%d) must be a multiple of 8", a.Cs);
     return EVK_E_UNSUPPORTED;
+  }
+  static const bool tune = getenv("EVK_TUNE") != nullptr;
+  if (tune) {   // tools/autotune_convs.py: EVK_X3_FORCE names the tile shape (read on every launch)
+    const char* f = getenv("EVK_X3_FORCE");
+    if (f && *f) {
+      if (!strcmp(f, "w256")) return launch_igemm_x3ws_forced(a, 256, stream);
+      if (!strcmp(f, "w128")) return launch_igemm_x3ws_forced(a, 128, stream);
+      if (!strcmp(f, "w64")) return launch_igemm_x3ws_forced(a, 64, stream);
+      if (!strcmp(f, "c128x128")) return launch_cfg3<128, 128, 2, 2, 1>(a, stream);
+      if (!strcmp(f, "c64x128")) return launch_cfg3<64, 128, 2, 2, 1>(a, stream);
+      if (!strcmp(f, "c128x64")) return launch_cfg3<128, 64, 2, 2, 1>(a, stream);
+      if (!strcmp(f, "c64x64")) return launch_cfg3<64, 64, 2, 2, 1>(a, stream);
+    }
   }
   {
     const int rc = launch_igemm_x3dma(a, stream);  // LDS-DMA form for the one-tap (1x1) convolutions

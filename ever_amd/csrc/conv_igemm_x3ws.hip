@@ -318,6 +318,13 @@ static int launch_ws(IGemmArgs& a, hipStream_t stream) {
 }
 
 // returns 1 when this form does not apply (caller falls back to the single-role kernel)
+// tuning aid (EVK_TUNE=1, tools/autotune_convs.py): run the named tile shape whatever the heuristics below would pick
+int launch_igemm_x3ws_forced(IGemmArgs& a, int bn, hipStream_t stream) {
+  if (bn == 256) return launch_ws<128, 256, 2, 2, 2>(a, stream);
+  if (bn == 128) return launch_ws<128, 128, 2, 2, 2>(a, stream);
+  return launch_ws<128, 64, 2, 2, 2>(a, stream);
+}
+
 int launch_igemm_x3ws(IGemmArgs& a, hipStream_t stream) {
   // EVK_X3_WS: 0 never, 1 (default) where measured faster, 2 wherever the tile shapes allow
   static const int mode = getenv("EVK_X3_WS") ? atoi(getenv("EVK_X3_WS")) : 1;
@@ -325,7 +332,14 @@ int launch_igemm_x3ws(IGemmArgs& a, hipStream_t stream) {
   const int bn = (a.Cd <= 64) ? 64 : 128;
   const long long tn = ceil_div(a.Cd, bn);
   const long long t128 = (long long)ceil_div(a.M, 128) * tn;
-  if (t128 < 256) return 1;  // cannot fill the chip at one workgroup per CU
+  if (t128 < 256) {
+    // 16^2 maps with wide outputs and a long reduction (stage-4 layers: 512->512 3x3, 2048<->512 1x1; M = 4096 rows):
+    // 128 x 64 tiles still give every CU a workgroup, and the two-role form beats 64-row single-role tiles there
+    // (tools/autotune_convs.py, same process: 64-65 vs 71-83 us on the 1x1 layers, 138 vs 152 us on the strided 3x3)
+    if (mode >= 1 && a.Kpad >= 1024 && a.Cd >= 128 && (long long)ceil_div(a.M, 128) * ceil_div(a.Cd, 64) >= 256)
+      return launch_ws<128, 64, 2, 2, 2>(a, stream);
+    return 1;  // cannot fill the chip at one workgroup per CU
+  }
   // One 8-wave workgroup per CU: nothing overlaps a tile's prologue / epilogue, so short reductions
   // (1x1 convolutions, K <= 512: 2..16 steps) run better as 2-3 single-role workgroups per CU, unless the
   // grid is below two per CU anyway.  Measured on the FarSeg-R50 layer set (tools/bench_conv_x3.py).
@@ -334,6 +348,11 @@ int launch_igemm_x3ws(IGemmArgs& a, hipStream_t stream) {
   // An accumulate / residual epilogue (one more load per store, in the matrix waves) turns the gain into a loss:
   // folded-BatchNorm inference 1370 -> 1325 tiles/s.
   if (mode == 1 && a.Kpad < 1024 && t128 >= 512 && (!ws_persist() || a.Cd < 128 || a.accum)) return 1;
+  // with the statistics epilogue the workgroups are not persistent: on the 128^2 maps (>= 2048 tiles, K <= 256) the
+  // single-role kernel is ahead again (64->256: 129 -> 117 us, 256->128: 158 -> 140), on the smaller maps it is not
+  if (mode == 1 && a.bn_want && a.Kpad < 1024 &&
+      (long long)ceil_div(a.M, 128) * ceil_div(a.Cd, a.Cd >= 256 ? 256 : 128) >= 2048)
+    return 1;
   // 128x256 tiles where the output is wide enough: the activation split (VALU) and the L2 -> CU bytes per MFMA
   // drop by half / a fifth
   static const int wide = getenv("EVK_X3_WIDE") ? atoi(getenv("EVK_X3_WIDE")) : 1;

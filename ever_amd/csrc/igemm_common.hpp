@@ -261,6 +261,7 @@ inline void bn_stats_setup(IGemmArgs& a, int BM, int BN, int WAVES_M, long long 
 int launch_igemm(IGemmArgs& a, hipStream_t stream);
 int launch_igemm_x3(IGemmArgs& a, hipStream_t stream);
 int launch_igemm_x3ws(IGemmArgs& a, hipStream_t stream);  // 1 = not applicable
+int launch_igemm_x3ws_forced(IGemmArgs& a, int bn, hipStream_t stream);
 int launch_igemm_x3dma(IGemmArgs& a, hipStream_t stream);  // 1 = not applicable
 int launch_conv3x3_halo(IGemmArgs& a, hipStream_t stream);  // 1 = not applicable
 bool conv_desc_uses_halo(const evk_conv_desc* d, int for_dgrad);
