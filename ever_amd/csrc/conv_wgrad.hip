@@ -271,7 +271,11 @@ WGradPlan plan_wgrad(const evk_conv_desc* d, int x3) {
   pl.bm = d->Cout <= 64 ? 64 : 128;
   pl.bn = Ktot <= 64 ? 64 : 128;
   // wide wave-specialised tile (128 x 256, one 8-wave workgroup per CU) when both dimensions are there
-  static const int ws_mode = getenv("EVK_WG_WS") ? atoi(getenv("EVK_WG_WS")) : 1;
+  // (under EVK_TUNE=1 the three knobs are re-read on every call: tools/autotune_wgrad.py)
+  static const bool tune = getenv("EVK_TUNE") != nullptr;
+  auto knob = [&](const char* name, int cached) { const char* v = tune ? getenv(name) : nullptr; return (v && *v) ? atoi(v) : cached; };
+  static const int ws_mode0 = getenv("EVK_WG_WS") ? atoi(getenv("EVK_WG_WS")) : 1;
+  const int ws_mode = knob("EVK_WG_WS", ws_mode0);
   // (its gathers are raw buffer loads: 32-bit byte offsets, so both tensors must stay below 2 GiB)
   const bool fits32 = (long long)d->N * d->H * d->W * d->Cin * 4 < 0x7fffffffLL &&
                       (long long)d->N * d->Ho * d->Wo * d->Cout * 4 < 0x7fffffffLL;
@@ -283,8 +287,9 @@ WGradPlan plan_wgrad(const evk_conv_desc* d, int x3) {
   // Split the pixel reduction so that the grid fills WHOLE rounds of the machine: slots = 256 CUs x
   // resident workgroups per CU (LDS-limited: 64 KB tiles -> 2, 48 KB -> 3, 32 KB -> 4).  A grid of
   // 2.04 rounds costs 3 (measured: 1044 workgroups on 512 slots ran at 63 % MFMA utilisation).
-  static const int rounds = getenv("EVK_WG_ROUNDS") ? atoi(getenv("EVK_WG_ROUNDS")) : 1;
-  static const int min_chunk = getenv("EVK_WG_MINCHUNK") ? atoi(getenv("EVK_WG_MINCHUNK")) : 256;
+  static const int rounds0 = getenv("EVK_WG_ROUNDS") ? atoi(getenv("EVK_WG_ROUNDS")) : 1;
+  static const int min_chunk0 = getenv("EVK_WG_MINCHUNK") ? atoi(getenv("EVK_WG_MINCHUNK")) : 256;
+  const int rounds = knob("EVK_WG_ROUNDS", rounds0), min_chunk = knob("EVK_WG_MINCHUNK", min_chunk0);
   const int lds_kb = 2 * BKP * (pl.bm + pl.bn) * 4 / 1024;
   // split kernel: single-buffered 3-plane bf16 stage (48 KB at 128x128), residency set by its VGPRs
   const int per_cu = pl.ws ? 1 : x3 ? (pl.bm + pl.bn >= 256 ? 3 : 4)
