@@ -50,8 +50,9 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--ddp', choices=['flat', 'torch'], default='flat',
                    help='gradient exchange under --gpus N>1: ever_amd FlatGradDDP (default) or torch DistributedDataParallel')
-    p.add_argument('--conv-math', choices=['bf16x3', 'f32', 'bf16'], default=None,
-                   help='convolution arithmetic (default: ever_amd default = bf16x3 split MFMA, fp32 grade; f32 = exact fp32 '
+    p.add_argument('--conv-math', choices=['f16x2', 'bf16x3', 'f32', 'bf16'], default=None,
+                   help='convolution arithmetic (default: ever_amd default = f16x2, 2-term fp16 split with per-tensor scale, 3 '
+                        'MFMA products, fp32 grade; bf16x3 = 3-term bf16 split, 6 products, fp32 grade; f32 = exact fp32 '
                         'MFMA; bf16 = plain bf16 operands, the --mixed_precision bf16 mode: NOT the headline configuration)')
     p.add_argument('--no-kernel-timer', action='store_true')
     return p.parse_args()
@@ -215,8 +216,12 @@ def main():
                                    f'batch {args.batch}/GPU, fwd+bwd+SGD step, inputs resident in HBM',
                        'global_batch': world * args.batch, 'tile': [BANDS, TILE, TILE],
                        'parallelism': f'dp{world}' if world > 1 else 'single',
-                       'arithmetic': ('fp32 in / fp32 accumulate / fp32 out; conv products from an exact 3-term bf16 split, '
-                                      '6 bf16-MFMA partial products each (error < 2^-24 per product)') if conv_math == 'bf16x3'
+                       'arithmetic': ('fp32 in / fp32 accumulate / fp32 out; conv operands divided by a per-tensor power of two '
+                                      'and split into 2 fp16 terms (22-bit operands), 3 fp16-MFMA partial products each '
+                                      '(error < 2^-21 per product; as accurate vs fp64 as the 6-product bf16 split on every '
+                                      'layer shape, tools/check_f16x2.py)') if conv_math == 'f16x2'
+                       else ('fp32 in / fp32 accumulate / fp32 out; conv products from an exact 3-term bf16 split, '
+                             '6 bf16-MFMA partial products each (error < 2^-24 per product)') if conv_math == 'bf16x3'
                        else ('fp32 tensors; conv operands rounded to bf16 once, 1 bf16-MFMA product, fp32 accumulate '
                              '(--mixed_precision bf16; BatchNorm, resampling, losses fp32)') if conv_math == 'bf16'
                        else 'fp32 MFMA (exact fmaf chain)',
@@ -228,18 +233,18 @@ def main():
                 (' (world 1, forced by EVK_BENCH_FORCE_DDP)' if world == 1 else '')
         if timer is not None:
             fam = timer.summary()
-            x3 = conv_math in ('bf16x3', 'bf16')
-            passes = X3_PASSES if conv_math == 'bf16x3' else 1
+            x3 = conv_math in ('f16x2', 'bf16x3', 'bf16')
+            passes = {'f16x2': 3, 'bf16x3': X3_PASSES, 'bf16': 1}.get(conv_math, 1)
             # split kernels: every algorithmic fp32 FLOP costs X3_PASSES bf16 MFMA FLOPs, so the roofline for
             # algorithmic FLOP/s is the dense bf16 MFMA peak / X3_PASSES
             peak = PEAK_BF16_MFMA_TFLOPS / passes if x3 else PEAK_FP32_MFMA_TFLOPS
-            peak_note = (f'dense bf16 MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} TF / {passes} partial product(s) per product'
+            peak_note = (f'dense bf16/fp16 MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} TF / {passes} partial product(s) per product'
                          if x3 else 'dense f32-input MFMA peak (v_mfma_f32_32x32x2_f32)')
             ig = fam.get('conv_igemm' if x3 else 'conv_igemm_f32')
             if ig:
                 ach = ig['flops'] / ig['seconds'] / 1e12
                 # the committed PMC passes were collected under the default arithmetic
-                traffic, traffic_file = pmc_traffic('conv_igemm') if conv_math == 'bf16x3' else (None, None)
+                traffic, traffic_file = pmc_traffic('conv_igemm') if conv_math == 'f16x2' else (None, None)
                 line['roofline'] = {
                     'bound': 'mfma',
                     'kernel': ('evk::conv3x3_halo_x3_kernel / conv_igemm_x3ws_kernel / conv_igemm_x3_kernel' if x3
@@ -254,7 +259,7 @@ def main():
             wg = fam.get('conv_wgrad' if x3 else 'conv_wgrad_f32')
             if wg:
                 ach = wg['flops'] / wg['seconds'] / 1e12
-                wtraffic, _ = pmc_traffic('conv_wgrad') if conv_math == 'bf16x3' else (None, None)
+                wtraffic, _ = pmc_traffic('conv_wgrad') if conv_math == 'f16x2' else (None, None)
                 line['roofline_wgrad'] = {'bound': 'mfma',
                                           'kernel': ('evk::conv_wgrad_x3ws_kernel / conv_wgrad_x3_kernel' if x3 else
                                                      'evk::conv_wgrad_kernel') + ' (+split-K reduce)',

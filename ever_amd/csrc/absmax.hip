@@ -1,0 +1,111 @@
+// max |x| of a tensor as the bit image of a non-negative float (unsigned order = float order), left in device memory:
+// the per-tensor operand scale of the f16x2 convolution arithmetic (x3_common.hpp: op_scale).  No reference call site —
+// operand preparation of this engine's arithmetic, like the weight planes.  HBM-bound: one read pass.
+//   evk_absmax        one tensor; partial maxima per workgroup, folded by the LAST-ARRIVING workgroup (no second launch,
+//                     no pre-zeroed output; the caller's workspace holds the partials and a ticket counter that must be
+//                     zero before the first call and is left zero by every call — calls on ONE stream only)
+//   evk_absmax_multi  n tensors in one launch (the convolution weights, once per optimiser step): atomic max into a
+//                     zeroed output array
+#include "common.hpp"
+
+namespace evk {
+
+constexpr int kAbsBlocks = 1024;
+
+__device__ __forceinline__ uint32_t abs_bits(float v) { return __builtin_bit_cast(uint32_t, v) & 0x7fffffffu; }
+__device__ __forceinline__ uint32_t max4(uint32_t m, const f32x4 v) {
+  m = max(m, abs_bits(v.x)); m = max(m, abs_bits(v.y));
+  m = max(m, abs_bits(v.z)); m = max(m, abs_bits(v.w));
+  return m;
+}
+__device__ __forceinline__ uint32_t block_max(uint32_t m) {
+  __shared__ uint32_t red[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  return max(max(red[0], red[1]), max(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n, size_t span4,
+                                                     uint32_t* __restrict__ out, uint32_t* __restrict__ ws) {
+  const size_t n4 = n >> 2;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  const size_t b0 = (size_t)blockIdx.x * span4, b1 = min(n4, b0 + span4);
+  uint32_t m = 0;
+  size_t i = b0 + threadIdx.x;
+  for (; i + 768 < b1; i += 1024) {   // four independent 16-byte loads in flight per lane
+    const f32x4 v0 = x4[i], v1 = x4[i + 256], v2 = x4[i + 512], v3 = x4[i + 768];
+    m = max4(max4(max4(max4(m, v0), v1), v2), v3);
+  }
+  for (; i < b1; i += 256) m = max4(m, x4[i]);
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = max(m, abs_bits(x[(n4 << 2) + threadIdx.x]));
+  m = block_max(m);
+  __shared__ bool last;
+  if (threadIdx.x == 0) {
+    ws[blockIdx.x] = m;
+    __threadfence();
+    last = atomicAdd(&ws[kAbsBlocks], 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  uint32_t t = 0;
+  for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) t = max(t, __builtin_nontemporal_load(ws + b));
+  __syncthreads();   // block_max's shared array is reused
+  t = block_max(t);
+  if (threadIdx.x == 0) {
+    out[0] = t;
+    ws[kAbsBlocks] = 0;   // ready for the next call on this stream
+  }
+}
+
+__global__ __launch_bounds__(256) void absmax_multi_kernel(const float* const* __restrict__ ptrs,
+                                                           const int64_t* __restrict__ sizes, uint32_t* __restrict__ out) {
+  const int t = blockIdx.y;
+  const float* x = ptrs[t];
+  const size_t n = (size_t)sizes[t];
+  uint32_t m = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = max(m, abs_bits(x[i]));
+  m = block_max(m);
+  if (threadIdx.x == 0 && m) atomicMax(out + t, m);
+}
+
+}  // namespace evk
+
+using namespace evk;
+
+extern "C" size_t evk_absmax_workspace_bytes(void) { return (size_t)(kAbsBlocks + 1) * sizeof(uint32_t); }
+
+extern "C" int evk_absmax(const float* x, int64_t n, uint32_t* out_bits, void* workspace, void* stream) {
+  EVK_REQUIRE(x && out_bits && workspace && n > 0, EVK_E_INVALID, "absmax: bad argument");
+  if (((uintptr_t)x & 15) != 0) {   // (every tensor the path produces is 16-byte aligned; odd views are refused)
+    set_error("absmax: tensor must be 16-byte aligned");
+    return EVK_E_INVALID;
+  }
+  const size_t n4 = (size_t)n >> 2;
+  size_t blocks = (n4 + 4095) / 4096;            // >= 16 float4 per thread
+  if (blocks > (size_t)kAbsBlocks) blocks = kAbsBlocks;
+  if (blocks < 1) blocks = 1;
+  size_t span4 = (n4 + blocks - 1) / blocks;
+  span4 = (span4 + 255) & ~(size_t)255;
+  blocks = n4 ? (n4 + span4 - 1) / span4 : 1;
+  if (span4 == 0) span4 = 256;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, span4, out_bits,
+                     (uint32_t*)workspace);
+  return check_launch("absmax");
+}
+
+extern "C" int evk_absmax_multi(const float* const* ptrs_dev, const int64_t* sizes_dev, int32_t n_tensors,
+                                uint32_t* out_bits, void* stream) {
+  EVK_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || (ptrs_dev && sizes_dev && out_bits)), EVK_E_INVALID,
+              "absmax_multi: bad argument");
+  if (n_tensors == 0) return EVK_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(out_bits, 0, (size_t)n_tensors * sizeof(uint32_t), st) != hipSuccess) {
+    set_error("absmax_multi: memset failed");
+    return EVK_E_LAUNCH;
+  }
+  hipLaunchKernelGGL(absmax_multi_kernel, dim3(16, (unsigned)n_tensors), dim3(256), 0, st, ptrs_dev, sizes_dev, out_bits);
+  return check_launch("absmax_multi");
+}

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
       const int e = b_has[i] ? e0 : 0;
       const int half = e & 1, row = (e >> 1) % BN, rest = e / (2 * BN);  // rest = jx * 3 + pt
       const int pt = rest % 3, jx = rest / 3;
-      b_has[i] = b_has[i] && (NP == 3 || pt == 0);   // plain bf16: only the h plane of the weights is staged
+      b_has[i] = b_has[i] && pt < NP;   // plain bf16 / f16x2: only the h / the h and l planes of the weights are staged
       int co = n0 + row;
       co = co < p.Cd ? co : p.Cd - 1;
       b_src[i] = (int)(pt * plane_stride + (size_t)jx * tap_stride + (size_t)co * kCh + half * 8);
@@ -99,6 +99,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
     }
     f32x4 ra[AI];
     u32x4 rbv[BI];
+    float a_inv = 1.f;   // f16x2: 1 / activation scale
+    if constexpr (NP == 2) a_inv = op_scale(*p.a_scale).inv;
     auto load_a = [&](int c) {
 #pragma unroll
       for (int i = 0; i < AI; ++i) ra[i] = *reinterpret_cast<const f32x4*>(p.src + a_src[i] + (a_ok[i] ? c * kCh : 0));
@@ -110,17 +112,12 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
         if (!a_has[i]) continue;
         const f32x4 v = ra[i];
         const bool ok = a_ok[i];
-        if (NP == 3) {
-          uint32_t h0, m0, l0, h1, m1, l1;
-          split2(ok ? v.x : 0.f, ok ? v.y : 0.f, h0, m0, l0);
-          split2(ok ? v.z : 0.f, ok ? v.w : 0.f, h1, m1, l1);
-          *reinterpret_cast<uint2*>(A + a_lds[i]) = make_uint2(h0, h1);
-          *reinterpret_cast<uint2*>(A + kHSlots * kRB + a_lds[i]) = make_uint2(m0, m1);
-          *reinterpret_cast<uint2*>(A + 2 * kHSlots * kRB + a_lds[i]) = make_uint2(l0, l1);
-        } else {
-          *reinterpret_cast<uint2*>(A + a_lds[i]) =
-              make_uint2(cvt2(ok ? v.x : 0.f, ok ? v.y : 0.f), cvt2(ok ? v.z : 0.f, ok ? v.w : 0.f));
-        }
+        uint32_t h0, m0 = 0, l0 = 0, h1, m1 = 0, l1 = 0;
+        split_np<NP>(ok ? v.x : 0.f, ok ? v.y : 0.f, a_inv, h0, m0, l0);
+        split_np<NP>(ok ? v.z : 0.f, ok ? v.w : 0.f, a_inv, h1, m1, l1);
+        *reinterpret_cast<uint2*>(A + a_lds[i]) = make_uint2(h0, h1);
+        if (NP >= 2) *reinterpret_cast<uint2*>(A + kHSlots * kRB + a_lds[i]) = make_uint2(m0, m1);
+        if (NP == 3) *reinterpret_cast<uint2*>(A + 2 * kHSlots * kRB + a_lds[i]) = make_uint2(l0, l1);
       }
     };
     // iteration it = 3*c + jy reads taps (jy, 0..2) of chunk c
@@ -209,11 +206,12 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
         for (int a = 0; a < MB; ++a)
 #pragma unroll
           for (int b = 0; b < NB; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fbv[b][x3_pb(NP, t6)], fa[a][x3_pa(NP, t6)], acc[a][b], 0, 0, 0);
+            acc[a][b] = mfma_np<NP>(fbv[b][x3_pb(NP, t6)], fa[a][x3_pa(NP, t6)], acc[a][b]);
     }
     __syncthreads();
   }
 
+  if constexpr (NP == 2) igemm_scale_acc<MB, NB>(acc, op_scale(*p.a_scale).s * op_scale(*p.w_scale).s);
   if (p.bn_part) {
     // BatchNorm statistics of the output from the epilogue: the loop ended on a barrier of all eight waves and the
     // staging waves have nothing left to write, so the LDS is free to park the tile (igemm_common.hpp)
@@ -288,7 +286,9 @@ static int launch_halo_np(IGemmArgs& a, hipStream_t stream) {
 
 template <int BN, int PH>
 static int launch_halo(IGemmArgs& a, hipStream_t stream) {
-  return a.planes == 1 ? launch_halo_np<BN, PH, 1>(a, stream) : launch_halo_np<BN, PH, 3>(a, stream);
+  if (a.planes == 1) return launch_halo_np<BN, PH, 1>(a, stream);
+  if (a.planes == 2) return launch_halo_np<BN, PH, 2>(a, stream);
+  return launch_halo_np<BN, PH, 3>(a, stream);
 }
 
 int launch_conv3x3_halo(IGemmArgs& a, hipStream_t stream) {
@@ -316,17 +316,18 @@ int launch_conv3x3_halo(IGemmArgs& a, hipStream_t stream) {
 // order, which is (ky, kx) for the forward and for the stride-1 data gradient alike (the sign of oys flips the
 // direction, not the index).  rows = Cout (forward: w[row][ky][kx][ci]) or Cin (data gradient: w[co][ky][kx][row]).
 __global__ void split_weight_halo_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int Cout, int Cin,
-                                         int for_dgrad) {
+                                         int for_dgrad, const uint32_t* __restrict__ wscale) {
   static_assert(kHaloCh == kCh, "split_weight.hpp chunk width");
   split_halo_body(w, out, Cout, Cin, for_dgrad, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
-                  (size_t)gridDim.x * blockDim.x);
+                  (size_t)gridDim.x * blockDim.x, wscale);
 }
 
-int launch_split_weight_halo(const float* w, uint16_t* out, int Cout, int Cin, int for_dgrad, hipStream_t st) {
+int launch_split_weight_halo(const float* w, uint16_t* out, int Cout, int Cin, int for_dgrad, hipStream_t st,
+                             const uint32_t* wscale) {
   const int rows = for_dgrad ? Cin : Cout, K = for_dgrad ? Cout : Cin;
   const size_t total = (size_t)9 * (K / kCh) * rows * (kCh / 2);
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  hipLaunchKernelGGL(split_weight_halo_kernel, dim3(blocks), dim3(256), 0, st, w, out, Cout, Cin, for_dgrad);
+  hipLaunchKernelGGL(split_weight_halo_kernel, dim3(blocks), dim3(256), 0, st, w, out, Cout, Cin, for_dgrad, wscale);
   return check_launch("split_weight_halo");
 }
 

@@ -348,7 +348,8 @@ static inline int kpad32(int k) { return (k + 31) & ~31; }
 // w3 != nullptr selects the bf16-split kernel (conv_igemm_x3.hip) on pre-split weight planes
 static int conv_fwd_any(const evk_conv_desc* d, const float* x, const float* w, const uint16_t* w3, const float* bias,
                         float* y, uint32_t flags, void* stream, const float* residual = nullptr,
-                        float* bn_parts = nullptr, int32_t bn_cap = 0, int32_t* nparts = nullptr, int planes = 3) {
+                        float* bn_parts = nullptr, int32_t bn_cap = 0, int32_t* nparts = nullptr, int planes = 3,
+                        const uint32_t* a_scale = nullptr, const uint32_t* w_scale = nullptr) {
   int rc = check_desc(d);
   if (rc) return rc;
   EVK_REQUIRE(x && (w || w3) && y, EVK_E_INVALID, "conv2d_fwd: null pointer");
@@ -366,6 +367,7 @@ static int conv_fwd_any(const evk_conv_desc* d, const float* x, const float* w, 
   a.relu = (flags & EVK_CONV_RELU) ? 1 : 0;
   a.Kpad = kpad32(a.Ktot);
   a.planes = planes;
+  a.a_scale = a_scale; a.w_scale = w_scale;
   a.bn_want = (bn_parts && w3 && d->Cout % 4 == 0) ? 1 : 0;
   a.bn_buf = bn_parts;
   a.bn_cap = bn_cap;
@@ -415,6 +417,18 @@ extern "C" int evk_conv2d_fwd_bf16(const evk_conv_desc* d, const float* x, const
                       bn_capacity, nparts, 1);
 }
 
+// 2-term fp16 split of operands scaled by a power of two (x3_common.hpp: NP = 2): three MFMA products per operand
+// pair, 22-bit operands, fp32 accumulate — fp32-grade at half the matrix work of the x3 forms.  x_absmax / w_absmax:
+// device words holding the bit image of max|x| (evk_absmax) and of max|w| (what the planes were produced with:
+// evk_conv2d_split_weight_f16x2 / evk_conv2d_split_multi_f16x2).  residual, bn_parts, nparts may be null.
+extern "C" int evk_conv2d_fwd_f16x2(const evk_conv_desc* d, const float* x, const uint32_t* x_absmax, const void* wsplit,
+                                    const uint32_t* w_absmax, const float* bias, const float* residual, float* y,
+                                    uint32_t flags, float* bn_parts, int32_t bn_capacity, int32_t* nparts, void* stream) {
+  EVK_REQUIRE(wsplit && x_absmax && w_absmax, EVK_E_INVALID, "conv2d_fwd_f16x2: null weight planes / scales");
+  return conv_fwd_any(d, x, nullptr, reinterpret_cast<const uint16_t*>(wsplit), bias, y, flags, stream, residual, bn_parts,
+                      bn_capacity, nparts, 2, x_absmax, w_absmax);
+}
+
 // y = act(conv(x, w) + bias + residual): the inference form of a ResNet block's last convolution once its
 // BatchNorm is folded into (w, bias) — reference _resnets.py:95-112 (`out += identity; relu`)
 extern "C" int evk_conv2d_fwd_res(const evk_conv_desc* d, const float* x, const float* w, const float* bias,
@@ -428,7 +442,8 @@ extern "C" int evk_conv2d_fwd_x3_res(const evk_conv_desc* d, const float* x, con
 }
 
 static int conv_dgrad_any(const evk_conv_desc* d, const float* dy, const float* wt, const uint16_t* wt3,
-                          const float* accum, float* dx, void* stream, int planes = 3) {
+                          const float* accum, float* dx, void* stream, int planes = 3,
+                          const uint32_t* a_scale = nullptr, const uint32_t* w_scale = nullptr) {
   int rc = check_desc(d);
   if (rc) return rc;
   EVK_REQUIRE(dy && (wt || wt3) && dx, EVK_E_INVALID, "conv2d_dgrad: null pointer");
@@ -457,6 +472,7 @@ static int conv_dgrad_any(const evk_conv_desc* d, const float* dy, const float* 
       if (py.nt > 0 && px.nt > 0 && Hm > 0 && Wm > 0) {
         IGemmArgs a{};
         a.planes = planes;
+        a.a_scale = a_scale; a.w_scale = w_scale;
         a.src = dy; a.wgt = wt ? wt + woff : nullptr; a.wgt3 = wt3 ? wt3 + woff3 : nullptr;
         a.bias = nullptr; a.accum = accum; a.dst = dx;
         a.N = d->N; a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Cout;
@@ -489,6 +505,14 @@ extern "C" int evk_conv2d_dgrad_bf16(const evk_conv_desc* d, const float* dy, co
                                      float* dx, void* stream) {
   EVK_REQUIRE(wsplit_t, EVK_E_INVALID, "conv2d_dgrad_bf16: null weight planes");
   return conv_dgrad_any(d, dy, nullptr, reinterpret_cast<const uint16_t*>(wsplit_t), accum, dx, stream, 1);
+}
+
+extern "C" int evk_conv2d_dgrad_f16x2(const evk_conv_desc* d, const float* dy, const uint32_t* dy_absmax,
+                                      const void* wsplit_t, const uint32_t* w_absmax, const float* accum, float* dx,
+                                      void* stream) {
+  EVK_REQUIRE(wsplit_t && dy_absmax && w_absmax, EVK_E_INVALID, "conv2d_dgrad_f16x2: null weight planes / scales");
+  return conv_dgrad_any(d, dy, nullptr, reinterpret_cast<const uint16_t*>(wsplit_t), accum, dx, stream, 2, dy_absmax,
+                        w_absmax);
 }
 
 extern "C" int evk_conv2d_dgrad_x3(const evk_conv_desc* d, const float* dy, const void* wsplit_t, const float* accum,

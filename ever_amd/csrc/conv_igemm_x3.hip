@@ -83,6 +83,12 @@ __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(const IGemmArgs p) {
   f32x4 ra[AR][2];
   u32x4 rbv[BR][3];
   uint32_t okmask = 0;
+  float a_inv = 1.f, out_scale = 1.f;   // f16x2: 1 / activation scale; activation scale x weight scale
+  if constexpr (NP == 2) {
+    const OpScale sa = op_scale(*p.a_scale), sw = op_scale(*p.w_scale);
+    a_inv = sa.inv;
+    out_scale = sa.s * sw.s;
+  }
 
   auto load_tiles = [&](int kt) {
     okmask = 0;
@@ -133,19 +139,13 @@ __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(const IGemmArgs p) {
       for (int e = 0; e < 4; ++e) {
         const f32x4 v = ra[j][e >> 1];
         const float x0 = ok ? v[2 * (e & 1)] : 0.f, x1 = ok ? v[2 * (e & 1) + 1] : 0.f;
-        if (NP == 3) {
-          uint32_t h, m, l;
-          split2(x0, x1, h, m, l);
-          H[e] = h; M[e] = m; L[e] = l;
-        } else {
-          H[e] = cvt2(x0, x1);
-        }
+        uint32_t h, m = 0, l = 0;
+        split_np<NP>(x0, x1, a_inv, h, m, l);
+        H[e] = h; M[e] = m; L[e] = l;
       }
       *reinterpret_cast<u32x4*>(Ab + off) = H;
-      if (NP == 3) {
-        *reinterpret_cast<u32x4*>(Ab + BM * kRowBytes + off) = M;
-        *reinterpret_cast<u32x4*>(Ab + 2 * BM * kRowBytes + off) = L;
-      }
+      if (NP >= 2) *reinterpret_cast<u32x4*>(Ab + BM * kRowBytes + off) = M;
+      if (NP == 3) *reinterpret_cast<u32x4*>(Ab + 2 * BM * kRowBytes + off) = L;
     }
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
@@ -189,10 +189,6 @@ __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(const IGemmArgs p) {
     for (int kk = 0; kk < 2; ++kk) fb_off[b][kk] = row * kRowBytes + (((2 * kk + lh) ^ ((row >> 2) & 3)) << 4);
   }
 
-  // the six retained partial products, smallest magnitude first: (A part, B part); 0 = h, 1 = m, 2 = l
-  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
-
   auto half_step = [&](const unsigned char* Ab, const unsigned char* Bb, int kk, int first, int last) {
     bf16x8 fa[MB][3], fb[NB][3];
 #pragma unroll
@@ -206,12 +202,12 @@ __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(const IGemmArgs p) {
       for (int pt = 0; pt < NP; ++pt)
         fb[b][pt] = *reinterpret_cast<const bf16x8*>(Bb + pt * BN * kRowBytes + fb_off[b][kk]);
 #pragma unroll
-    for (int t = first; t < (NP == 3 ? last : 1); ++t)
+    for (int t = first; t < (last < X3Prod<NP>::N ? last : X3Prod<NP>::N); ++t)
 #pragma unroll
       for (int a = 0; a < MB; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b][NP == 3 ? PB[t] : 0], fa[a][NP == 3 ? PA[t] : 0], acc[a][b], 0, 0, 0);
+          acc[a][b] = mfma_np<NP>(fb[b][x3_pb(NP, t)], fa[a][x3_pa(NP, t)], acc[a][b]);
   };
 
   for (int kt = 0; kt < nk; ++kt) {
@@ -230,6 +226,7 @@ __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(const IGemmArgs p) {
     }
   }
 
+  if constexpr (NP == 2) igemm_scale_acc<MB, NB>(acc, out_scale);
   if (p.bn_part) {
     // every wave is done with the last stage (the loop ends on a barrier): the ring becomes epilogue scratch
     igemm_epilogue_stats<MB, NB, WM, WN, WAVES_M, WAVES_N>(p, acc, m0, n0, wm, wn, li, lh, reinterpret_cast<float*>(smem3));
@@ -264,8 +261,9 @@ static int launch_cfg3_np(IGemmArgs& a, hipStream_t stream) {
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NBUF>
 static int launch_cfg3(IGemmArgs& a, hipStream_t stream) {
-  return a.planes == 1 ? launch_cfg3_np<BM, BN, WAVES_M, WAVES_N, NBUF, 1>(a, stream)
-                       : launch_cfg3_np<BM, BN, WAVES_M, WAVES_N, NBUF, 3>(a, stream);
+  if (a.planes == 1) return launch_cfg3_np<BM, BN, WAVES_M, WAVES_N, NBUF, 1>(a, stream);
+  if (a.planes == 2) return launch_cfg3_np<BM, BN, WAVES_M, WAVES_N, NBUF, 2>(a, stream);
+  return launch_cfg3_np<BM, BN, WAVES_M, WAVES_N, NBUF, 3>(a, stream);
 }
 
 int launch_igemm_x3(IGemmArgs& a, hipStream_t stream) {
@@ -327,17 +325,18 @@ int launch_igemm_x3(IGemmArgs& a, hipStream_t stream) {
 // Weight planes for the split kernel.  Forward (`classes == nullptr` form): row co, k = (ky, kx, ci) as in
 // the OHWI parameter.  out[pt][row][Kpad] bf16, zero padded along K.
 __global__ void split_weight_fwd_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int rows, int K,
-                                        int Kpad) {
-  split_fwd_body(w, out, rows, K, Kpad, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+                                        int Kpad, const uint32_t* __restrict__ wscale) {
+  split_fwd_body(w, out, rows, K, Kpad, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x,
+                 wscale);
 }
 
 // Data-gradient planes of one residue class: row ci, k = (jy, jx, co) with ky = ky0 + jy*ksy, kx = kx0 + jx*ksx
 // (the class-ordered layout of pack_dgrad_weight_kernel, produced straight from the OHWI parameter).
 __global__ void split_weight_dgrad_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int Cout, int kh,
                                           int kw, int Cin, int ky0, int ksy, int nty, int kx0, int ksx, int ntx,
-                                          int Kpad) {
+                                          int Kpad, const uint32_t* __restrict__ wscale) {
   split_dgrad_body(w, out, Cout, kh, kw, Cin, ky0, ksy, nty, kx0, ksx, ntx, Kpad,
-                   (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+                   (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x, wscale);
 }
 
 static inline int kpad32(int k) { return (k + 31) & ~31; }
@@ -359,8 +358,9 @@ extern "C" size_t evk_conv2d_split_weight_bytes(const evk_conv_desc* d, int32_t 
   return total;
 }
 
-extern "C" int evk_conv2d_split_weight(const evk_conv_desc* d, const float* w, int32_t for_dgrad, void* wsplit,
-                                       void* stream) {
+// wscale == nullptr: the three bf16 planes; else the two fp16 planes of w / s(wscale) (planes 0 and 1 of the same layout)
+static int split_weight_any(const evk_conv_desc* d, const float* w, int32_t for_dgrad, void* wsplit, const uint32_t* wscale,
+                            void* stream) {
   EVK_REQUIRE(d && w && wsplit, EVK_E_INVALID, "split_weight: null pointer");
   EVK_REQUIRE(d->stride_h > 0 && d->stride_w > 0 && d->dil_h > 0 && d->dil_w > 0, EVK_E_INVALID,
               "split_weight: bad stride/dilation");
@@ -370,12 +370,12 @@ extern "C" int evk_conv2d_split_weight(const evk_conv_desc* d, const float* w, i
   // decision is a pure function of the descriptor, so the consumer makes the same one); never larger than the
   // generic layout.
   if (d->kh == 3 && d->kw == 3 && conv_desc_uses_halo(d, for_dgrad ? 1 : 0))
-    return launch_split_weight_halo(w, out, d->Cout, d->Cin, for_dgrad ? 1 : 0, st);
+    return launch_split_weight_halo(w, out, d->Cout, d->Cin, for_dgrad ? 1 : 0, st, wscale);
   if (!for_dgrad) {
     const int K = d->kh * d->kw * d->Cin, Kp = kpad32(K);
     const size_t total = (size_t)d->Cout * (Kp >> 1);
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(split_weight_fwd_kernel, dim3(blocks), dim3(256), 0, st, w, out, d->Cout, K, Kp);
+    hipLaunchKernelGGL(split_weight_fwd_kernel, dim3(blocks), dim3(256), 0, st, w, out, d->Cout, K, Kp, wscale);
     return check_launch("split_weight_fwd");
   }
   size_t off = 0;
@@ -388,11 +388,21 @@ extern "C" int evk_conv2d_split_weight(const evk_conv_desc* d, const float* w, i
         const size_t total = (size_t)d->Cin * (Kp >> 1);
         const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
         hipLaunchKernelGGL(split_weight_dgrad_kernel, dim3(blocks), dim3(256), 0, st, w, out + off, d->Cout, d->kh,
-                           d->kw, d->Cin, py.k0, py.kstep, py.nt, px.k0, px.kstep, px.nt, Kp);
+                           d->kw, d->Cin, py.k0, py.kstep, py.nt, px.k0, px.kstep, px.nt, Kp, wscale);
         int rc = check_launch("split_weight_dgrad");
         if (rc) return rc;
       }
       off += (size_t)3 * d->Cin * Kp;
     }
   return EVK_OK;
+}
+
+extern "C" int evk_conv2d_split_weight(const evk_conv_desc* d, const float* w, int32_t for_dgrad, void* wsplit,
+                                       void* stream) {
+  return split_weight_any(d, w, for_dgrad, wsplit, nullptr, stream);
+}
+extern "C" int evk_conv2d_split_weight_f16x2(const evk_conv_desc* d, const float* w, int32_t for_dgrad, void* wsplit,
+                                             const uint32_t* w_absmax_bits, void* stream) {
+  EVK_REQUIRE(w_absmax_bits, EVK_E_INVALID, "split_weight_f16x2: null scale");
+  return split_weight_any(d, w, for_dgrad, wsplit, w_absmax_bits, stream);
 }

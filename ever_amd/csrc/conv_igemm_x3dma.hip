@@ -221,7 +221,7 @@ int launch_igemm_x3dma(IGemmArgs& a, hipStream_t stream) {
   // EVK_X3_DMA_CFG picks a tile / ring for A/B runs (0 = by shape)
   static const int mode = getenv("EVK_X3_DMA") ? atoi(getenv("EVK_X3_DMA")) : 0;
   static const int cfg = getenv("EVK_X3_DMA_CFG") ? atoi(getenv("EVK_X3_DMA_CFG")) : 0;
-  if (mode == 0 || a.bn_want) return 1;   // (no statistics epilogue in this kernel)
+  if (mode == 0 || a.bn_want || a.planes == 2) return 1;   // (no statistics epilogue in this kernel)
   if (a.kh != 1 || a.kw != 1 || (a.Cs & 31) != 0 || a.Kpad != a.Cs) return 1;
   const unsigned long long sb = (unsigned long long)a.N * a.Hs * a.Ws * a.Cs * 4ull;
   const unsigned long long wb = 3ull * a.Cd * a.Kpad * 2ull;

@@ -95,6 +95,8 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws_kernel(const IGemmArgs p)
     f32x4 ra[2][AR][2];
     u32x4 rbv[2][BR][3];
     uint32_t okmask[2] = {0, 0};
+    float a_inv = 1.f;   // f16x2: 1 / activation scale
+    if constexpr (NP == 2) a_inv = op_scale(*p.a_scale).inv;
 
     auto load_tiles = [&](auto SET) {
       constexpr int s = decltype(SET)::value;
@@ -153,19 +155,13 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws_kernel(const IGemmArgs p)
         for (int e = 0; e < 4; ++e) {
           const f32x4 v = ra[s][j][e >> 1];
           const float x0 = ok ? v[2 * (e & 1)] : 0.f, x1 = ok ? v[2 * (e & 1) + 1] : 0.f;
-          if (NP == 3) {
-            uint32_t h, m, l;
-            split2(x0, x1, h, m, l);
-            H[e] = h; M[e] = m; L[e] = l;
-          } else {
-            H[e] = cvt2(x0, x1);
-          }
+          uint32_t h, m = 0, l = 0;
+          split_np<NP>(x0, x1, a_inv, h, m, l);
+          H[e] = h; M[e] = m; L[e] = l;
         }
         *reinterpret_cast<u32x4*>(Ab + off) = H;
-        if (NP == 3) {
-          *reinterpret_cast<u32x4*>(Ab + BM * kRowBytes + off) = M;
-          *reinterpret_cast<u32x4*>(Ab + 2 * BM * kRowBytes + off) = L;
-        }
+        if (NP >= 2) *reinterpret_cast<u32x4*>(Ab + BM * kRowBytes + off) = M;
+        if (NP == 3) *reinterpret_cast<u32x4*>(Ab + 2 * BM * kRowBytes + off) = L;
       }
 #pragma unroll
       for (int j = 0; j < BR; ++j) {
@@ -224,6 +220,8 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws_kernel(const IGemmArgs p)
     for (int kk = 0; kk < 2; ++kk)
       fb_off[b][kk] = 3 * BM * kRowBytes + plane_off(wn * WN + b * 32 + li, 2 * kk + lh);
 
+  float out_scale = 1.f;   // f16x2: activation scale x weight scale
+  if constexpr (NP == 2) out_scale = op_scale(*p.a_scale).s * op_scale(*p.w_scale).s;
   bf16x8 fa[2][MB][3], fb[2][NB][3];  // fragment registers, double buffered across the two k-halves
   auto read_frags = [&](const unsigned char* S, int kk, int slot) {
 #pragma unroll
@@ -244,7 +242,7 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws_kernel(const IGemmArgs p)
       for (int a = 0; a < MB; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[slot][b][x3_pb(NP, t)], fa[slot][a][x3_pa(NP, t)], acc[a][b], 0, 0, 0);
+          acc[a][b] = mfma_np<NP>(fb[slot][b][x3_pb(NP, t)], fa[slot][a][x3_pa(NP, t)], acc[a][b]);
   };
 
   __syncthreads();
@@ -265,6 +263,7 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws_kernel(const IGemmArgs p)
       __syncthreads();
     }
     const int bid = xcd_remap((int)blockIdx.x + i * (int)gridDim.x, ntiles);
+    if constexpr (NP == 2) igemm_scale_acc<MB, NB>(acc, out_scale);
     if (p.bn_part) {
       // statistics mode is launched one tile per workgroup: the staging waves are done (the epilogue's one barrier
       // must not meet a staging wave's step barrier, which it would in a persistent workgroup), every matrix wave
@@ -313,8 +312,9 @@ static int launch_ws_np(IGemmArgs& a, hipStream_t stream) {
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE>
 static int launch_ws(IGemmArgs& a, hipStream_t stream) {
-  return a.planes == 1 ? launch_ws_np<BM, BN, WAVES_M, WAVES_N, NSTAGE, 1>(a, stream)
-                       : launch_ws_np<BM, BN, WAVES_M, WAVES_N, NSTAGE, 3>(a, stream);
+  if (a.planes == 1) return launch_ws_np<BM, BN, WAVES_M, WAVES_N, NSTAGE, 1>(a, stream);
+  if (a.planes == 2) return launch_ws_np<BM, BN, WAVES_M, WAVES_N, NSTAGE, 2>(a, stream);
+  return launch_ws_np<BM, BN, WAVES_M, WAVES_N, NSTAGE, 3>(a, stream);
 }
 
 // returns 1 when this form does not apply (caller falls back to the single-role kernel)

@@ -347,7 +347,8 @@ extern "C" size_t evk_conv2d_wgrad_workspace_bytes(const evk_conv_desc* d) { ret
 extern "C" size_t evk_conv2d_wgrad_x3_workspace_bytes(const evk_conv_desc* d) { return wgrad_ws_bytes(d, 1); }
 
 static int conv_wgrad_any(const evk_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
-                          void* workspace, size_t workspace_bytes, void* stream, int x3, int planes = 3) {
+                          void* workspace, size_t workspace_bytes, void* stream, int x3, int planes = 3,
+                          const uint32_t* x_scale = nullptr, const uint32_t* dy_scale = nullptr) {
   EVK_REQUIRE(d && x && dy && dw, EVK_E_INVALID, "conv2d_wgrad: null pointer");
   EVK_REQUIRE(d->Cin % 4 == 0 && d->Cout % 4 == 0, EVK_E_UNSUPPORTED,
               "conv2d_wgrad: Cin=%d and Cout=%d must be multiples of 4", d->Cin, d->Cout);
@@ -360,6 +361,7 @@ static int conv_wgrad_any(const evk_conv_desc* d, const float* x, const float* d
   const WGradPlan pl = plan_wgrad(d, x3);
   WGradArgs a{};
   a.planes = planes;
+  a.x_scale = x_scale; a.dy_scale = dy_scale;
   a.x = x; a.dy = dy;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
   a.kh = d->kh; a.kw = d->kw; a.cpt = d->Cin / 4;
@@ -413,6 +415,15 @@ extern "C" int evk_conv2d_wgrad_bf16(const evk_conv_desc* d, const float* x, con
                                      void* workspace, size_t workspace_bytes, void* stream) {
   EVK_REQUIRE(d && d->Cin % 4 == 0 && d->Cout % 4 == 0, EVK_E_UNSUPPORTED, "conv2d_wgrad_bf16: channels must be multiples of 4");
   return conv_wgrad_any(d, x, dy, dw, dbias, workspace, workspace_bytes, stream, 1, 1);
+}
+
+// f16x2 arithmetic (conv_igemm.hip: evk_conv2d_fwd_f16x2): both operands are scaled activations
+extern "C" int evk_conv2d_wgrad_f16x2(const evk_conv_desc* d, const float* x, const uint32_t* x_absmax, const float* dy,
+                                      const uint32_t* dy_absmax, float* dw, float* dbias, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  EVK_REQUIRE(d && d->Cin % 4 == 0 && d->Cout % 4 == 0, EVK_E_UNSUPPORTED, "conv2d_wgrad_f16x2: channels must be multiples of 4");
+  EVK_REQUIRE(x_absmax && dy_absmax, EVK_E_INVALID, "conv2d_wgrad_f16x2: null scales");
+  return conv_wgrad_any(d, x, dy, dw, dbias, workspace, workspace_bytes, stream, 1, 2, x_absmax, dy_absmax);
 }
 
 extern "C" int evk_conv2d_wgrad_x3(const evk_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,

@@ -77,6 +77,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const WGradArgs p) {
 
   f32x4 rv[8];
   uint32_t okmask = 0;
+  float st_inv = 1.f, out_scale = 1.f;   // f16x2: 1 / scale of the operand this thread stages; product of both scales
+  if constexpr (NP == 2) {
+    const OpScale sx = op_scale(*p.x_scale), sd = op_scale(*p.dy_scale);
+    st_inv = roleA ? sd.inv : sx.inv;
+    out_scale = sx.s * sd.s;
+  }
 
   auto load_tiles = [&](int pix0) {
     okmask = 0;
@@ -129,19 +135,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const WGradArgs p) {
       u32x4 H, M, L;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        if (NP == 3) {
-          uint32_t h, m, l;
-          split2(rv[2 * t][e], rv[2 * t + 1][e], h, m, l);
-          H[t] = h; M[t] = m; L[t] = l;
-        } else {
-          H[t] = cvt2(rv[2 * t][e], rv[2 * t + 1][e]);
-        }
+        uint32_t h, m = 0, l = 0;
+        split_np<NP>(rv[2 * t][e], rv[2 * t + 1][e], st_inv, h, m, l);
+        H[t] = h; M[t] = m; L[t] = l;
       }
       *reinterpret_cast<u32x4*>(st_base + off) = H;
-      if (NP == 3) {
-        *reinterpret_cast<u32x4*>(st_base + st_plane + off) = M;
-        *reinterpret_cast<u32x4*>(st_base + 2 * st_plane + off) = L;
-      }
+      if (NP >= 2) *reinterpret_cast<u32x4*>(st_base + st_plane + off) = M;
+      if (NP == 3) *reinterpret_cast<u32x4*>(st_base + 2 * st_plane + off) = L;
     }
   };
 
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const WGradArgs p) {
       for (int a = 0; a < MB; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][x3_pa(NP, t)], fb[b][x3_pb(NP, t)], acc[a][b], 0, 0, 0);
+          acc[a][b] = mfma_np<NP>(fa[a][x3_pa(NP, t)], fb[b][x3_pb(NP, t)], acc[a][b]);
   };
 
   const int nk = (pend - pbeg + BKP - 1) / BKP;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const WGradArgs p) {
       for (int b = 0; b < NB; ++b) {
         const int rb = wn * WN + b * 32 + li;
         const int col = k0 + 4 * (rb % QB) + rb / QB;
-        if (col < p.Ktot) out[(size_t)row * p.Ktot + col] = acc[a][b][r];
+        if (col < p.Ktot) out[(size_t)row * p.Ktot + col] = acc[a][b][r] * out_scale;
       }
     }
 }
@@ -230,6 +230,9 @@ static int launch_one(const WGradArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)3 * (BM + BN) * kRowBytes;
   if (a.planes == 1) {
     hipLaunchKernelGGL((conv_wgrad_x3_kernel<BM, BN, WAVES_M, WAVES_N, 1>), dim3(a.tiles_co * a.tiles_k * a.splitk),
+                       dim3(256), lds, stream, a);
+  } else if (a.planes == 2) {
+    hipLaunchKernelGGL((conv_wgrad_x3_kernel<BM, BN, WAVES_M, WAVES_N, 2>), dim3(a.tiles_co * a.tiles_k * a.splitk),
                        dim3(256), lds, stream, a);
   } else {
     hipLaunchKernelGGL((conv_wgrad_x3_kernel<BM, BN, WAVES_M, WAVES_N, 3>), dim3(a.tiles_co * a.tiles_k * a.splitk),

@@ -59,7 +59,7 @@ __device__ __forceinline__ void gather8(const WGradArgs& p, const WGather& g, in
 // split the micro-block and write channel 4*cq+e to LDS row e*Q + cq, 16-byte chunk pg, of the three planes
 template <int NP>
 __device__ __forceinline__ void split_store8(f32x4 (&rv)[8], uint32_t okmask, unsigned char* base, int plane_bytes, int Q,
-                                             int cq, int pg) {
+                                             int cq, int pg, float inv) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const bool ok = (okmask >> j) & 1u;
@@ -72,19 +72,13 @@ __device__ __forceinline__ void split_store8(f32x4 (&rv)[8], uint32_t okmask, un
     u32x4 H, M, L;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      if (NP == 3) {
-        uint32_t h, m, l;
-        split2(rv[2 * t][e], rv[2 * t + 1][e], h, m, l);
-        H[t] = h; M[t] = m; L[t] = l;
-      } else {
-        H[t] = cvt2(rv[2 * t][e], rv[2 * t + 1][e]);
-      }
+      uint32_t h, m = 0, l = 0;
+      split_np<NP>(rv[2 * t][e], rv[2 * t + 1][e], inv, h, m, l);
+      H[t] = h; M[t] = m; L[t] = l;
     }
     *reinterpret_cast<u32x4*>(base + off) = H;
-    if (NP == 3) {
-      *reinterpret_cast<u32x4*>(base + plane_bytes + off) = M;
-      *reinterpret_cast<u32x4*>(base + 2 * plane_bytes + off) = L;
-    }
+    if (NP >= 2) *reinterpret_cast<u32x4*>(base + plane_bytes + off) = M;
+    if (NP == 3) *reinterpret_cast<u32x4*>(base + 2 * plane_bytes + off) = L;
   }
 }
 
@@ -104,7 +98,7 @@ __device__ __forceinline__ void gather8h(const float* __restrict__ dy, int Cout,
 }
 template <int NP>
 __device__ __forceinline__ void split_store8h(f32x2v (&rv)[8], uint32_t okmask, unsigned char* base, int plane_bytes, int Q2,
-                                              int cq, int pg) {
+                                              int cq, int pg, float inv) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const bool ok = (okmask >> j) & 1u;
@@ -117,19 +111,13 @@ __device__ __forceinline__ void split_store8h(f32x2v (&rv)[8], uint32_t okmask, 
     u32x4 H, M, L;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      if (NP == 3) {
-        uint32_t h, m, l;
-        split2(rv[2 * t][e], rv[2 * t + 1][e], h, m, l);
-        H[t] = h; M[t] = m; L[t] = l;
-      } else {
-        H[t] = cvt2(rv[2 * t][e], rv[2 * t + 1][e]);
-      }
+      uint32_t h, m = 0, l = 0;
+      split_np<NP>(rv[2 * t][e], rv[2 * t + 1][e], inv, h, m, l);
+      H[t] = h; M[t] = m; L[t] = l;
     }
     *reinterpret_cast<u32x4*>(base + off) = H;
-    if (NP == 3) {
-      *reinterpret_cast<u32x4*>(base + plane_bytes + off) = M;
-      *reinterpret_cast<u32x4*>(base + 2 * plane_bytes + off) = L;
-    }
+    if (NP >= 2) *reinterpret_cast<u32x4*>(base + plane_bytes + off) = M;
+    if (NP == 3) *reinterpret_cast<u32x4*>(base + 2 * plane_bytes + off) = L;
   }
 }
 
@@ -184,6 +172,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
     f32x2v ra[2][8];
     f32x4 rb[2][8];
     uint32_t oka[2] = {0, 0}, okb[2] = {0, 0};
+    float x_inv = 1.f, dy_inv = 1.f;   // f16x2: 1 / operand scales
+    if constexpr (NP == 2) {
+      x_inv = op_scale(*p.x_scale).inv;
+      dy_inv = op_scale(*p.dy_scale).inv;
+    }
 
     auto load = [&](auto SET, int kt) {
       constexpr int s = decltype(SET)::value;
@@ -197,8 +190,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
       unsigned char* Ab = smem3 + stage * kStage;
       unsigned char* Bb = Ab + 3 * BM * kRowBytes;
       if (p.dbg & 2) return;   // ablation: no split, no LDS writes
-      split_store8<NP>(rb[s], okb[s], Bb, BN * kRowBytes, QB, bcq, bpg);
-      split_store8h<NP>(ra[s], oka[s], Ab, BM * kRowBytes, QA2, acq, apg);
+      split_store8<NP>(rb[s], okb[s], Bb, BN * kRowBytes, QB, bcq, bpg, x_inv);
+      split_store8h<NP>(ra[s], oka[s], Ab, BM * kRowBytes, QA2, acq, apg, dy_inv);
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
@@ -271,7 +264,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
       for (int a = 0; a < MB; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][x3_pa(NP, t)], fb[b][x3_pb(NP, t)], acc[a][b], 0, 0, 0);
+          acc[a][b] = mfma_np<NP>(fa[a][x3_pa(NP, t)], fb[b][x3_pb(NP, t)], acc[a][b]);
   };
 
   __syncthreads();
@@ -288,6 +281,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
     return;
   }
 
+  if constexpr (NP == 2) {   // f16x2: back to the operands' units
+    const float sc = op_scale(*p.x_scale).s * op_scale(*p.dy_scale).s;
+#pragma unroll
+    for (int a = 0; a < MB; ++a)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) acc[a][b] *= sc;
+  }
   float* out = p.out + (size_t)z * p.Cout * p.Ktot;
 #pragma unroll
   for (int a = 0; a < MB; ++a)
@@ -318,6 +318,8 @@ int launch_wgrad_x3ws(const WGradArgs& a, hipStream_t stream) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x3ws_kernel<BM, BN, 1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x3ws_kernel<BM, BN, 2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   WGradArgs b = a;
@@ -325,6 +327,8 @@ int launch_wgrad_x3ws(const WGradArgs& a, hipStream_t stream) {
   b.dbg = dbg;
   if (a.planes == 1) {
     hipLaunchKernelGGL((conv_wgrad_x3ws_kernel<BM, BN, 1>), dim3(a.tiles_co * a.tiles_k * a.splitk), dim3(512), lds, stream, b);
+  } else if (a.planes == 2) {
+    hipLaunchKernelGGL((conv_wgrad_x3ws_kernel<BM, BN, 2>), dim3(a.tiles_co * a.tiles_k * a.splitk), dim3(512), lds, stream, b);
   } else {
     hipLaunchKernelGGL((conv_wgrad_x3ws_kernel<BM, BN, 3>), dim3(a.tiles_co * a.tiles_k * a.splitk), dim3(512), lds, stream, b);
   }

@@ -23,7 +23,10 @@ struct IGemmArgs {
   int tiles_m, tiles_n;
   const uint16_t* wgt3;     // split kernel: weights as 3 bf16 planes [3][Cd][Kpad] (Kpad % 32 == 0, zero padded)
   int Kpad;
-  int planes;               // 3 (0 means 3): exact split, six products; 1: plain bf16 operands, one product (*_bf16 entry points)
+  int planes;               // 3 (0 means 3): exact split, six products; 1: plain bf16 operands, one product (*_bf16 entry points);
+                            // 2: 2-term fp16 split of scaled operands, three products (*_f16x2 entry points)
+  const uint32_t* a_scale;  // planes == 2: bit image of max|src| (evk_absmax) and of max|weight| (the planes' producer)
+  const uint32_t* w_scale;
   // BatchNorm statistics of the OUTPUT from the epilogue (forward convolutions followed by a training-mode BatchNorm):
   // bn_part[part][3][Cd] = (count, mean, M2 = sum (y - mean)^2) of the rows of row-part `part`; nullptr = off.
   // Written by igemm_store_rows_stats / bn_part_write; merged (Chan) by evk_bn_fwd_train_parts.
@@ -34,6 +37,15 @@ struct IGemmArgs {
   float* bn_buf;            // host side: the caller's partial buffer (bn_part is set from it when the kernel supports it)
   int bn_cap;               // host side: capacity of bn_buf in parts
 };
+
+// f16x2 arithmetic: the accumulators hold (x / s_a) * (w / s_w) sums; multiply by s_a * s_w before the epilogue
+template <int MB, int NB>
+__device__ __forceinline__ void igemm_scale_acc(f32x16 (&acc)[MB][NB], float s) {
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[a][b] *= s;
+}
 
 // Store one 32-row block of accumulators whose lane's GEMM row lives at element offset `roff` of dst: bias,
 // residual / accumulate, ReLU, 16-byte stores.  The MFMAs are issued as D = W_tile * X_tile^T, so a lane holds
@@ -265,7 +277,8 @@ int launch_igemm_x3ws_forced(IGemmArgs& a, int bn, hipStream_t stream);
 int launch_igemm_x3dma(IGemmArgs& a, hipStream_t stream);  // 1 = not applicable
 int launch_conv3x3_halo(IGemmArgs& a, hipStream_t stream);  // 1 = not applicable
 bool conv_desc_uses_halo(const evk_conv_desc* d, int for_dgrad);
-int launch_split_weight_halo(const float* w, uint16_t* out, int Cout, int Cin, int for_dgrad, hipStream_t st);
+int launch_split_weight_halo(const float* w, uint16_t* out, int Cout, int Cin, int for_dgrad, hipStream_t st,
+                             const uint32_t* wscale = nullptr);
 
 // One axis of the strided data gradient, for input pixels congruent to c (mod stride):
 // taps k = k0 + j*kstep (j < nt) reach them, from source row  g + o0 + j*ostep.

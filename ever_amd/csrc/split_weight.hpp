@@ -8,11 +8,29 @@
 namespace evk {
 
 constexpr int kSplitFwd = 0, kSplitDgrad = 1, kSplitHalo = 2;
+
+// one pair of weights -> its planes at o (uint32 index; `plane` = bf16/fp16 elements per plane).  wscale == nullptr: the
+// exact 3-term bf16 split; else the 2-term fp16 split of w / s, s from the weight's max |w| (x3_common.hpp), planes h, l.
+__device__ __forceinline__ void split_put(float x0, float x1, uint32_t* o, size_t plane, const uint32_t* wscale) {
+  if (wscale) {
+    const float inv = op_scale(*wscale).inv;
+    uint32_t h, l;
+    split2h(x0 * inv, x1 * inv, h, l);
+    o[0] = h;
+    o[plane >> 1] = l;
+  } else {
+    uint32_t h, m, l;
+    split2(x0, x1, h, m, l);
+    o[0] = h;
+    o[plane >> 1] = m;
+    o[plane] = l;
+  }
+}
 constexpr int kHaloCh = 16;  // channels per chunk of the halo kernel's planes (= its kCh)
 
 // Forward planes: row co, k = (ky, kx, ci) as in the OHWI parameter.  out[pt][row][Kpad] bf16, zero padded along K.
 __device__ __forceinline__ void split_fwd_body(const float* __restrict__ w, uint16_t* __restrict__ out, int rows, int K,
-                                               int Kpad, size_t t0, size_t nthreads) {
+                                               int Kpad, size_t t0, size_t nthreads, const uint32_t* wscale = nullptr) {
   const size_t total = (size_t)rows * (Kpad >> 1);
   const size_t plane = (size_t)rows * Kpad;
   for (size_t i = t0; i < total; i += nthreads) {
@@ -20,12 +38,7 @@ __device__ __forceinline__ void split_fwd_body(const float* __restrict__ w, uint
     const int k = (int)(i - (size_t)row * (Kpad >> 1)) * 2;
     const float x0 = k < K ? w[(size_t)row * K + k] : 0.f;
     const float x1 = k + 1 < K ? w[(size_t)row * K + k + 1] : 0.f;
-    uint32_t h, m, l;
-    split2(x0, x1, h, m, l);
-    uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)row * Kpad + k);
-    o[0] = h;
-    o[plane >> 1] = m;
-    o[plane] = l;
+    split_put(x0, x1, reinterpret_cast<uint32_t*>(out + (size_t)row * Kpad + k), plane, wscale);
   }
 }
 
@@ -33,7 +46,7 @@ __device__ __forceinline__ void split_fwd_body(const float* __restrict__ w, uint
 // (the class-ordered layout of pack_dgrad_weight_kernel, produced straight from the OHWI parameter).
 __device__ __forceinline__ void split_dgrad_body(const float* __restrict__ w, uint16_t* __restrict__ out, int Cout,
                                                  int kh, int kw, int Cin, int ky0, int ksy, int nty, int kx0, int ksx,
-                                                 int ntx, int Kpad, size_t t0, size_t nthreads) {
+                                                 int ntx, int Kpad, size_t t0, size_t nthreads, const uint32_t* wscale = nullptr) {
   const int K = nty * ntx * Cout;
   const size_t total = (size_t)Cin * (Kpad >> 1);
   const size_t plane = (size_t)Cin * Kpad;
@@ -53,12 +66,7 @@ __device__ __forceinline__ void split_dgrad_body(const float* __restrict__ w, ui
         x[e] = 0.f;
       }
     }
-    uint32_t h, m, l;
-    split2(x[0], x[1], h, m, l);
-    uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)ci * Kpad + k);
-    o[0] = h;
-    o[plane >> 1] = m;
-    o[plane] = l;
+    split_put(x[0], x[1], reinterpret_cast<uint32_t*>(out + (size_t)ci * Kpad + k), plane, wscale);
   }
 }
 
@@ -66,7 +74,7 @@ __device__ __forceinline__ void split_dgrad_body(const float* __restrict__ w, ui
 // tap order, which is (ky, kx) for the forward and for the stride-1 data gradient alike (the sign of oys flips the
 // direction, not the index).  rows = Cout (forward: w[row][ky][kx][ci]) or Cin (data gradient: w[co][ky][kx][row]).
 __device__ __forceinline__ void split_halo_body(const float* __restrict__ w, uint16_t* __restrict__ out, int Cout,
-                                                int Cin, int for_dgrad, size_t t0, size_t nthreads) {
+                                                int Cin, int for_dgrad, size_t t0, size_t nthreads, const uint32_t* wscale = nullptr) {
   const int rows = for_dgrad ? Cin : Cout, K = for_dgrad ? Cout : Cin;  // K = reduction channels
   const int nchunk = K / kHaloCh;
   const size_t total = (size_t)9 * nchunk * rows * (kHaloCh / 2);
@@ -87,12 +95,7 @@ __device__ __forceinline__ void split_halo_body(const float* __restrict__ w, uin
       x0 = w[((size_t)row * 9 + tap) * Cin + kc];
       x1 = w[((size_t)row * 9 + tap) * Cin + kc + 1];
     }
-    uint32_t h, m, l;
-    split2(x0, x1, h, m, l);
-    uint32_t* o = reinterpret_cast<uint32_t*>(out + (((size_t)tap * nchunk + ch) * rows + row) * kHaloCh + 2 * k2);
-    o[0] = h;
-    o[plane >> 1] = m;
-    o[plane] = l;
+    split_put(x0, x1, reinterpret_cast<uint32_t*>(out + (((size_t)tap * nchunk + ch) * rows + row) * kHaloCh + 2 * k2), plane, wscale);
   }
 }
 

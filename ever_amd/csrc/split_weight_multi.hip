@@ -11,20 +11,23 @@ namespace evk {
 
 // block_map[b] = (job, block index inside the job); job.arg[12] = blocks the host gave that job (so every workgroup
 // has work: a (blocks, jobs) grid sized for the largest weight would launch ~80 K empty workgroups for the small ones)
+// absmax != nullptr: the f16x2 planes; job.arg[11] = index of the job's weight in the absmax array (evk_absmax_multi)
 __global__ __launch_bounds__(256) void split_weight_multi_kernel(const evk_split_job* __restrict__ jobs,
-                                                                 const int32_t* __restrict__ block_map) {
+                                                                 const int32_t* __restrict__ block_map,
+                                                                 const uint32_t* __restrict__ absmax) {
   const int jb = block_map[2 * blockIdx.x], bj = block_map[2 * blockIdx.x + 1];
   const evk_split_job j = jobs[jb];
   const size_t t0 = (size_t)bj * 256 + threadIdx.x, nt = (size_t)j.arg[12] * 256;
   const float* w = j.w;
   uint16_t* out = reinterpret_cast<uint16_t*>(j.out);
+  const uint32_t* wscale = absmax ? absmax + j.arg[11] : nullptr;
   if (j.kind == kSplitFwd)
-    split_fwd_body(w, out, j.arg[0], j.arg[1], j.arg[2], t0, nt);
+    split_fwd_body(w, out, j.arg[0], j.arg[1], j.arg[2], t0, nt, wscale);
   else if (j.kind == kSplitDgrad)
     split_dgrad_body(w, out, j.arg[0], j.arg[1], j.arg[2], j.arg[3], j.arg[4], j.arg[5], j.arg[6], j.arg[7], j.arg[8],
-                     j.arg[9], j.arg[10], t0, nt);
+                     j.arg[9], j.arg[10], t0, nt, wscale);
   else
-    split_halo_body(w, out, j.arg[0], j.arg[1], j.arg[2], t0, nt);
+    split_halo_body(w, out, j.arg[0], j.arg[1], j.arg[2], t0, nt, wscale);
 }
 
 static inline int kpad32(int k) { return (k + 31) & ~31; }
@@ -82,13 +85,22 @@ extern "C" int evk_conv2d_split_jobs(const evk_conv_desc* d, const float* w, int
   return n;
 }
 
-extern "C" int evk_conv2d_split_multi(const evk_split_job* jobs_dev, const int32_t* block_map_dev, int32_t nblocks,
-                                      void* stream) {
+static int split_multi_any(const evk_split_job* jobs_dev, const int32_t* block_map_dev, int32_t nblocks,
+                           const uint32_t* absmax_dev, void* stream) {
   EVK_REQUIRE(nblocks >= 0 && (nblocks == 0 || (jobs_dev && block_map_dev)), EVK_E_INVALID, "split_multi: bad argument");
   if (nblocks == 0) return EVK_OK;
   hipLaunchKernelGGL(split_weight_multi_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, jobs_dev,
-                     block_map_dev);
+                     block_map_dev, absmax_dev);
   return check_launch("split_weight_multi");
+}
+extern "C" int evk_conv2d_split_multi(const evk_split_job* jobs_dev, const int32_t* block_map_dev, int32_t nblocks,
+                                      void* stream) {
+  return split_multi_any(jobs_dev, block_map_dev, nblocks, nullptr, stream);
+}
+extern "C" int evk_conv2d_split_multi_f16x2(const evk_split_job* jobs_dev, const int32_t* block_map_dev, int32_t nblocks,
+                                            const uint32_t* absmax_dev, void* stream) {
+  EVK_REQUIRE(absmax_dev, EVK_E_INVALID, "split_multi_f16x2: null scale array");
+  return split_multi_any(jobs_dev, block_map_dev, nblocks, absmax_dev, stream);
 }
 
 extern "C" int64_t evk_split_job_pairs(const evk_split_job* job) { return job ? (int64_t)split_job_pairs(*job) : 0; }

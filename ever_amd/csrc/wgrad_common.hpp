@@ -15,7 +15,10 @@ struct WGradArgs {
   int chunk;  // pixels per split (multiple of 32)
   int tiles_co, tiles_k, splitk;
   FastDiv fd_hw, fd_w;
-  int planes;  // 3 (0 means 3): exact split, six products; 1: plain bf16 operands, one product (evk_conv2d_wgrad_bf16)
+  int planes;  // 3 (0 means 3): exact split, six products; 1: plain bf16 operands, one product (evk_conv2d_wgrad_bf16);
+               // 2: 2-term fp16 split of scaled operands, three products (evk_conv2d_wgrad_f16x2)
+  const uint32_t* x_scale;   // planes == 2: bit images of max|x| and max|dy| (evk_absmax)
+  const uint32_t* dy_scale;
   int dbg;  // EVK_WG_DBG ablation switches of the wave-specialised kernel (0 in production)
 };
 

@@ -28,17 +28,65 @@ __device__ __forceinline__ void split2(float x0, float x1, uint32_t& H, uint32_t
   L = __builtin_bit_cast(uint32_t, __builtin_convertvector(s, bf16x2));
 }
 
-// NP = number of bf16 planes per operand: 3 = the exact split above (six partial products, fp32-grade);
-// 1 = plain bf16 (operands rounded to bf16 once, ONE product, fp32 accumulate): the counterpart of the reference's
-// `--mixed_precision bf16` (launcher.py:40-80), selected by the *_bf16 entry points.  LDS / HBM plane layouts are
-// the same; only plane 0 (h) is produced and read.
-template <int NP> struct X3Prod { static constexpr int N = NP == 3 ? 6 : 1; };
-__device__ __forceinline__ constexpr int x3_pa(int np, int t) { return np == 3 ? kPA[t] : 0; }
-__device__ __forceinline__ constexpr int x3_pb(int np, int t) { return np == 3 ? kPB[t] : 0; }
+// NP selects the arithmetic of a kernel instantiation (the LDS / HBM plane geometry is the same for all three):
+//   3  exact 3-term bf16 split above: six partial products, error per product < 2^-24 ("bf16x3", fp32 grade)
+//   2  2-term fp16 split of the operand scaled by a power of two ("f16x2"): x / s = h + l with h, l fp16 (11-bit
+//      significands, round-to-nearest-even at both levels, |x/s - h - l| <= 2^-22 |x/s|), three partial products
+//      l*wh + h*wl + h*wh (dropped: l*wl <= 2^-22 |x*w|) on v_mfma_f32_32x32x16_f16, the accumulator multiplied by the
+//      two operands' scales at the end.  s = 2^(floor(log2 max|x|) - 13) per TENSOR (evk_absmax), so the largest
+//      element lands in [2^13, 2^14): every element down to 2^-17 of the largest keeps its 22 bits, smaller ones an
+//      absolute 2^-38 of the largest; products cannot overflow fp32 (2^28 * K).  Only planes 0 (h) and 1 (l) exist.
+//   1  plain bf16 (operands rounded to bf16 once, ONE product, fp32 accumulate): the counterpart of the reference's
+//      `--mixed_precision bf16` (launcher.py:40-80), selected by the *_bf16 entry points.  Only plane 0 exists.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+template <int NP> struct X3Prod { static constexpr int N = NP == 3 ? 6 : (NP == 2 ? 3 : 1); };
+__device__ constexpr int kHA[3] = {1, 0, 0};   // f16x2: (A part, B part), smallest magnitude first; 0 = h, 1 = l
+__device__ constexpr int kHB[3] = {0, 1, 0};
+__device__ __forceinline__ constexpr int x3_pa(int np, int t) { return np == 3 ? kPA[t] : (np == 2 ? kHA[t] : 0); }
+__device__ __forceinline__ constexpr int x3_pb(int np, int t) { return np == 3 ? kPB[t] : (np == 2 ? kHB[t] : 0); }
 // two floats -> packed bf16 pair (round-to-nearest-even), first element in the low half
 __device__ __forceinline__ uint32_t cvt2(float x0, float x1) {
   const f32x2 v = {x0, x1};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+// 2-term fp16 split of two (already scaled) floats; each result packs the pair, first element in the low half
+__device__ __forceinline__ void split2h(float x0, float x1, uint32_t& H, uint32_t& L) {
+  const f32x2 v = {x0, x1};
+  const f16x2 h = __builtin_convertvector(v, f16x2);
+  const f32x2 r = v - __builtin_convertvector(h, f32x2);   // exact: at most 13 significant bits remain
+  H = __builtin_bit_cast(uint32_t, h);
+  L = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+}
+// the planes of one pair of operand values (M is the l plane of the f16x2 arithmetic); `inv` = 1 / operand scale (NP == 2)
+template <int NP>
+__device__ __forceinline__ void split_np(float x0, float x1, float inv, uint32_t& H, uint32_t& M, uint32_t& L) {
+  if constexpr (NP == 3) split2(x0, x1, H, M, L);
+  else if constexpr (NP == 2) split2h(x0 * inv, x1 * inv, H, M);
+  else H = cvt2(x0, x1);
+}
+// one MFMA of the instantiation's operand type on two 16-byte LDS fragments
+template <int NP>
+__device__ __forceinline__ f32x16 mfma_np(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (NP == 2)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// Operand scale of the f16x2 arithmetic from the bit image of max|x| (what evk_absmax leaves in device memory):
+// s = 2^(E - 13) with E the biased exponent, clamped to the normal range; zero / non-finite tensors use s = 1.
+struct OpScale { float inv, s; };
+__device__ __forceinline__ OpScale op_scale(uint32_t absmax_bits) {
+  const int E = (int)((absmax_bits >> 23) & 0xff);
+  int f = E - 13;
+  if (E == 0 || E == 255) f = 127;
+  f = f < 1 ? 1 : f;
+  OpScale o;
+  o.s = __builtin_bit_cast(float, (uint32_t)f << 23);
+  o.inv = __builtin_bit_cast(float, (uint32_t)(254 - f) << 23);
+  return o;
 }
 
 // byte offset of 16-byte chunk c16 (0..3) of row `row` inside one plane; the XOR spreads the

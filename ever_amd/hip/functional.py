@@ -35,18 +35,62 @@ class HipPathError(RuntimeError):
 #   'f32'    v_mfma_f32_32x32x2_f32, an exact fmaf chain (the parity yardstick for the split kernels).
 #   'bf16'   plain bf16 operands (rounded once), ONE bf16 MFMA product per operand pair, fp32 accumulate, fp32 tensors:
 #            the counterpart of the reference's `--mixed_precision bf16` (core/launcher.py:40-80).  Opt-in only.
-_CONV_MATH = os.environ.get('EVK_CONV_MATH', 'bf16x3')
-_MATH_MODES = ('bf16x3', 'f32', 'bf16')
+#   'f16x2'  each fp32 operand is divided by a per-tensor power of two and split into two fp16 terms; three partial
+#            products on the fp16 matrix pipe, fp32 accumulate, scales multiplied back (csrc/x3_common.hpp).  As accurate
+#            against fp64 as 'bf16x3' on every layer shape (tools/check_f16x2.py) at half the matrix work.
+_CONV_MATH = os.environ.get('EVK_CONV_MATH', 'f16x2')
+_MATH_MODES = ('f16x2', 'bf16x3', 'f32', 'bf16')
 
 
 def _planes_math():
     """True when the convolutions run on the bf16 matrix pipe from weight planes (exact split or plain bf16)."""
-    return _CONV_MATH in ('bf16x3', 'bf16')
+    return _CONV_MATH in ('f16x2', 'bf16x3', 'bf16')
+
+
+def _f16x2():
+    return _CONV_MATH == 'f16x2'
+
+
+def absmax_bits(t, st):
+    """int32[1] device tensor holding the bit image of max|t| (the f16x2 operand scale derives from it inside the
+    kernels).  Cached on the tensor object: the forward's scale of x serves the weight gradient, the scale of dy serves
+    data and weight gradient, a block input serves both convolutions that read it."""
+    hit = getattr(t, '_evk_amax', None)
+    if hit is not None and hit[0] == t._version and hit[1] == t.data_ptr():
+        return hit[2]
+    bits = torch.empty((1,), device=t.device, dtype=torch.int32)
+    sp = timing.span('absmax', 0.0, 4.0 * t.numel())
+    _C.call('evk_absmax', t.data_ptr(), t.numel(), bits.data_ptr(), weight_planes.absmax_workspace(t.device, st).data_ptr(), st)
+    if sp is not None:
+        sp.stop()
+    try:
+        t._evk_amax = (t._version, t.data_ptr(), bits)
+    except (AttributeError, RuntimeError):
+        pass
+    return bits
+
+
+def _weight_planes(weight, w_dense, w_ptr, d, for_dgrad, st, dev):
+    """(planes pointer, weight absmax pointer or None, keep-alive) for the current plane arithmetic: from the cache of
+    registered weights, else split into the shared workspace on this call (a transient re-laid-out copy)."""
+    h2 = _f16x2()
+    hit = weight_planes.planes_for(weight, w_dense, d, for_dgrad, st, f16x2=h2)
+    if hit is not None:
+        return (hit[0], hit[1], None) if h2 else (hit, None, None)
+    planes = workspace(dev, _C.load().evk_conv2d_split_weight_bytes(ctypes.byref(d), for_dgrad))
+    if h2:
+        wb = torch.empty((1,), device=dev, dtype=torch.int32)
+        nel = d.Cout * d.kh * d.kw * d.Cin
+        _C.call('evk_absmax', w_ptr, nel, wb.data_ptr(), weight_planes.absmax_workspace(dev, st).data_ptr(), st)
+        _C.call('evk_conv2d_split_weight_f16x2', ctypes.byref(d), w_ptr, for_dgrad, planes.data_ptr(), wb.data_ptr(), st)
+        return planes.data_ptr(), wb.data_ptr(), wb
+    _C.call('evk_conv2d_split_weight', ctypes.byref(d), w_ptr, for_dgrad, planes.data_ptr(), st)
+    return planes.data_ptr(), None, None
 
 
 def _entry(x3_name):
     """C-ABI entry point of the current plane arithmetic: evk_*_x3 or its plain-bf16 twin evk_*_bf16."""
-    return x3_name if _CONV_MATH == 'bf16x3' else x3_name.replace('_x3', '_bf16')
+    return x3_name if _CONV_MATH != 'bf16' else x3_name.replace('_x3', '_bf16')
 
 
 def set_conv_math(mode):
@@ -235,18 +279,18 @@ def _conv_forward(x, weight, bias, stride, padding, dilation, relu, want_stats=F
         # weights -> three bf16 planes, then the split-MFMA kernel.  The planes of every registered weight are
         # refreshed by one launch per weight update (weight_planes); a weight the cache cannot follow (a transient
         # re-laid-out copy) is split into the shared workspace on every call.
-        pl_ptr = weight_planes.planes_for(weight, w_ohwi, d, 0, st)
-        if pl_ptr is None:
-            planes = workspace(dev, _C.load().evk_conv2d_split_weight_bytes(ctypes.byref(d), 0))
-            _C.call('evk_conv2d_split_weight', ctypes.byref(d), w_ptr, 0, planes.data_ptr(), st)
-            pl_ptr = planes.data_ptr()
+        pl_ptr, wabs_ptr, _keep = _weight_planes(weight, w_ohwi, w_ptr, d, 0, st, dev)
+        xbits = absmax_bits(x, st) if wabs_ptr is not None else None
         sp = timing.span('conv_igemm', cs.flops, cs.abytes)
         stats = want_stats and _BN_EPILOGUE and not relu and cout % 4 == 0
         parts, cap, nparts = None, 0, ctypes.c_int32(0)
         if stats:
             cap = int(_C.load().evk_conv2d_stats_max_parts(ctypes.byref(d)))
             parts = torch.empty((cap * 3 * cout,), device=dev, dtype=torch.float32)
-        if _CONV_MATH == 'bf16':
+        if wabs_ptr is not None:
+            _C.call('evk_conv2d_fwd_f16x2', ctypes.byref(d), x_ptr, xbits.data_ptr(), pl_ptr, wabs_ptr, _ptr(bias), None,
+                    y.data_ptr(), 1 if relu else 0, _ptr(parts), cap, ctypes.byref(nparts), st)
+        elif _CONV_MATH == 'bf16':
             _C.call('evk_conv2d_fwd_bf16', ctypes.byref(d), x_ptr, pl_ptr, _ptr(bias), y.data_ptr(), 1 if relu else 0,
                     _ptr(parts), cap, ctypes.byref(nparts), st)
         elif stats:
@@ -303,21 +347,21 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None):
         if narrow8:     # zero rows appended to the (tiny) weight: a transient copy, split on every call
             w_src = torch.zeros((cout_p, taps, cin), device=dev, dtype=torch.float32)
             w_src[:cout].copy_(w_ohwi.permute(0, 2, 3, 1).reshape(cout, taps, cin))
-            pl_ptr = None
         else:
             w_src = w_ohwi
-            pl_ptr = weight_planes.planes_for(cs.weight, w_ohwi, dk, 1, st)
-        if pl_ptr is None:
-            planes = workspace(dev, _C.load().evk_conv2d_split_weight_bytes(ctypes.byref(dk), 1))
-            _C.call('evk_conv2d_split_weight', ctypes.byref(dk), w_src.data_ptr(), 1, planes.data_ptr(), st)
-            pl_ptr = planes.data_ptr()
+        pl_ptr, wabs_ptr, _keep = _weight_planes(cs.weight, w_src, w_src.data_ptr(), dk, 1, st, dev)
         acc_ptr = None
         if accum is not None:
             accum = as_nhwc(accum, 'conv2d.backward.accum')
             acc_ptr = accum.data_ptr()
         dx = empty_nhwc(n, cin, d.H, d.W, dev)
+        dybits = absmax_bits(dyk, st) if wabs_ptr is not None else None
         sp = timing.span('conv_igemm', cs.flops, cs.abytes, cs.scope)
-        _C.call(_entry('evk_conv2d_dgrad_x3'), ctypes.byref(dk), dy_ptr, pl_ptr, acc_ptr, dx.data_ptr(), st)
+        if wabs_ptr is not None:
+            _C.call('evk_conv2d_dgrad_f16x2', ctypes.byref(dk), dy_ptr, dybits.data_ptr(), pl_ptr, wabs_ptr, acc_ptr,
+                    dx.data_ptr(), st)
+        else:
+            _C.call(_entry('evk_conv2d_dgrad_x3'), ctypes.byref(dk), dy_ptr, pl_ptr, acc_ptr, dx.data_ptr(), st)
         if sp is not None:
             sp.stop()
     elif need_dx:
@@ -355,9 +399,16 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None):
         ws = workspace(dev, ws_bytes)
         dwk = torch.empty((cout_p, taps, cin_p), device=dev, dtype=torch.float32)
         dbk = torch.empty((cout_p,), device=dev, dtype=torch.float32) if need_db else None
+        h2 = x3 and _f16x2()
+        if h2:
+            xbits, dybits = absmax_bits(xk, st), absmax_bits(dyk, st)
         sp = timing.span('conv_wgrad' if x3 else 'conv_wgrad_f32', cs.flops, cs.abytes, cs.scope)
-        _C.call(_entry('evk_conv2d_wgrad_x3') if x3 else 'evk_conv2d_wgrad', ctypes.byref(dk), xk.data_ptr(), dy_ptr,
-                dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes, st)
+        if h2:
+            _C.call('evk_conv2d_wgrad_f16x2', ctypes.byref(dk), xk.data_ptr(), xbits.data_ptr(), dy_ptr, dybits.data_ptr(),
+                    dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes, st)
+        else:
+            _C.call(_entry('evk_conv2d_wgrad_x3') if x3 else 'evk_conv2d_wgrad', ctypes.byref(dk), xk.data_ptr(), dy_ptr,
+                    dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes, st)
         if sp is not None:
             sp.stop()
         if need_dw:

@@ -18,7 +18,7 @@ __all__ = ['fold_batchnorm', 'unfold_batchnorm', 'conv_bn']
 
 
 class _Folded(object):
-    __slots__ = ('weight', 'bias', 'planes', 'planes_key', 'cin', 'cin_p', 'stamp')
+    __slots__ = ('weight', 'bias', 'planes', 'planes_key', 'cin', 'cin_p', 'stamp', 'wbits')
 
 
 def _stamp(conv, bn):
@@ -146,16 +146,28 @@ def folded_conv2d(x, conv, residual=None, relu=False):
             raise ValueError('folded conv: residual shape mismatch')
         res_ptr = residual.data_ptr()
     flags = 1 if relu else 0
-    if HF.get_conv_math() in ('bf16x3', 'bf16') and f.cin_p == cin and cin % 8 == 0:
-        # constant at inference: split once per input geometry (the plane layout follows the kernel the
+    math = HF.get_conv_math()
+    if math in ('f16x2', 'bf16x3', 'bf16') and f.cin_p == cin and cin % 8 == 0:
+        # constant at inference: split once per input geometry and arithmetic (the plane layout follows the kernel the
         # descriptor selects)
-        if f.planes is None or f.planes_key != (n, h, w):
-            f.planes_key = (n, h, w)
+        h2 = math == 'f16x2'
+        if f.planes is None or f.planes_key != (n, h, w, h2):
+            f.planes_key = (n, h, w, h2)
             lib = _C.load()
             f.planes = torch.empty((lib.evk_conv2d_split_weight_bytes(ctypes.byref(d), 0),), dtype=torch.uint8, device=dev)
-            _C.call('evk_conv2d_split_weight', ctypes.byref(d), f.weight.data_ptr(), 0, f.planes.data_ptr(), st)
-        _C.call('evk_conv2d_fwd_x3_res', ctypes.byref(d), x_ptr, f.planes.data_ptr(), f.bias.data_ptr(), res_ptr,
-                y.data_ptr(), flags, st)
+            if h2:
+                f.wbits = HF.absmax_bits(f.weight, st)
+                _C.call('evk_conv2d_split_weight_f16x2', ctypes.byref(d), f.weight.data_ptr(), 0, f.planes.data_ptr(),
+                        f.wbits.data_ptr(), st)
+            else:
+                _C.call('evk_conv2d_split_weight', ctypes.byref(d), f.weight.data_ptr(), 0, f.planes.data_ptr(), st)
+        if h2:
+            xbits = HF.absmax_bits(x, st)
+            _C.call('evk_conv2d_fwd_f16x2', ctypes.byref(d), x_ptr, xbits.data_ptr(), f.planes.data_ptr(), f.wbits.data_ptr(),
+                    f.bias.data_ptr(), res_ptr, y.data_ptr(), flags, None, 0, ctypes.byref(ctypes.c_int32(0)), st)
+        else:
+            _C.call('evk_conv2d_fwd_x3_res', ctypes.byref(d), x_ptr, f.planes.data_ptr(), f.bias.data_ptr(), res_ptr,
+                    y.data_ptr(), flags, st)
     else:
         _C.call('evk_conv2d_fwd_res', ctypes.byref(d), x_ptr, f.weight.data_ptr(), f.bias.data_ptr(), res_ptr, y.data_ptr(),
                 flags, st)

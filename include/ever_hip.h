@@ -127,6 +127,34 @@ int evk_conv2d_dgrad_bf16(const evk_conv_desc* d, const float* dy, const void* w
                           void* stream);
 int evk_conv2d_wgrad_bf16(const evk_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* "f16x2" arithmetic — the default of the training step since round 2: every fp32 operand is divided by a per-tensor
+ * power of two s and split into TWO fp16 terms x / s = h + l (11-bit significands, round-to-nearest-even; the largest
+ * element lands in [2^13, 2^14), |x/s - h - l| <= 2^-22 |x/s|), the product is rebuilt from the three partial products
+ * l*wh + h*wl + h*wh on v_mfma_f32_32x32x16_f16 (dropped: l*wl <= 2^-22 |x*w|), accumulated in fp32 and multiplied by
+ * the two scales at the end.  Same call sites as the x3 forms (nn.Conv2d at _resnets.py:21-29,149, fpn.py:23-37,
+ * fs_relation.py:23-53), same plane buffers (planes 0 and 1 are used), half the matrix work.
+ *   evk_absmax:        bit image of max|x| (a non-negative float read as uint32) -> *out_bits (device); `workspace` =
+ *                      evk_absmax_workspace_bytes() bytes, ZERO before the first call, private to one stream
+ *   evk_absmax_multi:  the same for n tensors in one launch (the weights, once per optimiser step)
+ *   *_absmax arguments below are such device words; the kernels derive s = 2^(exponent - 13) from them. */
+size_t evk_absmax_workspace_bytes(void);
+int evk_absmax(const float* x, int64_t n, uint32_t* out_bits, void* workspace, void* stream);
+int evk_absmax_multi(const float* const* ptrs_dev, const int64_t* sizes_dev, int32_t n_tensors, uint32_t* out_bits,
+                     void* stream);
+int evk_conv2d_split_weight_f16x2(const evk_conv_desc* d, const float* w, int32_t for_dgrad, void* wsplit,
+                                  const uint32_t* w_absmax, void* stream);
+/* job.arg[11] = index of the job's weight in absmax_dev */
+int evk_conv2d_split_multi_f16x2(const evk_split_job* jobs_dev, const int32_t* block_map_dev, int32_t nblocks,
+                                 const uint32_t* absmax_dev, void* stream);
+/* residual, bn_parts (+ nparts) may be NULL; with bn_parts the epilogue also emits the BatchNorm records (fwd_x3_stats) */
+int evk_conv2d_fwd_f16x2(const evk_conv_desc* d, const float* x, const uint32_t* x_absmax, const void* wsplit,
+                         const uint32_t* w_absmax, const float* bias, const float* residual, float* y, uint32_t flags,
+                         float* bn_parts, int32_t bn_capacity, int32_t* nparts /* host */, void* stream);
+int evk_conv2d_dgrad_f16x2(const evk_conv_desc* d, const float* dy, const uint32_t* dy_absmax, const void* wsplit_t,
+                           const uint32_t* w_absmax, const float* accum, float* dx, void* stream);
+int evk_conv2d_wgrad_f16x2(const evk_conv_desc* d, const float* x, const uint32_t* x_absmax, const float* dy,
+                           const uint32_t* dy_absmax, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                           void* stream);
 /* y = act(conv(x, w) + bias + residual): inference form of a residual block's last convolution with its
  * BatchNorm folded into (w, bias) — `out += identity; relu` of reference _resnets.py:95-112 in the epilogue. */
 int evk_conv2d_fwd_res(const evk_conv_desc* d, const float* x, const float* w, const float* bias,

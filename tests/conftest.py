@@ -33,9 +33,10 @@ def cuda():
     return torch.device('cuda:0')
 
 
-@pytest.fixture(params=['bf16x3', 'f32'])
+@pytest.fixture(params=['f16x2', 'bf16x3', 'f32'])
 def conv_math(request):
-    """Run the test under both convolution arithmetics (split-bf16 MFMA default, exact fp32 MFMA yardstick)."""
+    """Run the test under the three fp32-grade convolution arithmetics (fp16 2-term split = default, bf16 3-term split,
+    exact fp32 MFMA = yardstick)."""
     from ever_amd.hip import functional as HF
     prev = HF.set_conv_math(request.param)
     yield request.param
