@@ -131,7 +131,9 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __rest
                                                              float* __restrict__ running_var, float momentum,
                                                              float eps, float* __restrict__ save_mean,
                                                              float* __restrict__ save_invstd,
-                                                             float* __restrict__ scale_shift) {
+                                                             float* __restrict__ scale_shift,
+                                                             uint32_t* __restrict__ amax) {
+  if (amax && blockIdx.x == 0 && threadIdx.x == 0) *amax = 0;   // the apply pass accumulates max|y| into it
   int c;
   double s, q;
   if (!reduce_partials(partial, nblk, C, c, s, q)) return;
@@ -154,8 +156,9 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __rest
 __global__ void bn_eval_coef_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                     const float* __restrict__ rm, const float* __restrict__ rv, float eps, int C,
                                     float* __restrict__ scale_shift, float* __restrict__ save_mean,
-                                    float* __restrict__ save_invstd) {
+                                    float* __restrict__ save_invstd, uint32_t* __restrict__ amax) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (amax && c == 0) *amax = 0;
   if (c >= C) return;
   const float invstd = (float)(1.0 / sqrt((double)rv[c] + (double)eps));
   if (save_mean) save_mean[c] = rm[c];
@@ -176,6 +179,40 @@ __device__ __forceinline__ int chunk_of(size_t blk_base, int c4) {
   return r >= c4 ? r - c4 : r;
 }
 
+// max|v| over a workgroup's 16-byte elements -> amax_partial[blockIdx.x] (bit image; the f16x2 convolution arithmetic's
+// operand scale of the tensor being written, csrc/absmax.hip), folded into one word by absmax_fold_kernel right after.
+// Plain stores only: an atomic (or even a guarded read) of ONE word from every workgroup of a 268 MB map is a
+// same-address hot spot across the eight XCDs — measured 0.4 TB/s for the whole pass instead of 4.6.
+__device__ __forceinline__ void block_absmax(const f32x4 v, bool valid, uint32_t* __restrict__ amax_partial) {
+  __shared__ uint32_t red[4];
+  uint32_t m = 0;
+  if (valid) {
+    m = __builtin_bit_cast(uint32_t, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    const uint32_t nan_or = ((__builtin_bit_cast(uint32_t, v.x) | __builtin_bit_cast(uint32_t, v.y) |
+                              __builtin_bit_cast(uint32_t, v.z) | __builtin_bit_cast(uint32_t, v.w)) & 0x7fffffffu);
+    if (nan_or > 0x7f800000u && (v.x != v.x || v.y != v.y || v.z != v.z || v.w != v.w)) m = 0x7fc00000u;  // keep NaNs visible
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) amax_partial[blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
+}
+// out (zeroed by the finalisation kernel launched before the apply pass) = max over the workgroups' words
+__global__ __launch_bounds__(256) void absmax_fold_kernel(const uint32_t* __restrict__ partial, size_t n,
+                                                          uint32_t* __restrict__ out) {
+  uint32_t m = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = max(m, partial[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+static int launch_absmax_fold(const uint32_t* partial, size_t n, uint32_t* out, hipStream_t st) {
+  const unsigned blocks = (unsigned)((n + 4095) / 4096 > 64 ? 64 : (n + 4095) / 4096);
+  hipLaunchKernelGGL(absmax_fold_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, partial, n, out);
+  return check_launch("absmax_fold");
+}
+
 // y = act(x*scale + shift [+ residual]).
 // ONE 16-byte element per thread and a grid of n4/256 workgroups: on the 268 MB maps a 1-read + 1-write stream
 // runs at 6.1 TB/s this way against 4.3 TB/s for 2048 grid-striding workgroups with four loads in flight each
@@ -184,20 +221,24 @@ __device__ __forceinline__ int chunk_of(size_t blk_base, int c4) {
 // per workgroup would cost more than the 4 KB a workgroup streams.
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ residual,
                                                        const float* __restrict__ scale_shift, float* __restrict__ y,
-                                                       size_t n4, int C, int relu) {
+                                                       size_t n4, int C, int relu, uint32_t* __restrict__ amax) {
   const size_t base = (size_t)blockIdx.x * 256;
   const size_t i = base + threadIdx.x;
-  if (i >= n4) return;
-  const int c4 = C >> 2;
-  const int cb = chunk_of(base, c4);
-  const f32x4 sc = reinterpret_cast<const f32x4*>(scale_shift)[cb];
-  const f32x4 sh = reinterpret_cast<const f32x4*>(scale_shift + C)[cb];
-  f32x4 v = reinterpret_cast<const f32x4*>(x)[i] * sc + sh;
-  if (residual) v += reinterpret_cast<const f32x4*>(residual)[i];
-  if (relu) {
-    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  const bool valid = i < n4;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (valid) {
+    const int c4 = C >> 2;
+    const int cb = chunk_of(base, c4);
+    const f32x4 sc = reinterpret_cast<const f32x4*>(scale_shift)[cb];
+    const f32x4 sh = reinterpret_cast<const f32x4*>(scale_shift + C)[cb];
+    v = reinterpret_cast<const f32x4*>(x)[i] * sc + sh;
+    if (residual) v += reinterpret_cast<const f32x4*>(residual)[i];
+    if (relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    reinterpret_cast<f32x4*>(y)[i] = v;
   }
-  reinterpret_cast<f32x4*>(y)[i] = v;
+  if (amax) block_absmax(v, valid, amax);   // all lanes of the workgroup arrive here together
 }
 
 // Backward stage 1: g = dy * (y > 0) ; partial[blk][0][C] = sum g, [1][C] = sum g * xhat.
@@ -294,7 +335,9 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
                                                            double inv_rows, const float* __restrict__ gamma,
                                                            const float* __restrict__ invstd,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           float* __restrict__ coef, int train) {
+                                                           float* __restrict__ coef, int train,
+                                                           uint32_t* __restrict__ amax) {
+  if (amax && blockIdx.x == 0 && threadIdx.x == 0) *amax = 0;   // stage 3 accumulates max|dx| into it
   int c;
   double s, q;
   if (!reduce_partials(partial, nblk, C, c, s, q)) return;
@@ -314,34 +357,39 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ coef,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ dx,
-                                                           size_t n4, int C, int relu) {
+                                                           size_t n4, int C, int relu, uint32_t* __restrict__ amax) {
   const size_t base = (size_t)blockIdx.x * 256;
   const size_t i = base + threadIdx.x;
-  if (i >= n4) return;
-  const int c4 = C >> 2;
-  const int c = chunk_of(base, c4);
-  const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, z4 = {0.f, 0.f, 0.f, 0.f};
-  const f32x4 k0 = reinterpret_cast<const f32x4*>(coef)[c];
-  const f32x4 k1 = reinterpret_cast<const f32x4*>(coef + C)[c];
-  const f32x4 k2 = reinterpret_cast<const f32x4*>(coef + 2 * C)[c];
-  const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c];
-  const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[c];
-  f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
-  const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
-  if (relu) {
-    f32x4 yy;
-    if (relu == 1) {
-      yy = reinterpret_cast<const f32x4*>(y)[i];
-    } else {  // the forward's pre-activation, same sc/sh arithmetic as bn_stats_final_kernel
-      const f32x4 sc = (gamma ? reinterpret_cast<const f32x4*>(gamma)[c] : one4) * is;
-      const f32x4 sh = (beta ? reinterpret_cast<const f32x4*>(beta)[c] : z4) - mu * sc;
-      yy = xv * sc + sh;
+  const bool valid = i < n4;
+  f32x4 out = {0.f, 0.f, 0.f, 0.f};
+  if (valid) {
+    const int c4 = C >> 2;
+    const int c = chunk_of(base, c4);
+    const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, z4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 k0 = reinterpret_cast<const f32x4*>(coef)[c];
+    const f32x4 k1 = reinterpret_cast<const f32x4*>(coef + C)[c];
+    const f32x4 k2 = reinterpret_cast<const f32x4*>(coef + 2 * C)[c];
+    const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c];
+    const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[c];
+    f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+    const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+    if (relu) {
+      f32x4 yy;
+      if (relu == 1) {
+        yy = reinterpret_cast<const f32x4*>(y)[i];
+      } else {  // the forward's pre-activation, same sc/sh arithmetic as bn_stats_final_kernel
+        const f32x4 sc = (gamma ? reinterpret_cast<const f32x4*>(gamma)[c] : one4) * is;
+        const f32x4 sh = (beta ? reinterpret_cast<const f32x4*>(beta)[c] : z4) - mu * sc;
+        yy = xv * sc + sh;
+      }
+      g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+      g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
     }
-    g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
-    g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+    const f32x4 xh = (xv - mu) * is;
+    out = k0 * (g - k1 - xh * k2);
+    reinterpret_cast<f32x4*>(dx)[i] = out;
   }
-  const f32x4 xh = (xv - mu) * is;
-  reinterpret_cast<f32x4*>(dx)[i] = k0 * (g - k1 - xh * k2);
+  if (amax) block_absmax(out, valid, amax);   // all lanes of the workgroup arrive here together
 }
 
 // Statistics that arrive as per-row-part records (count, mean, M2) from the producing convolution's epilogue
@@ -353,7 +401,9 @@ __global__ __launch_bounds__(256) void bn_parts_final_kernel(const float* __rest
                                                              float* __restrict__ running_mean,
                                                              float* __restrict__ running_var, float momentum, float eps,
                                                              float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                                             float* __restrict__ scale_shift) {
+                                                             float* __restrict__ scale_shift,
+                                                             uint32_t* __restrict__ amax) {
+  if (amax && blockIdx.x == 0 && threadIdx.x == 0) *amax = 0;   // the apply pass accumulates max|y| into it
   // With a common pivot p (the first record's mean) the merge of all records is three plain sums,
   //   N = sum n_i,  A = sum n_i (mean_i - p),  B = sum [M2_i + n_i (mean_i - p)^2]:  mean = p + A/N,  M2 = B - A^2/N
   // (Chan's pairwise formula telescoped; no division inside the loop, no order dependence beyond the fixed one below).
@@ -421,13 +471,18 @@ using namespace evk;
 
 extern "C" size_t evk_bn_workspace_bytes(int64_t rows, int32_t C) {
   if (rows <= 0 || C <= 0) return 0;
-  return ((size_t)kMaxStatBlocks * 2 * C + 8 * (size_t)C) * sizeof(float);
+  // statistics partials + per-channel vectors + one word per workgroup of the apply pass (fused max|output|)
+  return ((size_t)kMaxStatBlocks * 2 * C + 8 * (size_t)C + ((size_t)rows * C / 4 + 255) / 256 + 64) * sizeof(float);
+}
+
+static inline uint32_t* amax_words(void* workspace, int32_t C) {
+  return reinterpret_cast<uint32_t*>((float*)workspace + (size_t)kMaxStatBlocks * 2 * C + 8 * (size_t)C);
 }
 
 extern "C" int evk_bn_fwd_train(const float* x, const float* residual, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, float momentum, float eps, float* y,
                                 float* save_mean, float* save_invstd, int64_t rows, int32_t C, uint32_t flags,
-                                void* workspace, size_t workspace_bytes, void* stream) {
+                                void* workspace, size_t workspace_bytes, uint32_t* y_absmax, void* stream) {
   EVK_REQUIRE(x && y && save_mean && save_invstd, EVK_E_INVALID, "bn_fwd_train: null pointer");
   EVK_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 2048, EVK_E_UNSUPPORTED, "bn_fwd_train: rows=%lld C=%d",
               (long long)rows, C);
@@ -444,20 +499,22 @@ extern "C" int evk_bn_fwd_train(const float* x, const float* residual, const flo
   const double unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
   hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, x, partial, pl.nblk, C,
                      1.0 / (double)rows, unbias, gamma, beta, running_mean, running_var, momentum, eps, save_mean,
-                     save_invstd, scale_shift);
+                     save_invstd, scale_shift, y_absmax);
   rc = check_launch("bn_stats_final");
   if (rc) return rc;
   const size_t n4 = (size_t)rows * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, x, residual,
-                     scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0);
-  return check_launch("bn_apply");
+                     scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, y_absmax ? amax_words(workspace, C) : nullptr);
+  rc = check_launch("bn_apply");
+  if (rc || !y_absmax) return rc;
+  return launch_absmax_fold(amax_words(workspace, C), oneshot_grid(n4), y_absmax, st);
 }
 
 extern "C" int evk_bn_fwd_train_parts(const float* x, const float* residual, const float* gamma, const float* beta,
                                       float* running_mean, float* running_var, float momentum, float eps, float* y,
                                       float* save_mean, float* save_invstd, int64_t rows, int32_t C, uint32_t flags,
                                       const float* parts, int32_t nparts, void* workspace, size_t workspace_bytes,
-                                      void* stream) {
+                                      uint32_t* y_absmax, void* stream) {
   EVK_REQUIRE(x && y && save_mean && save_invstd && parts && nparts > 0, EVK_E_INVALID, "bn_fwd_train_parts: bad argument");
   EVK_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 2048, EVK_E_UNSUPPORTED, "bn_fwd_train_parts: rows=%lld C=%d",
               (long long)rows, C);
@@ -467,40 +524,44 @@ extern "C" int evk_bn_fwd_train_parts(const float* x, const float* residual, con
   float* scale_shift = (float*)workspace + (size_t)kMaxStatBlocks * 2 * C;
   hipLaunchKernelGGL(bn_parts_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, parts, nparts, C,
                      (double)rows, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
-                     scale_shift);
+                     scale_shift, y_absmax);
   int rc = check_launch("bn_parts_final");
   if (rc) return rc;
   const size_t n4 = (size_t)rows * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, x, residual,
-                     scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0);
-  return check_launch("bn_apply");
+                     scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, y_absmax ? amax_words(workspace, C) : nullptr);
+  rc = check_launch("bn_apply");
+  if (rc || !y_absmax) return rc;
+  return launch_absmax_fold(amax_words(workspace, C), oneshot_grid(n4), y_absmax, st);
 }
 
 extern "C" int evk_bn_fwd_eval(const float* x, const float* residual, const float* gamma, const float* beta,
                                const float* running_mean, const float* running_var, float eps, float* y,
                                float* save_mean, float* save_invstd, int64_t rows, int32_t C, uint32_t flags,
-                               void* workspace, size_t workspace_bytes, void* stream) {
+                               void* workspace, size_t workspace_bytes, uint32_t* y_absmax, void* stream) {
   EVK_REQUIRE(x && y && running_mean && running_var, EVK_E_INVALID, "bn_fwd_eval: null pointer");
   EVK_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 2048, EVK_E_UNSUPPORTED, "bn_fwd_eval: rows=%lld C=%d",
               (long long)rows, C);
-  EVK_REQUIRE(workspace && workspace_bytes >= 2 * (size_t)C * sizeof(float), EVK_E_WORKSPACE,
-              "bn_fwd_eval: workspace too small");
+  EVK_REQUIRE(workspace && workspace_bytes >= (y_absmax ? evk_bn_workspace_bytes(rows, C) : 2 * (size_t)C * sizeof(float)),
+              EVK_E_WORKSPACE, "bn_fwd_eval: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   float* scale_shift = (float*)workspace;
   hipLaunchKernelGGL(bn_eval_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, st, gamma, beta, running_mean,
-                     running_var, eps, C, scale_shift, save_mean, save_invstd);
+                     running_var, eps, C, scale_shift, save_mean, save_invstd, y_absmax);
   int rc = check_launch("bn_eval_coef");
   if (rc) return rc;
   const size_t n4 = (size_t)rows * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, x, residual,
-                     scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0);
-  return check_launch("bn_apply");
+                     scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, y_absmax ? amax_words(workspace, C) : nullptr);
+  rc = check_launch("bn_apply");
+  if (rc || !y_absmax) return rc;
+  return launch_absmax_fold(amax_words(workspace, C), oneshot_grid(n4), y_absmax, st);
 }
 
 extern "C" int evk_bn_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
                           const float* save_mean, const float* save_invstd, float* dx, float* d_residual,
                           float* dgamma, float* dbeta, int64_t rows, int32_t C, uint32_t flags, int32_t train,
-                          void* workspace, size_t workspace_bytes, void* stream) {
+                          void* workspace, size_t workspace_bytes, uint32_t* dx_absmax, void* stream) {
   EVK_REQUIRE(dy && x && save_mean && save_invstd && dx, EVK_E_INVALID, "bn_bwd: null pointer");
   // ReLU mask: from the saved output y when given (needed with a residual), else recomputed from x
   const int relu = (flags & EVK_BN_RELU) ? (y ? 1 : 2) : 0;
@@ -519,7 +580,7 @@ extern "C" int evk_bn_bwd(const float* dy, const float* x, const float* y, const
   int rc = check_launch("bn_bwd_partial");
   if (rc) return rc;
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, partial, pl.nblk, C,
-                     1.0 / (double)rows, gamma, save_invstd, dgamma, dbeta, coef, train ? 1 : 0);
+                     1.0 / (double)rows, gamma, save_invstd, dgamma, dbeta, coef, train ? 1 : 0, dx_absmax);
   rc = check_launch("bn_bwd_final");
   if (rc) return rc;
   const size_t n4 = (size_t)rows * C / 4;
@@ -527,8 +588,11 @@ extern "C" int evk_bn_bwd(const float* dy, const float* x, const float* y, const
   const float* gsrc = d_residual ? d_residual : dy;
   const int relu3 = d_residual ? 0 : relu;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, gsrc, x, y,
-                     save_mean, save_invstd, coef, gamma, beta, dx, n4, C, relu3);
-  return check_launch("bn_bwd_apply");
+                     save_mean, save_invstd, coef, gamma, beta, dx, n4, C, relu3,
+                     dx_absmax ? amax_words(workspace, C) : nullptr);
+  rc = check_launch("bn_bwd_apply");
+  if (rc || !dx_absmax) return rc;
+  return launch_absmax_fold(amax_words(workspace, C), oneshot_grid(n4), dx_absmax, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -612,7 +676,7 @@ extern "C" int evk_bn_apply_stats(const float* x, const float* residual, const f
                      scale_shift);
   const size_t n4 = (size_t)rows * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, x, residual,
-                     (const float*)scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0);
+                     (const float*)scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, (uint32_t*)nullptr);
   return check_launch("bn_apply_stats");
 }
 
@@ -648,6 +712,6 @@ extern "C" int evk_bn_bwd_apply_sums(const float* dy, const float* x, const floa
   hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, st, gamma, invstd, mean_g, mean_gx, C, coef);
   const size_t n4 = (size_t)rows * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, dy, x, y, mean,
-                     invstd, (const float*)coef, gamma, beta, dx, n4, C, relu);
+                     invstd, (const float*)coef, gamma, beta, dx, n4, C, relu, (uint32_t*)nullptr);
   return check_launch("bn_bwd_apply_sums");
 }

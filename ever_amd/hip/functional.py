@@ -51,13 +51,33 @@ def _f16x2():
     return _CONV_MATH == 'f16x2'
 
 
+absmax_stats = {'hits': 0, 'standalone': 0, 'fused': 0}   # where the operand scales came from (tools / tests)
+_FUSED_AMAX = os.environ.get('EVK_FUSED_ABSMAX', '1') != '0'
+
+
+def _note_amax(t, bits):
+    """Record that `bits` holds max|t| (written by the kernel that produced t)."""
+    try:
+        t._evk_amax = (t._version, t.data_ptr(), bits)
+        absmax_stats['fused'] += 1
+    except (AttributeError, RuntimeError):
+        pass
+
+
+def _amax_out(dev):
+    """A device word for a producer kernel to leave max|output| in, or None when no consumer will want it."""
+    return torch.empty((1,), device=dev, dtype=torch.int32) if (_FUSED_AMAX and _f16x2()) else None
+
+
 def absmax_bits(t, st):
     """int32[1] device tensor holding the bit image of max|t| (the f16x2 operand scale derives from it inside the
     kernels).  Cached on the tensor object: the forward's scale of x serves the weight gradient, the scale of dy serves
     data and weight gradient, a block input serves both convolutions that read it."""
     hit = getattr(t, '_evk_amax', None)
     if hit is not None and hit[0] == t._version and hit[1] == t.data_ptr():
+        absmax_stats['hits'] += 1
         return hit[2]
+    absmax_stats['standalone'] += 1
     bits = torch.empty((1,), device=t.device, dtype=torch.int32)
     sp = timing.span('absmax', 0.0, 4.0 * t.numel())
     _C.call('evk_absmax', t.data_ptr(), t.numel(), bits.data_ptr(), weight_planes.absmax_workspace(t.device, st).data_ptr(), st)
@@ -793,6 +813,7 @@ class _BatchNormActFn(Function):
         save_mean = torch.empty((c,), device=dev, dtype=torch.float32)
         save_invstd = torch.empty((c,), device=dev, dtype=torch.float32)
         flags = 1 if relu else 0
+        abits = _amax_out(dev)
         # algorithmic bytes (fp32): statistics read + apply read/write (+ residual read)
         nb = 4.0 * x.numel() * ((3 if training else 2) + (1 if residual is not None else 0))
         if training and parts is not None:
@@ -800,15 +821,17 @@ class _BatchNormActFn(Function):
             _timed_call('bn', nb - 4.0 * x.numel(), 'evk_bn_fwd_train_parts', x.data_ptr(), _ptr(residual), _ptr(weight),
                         _ptr(bias), _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), y.data_ptr(),
                         save_mean.data_ptr(), save_invstd.data_ptr(), rows, c, flags, parts[0].data_ptr(), parts[1],
-                        ws.data_ptr(), ws_bytes, st)
+                        ws.data_ptr(), ws_bytes, _ptr(abits), st)
         elif training:
             _timed_call('bn', nb, 'evk_bn_fwd_train', x.data_ptr(), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(running_mean),
                     _ptr(running_var), float(momentum), float(eps), y.data_ptr(), save_mean.data_ptr(),
-                    save_invstd.data_ptr(), rows, c, flags, ws.data_ptr(), ws_bytes, st)
+                    save_invstd.data_ptr(), rows, c, flags, ws.data_ptr(), ws_bytes, _ptr(abits), st)
         else:
             _timed_call('bn', nb, 'evk_bn_fwd_eval', x.data_ptr(), _ptr(residual), _ptr(weight), _ptr(bias), running_mean.data_ptr(),
                     running_var.data_ptr(), float(eps), y.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(),
-                    rows, c, flags, ws.data_ptr(), ws_bytes, st)
+                    rows, c, flags, ws.data_ptr(), ws_bytes, _ptr(abits), st)
+        global _AMAX_HANDOFF
+        _AMAX_HANDOFF = abits
         ctx.training = training
         ctx.relu = relu
         ctx.has_res = residual is not None
@@ -837,9 +860,12 @@ class _BatchNormActFn(Function):
         dbeta = torch.empty((c,), device=dev, dtype=torch.float32) if has_affine else None
         # reduce pass reads dy, x (+y mask); apply pass reads g, x and writes dx (+ the residual gradient write)
         nb = 4.0 * x.numel() * (5 + (1 if y is not None else 0) + (1 if need_res else 0))
+        abits = _amax_out(dev)
         _timed_call('bn', nb, 'evk_bn_bwd', dy.data_ptr(), x.data_ptr(), _ptr(y), _ptr(weight), _ptr(bias), save_mean.data_ptr(),
                 save_invstd.data_ptr(), dx.data_ptr(), _ptr(dres), _ptr(dgamma), _ptr(dbeta), rows, c,
-                1 if ctx.relu else 0, 1 if ctx.training else 0, ws.data_ptr(), ws_bytes, st)
+                1 if ctx.relu else 0, 1 if ctx.training else 0, ws.data_ptr(), ws_bytes, _ptr(abits), st)
+        if abits is not None:
+            _note_amax(dx, abits)       # dx is the producing convolution's dy (data and weight gradient operand)
         if ctx.has_res and not need_res:
             dres = None
         return (dx, dres, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None,
@@ -857,8 +883,17 @@ def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentu
     parts = getattr(x, '_evk_bn_parts', None) if use_batch_stats else None
     if parts is not None:
         del x._evk_bn_parts
-    return _BatchNormActFn.apply(x, residual, weight, bias, running_mean, running_var, bool(use_batch_stats),
-                                 0.0 if momentum is None else momentum, eps, bool(relu), parts)
+    global _AMAX_HANDOFF
+    _AMAX_HANDOFF = None
+    y = _BatchNormActFn.apply(x, residual, weight, bias, running_mean, running_var, bool(use_batch_stats),
+                              0.0 if momentum is None else momentum, eps, bool(relu), parts)
+    if _AMAX_HANDOFF is not None:       # the apply pass left max|y| in this word: y is the next convolution's operand
+        _note_amax(y, _AMAX_HANDOFF)
+        _AMAX_HANDOFF = None
+    return y
+
+
+_AMAX_HANDOFF = None
 
 
 # ------------------------------------------------------------------------------------ pointwise

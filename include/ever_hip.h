@@ -235,19 +235,23 @@ size_t evk_bn_workspace_bytes(int64_t rows, int32_t C);
 int evk_bn_fwd_train(const float* x, const float* residual, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, float momentum, float eps,
                      float* y, float* save_mean, float* save_invstd, int64_t rows, int32_t C,
-                     uint32_t flags, void* workspace, size_t workspace_bytes, void* stream);
+                     uint32_t flags, void* workspace, size_t workspace_bytes, uint32_t* y_absmax, void* stream);
+/* y_absmax / dx_absmax (may be NULL) in the four calls of this section: the apply pass also leaves the bit image of
+ * max|output| in that device word (what evk_absmax would compute) — the tensor is the next convolution's operand and
+ * the f16x2 arithmetic needs its scale; producing it here saves that tensor one read pass. */
 /* Eval forward (running statistics): y = act((x-rm)/sqrt(rv+eps)*gamma+beta [+ residual]). */
 /* evk_bn_fwd_train with the statistics pass replaced by the merge (Chan, fp64, fixed order) of the (count, mean, M2)
  * records a convolution epilogue wrote (evk_conv2d_fwd_x3_stats): one pass over x less per layer. */
 int evk_bn_fwd_train_parts(const float* x, const float* residual, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, float momentum, float eps, float* y,
                            float* save_mean, float* save_invstd, int64_t rows, int32_t C, uint32_t flags,
-                           const float* parts, int32_t nparts, void* workspace, size_t workspace_bytes, void* stream);
+                           const float* parts, int32_t nparts, void* workspace, size_t workspace_bytes,
+                           uint32_t* y_absmax, void* stream);
 int evk_bn_fwd_eval(const float* x, const float* residual, const float* gamma, const float* beta,
                     const float* running_mean, const float* running_var, float eps, float* y,
                     float* save_mean /* may be NULL */, float* save_invstd /* may be NULL */,
                     int64_t rows, int32_t C, uint32_t flags, void* workspace, size_t workspace_bytes,
-                    void* stream);
+                    uint32_t* y_absmax, void* stream);
 /* Backward of the training forward.  ReLU mask: taken from the forward output y when y != NULL
  * (required when the forward had a residual), else recomputed from x, gamma, beta and the saved
  * statistics (one HBM read less per pass).  d_residual (may be NULL) receives the masked upstream
@@ -255,7 +259,7 @@ int evk_bn_fwd_eval(const float* x, const float* residual, const float* gamma, c
 int evk_bn_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
                const float* save_mean, const float* save_invstd, float* dx, float* d_residual,
                float* dgamma, float* dbeta, int64_t rows, int32_t C, uint32_t flags, int32_t train,
-               void* workspace, size_t workspace_bytes, void* stream);
+               void* workspace, size_t workspace_bytes, uint32_t* dx_absmax, void* stream);
 
 /* ------------------------------------------------------------------ pointwise / resampling - */
 /* nn.ReLU (fs_relation.py:25) and its backward; elementwise add (fpn.py:105). */

@@ -191,7 +191,7 @@ def test_library_exports_every_declared_symbol():
     d = _C.ConvDesc(1, 8, 8, 3, 8, 8, 4, 1, 1, 1, 1, 0, 0, 1, 1)
     rc = lib.evk_conv2d_fwd(ctypes.byref(d), 1, 1, None, 1, 0, None)
     assert rc == -2 and b'multiple of 4' in lib.evk_last_error()   # EVK_E_UNSUPPORTED: Cin % 4
-    assert lib.evk_bn_fwd_train(None, None, None, None, None, None, 0.1, 1e-5, None, None, None, 4, 4, 0, None, 0, None) == -1
+    assert lib.evk_bn_fwd_train(None, None, None, None, None, None, 0.1, 1e-5, None, None, None, 4, 4, 0, None, 0, None, None) == -1
     assert lib.evk_conv2d_wgrad_workspace_bytes(ctypes.byref(_C.ConvDesc(2, 8, 8, 64, 8, 8, 64, 3, 3, 1, 1, 1, 1, 1, 1))) > 0
 
 
