@@ -33,12 +33,13 @@ def record_problems():
     orig = _C.call
 
     def spy(name, *args):
-        if name in ('evk_conv2d_fwd_x3', 'evk_conv2d_fwd_x3_stats', 'evk_conv2d_dgrad_x3'):
+        if name in ('evk_conv2d_fwd_f16x2', 'evk_conv2d_dgrad_f16x2'):
             d = args[0]._obj
             key = tuple(getattr(d, f) for f in FIELDS)
-            kind = {'evk_conv2d_fwd_x3': 'fwd', 'evk_conv2d_fwd_x3_stats': 'fwd_stats', 'evk_conv2d_dgrad_x3': 'dgrad'}[name]
-            if kind == 'dgrad' and args[3]:
-                kind = 'dgrad_accum'
+            if name == 'evk_conv2d_fwd_f16x2':
+                kind = 'fwd_stats' if args[9] else 'fwd'
+            else:
+                kind = 'dgrad_accum' if args[5] else 'dgrad'
             probs[(kind, key)] += 1
         return orig(name, *args)
     _C.call = spy
@@ -80,22 +81,25 @@ def main():
         dy = torch.randn(n, ho, wo, cout, generator=g).to(dev)
         for_dgrad = 1 if kind.startswith('dgrad') else 0
         planes = torch.empty(lib.evk_conv2d_split_weight_bytes(ctypes.byref(d), for_dgrad), dtype=torch.uint8, device=dev)
-        _C.call('evk_conv2d_split_weight', ctypes.byref(d), wt.data_ptr(), for_dgrad, planes.data_ptr(), st)
-        if kind == 'fwd':
+        bits = torch.zeros(4, dtype=torch.int32, device=dev)
+        aws = torch.zeros(lib.evk_absmax_workspace_bytes(), dtype=torch.uint8, device=dev)
+        src = dy if for_dgrad else x
+        _C.call('evk_absmax', src.data_ptr(), src.numel(), bits[0:1].data_ptr(), aws.data_ptr(), st)
+        _C.call('evk_absmax', wt.data_ptr(), wt.numel(), bits[1:2].data_ptr(), aws.data_ptr(), st)
+        _C.call('evk_conv2d_split_weight_f16x2', ctypes.byref(d), wt.data_ptr(), for_dgrad, planes.data_ptr(), bits[1:2].data_ptr(), st)
+        npart = ctypes.c_int32(0)
+        if kind in ('fwd', 'fwd_stats'):
             out = torch.empty(n, ho, wo, cout, device=dev)
-            fn = lambda: _C.call('evk_conv2d_fwd_x3', ctypes.byref(d), x.data_ptr(), planes.data_ptr(), None, out.data_ptr(), 0, st)
-        elif kind == 'fwd_stats':
-            out = torch.empty(n, ho, wo, cout, device=dev)
-            cap = int(lib.evk_conv2d_stats_max_parts(ctypes.byref(d)))
-            parts = torch.empty(cap * 3 * cout, device=dev)
-            npart = ctypes.c_int32(0)
-            fn = lambda: _C.call('evk_conv2d_fwd_x3_stats', ctypes.byref(d), x.data_ptr(), planes.data_ptr(), None,
-                                 out.data_ptr(), 0, parts.data_ptr(), cap, ctypes.byref(npart), st)
+            cap = int(lib.evk_conv2d_stats_max_parts(ctypes.byref(d))) if kind == 'fwd_stats' else 0
+            parts = torch.empty(max(cap, 1) * 3 * cout, device=dev)
+            fn = lambda: _C.call('evk_conv2d_fwd_f16x2', ctypes.byref(d), x.data_ptr(), bits[0:1].data_ptr(), planes.data_ptr(),
+                                 bits[1:2].data_ptr(), None, None, out.data_ptr(), 0, parts.data_ptr() if cap else None, cap,
+                                 ctypes.byref(npart), st)
         else:
             out = torch.empty(n, h, w, cin, device=dev)
             acc = torch.randn(n, h, w, cin, device=dev) if kind == 'dgrad_accum' else None
-            fn = lambda: _C.call('evk_conv2d_dgrad_x3', ctypes.byref(d), dy.data_ptr(), planes.data_ptr(),
-                                 acc.data_ptr() if acc is not None else None, out.data_ptr(), st)
+            fn = lambda: _C.call('evk_conv2d_dgrad_f16x2', ctypes.byref(d), dy.data_ptr(), bits[0:1].data_ptr(), planes.data_ptr(),
+                                 bits[1:2].data_ptr(), acc.data_ptr() if acc is not None else None, out.data_ptr(), st)
         gf = 2.0 * n * ho * wo * cout * cin * kh * kw / 1e9
         iters = 20 if gf < 50 else 8
         os.environ['EVK_X3_FORCE'] = ''
