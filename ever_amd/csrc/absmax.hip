@@ -68,7 +68,14 @@ __global__ __launch_bounds__(256) void absmax_multi_kernel(const float* const* _
   const float* x = ptrs[t];
   const size_t n = (size_t)sizes[t];
   uint32_t m = 0;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = max(m, abs_bits(x[i]));
+  if ((((uintptr_t)x) & 15) == 0) {
+    const size_t n4 = n >> 2;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) m = max4(m, x4[i]);
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = max(m, abs_bits(x[(n4 << 2) + threadIdx.x]));
+  } else {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = max(m, abs_bits(x[i]));
+  }
   m = block_max(m);
   if (threadIdx.x == 0 && m) atomicMax(out + t, m);
 }
@@ -109,6 +116,6 @@ extern "C" int evk_absmax_multi(const float* const* ptrs_dev, const int64_t* siz
     set_error("absmax_multi: memset failed");
     return EVK_E_LAUNCH;
   }
-  hipLaunchKernelGGL(absmax_multi_kernel, dim3(16, (unsigned)n_tensors), dim3(256), 0, st, ptrs_dev, sizes_dev, out_bits);
+  hipLaunchKernelGGL(absmax_multi_kernel, dim3(32, (unsigned)n_tensors), dim3(256), 0, st, ptrs_dev, sizes_dev, out_bits);
   return check_launch("absmax_multi");
 }

@@ -64,6 +64,16 @@ def _note_amax(t, bits):
         pass
 
 
+def _inherit_amax(out, src):
+    """`out` is bounded element-wise by max|src| (a convex combination, a selection, a product with a factor in [0, 1]):
+    src's word is a valid — at most slightly loose — scale source for out, and saves its read pass.  The f16x2 operand
+    keeps its 22 bits for every element within 2^-17 of the bound (csrc/x3_common.hpp)."""
+    hit = getattr(src, '_evk_amax', None)
+    if _FUSED_AMAX and hit is not None and hit[0] == src._version and hit[1] == src.data_ptr():
+        _note_amax(out, hit[2])
+    return out
+
+
 def _amax_out(dev):
     """A device word for a producer kernel to leave max|output| in, or None when no consumer will want it."""
     return torch.empty((1,), device=dev, dtype=torch.int32) if (_FUSED_AMAX and _f16x2()) else None
@@ -738,17 +748,20 @@ class _StemConvFn(Function):
         w4 = torch.empty((cout, 4, 4, 16), device=dev, dtype=torch.float32)
         _C.call('evk_stem_s2d_weight', w7.data_ptr(), w4.data_ptr(), cout, c, st)
         d = _C.ConvDesc(n, h // 2 + 3, w // 2 + 3, 16, h // 2, w // 2, cout, 4, 4, 1, 1, 0, 0, 1, 1)
-        planes = workspace(dev, _C.load().evk_conv2d_split_weight_bytes(ctypes.byref(d), 0))
-        _C.call('evk_conv2d_split_weight', ctypes.byref(d), w4.data_ptr(), 0, planes.data_ptr(), st)
+        pl_ptr, wabs_ptr, _keep = _weight_planes(weight, w4, w4.data_ptr(), d, 0, st, dev)   # (w4 is transient: split here)
+        xbits = absmax_bits(xs, st) if wabs_ptr is not None else None
         y = empty_nhwc(n, cout, h // 2, w // 2, dev)
         flops = 2.0 * n * (h // 2) * (w // 2) * cout * c * 49     # algorithmic: the 7x7 taps, not the 4x4x16 padding
         nbytes = 4.0 * (x.numel() + y.numel() + weight.numel())
         sp = timing.span('conv_igemm', flops, nbytes)
-        if _CONV_MATH == 'bf16':
-            _C.call('evk_conv2d_fwd_bf16', ctypes.byref(d), xs.data_ptr(), planes.data_ptr(), None, y.data_ptr(), 0, None, 0,
+        if wabs_ptr is not None:
+            _C.call('evk_conv2d_fwd_f16x2', ctypes.byref(d), xs.data_ptr(), xbits.data_ptr(), pl_ptr, wabs_ptr, None, None,
+                    y.data_ptr(), 0, None, 0, ctypes.byref(ctypes.c_int32(0)), st)
+        elif _CONV_MATH == 'bf16':
+            _C.call('evk_conv2d_fwd_bf16', ctypes.byref(d), xs.data_ptr(), pl_ptr, None, y.data_ptr(), 0, None, 0,
                     ctypes.byref(ctypes.c_int32(0)), st)
         else:
-            _C.call('evk_conv2d_fwd_x3', ctypes.byref(d), xs.data_ptr(), planes.data_ptr(), None, y.data_ptr(), 0, st)
+            _C.call('evk_conv2d_fwd_x3', ctypes.byref(d), xs.data_ptr(), pl_ptr, None, y.data_ptr(), 0, st)
         if sp is not None:
             sp.stop()
         ctx.desc, ctx.flops, ctx.nbytes, ctx.cin, ctx.scope = d, flops, nbytes, c, timing.current_scope()
@@ -767,9 +780,16 @@ class _StemConvFn(Function):
         ws_bytes = lib.evk_conv2d_wgrad_x3_workspace_bytes(ctypes.byref(d))
         ws = workspace(dev, ws_bytes)
         dw4 = torch.empty((d.Cout, 4, 4, 16), device=dev, dtype=torch.float32)
+        h2 = _f16x2()
+        if h2:
+            xbits, dybits = absmax_bits(xs, st), absmax_bits(dy, st)
         sp = timing.span('conv_wgrad', ctx.flops, ctx.nbytes, ctx.scope)
-        _C.call(_entry('evk_conv2d_wgrad_x3'), ctypes.byref(d), xs.data_ptr(), dy.data_ptr(), dw4.data_ptr(), None,
-                ws.data_ptr(), ws_bytes, st)
+        if h2:
+            _C.call('evk_conv2d_wgrad_f16x2', ctypes.byref(d), xs.data_ptr(), xbits.data_ptr(), dy.data_ptr(), dybits.data_ptr(),
+                    dw4.data_ptr(), None, ws.data_ptr(), ws_bytes, st)
+        else:
+            _C.call(_entry('evk_conv2d_wgrad_x3'), ctypes.byref(d), xs.data_ptr(), dy.data_ptr(), dw4.data_ptr(), None,
+                    ws.data_ptr(), ws_bytes, st)
         if sp is not None:
             sp.stop()
         dw7 = torch.empty((d.Cout, 7, 7, c), device=dev, dtype=torch.float32)
@@ -973,7 +993,7 @@ def max_pool3x3s2(x):
     x = as_nhwc(x, 'max_pool')
     if x.shape[1] % 4:
         raise HipPathError('max_pool: channels must be a multiple of 4')
-    return _MaxPoolFn.apply(x)
+    return _inherit_amax(_MaxPoolFn.apply(x), x)      # a selection of x's elements
 
 
 class _Nearest2xAddFn(Function):
@@ -1037,7 +1057,7 @@ def upsample_bilinear(x, scale_factor):
     x = as_nhwc(x, 'upsample_bilinear')
     sh, sw = (scale_factor, scale_factor) if not isinstance(scale_factor, (tuple, list)) else scale_factor
     ho, wo = int(x.shape[2] * sh), int(x.shape[3] * sw)  # floor(in * scale), as aten
-    return _BilinearFn.apply(x, ho, wo)
+    return _inherit_amax(_BilinearFn.apply(x, ho, wo), x)   # convex combinations of x's elements
 
 
 class _GapFn(Function):
@@ -1102,7 +1122,7 @@ def fs_relation(scene, content, feat):
     content, feat = as_nhwc(content, 'fs_relation.content'), as_nhwc(feat, 'fs_relation.feat')
     n, c, h, w = content.shape
     scene = as_nhwc(scene.reshape(n, c, 1, 1), 'fs_relation.scene')
-    return _RelationFn.apply(scene, content, feat)
+    return _inherit_amax(_RelationFn.apply(scene, content, feat), feat)   # sigmoid(.) * feat
 
 
 class _Mean4Fn(Function):

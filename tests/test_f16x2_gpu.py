@@ -1,0 +1,203 @@
+"""The f16x2 convolution arithmetic (default): per-tensor power-of-two scale from max|x| (evk_absmax or the kernel that
+produced the tensor), 2-term fp16 split, 3 MFMA products (csrc/x3_common.hpp).  What is pinned here, through the C-ABI:
+
+* evk_absmax / evk_absmax_multi return the exact bit image of max|x| (ragged sizes, zeros, negatives, non-finite values);
+* the convolution is SCALE-INVARIANT: operands of magnitude 1e-12 .. 1e12 give the same relative error against an fp64
+  evaluation as operands of magnitude 1 (fp16's 5-bit exponent never shows), all-zero operands give exact zeros, and a
+  tensor with one element 2^20 times its typical magnitude still meets the fp32-grade bound relative to the result;
+* scales produced by the BatchNorm apply passes equal the stand-alone ones; inherited bounds (bilinear, max-pool,
+  relation) are upper bounds;
+* cached weight planes follow the weights (optimizer-style raw writes + note_weights_changed, in-place torch writes).
+"""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(t):
+    return int(t.detach().abs().max().float().view(torch.int32).item()) if t.numel() else 0
+
+
+@pytest.mark.parametrize('n', [1, 3, 4, 5, 255, 1024, 4099, 1 << 20, (1 << 22) + 3])
+def test_absmax_is_the_exact_bit_image(cuda, n):
+    from ever_amd import _C
+    from ever_amd.hip import weight_planes
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(n)
+    x = (torch.randn(n, generator=g) * 3.0).to(cuda)
+    x[n // 2] = -77.5                      # the maximum is a negative element
+    out = torch.full((1,), -1, dtype=torch.int32, device=cuda)
+    ws = weight_planes.absmax_workspace(cuda, st)
+    for _ in range(2):                     # twice: the ticket counter must come back to zero
+        _C.call('evk_absmax', x.data_ptr(), n, out.data_ptr(), ws.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert int(out.item()) == _bits(x) == int(torch.tensor(77.5).view(torch.int32))
+    z = torch.zeros(max(n, 4), device=cuda)
+    _C.call('evk_absmax', z.data_ptr(), z.numel(), out.data_ptr(), ws.data_ptr(), st)
+    assert int(out.item()) == 0
+    x[0] = float('inf')
+    _C.call('evk_absmax', x.data_ptr(), n, out.data_ptr(), ws.data_ptr(), st)
+    assert int(out.item()) == 0x7f800000
+    x[0] = float('nan')
+    _C.call('evk_absmax', x.data_ptr(), n, out.data_ptr(), ws.data_ptr(), st)
+    assert (int(out.item()) >> 23) == 0xff           # a NaN anywhere is visible as a non-finite maximum
+
+
+def test_absmax_multi(cuda):
+    from ever_amd import _C
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(3)
+    ts = [(torch.randn(n, generator=g) * (10.0 ** e)).to(cuda) for n, e in ((7, 0), (4096, -3), (300001, 5), (64, -20), (12, 0))]
+    ts[4].zero_()
+    ptrs = torch.tensor([t.data_ptr() for t in ts] + [0], dtype=torch.int64, device=cuda)      # + an empty slot
+    sizes = torch.tensor([t.numel() for t in ts] + [0], dtype=torch.int64, device=cuda)
+    out = torch.full((6,), -1, dtype=torch.int32, device=cuda)
+    _C.call('evk_absmax_multi', ptrs.data_ptr(), sizes.data_ptr(), 6, out.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert [int(v) for v in out] == [_bits(t) for t in ts] + [0]
+
+
+def _conv_errs(cuda, xs, ws, gs, shape=(2, 64, 24, 24, 96, 3)):
+    """max relative error (vs fp64, relative to the result's max) of y, dx, dw under the current arithmetic with the
+    operands multiplied by xs / ws / gs."""
+    from ever_amd.hip import functional as F
+    n, cin, h, w, cout, k = shape
+    g = torch.Generator().manual_seed(17)
+    x = (torch.randn(n, cin, h, w, generator=g) + 0.5) * xs
+    wt = (torch.randn(cout, cin, k, k, generator=g) + 0.1) / (cin * k * k) ** 0.5 * ws
+    gy = (torch.randn(n, cout, h, w, generator=g) + 0.25) * gs
+    x64, w64 = x.double().requires_grad_(), wt.double().requires_grad_()
+    y64 = TF.conv2d(x64, w64, None, padding=k // 2)
+    y64.backward(gy.double())
+    xg = x.to(cuda).requires_grad_()
+    wg = wt.to(cuda).contiguous(memory_format=torch.channels_last).requires_grad_()
+    yg = F.conv2d(xg, wg, None, padding=k // 2)
+    yg.backward(gy.to(cuda))
+    torch.cuda.synchronize()
+    rel = lambda a, b: ((a.detach().cpu().double() - b).abs().max() / b.abs().max()).item()
+    return rel(yg, y64.detach()), rel(xg.grad, x64.grad), rel(wg.grad, w64.grad)
+
+
+@pytest.mark.parametrize('xs,ws,gs', [(1.0, 1.0, 1.0), (1e-12, 1.0, 1e-9), (1e12, 1e-6, 1e8), (3e-7, 2e3, 1e-20),
+                                      (1e-25, 1e-5, 1e-8)])
+def test_conv_f16x2_is_scale_invariant_and_fp32_grade(cuda, xs, ws, gs):
+    from ever_amd.hip import functional as F
+    prev = F.set_conv_math('f16x2')
+    try:
+        errs = _conv_errs(cuda, xs, ws, gs)
+        base = _conv_errs(cuda, 1.0, 1.0, 1.0)
+    finally:
+        F.set_conv_math(prev)
+    print('relative error vs fp64 (y, dx, dw):', errs, 'at unit scale:', base)
+    for e, b in zip(errs, base):
+        assert e < 5e-6, errs                          # the bound the fp32-MFMA and bf16x3 kernels are held to
+        assert e < 4.0 * b + 1e-7, (errs, base)        # and no worse than at unit scale: the exponent range never shows
+
+
+def test_conv_f16x2_zero_and_outlier_operands(cuda):
+    from ever_amd.hip import functional as F
+    prev = F.set_conv_math('f16x2')
+    try:
+        g = torch.Generator().manual_seed(2)
+        x = torch.zeros(2, 32, 16, 16, device=cuda)
+        w = torch.randn(64, 32, 3, 3, generator=g).to(cuda).contiguous(memory_format=torch.channels_last)
+        y = F.conv2d(x, w, None, padding=1)
+        assert float(y.abs().max()) == 0.0
+        # one element 2^20 times the typical magnitude: every other element sits 20 binary orders below the scale's top
+        xo = torch.randn(2, 32, 16, 16, generator=g)
+        xo[0, 0, 0, 0] = 2.0 ** 20
+        yo = F.conv2d(xo.to(cuda), w, None, padding=1)
+        ref = TF.conv2d(xo.double(), w.cpu().double(), None, padding=1)
+        far = torch.ones_like(ref, dtype=torch.bool)
+        far[0, :, :2, :2] = False                      # outputs the outlier does not reach
+        err = ((yo.cpu().double() - ref)[far].abs().max() / ref[far].abs().max()).item()
+        print('error away from the outlier, relative to those outputs:', err)
+        assert err < 2e-5, err                         # 2^-38 of the top per element: still far inside the 1e-3 contract
+        assert ((yo.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 5e-6
+    finally:
+        F.set_conv_math(prev)
+
+
+@pytest.mark.parametrize('res,relu', [(False, True), (True, True), (False, False)])
+def test_scales_from_the_batchnorm_passes_equal_standalone(cuda, res, relu):
+    from ever_amd.hip import functional as F
+    prev = F.set_conv_math('f16x2')
+    try:
+        g = torch.Generator().manual_seed(5)
+        x = (torch.randn(3, 64, 20, 12, generator=g) * 2 + 0.3).to(cuda).requires_grad_()
+        r = torch.randn(3, 64, 20, 12, generator=g).to(cuda) if res else None
+        gamma, beta = (torch.rand(64, generator=g) + 0.5).to(cuda).requires_grad_(), torch.randn(64, generator=g).to(cuda).requires_grad_()
+        rm, rv = torch.zeros(64, device=cuda), torch.ones(64, device=cuda)
+        y = F.batch_norm_act(x, gamma, beta, rm, rv, True, 0.1, 1e-5, residual=r, relu=relu)
+        hit = getattr(y, '_evk_amax', None)
+        assert hit is not None, 'the apply pass left no scale'
+        torch.cuda.synchronize()
+        assert int(hit[2].item()) == _bits(y)
+        seen = {}
+        probe = torch.autograd.Function
+
+        class Probe(probe):
+            @staticmethod
+            def forward(ctx, t):
+                return t.view_as(t)
+
+            @staticmethod
+            def backward(ctx, gt):
+                seen['dx'] = gt
+                return gt
+        # a consumer upstream of the BatchNorm sees the dx tensor the backward produced, with its scale attached
+        x2 = Probe.apply(x)
+        y2 = F.batch_norm_act(x2, gamma, beta, rm, rv, True, 0.1, 1e-5, residual=r, relu=relu)
+        y2.backward(torch.randn(y2.shape, generator=g).to(cuda))
+        torch.cuda.synchronize()
+        dx = seen['dx']
+        hit = getattr(dx, '_evk_amax', None)
+        assert hit is not None, 'the backward apply pass left no scale on dx'
+        assert int(hit[2].item()) == _bits(dx)
+    finally:
+        F.set_conv_math(prev)
+
+
+def test_inherited_scales_are_upper_bounds(cuda):
+    from ever_amd.hip import functional as F
+    prev = F.set_conv_math('f16x2')
+    try:
+        g = torch.Generator().manual_seed(9)
+        st = torch.cuda.current_stream().cuda_stream
+        x = F.as_nhwc(torch.randn(2, 32, 16, 16, generator=g).to(cuda), 't')
+        F.absmax_bits(x, st)                                   # registers x's scale
+        for name, out in (('bilinear', F.upsample_bilinear(x, 2)), ('max_pool', F.max_pool3x3s2(x))):
+            hit = getattr(out, '_evk_amax', None)
+            assert hit is not None, name
+            torch.cuda.synchronize()
+            assert int(hit[2].item()) >= _bits(out), name
+    finally:
+        F.set_conv_math(prev)
+
+
+def test_cached_weight_planes_follow_the_weights(cuda):
+    """raw-pointer optimiser writes (note_weights_changed) and in-place torch writes both re-derive scale and planes"""
+    import ever_amd as er
+    from ever_amd.hip import functional as F, weight_planes
+    prev = F.set_conv_math('f16x2')
+    try:
+        torch.manual_seed(4)
+        conv = er.module.Conv2d(64, 64, 3, 1, 1, bias=False).to(cuda)
+        x = torch.randn(2, 64, 16, 16, device=cuda)
+        ref = lambda: TF.conv2d(x.cpu().double(), conv.weight.detach().cpu().double(), None, padding=1)
+        rel = lambda y: ((y.detach().cpu().double() - ref()).abs().max() / ref().abs().max()).item()
+        assert rel(conv(x)) < 5e-6
+        opt = er.opt.FusedSGD(conv.parameters(), lr=1.0)
+        conv.weight.grad = -999.0 * conv.weight.detach().clone()      # w <- 1000 w through the raw-pointer kernel
+        opt.step()
+        weight_planes.note_weights_changed()
+        assert rel(conv(x)) < 5e-6
+        with torch.no_grad():
+            conv.weight.mul_(1e-9)                                    # autograd's version counter moves
+        assert rel(conv(x)) < 5e-6
+    finally:
+        F.set_conv_math(prev)

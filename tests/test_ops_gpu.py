@@ -72,7 +72,7 @@ def test_conv2d_fwd_bwd(cuda, case, conv_math):
 
 
 def test_conv_split_matches_fp64_as_well_as_fp32_mfma(cuda):
-    """The split-bf16 kernels must be as close to an fp64 evaluation as the exact-fp32 MFMA kernels are
+    """The split kernels (3-term bf16, 2-term scaled fp16) must be as close to an fp64 evaluation as the exact-fp32 MFMA kernels are
     (forward, data gradient, weight gradient), on operands with a non-zero mean (no cancellation luck)."""
     from ever_amd.hip import functional as F
     g = torch.Generator().manual_seed(99)
@@ -84,7 +84,7 @@ def test_conv_split_matches_fp64_as_well_as_fp32_mfma(cuda):
     y64 = TF.conv2d(x64, w64, None, padding=1)
     y64.backward(gy.double())
     errs = {}
-    for mode in ('f32', 'bf16x3'):
+    for mode in ('f32', 'bf16x3', 'f16x2'):
         prev = F.set_conv_math(mode)
         try:
             xg = x.to(cuda).requires_grad_()
@@ -97,9 +97,10 @@ def test_conv_split_matches_fp64_as_well_as_fp32_mfma(cuda):
         rel = lambda a, b: ((a.detach().cpu().double() - b).abs().max() / b.abs().max()).item()
         errs[mode] = (rel(yg, y64.detach()), rel(xg.grad, x64.grad), rel(wg.grad, w64.grad))
     print('max rel err vs fp64 (y, dx, dw):', errs)
-    for e32, e3 in zip(errs['f32'], errs['bf16x3']):
-        assert e3 <= 2.0 * e32 + 2e-7, errs
-        assert e3 < 5e-6, errs
+    for split in ('bf16x3', 'f16x2'):
+        for e32, e3 in zip(errs['f32'], errs[split]):
+            assert e3 <= 2.0 * e32 + 2e-7, errs
+            assert e3 < 5e-6, errs
 
 
 def test_conv2d_relu_epilogue(cuda):
