@@ -13,8 +13,9 @@ Rank 0 prints ONE JSON line: the contract fields plus
   roofline     — achieved MFMA rate of the dominant kernel family (conv forward + data gradient:
                  conv3x3_halo_x3 / conv_igemm_x3ws / conv_igemm_x3 kernels) = algorithmic FLOPs / HIP-event
                  time of its launches over the timed region, against the peak of the instruction the
-                 default arithmetic issues: dense bf16 MFMA 2500 TF / 6 partial products per fp32 product
-                 = 416.7 TF (157.3 TF, v_mfma_f32_32x32x2_f32, under --conv-math f32);
+                 arithmetic issues: dense 16-bit MFMA 2500 TF / partial products per fp32 product — 3 for the default
+                 f16x2 arithmetic (2-term scaled fp16 split) = 833.3 TF, 6 under --conv-math bf16x3 = 416.7 TF
+                 (157.3 TF, v_mfma_f32_32x32x2_f32, under --conv-math f32);
   roofline_wgrad / roofline_encoder — the same for the weight-gradient family and for the ResNet-50
                  encoder's convolutions alone (forward + data gradient + weight gradient of `en.*`:
                  the stack BASELINE.json's 0.6 target is stated on);
@@ -34,7 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-in MFMA peak (= fp32 vector peak)
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (v_mfma_f32_32x32x16_{bf16,f16})
 X3_PASSES = 6                   # bf16 MFMA partial products per fp32 product in the split kernels
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable on a float4 copy)
 GF_FWD_BWD_PER_TILE = 342.7     # conv GFLOP fwd+bwd per 512x512x3 tile, default head
