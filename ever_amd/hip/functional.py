@@ -540,7 +540,11 @@ class _SlotOutFn(Function):
 
 def slot_output(x, slot):
     """The view of `x` to hand to the later consumer: its gradient goes to `slot` instead of to autograd's sum."""
-    return _SlotOutFn.apply(x, slot)
+    out = _SlotOutFn.apply(x, slot)
+    hit = getattr(x, '_evk_amax', None)          # the same values under another tensor object: keep the operand scale
+    if hit is not None and hit[0] == x._version and out.data_ptr() == x.data_ptr():
+        _note_amax(out, hit[2])
+    return out
 
 
 def grad_slots_enabled():
