@@ -35,6 +35,7 @@ _SLOTS = 8192                    # capacity of the weights' absmax array (one wo
 _wabs = {}                       # device -> int32[_SLOTS]: bit image of max|w| per slot
 _slot_of = WeakIdKeyDictionary() # weight tensor object -> slot
 _next_slot = [0]
+_free_slots = []
 _abs_ws = {}                     # (device, stream) -> zeroed workspace of evk_absmax
 
 
@@ -59,12 +60,19 @@ def _wabs_for(device):
 
 
 def _slot(weight):
+    """Index of `weight`'s word in the absmax array; indices of dead weight tensors are handed out again."""
     sl = _slot_of.get(weight)
     if sl is None:
-        if _next_slot[0] >= _SLOTS:
-            raise RuntimeError('weight_planes: more than %d weight tensors registered' % _SLOTS)
-        sl = _slot_of[weight] = _next_slot[0]
-        _next_slot[0] += 1
+        if not _free_slots:
+            if _next_slot[0] < _SLOTS:
+                _free_slots.append(_next_slot[0])
+                _next_slot[0] += 1
+            else:       # the range is used up: collect the indices whose tensors have died since
+                live = set(_slot_of.values())
+                _free_slots.extend(i for i in range(_SLOTS) if i not in live)
+                if not _free_slots:
+                    raise RuntimeError('weight_planes: more than %d live weight tensors registered' % _SLOTS)
+        sl = _slot_of[weight] = _free_slots.pop()
     return sl
 
 
@@ -85,6 +93,7 @@ def clear():
         _table = None
         _slot_of.clear()
         _next_slot[0] = 0
+        del _free_slots[:]
 
 
 def _desc_key(d, for_dgrad):

@@ -313,3 +313,30 @@ def test_farsegpp_head_builds_fsrelation_v2_with_reference_keys():
     ora = farseg_ref.FarSegHeadRef(relation_version='v2')
     assert list(ora.state_dict().keys()) == list(h.state_dict().keys())
     assert er.registry.MODEL['FarSegPP'] is er.module.FarSegPP
+
+
+def test_weight_scale_slots_are_reused_when_weights_die():
+    """hip/weight_planes.py: one word of the absmax array per live weight tensor; a long session (many models built and
+    dropped) must not run out of words."""
+    import gc
+    import torch
+    from ever_amd.hip import weight_planes as wp
+    saved = (wp._SLOTS, wp._next_slot[0], list(wp._free_slots))
+    wp.clear()
+    wp._SLOTS = 4
+    try:
+        ts = [torch.zeros(1) for _ in range(4)]
+        assert sorted(wp._slot(t) for t in ts) == [0, 1, 2, 3]
+        assert wp._slot(ts[2]) == wp._slot(ts[2])
+        dead = wp._slot(ts[1])
+        del ts[1]
+        gc.collect()
+        t = torch.zeros(1)
+        assert wp._slot(t) == dead
+        import pytest
+        with pytest.raises(RuntimeError, match='live weight tensors'):
+            wp._slot(torch.zeros(1))
+    finally:
+        wp.clear()
+        wp._SLOTS, wp._next_slot[0] = saved[0], saved[1]
+        wp._free_slots.extend(saved[2])

@@ -16,7 +16,10 @@ for it in range(3):
     if t: t.__exit__()
     m.zero_grad(set_to_none=True)
 torch.cuda.synchronize()
-PEAK_TF, PEAK_HBM = 416.7e12, 8.0e12       # bf16x3 matrix-pipe peak (2500/6), HBM3E peak
+from ever_amd.hip import functional as _HF
+_PASSES = {'f16x2': 3, 'bf16x3': 6, 'bf16': 1}.get(_HF.get_conv_math())
+PEAK_TF = 2500e12 / _PASSES if _PASSES else 157.3e12   # 16-bit MFMA peak / partial products of the arithmetic in use
+PEAK_HBM = 8.0e12                                      # HBM3E peak
 rows = [(f, fl, nb, s.elapsed_time(e) * 1e3) for f, fl, nb, s, e, _sc in t.records if fl > 0]
 tot = sum(r[3] for r in rows)
 agg = {}
@@ -24,7 +27,7 @@ for f, fl, nb, us in rows:
     k = (f, round(fl / 1e9, 3), round(nb / 1e6, 1))
     a = agg.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += us
 print(f'conv launches {len(rows)}, total {tot/1e3:.2f} ms')
-print('bound = max(flop / 416.7 TF, algorithmic bytes / 8 TB/s) per launch; frac = bound / measured')
+print(f'arithmetic {_HF.get_conv_math()}: bound = max(flop / {PEAK_TF / 1e12:.1f} TF, algorithmic bytes / 8 TB/s) per launch; frac = bound / measured')
 cum, bound_tot = 0, 0.0
 for (f, gf, mb), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
     cum += us
