@@ -20,10 +20,14 @@ struct WGather {
   bool cvalid;
 };
 
+// W8: Wo % 8 == 0 (every map of this network): the 8 pixels of a micro-block lie in one image row, one decomposition
+// (two fast divisions) per micro-block, running sums for the column and the address.  The instantiation carries no
+// code of the per-pixel path — the staging waves are VALU-issue bound (PMC: 83 % VALU-busy with the matrix waves idle).
+template <bool W8>
 __device__ __forceinline__ void gather8(const WGradArgs& p, const WGather& g, int m0, int pend, f32x4 (&rv)[8],
                                         uint32_t& okmask) {
   okmask = 0;
-  if ((p.Wo & 7) == 0) {
+  if (W8) {
     const uint32_t mm = (uint32_t)min(m0, p.M - 1);
     const uint32_t n = fdiv(mm, p.fd_hw);
     const uint32_t rem = mm - n * p.fd_hw.div;
@@ -31,13 +35,16 @@ __device__ __forceinline__ void gather8(const WGradArgs& p, const WGather& g, in
     const int ox = (int)(rem - oy * p.fd_w.div);
     const int sy = (int)oy * g.ssh + g.offy;
     const bool rowok = g.cvalid && m0 < pend && (unsigned)sy < (unsigned)g.Hs;
-    const int base = ((int)n * g.Hs + sy) * g.Ws * g.Cs + g.coff;
+    int sx = ox * g.ssw + g.offx;
+    int off = (((int)n * g.Hs + sy) * g.Ws + sx) * g.Cs + g.coff;
+    const int dsx = g.ssw, doff = g.ssw * g.Cs;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int sx = (ox + j) * g.ssw + g.offx;
       const bool ok = rowok && (unsigned)sx < (unsigned)g.Ws;
       okmask |= ok ? (1u << j) : 0u;
-      rv[j] = *reinterpret_cast<const f32x4*>(g.src + (ok ? base + sx * g.Cs : 0));
+      rv[j] = *reinterpret_cast<const f32x4*>(g.src + (ok ? off : 0));
+      sx += dsx;
+      off += doff;
     }
   } else {
 #pragma unroll
@@ -88,14 +95,95 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void gather8h(const float* __restrict__ dy, int Cout, int coff, bool cvalid, int m0, int pend,
                                          f32x2v (&rv)[8], uint32_t& okmask) {
   okmask = 0;
+  int off = m0 * Cout + coff;      // (both tensors are below 2^31 bytes: plan_wgrad's fits32)
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int m = m0 + j;
-    const bool ok = cvalid && m < pend;
+    const bool ok = cvalid && m0 + j < pend;
     okmask |= ok ? (1u << j) : 0u;
-    rv[j] = *reinterpret_cast<const f32x2v*>(dy + (ok ? (size_t)m * Cout + coff : 0));
+    rv[j] = *reinterpret_cast<const f32x2v*>(dy + (ok ? off : 0));
+    off += Cout;
   }
 }
+// ---- buffer-load gathers (the f16x2 instantiation, where they measure faster: staging alone 874 -> 771 us, whole
+// kernel 1326 -> 1301 / 320 -> 277 / 90 -> 80 us on 3x3x256 @128^2 / 64^2 / 32^2; under bf16x3 they are slower, 1567 ->
+// 1726): 32-bit byte offsets on a buffer resource, out-of-image pixels get an
+// out-of-range offset and the hardware returns zeros — no 64-bit address arithmetic, no selects on the loaded data.
+// The pixel decomposition (two fast divisions) is done once per micro-block when Wo % 8 == 0 (always the case for the
+// maps of this network); the generic path decomposes every pixel.
+constexpr uint32_t kOOBOff = 0x80000000u;
+typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 bload16(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ f32x2v bload8(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+  return __builtin_bit_cast(f32x2v, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0));
+}
+template <bool W8>
+__device__ __forceinline__ void gather8_buf(const WGradArgs& p, const WGather& g, __amdgpu_buffer_rsrc_t rs, int m0, int pend,
+                                            f32x4 (&rv)[8]) {
+  if (W8) {
+    const uint32_t mm = (uint32_t)min(m0, p.M - 1);
+    const uint32_t n = fdiv(mm, p.fd_hw);
+    const uint32_t rem = mm - n * p.fd_hw.div;
+    const uint32_t oy = fdiv(rem, p.fd_w);
+    const int ox = (int)(rem - oy * p.fd_w.div);
+    const int sy = (int)oy * g.ssh + g.offy;
+    const bool rowok = g.cvalid && m0 < pend && (unsigned)sy < (unsigned)g.Hs;
+    int sx = ox * g.ssw + g.offx;
+    const uint32_t step = (uint32_t)(g.ssw * g.Cs) << 2;
+    uint32_t off = (uint32_t)((((int)n * g.Hs + sy) * g.Ws + sx) * g.Cs + g.coff) << 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = rowok && (unsigned)sx < (unsigned)g.Ws;
+      rv[j] = bload16(rs, ok ? off : kOOBOff);
+      sx += g.ssw;
+      off += step;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int m = m0 + j;
+      const uint32_t mm = (uint32_t)min(m, p.M - 1);
+      const uint32_t n = fdiv(mm, p.fd_hw);
+      const uint32_t rem = mm - n * p.fd_hw.div;
+      const uint32_t oy = fdiv(rem, p.fd_w);
+      const int ox = (int)(rem - oy * p.fd_w.div);
+      const int sy = (int)oy * g.ssh + g.offy, sx = ox * g.ssw + g.offx;
+      const bool ok = g.cvalid && m < pend && (unsigned)sy < (unsigned)g.Hs && (unsigned)sx < (unsigned)g.Ws;
+      rv[j] = bload16(rs, ok ? (uint32_t)((((int)n * g.Hs + sy) * g.Ws + sx) * g.Cs + g.coff) << 2 : kOOBOff);
+    }
+  }
+}
+__device__ __forceinline__ void gather8h_buf(__amdgpu_buffer_rsrc_t rs, int Cout, int coff, bool cvalid, int m0, int pend,
+                                             f32x2v (&rv)[8]) {
+  uint32_t off = (uint32_t)(m0 * Cout + coff) << 2;
+  const uint32_t step = (uint32_t)Cout << 2;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    rv[j] = bload8(rs, (cvalid && m0 + j < pend) ? off : kOOBOff);
+    off += step;
+  }
+}
+// split the micro-block (already zero where out of range) and write channel 4*cq+e to LDS row e*Q + cq, chunk pg
+template <int NP, int NCH, typename V>
+__device__ __forceinline__ void split_store_buf(V (&rv)[8], unsigned char* base, int plane_bytes, int Q, int cq, int pg,
+                                                float inv) {
+#pragma unroll
+  for (int e = 0; e < NCH; ++e) {
+    const int off = plane_off(e * Q + cq, pg);
+    u32x4 H, M, L;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      uint32_t h, m = 0, l = 0;
+      split_np<NP>(rv[2 * t][e], rv[2 * t + 1][e], inv, h, m, l);
+      H[t] = h; M[t] = m; L[t] = l;
+    }
+    *reinterpret_cast<u32x4*>(base + off) = H;
+    if (NP >= 2) *reinterpret_cast<u32x4*>(base + plane_bytes + off) = M;
+    if (NP == 3) *reinterpret_cast<u32x4*>(base + 2 * plane_bytes + off) = L;
+  }
+}
+
 template <int NP>
 __device__ __forceinline__ void split_store8h(f32x2v (&rv)[8], uint32_t okmask, unsigned char* base, int plane_bytes, int Q2,
                                               int cq, int pg, float inv) {
@@ -121,7 +209,7 @@ __device__ __forceinline__ void split_store8h(f32x2v (&rv)[8], uint32_t okmask, 
   }
 }
 
-template <int BM, int BN, int NP>
+template <int BM, int BN, int NP, bool W8>
 __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MB = WM / 32, NB = WN / 32;
@@ -172,6 +260,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
     f32x2v ra[2][8];
     f32x4 rb[2][8];
     uint32_t oka[2] = {0, 0}, okb[2] = {0, 0};
+    constexpr bool kBuf = NP == 2;   // buffer loads with out-of-range zero fill
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.N * p.H * p.W * p.Cin * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.M * p.Cout * 4, 0x00020000);
     float x_inv = 1.f, dy_inv = 1.f;   // f16x2: 1 / operand scales
     if constexpr (NP == 2) {
       x_inv = op_scale(*p.x_scale).inv;
@@ -182,16 +273,26 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
       constexpr int s = decltype(SET)::value;
       const int pix0 = pbeg + kt * BKP;
       if (p.dbg & 1) return;   // ablation: no global loads
-      gather8(p, gb, pix0 + bpg * 8, pend, rb[s], okb[s]);
-      gather8h(p.dy, p.Cout, a_coff, a_cvalid, pix0 + apg * 8, pend, ra[s], oka[s]);
+      if constexpr (kBuf) {
+        gather8_buf<W8>(p, gb, rs_x, pix0 + bpg * 8, pend, rb[s]);
+        gather8h_buf(rs_dy, p.Cout, a_coff, a_cvalid, pix0 + apg * 8, pend, ra[s]);
+      } else {
+        gather8<W8>(p, gb, pix0 + bpg * 8, pend, rb[s], okb[s]);
+        gather8h(p.dy, p.Cout, a_coff, a_cvalid, pix0 + apg * 8, pend, ra[s], oka[s]);
+      }
     };
     auto store = [&](auto SET, int stage) {
       constexpr int s = decltype(SET)::value;
       unsigned char* Ab = smem3 + stage * kStage;
       unsigned char* Bb = Ab + 3 * BM * kRowBytes;
       if (p.dbg & 2) return;   // ablation: no split, no LDS writes
-      split_store8<NP>(rb[s], okb[s], Bb, BN * kRowBytes, QB, bcq, bpg, x_inv);
-      split_store8h<NP>(ra[s], oka[s], Ab, BM * kRowBytes, QA2, acq, apg, dy_inv);
+      if constexpr (kBuf) {
+        split_store_buf<NP, 4>(rb[s], Bb, BN * kRowBytes, QB, bcq, bpg, x_inv);
+        split_store_buf<NP, 2>(ra[s], Ab, BM * kRowBytes, QA2, acq, apg, dy_inv);
+      } else {
+        split_store8<NP>(rb[s], okb[s], Bb, BN * kRowBytes, QB, bcq, bpg, x_inv);
+        split_store8h<NP>(ra[s], oka[s], Ab, BM * kRowBytes, QA2, acq, apg, dy_inv);
+      }
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
@@ -309,30 +410,28 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
     }
 }
 
-int launch_wgrad_x3ws(const WGradArgs& a, hipStream_t stream) {
+template <int NP, bool W8>
+static int launch_wgrad_x3ws_t(const WGradArgs& b, hipStream_t stream) {
   constexpr int BM = 128, BN = 256;
   const size_t lds = (size_t)2 * 3 * (BM + BN) * kRowBytes;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x3ws_kernel<BM, BN, 3>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x3ws_kernel<BM, BN, 1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x3ws_kernel<BM, BN, 2>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x3ws_kernel<BM, BN, NP, W8>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  hipLaunchKernelGGL((conv_wgrad_x3ws_kernel<BM, BN, NP, W8>), dim3(b.tiles_co * b.tiles_k * b.splitk), dim3(512), lds, stream, b);
+  return check_launch("conv_wgrad_x3ws");
+}
+
+int launch_wgrad_x3ws(const WGradArgs& a, hipStream_t stream) {
   WGradArgs b = a;
   static const int dbg = getenv("EVK_WG_DBG") ? atoi(getenv("EVK_WG_DBG")) : 0;
   b.dbg = dbg;
-  if (a.planes == 1) {
-    hipLaunchKernelGGL((conv_wgrad_x3ws_kernel<BM, BN, 1>), dim3(a.tiles_co * a.tiles_k * a.splitk), dim3(512), lds, stream, b);
-  } else if (a.planes == 2) {
-    hipLaunchKernelGGL((conv_wgrad_x3ws_kernel<BM, BN, 2>), dim3(a.tiles_co * a.tiles_k * a.splitk), dim3(512), lds, stream, b);
-  } else {
-    hipLaunchKernelGGL((conv_wgrad_x3ws_kernel<BM, BN, 3>), dim3(a.tiles_co * a.tiles_k * a.splitk), dim3(512), lds, stream, b);
-  }
-  return check_launch("conv_wgrad_x3ws");
+  const bool w8 = (a.Wo & 7) == 0;
+  if (a.planes == 1) return w8 ? launch_wgrad_x3ws_t<1, true>(b, stream) : launch_wgrad_x3ws_t<1, false>(b, stream);
+  if (a.planes == 2) return w8 ? launch_wgrad_x3ws_t<2, true>(b, stream) : launch_wgrad_x3ws_t<2, false>(b, stream);
+  return w8 ? launch_wgrad_x3ws_t<3, true>(b, stream) : launch_wgrad_x3ws_t<3, false>(b, stream);
 }
 
 }  // namespace evk
