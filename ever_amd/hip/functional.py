@@ -306,7 +306,7 @@ def _conv_forward(x, weight, bias, stride, padding, dilation, relu, want_stats=F
     small_m = n * d.Ho * d.Wo <= 32
     bn_parts = None
     if _planes_math() and cin_p == cin and cin % 8 == 0 and not small_m:
-        # weights -> three bf16 planes, then the split-MFMA kernel.  The planes of every registered weight are
+        # weights -> planes (two fp16 of w / s, or three bf16), then the split-MFMA kernel.  The planes of every registered weight are
         # refreshed by one launch per weight update (weight_planes); a weight the cache cannot follow (a transient
         # re-laid-out copy) is split into the shared workspace on every call.
         pl_ptr, wabs_ptr, _keep = _weight_planes(weight, w_ohwi, w_ptr, d, 0, st, dev)
