@@ -1,11 +1,11 @@
 """dev tool: a few hundred optimiser steps of FarSeg on a learnable synthetic task (label = smoothed band-0 threshold):
-the loss must fall and stay finite under both convolution arithmetics."""
+the loss must fall and stay finite under the three fp32-grade convolution arithmetics."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ever_amd as er
 from ever_amd.hip import functional as HF
 dev = torch.device('cuda:0')
-for mode in ('bf16x3', 'f32'):
+for mode in ('f16x2', 'bf16x3', 'f32'):
     HF.set_conv_math(mode)
     torch.manual_seed(0)
     widths = (64, 128, 256, 512)
