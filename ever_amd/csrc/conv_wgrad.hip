@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
   }
 }
 
-WGradPlan plan_wgrad(const evk_conv_desc* d, int x3) {
+WGradPlan plan_wgrad(const evk_conv_desc* d, int x3, int planes) {
   WGradPlan pl;
   const int Ktot = d->kh * d->kw * d->Cin;
   const int M = d->N * d->Ho * d->Wo;
@@ -281,8 +281,17 @@ WGradPlan plan_wgrad(const evk_conv_desc* d, int x3) {
                       (long long)d->N * d->Ho * d->Wo * d->Cout * 4 < 0x7fffffffLL;
   pl.ws = (x3 && ws_mode && d->Cout >= 128 && Ktot >= 256 && fits32) ? 1 : 0;
   if (pl.ws) pl.bn = 256;
+  // nine-tap form (f16x2 only): 3x3 / stride 1 / padding 1, rows of whole 32-pixel segments, 32-channel column tiles
+  static const int tap9_0 = getenv("EVK_WG_TAP9") ? atoi(getenv("EVK_WG_TAP9")) : 1;
+  const int tap9 = knob("EVK_WG_TAP9", tap9_0);
+  if (pl.ws && tap9 && planes == 2 && d->kh == 3 && d->kw == 3 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 1 &&
+      d->pad_w == 1 && d->dil_h == 1 && d->dil_w == 1 && d->Wo == d->W && d->Ho == d->H && (d->W % 32) == 0 &&
+      (d->Cin % 32) == 0) {
+    pl.ws = 2;
+    pl.bn = 32;   // column tiles are 32 channels wide (x 9 taps)
+  }
   pl.tiles_co = ceil_div(d->Cout, pl.bm);
-  pl.tiles_k = ceil_div(Ktot, pl.bn);
+  pl.tiles_k = pl.ws == 2 ? d->Cin / 32 : ceil_div(Ktot, pl.bn);
   const int tiles = pl.tiles_co * pl.tiles_k;
   // Split the pixel reduction so that the grid fills WHOLE rounds of the machine: slots = 256 CUs x
   // resident workgroups per CU (LDS-limited: 64 KB tiles -> 2, 48 KB -> 3, 32 KB -> 4).  A grid of
@@ -336,9 +345,10 @@ using namespace evk;
 
 static size_t wgrad_ws_bytes(const evk_conv_desc* d, int x3) {
   if (!d) return 0;
-  const WGradPlan pl = plan_wgrad(d, x3);
+  const WGradPlan pl = plan_wgrad(d, x3), pl2 = plan_wgrad(d, x3, 2);   // the f16x2 plan may split differently
   const size_t Ktot = (size_t)d->kh * d->kw * d->Cin;
-  size_t a = pl.splitk > 1 ? (size_t)pl.splitk * d->Cout * Ktot * sizeof(float) : 0;
+  const int sk = pl.splitk > pl2.splitk ? pl.splitk : pl2.splitk;
+  size_t a = sk > 1 ? (size_t)sk * d->Cout * Ktot * sizeof(float) : 0;
   size_t b = (size_t)colsum_blocks((int64_t)d->N * d->Ho * d->Wo) * d->Cout * sizeof(float);
   return (a > b ? a : b) + 256;
 }
@@ -358,7 +368,7 @@ static int conv_wgrad_any(const evk_conv_desc* d, const float* x, const float* d
                   (long long)d->N * d->Ho * d->Wo * d->Cout < 0x7fffffffLL,
               EVK_E_UNSUPPORTED, "conv2d_wgrad: tensors of 2^31 or more elements are not supported");
   hipStream_t st = (hipStream_t)stream;
-  const WGradPlan pl = plan_wgrad(d, x3);
+  const WGradPlan pl = plan_wgrad(d, x3, planes);
   WGradArgs a{};
   a.planes = planes;
   a.x_scale = x_scale; a.dy_scale = dy_scale;

@@ -201,3 +201,35 @@ def test_cached_weight_planes_follow_the_weights(cuda):
         assert rel(conv(x)) < 5e-6
     finally:
         F.set_conv_math(prev)
+
+
+TAP9_CASES = [
+    # n, cin, h, w, cout   (3x3 / stride 1 / padding 1, W % 32 == 0, Cin % 32 == 0, Cout >= 128: the nine-tap weight gradient)
+    (2, 32, 8, 32, 128), (3, 64, 5, 64, 160), (2, 256, 32, 32, 256), (1, 96, 7, 96, 128), (4, 128, 64, 64, 128),
+]
+
+
+@pytest.mark.parametrize('case', TAP9_CASES)
+def test_nine_tap_weight_gradient(cuda, case):
+    """conv_wgrad_tap9_kernel against fp64 and against the one-tap-per-tile kernel (EVK_WG_TAP9=0 semantics through the
+    planner knob): image borders (the halo's zero rows / columns), several segments per row, ragged Cout tile, odd row
+    counts, split-K chunk boundaries."""
+    import os
+    from ever_amd.hip import functional as F
+    n, cin, h, w, cout = case
+    g = torch.Generator().manual_seed(100 + cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g) + 0.3
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    gy = torch.randn(n, cout, h, w, generator=g) * 1e-3
+    w64 = wt.double().requires_grad_()
+    TF.conv2d(x.double(), w64, None, padding=1).backward(gy.double())
+    prev = F.set_conv_math('f16x2')
+    try:
+        wg = wt.to(cuda).contiguous(memory_format=torch.channels_last).requires_grad_()
+        F.conv2d(x.to(cuda), wg, None, padding=1).backward(gy.to(cuda))
+        torch.cuda.synchronize()
+    finally:
+        F.set_conv_math(prev)
+    err = ((wg.grad.cpu().double() - w64.grad).abs().max() / w64.grad.abs().max()).item()
+    print('dw relative error vs fp64:', err)
+    assert err < 5e-6, err
