@@ -281,17 +281,8 @@ WGradPlan plan_wgrad(const evk_conv_desc* d, int x3, int planes) {
                       (long long)d->N * d->Ho * d->Wo * d->Cout * 4 < 0x7fffffffLL;
   pl.ws = (x3 && ws_mode && d->Cout >= 128 && Ktot >= 256 && fits32) ? 1 : 0;
   if (pl.ws) pl.bn = 256;
-  // nine-tap form (f16x2 only): 3x3 / stride 1 / padding 1, rows of whole 32-pixel segments, 32-channel column tiles
-  static const int tap9_0 = getenv("EVK_WG_TAP9") ? atoi(getenv("EVK_WG_TAP9")) : 1;
-  const int tap9 = knob("EVK_WG_TAP9", tap9_0);
-  if (pl.ws && tap9 && planes == 2 && d->kh == 3 && d->kw == 3 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 1 &&
-      d->pad_w == 1 && d->dil_h == 1 && d->dil_w == 1 && d->Wo == d->W && d->Ho == d->H && (d->W % 32) == 0 &&
-      (d->Cin % 32) == 0) {
-    pl.ws = 2;
-    pl.bn = 32;   // column tiles are 32 channels wide (x 9 taps)
-  }
   pl.tiles_co = ceil_div(d->Cout, pl.bm);
-  pl.tiles_k = pl.ws == 2 ? d->Cin / 32 : ceil_div(Ktot, pl.bn);
+  pl.tiles_k = ceil_div(Ktot, pl.bn);
   const int tiles = pl.tiles_co * pl.tiles_k;
   // Split the pixel reduction so that the grid fills WHOLE rounds of the machine: slots = 256 CUs x
   // resident workgroups per CU (LDS-limited: 64 KB tiles -> 2, 48 KB -> 3, 32 KB -> 4).  A grid of

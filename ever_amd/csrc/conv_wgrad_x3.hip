@@ -242,7 +242,6 @@ static int launch_one(const WGradArgs& a, hipStream_t stream) {
 }
 
 int launch_wgrad_x3(const WGradArgs& a, const WGradPlan& pl, hipStream_t stream) {
-  if (pl.ws == 2) return launch_wgrad_tap9(a, stream);
   if (pl.ws) return launch_wgrad_x3ws(a, stream);
   if (pl.bm == 128 && pl.bn == 128) return launch_one<128, 128, 2, 2>(a, stream);
   if (pl.bm == 64 && pl.bn == 128) return launch_one<64, 128, 2, 2>(a, stream);

@@ -410,228 +410,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// NINE-TAP form for 3x3 / stride 1 / padding 1 weight gradients under f16x2 (W % 32 == 0, Cin % 32 == 0).
-// The kernel above stages, per 32-pixel step, a 128-row dy tile and ONE tap's 256 x-rows, so every dy tile is staged
-// once per 256 columns of K = 9 Cin and every x element once per tap: with the matrix work of f16x2 the staging waves set
-// the pace (PMC: matrix pipe 31 % busy).  Here a workgroup owns 128 co x (9 taps x 32 ci): per step (one 32-pixel ROW
-// SEGMENT) it stages the dy tile (4096 elements) and the 3 x 34-pixel halo of 32 channels (3264 elements) ONCE, splits
-// them once, and writes the halo as nine per-tap images — the three horizontal shifts of a halo row are the same packed
-// fp16 pairs taken from word 0, from word 1, or through one v_alignbit per word.  Staged elements per MFMA: 0.6 of the
-// one-tap form.  Matrix waves: 2 row blocks x 5 (taps 0-4) or 4 (taps 5-8) column blocks each.
-// LDS: 2 stages x 2 planes x (128 + 288) rows x 64 B = 104 KB.
-constexpr int kT9Rows = 288;
-template <int NP>
-__global__ __launch_bounds__(512) void conv_wgrad_tap9_kernel(const WGradArgs p) {
-  static_assert(NP == 2, "two-plane stages only (three planes of 416 rows do not fit twice)");
-  constexpr int BM = 128;
-  constexpr int kAPlane = BM * kRowBytes, kBPlane = kT9Rows * kRowBytes;
-  constexpr int kStage = NP * (kAPlane + kBPlane);
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int ntile = p.tiles_co * p.tiles_k;          // tiles_k = Cin / 32
-  const int z = bid / ntile;
-  const int tile = bid - z * ntile;
-  const int tile_ci = tile % p.tiles_k;
-  const int tile_co = tile / p.tiles_k;
-  const int co0 = tile_co * BM, ci0 = tile_ci * 32;
-  const int pbeg = z * p.chunk;                      // chunk and M are multiples of 32: every step is a whole segment
-  const int pend = min(p.M, pbeg + p.chunk);
-  const int nk = (pend - pbeg) / BKP;
-  const int tid = threadIdx.x;
-
-  if (tid >= 256) {
-    // ------------------------------------------------------------------ staging waves
-    const int ptid = tid - 256;
-    constexpr int QA2 = BM / 2;
-    const int acq = ptid % QA2, apg = ptid / QA2;    // dy: 8 pixels x 2 channels per thread, all 256 threads
-    const int a_coff = co0 + acq * 2;
-    const bool a_cvalid = a_coff < p.Cout;
-    const bool xth = ptid < 192;                     // x halo: 3 rows (one per wave) x 4 pixel octets x 16 channel pairs
-    const int hr = ptid >> 6, ho = (ptid >> 4) & 3, hq = ptid & 15;
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.N * p.H * p.W * p.Cin * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.M * p.Cout * 4, 0x00020000);
-    const OpScale sx = op_scale(*p.x_scale), sd = op_scale(*p.dy_scale);
-    f32x2v ra[2][8];
-    f32x2v rx[2][10];
-
-    auto load = [&](auto SET, int kt) {
-      constexpr int s = decltype(SET)::value;
-      const int pix0 = pbeg + kt * BKP;
-      if (p.dbg & 1) return;
-      gather8h_buf(rs_dy, p.Cout, a_coff, a_cvalid, pix0 + apg * 8, pend, ra[s]);
-      if (xth) {
-        const uint32_t n = fdiv((uint32_t)pix0, p.fd_hw);
-        const uint32_t rem = (uint32_t)pix0 - n * p.fd_hw.div;
-        const uint32_t oy = fdiv(rem, p.fd_w);
-        const int ox0 = (int)(rem - oy * p.fd_w.div);
-        const int sy = (int)oy + hr - 1;
-        const bool rowok = (unsigned)sy < (unsigned)p.H;
-        int sxp = ox0 - 1 + 8 * ho;
-        uint32_t off = (uint32_t)((((int)n * p.H + sy) * p.W + sxp) * p.Cin + ci0 + 2 * hq) << 2;
-        const uint32_t step = (uint32_t)p.Cin << 2;
-#pragma unroll
-        for (int i = 0; i < 10; ++i) {
-          const bool ok = rowok && (unsigned)sxp < (unsigned)p.W;
-          rx[s][i] = bload8(rs_x, ok ? off : kOOBOff);
-          ++sxp;
-          off += step;
-        }
-      }
-    };
-    auto store = [&](auto SET, int stage) {
-      constexpr int s = decltype(SET)::value;
-      unsigned char* Ab = smem3 + stage * kStage;
-      unsigned char* Bb = Ab + NP * kAPlane;
-      if (p.dbg & 2) return;
-      split_store_buf<NP, 2>(ra[s], Ab, kAPlane, QA2, acq, apg, sd.inv);
-      if (xth) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          uint32_t H[5], M[5];
-#pragma unroll
-          for (int i = 0; i < 5; ++i) {
-            uint32_t l = 0;
-            split_np<NP>(rx[s][2 * i][e], rx[s][2 * i + 1][e], sx.inv, H[i], M[i], l);
-          }
-          const int row0 = hr * 96 + e * 16 + hq;         // tap (hr, 0), channel 2 hq + e -> row e * 16 + hq of its 32
-#pragma unroll
-          for (int sh = 0; sh < 3; ++sh) {
-            const int off = plane_off(row0 + sh * 32, ho);
-            u32x4 vh, vm;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              if (sh == 0) { vh[i] = H[i]; vm[i] = M[i]; }
-              else if (sh == 2) { vh[i] = H[i + 1]; vm[i] = M[i + 1]; }
-              else {
-                vh[i] = __builtin_amdgcn_alignbit(H[i + 1], H[i], 16);
-                vm[i] = __builtin_amdgcn_alignbit(M[i + 1], M[i], 16);
-              }
-            }
-            *reinterpret_cast<u32x4*>(Bb + off) = vh;
-            *reinterpret_cast<u32x4*>(Bb + kBPlane + off) = vm;
-          }
-        }
-      }
-    };
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-    if (nk > 0) {
-      load(S0{}, 0);
-      if (1 < nk) load(S1{}, 1);
-      store(S0{}, 0);
-      if (2 < nk) load(S0{}, 2);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-      if (kt + 1 < nk) {
-        store(S1{}, 1);
-        if (kt + 3 < nk) load(S1{}, kt + 3);
-      }
-      __syncthreads();
-      if (kt + 1 < nk) {
-        if (kt + 2 < nk) {
-          store(S0{}, 0);
-          if (kt + 4 < nk) load(S0{}, kt + 4);
-        }
-        __syncthreads();
-      }
-    }
-    return;
-  }
-
-  // -------------------------------------------------------------------- matrix waves
-  __builtin_amdgcn_s_setprio(3);
-  const int wave = tid >> 6, lane = tid & 63;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int li = lane & 31, lh = lane >> 5;
-  const int nb = wn ? 4 : 5;                           // column blocks (taps) of this wave: 0-4 or 5-8
-
-  f32x16 acc[2][5];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 5; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  int fa_off[2][2], fb_off[5][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) fa_off[a][kk] = plane_off(wm * 64 + a * 32 + li, 2 * kk + lh);
-#pragma unroll
-  for (int b = 0; b < 5; ++b)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) fb_off[b][kk] = NP * kAPlane + plane_off(min(wn * 5 + b, 8) * 32 + li, 2 * kk + lh);
-
-  auto half_step = [&](const unsigned char* S, int kk) {
-    bf16x8 fa[2][NP], fb[5][NP];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int pt = 0; pt < NP; ++pt) fa[a][pt] = *reinterpret_cast<const bf16x8*>(S + pt * kAPlane + fa_off[a][kk]);
-#pragma unroll
-    for (int b = 0; b < 5; ++b)
-#pragma unroll
-      for (int pt = 0; pt < NP; ++pt)
-        if (b < nb) fb[b][pt] = *reinterpret_cast<const bf16x8*>(S + pt * kBPlane + fb_off[b][kk]);
-#pragma unroll
-    for (int t = 0; t < X3Prod<NP>::N; ++t)
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 5; ++b)
-          if (b < nb) acc[a][b] = mfma_np<NP>(fa[a][x3_pa(NP, t)], fb[b][x3_pb(NP, t)], acc[a][b]);
-  };
-
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const unsigned char* S = smem3 + (kt & 1) * kStage;
-    if (!(p.dbg & 4)) {
-      half_step(S, 0);
-      half_step(S, 1);
-    }
-    __syncthreads();
-  }
-  if (p.dbg & 8) {
-    if (acc[0][0][0] == 12345.f) p.out[0] = 0.f;
-    return;
-  }
-
-  const float sc = op_scale(*p.x_scale).s * op_scale(*p.dy_scale).s;
-  float* out = p.out + (size_t)z * p.Cout * p.Ktot;
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ra_ = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int row = co0 + 2 * (ra_ % (BM / 2)) + ra_ / (BM / 2);   // inverse of the dy staging permutation
-      if (row >= p.Cout) continue;
-      float* orow = out + (size_t)row * p.Ktot + ci0 + 2 * (li & 15) + (li >> 4);   // inverse of the channel permutation
-#pragma unroll
-      for (int b = 0; b < 5; ++b)
-        if (b < nb) orow[(size_t)(wn * 5 + b) * p.Cin] = acc[a][b][r] * sc;
-    }
-}
-
-int launch_wgrad_tap9(const WGradArgs& a, hipStream_t stream) {
-  const size_t lds = (size_t)2 * 2 * (128 + kT9Rows) * kRowBytes;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_tap9_kernel<2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  WGradArgs b = a;
-  static const int dbg = getenv("EVK_WG_DBG") ? atoi(getenv("EVK_WG_DBG")) : 0;
-  b.dbg = dbg;
-  hipLaunchKernelGGL((conv_wgrad_tap9_kernel<2>), dim3(a.tiles_co * a.tiles_k * a.splitk), dim3(512), lds, stream, b);
-  return check_launch("conv_wgrad_tap9");
-}
-
 template <int NP, bool W8>
 static int launch_wgrad_x3ws_t(const WGradArgs& b, hipStream_t stream) {
   constexpr int BM = 128, BN = 256;

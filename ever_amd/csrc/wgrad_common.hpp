@@ -26,12 +26,11 @@ constexpr int BKP = 32;  // pixels per step
 
 struct WGradPlan {
   int bm, bn, tiles_co, tiles_k, splitk, chunk;
-  int ws;  // 1: wave-specialised 128x256 kernel (conv_wgrad_x3ws.hip); 2: its nine-tap form (3x3 / stride 1, f16x2)
+  int ws;  // 1: wave-specialised 128x256 kernel (conv_wgrad_x3ws.hip)
 };
 // x3 = 1: plan for the bf16-split kernel (different LDS footprint => different residency)
 WGradPlan plan_wgrad(const evk_conv_desc* d, int x3, int planes = 3);
 int launch_wgrad_x3(const WGradArgs& a, const WGradPlan& pl, hipStream_t stream);
 int launch_wgrad_x3ws(const WGradArgs& a, hipStream_t stream);
-int launch_wgrad_tap9(const WGradArgs& a, hipStream_t stream);
 
 }  // namespace evk

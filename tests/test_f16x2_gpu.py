@@ -204,16 +204,16 @@ def test_cached_weight_planes_follow_the_weights(cuda):
 
 
 TAP9_CASES = [
-    # n, cin, h, w, cout   (3x3 / stride 1 / padding 1, W % 32 == 0, Cin % 32 == 0, Cout >= 128: the nine-tap weight gradient)
+    # n, cin, h, w, cout   (3x3 / stride 1 / padding 1, W % 32 == 0, Cin % 32 == 0, Cout >= 128)
     (2, 32, 8, 32, 128), (3, 64, 5, 64, 160), (2, 256, 32, 32, 256), (1, 96, 7, 96, 128), (4, 128, 64, 64, 128),
 ]
 
 
 @pytest.mark.parametrize('case', TAP9_CASES)
-def test_nine_tap_weight_gradient(cuda, case):
-    """conv_wgrad_tap9_kernel against fp64 and against the one-tap-per-tile kernel (EVK_WG_TAP9=0 semantics through the
-    planner knob): image borders (the halo's zero rows / columns), several segments per row, ragged Cout tile, odd row
-    counts, split-K chunk boundaries."""
+def test_weight_gradient_3x3_wide_rows(cuda, case):
+    """3x3 weight gradients of the shapes a nine-tap kernel would take (built and measured in round 2, not adopted:
+    DESIGN 2.5) against fp64: image borders, several 32-pixel segments per row, ragged Cout tile, odd row counts,
+    split-K chunk boundaries."""
     import os
     from ever_amd.hip import functional as F
     n, cin, h, w, cout = case
