@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const WGradArgs p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int row = e * Q + cq;
-      const int off = plane_off(row, pg);
+      const int off = wg_off(row, pg);
       u32x4 H, M, L;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -161,11 +161,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const WGradArgs p) {
 #pragma unroll
   for (int a = 0; a < MB; ++a)
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) fa_off[a][kk] = plane_off(wm * WM + a * 32 + li, 2 * kk + lh);
+    for (int kk = 0; kk < 2; ++kk) fa_off[a][kk] = wg_off(wm * WM + a * 32 + li, 2 * kk + lh);
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) fb_off[b][kk] = plane_off(wn * WN + b * 32 + li, 2 * kk + lh);
+    for (int kk = 0; kk < 2; ++kk) fb_off[b][kk] = wg_off(wn * WN + b * 32 + li, 2 * kk + lh);
 
   auto half_step = [&](int kk) {
     bf16x8 fa[MB][3], fb[NB][3];

@@ -75,7 +75,7 @@ __device__ __forceinline__ void split_store8(f32x4 (&rv)[8], uint32_t okmask, un
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const int off = plane_off(e * Q + cq, pg);
+    const int off = wg_off(e * Q + cq, pg);
     u32x4 H, M, L;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -170,7 +170,7 @@ __device__ __forceinline__ void split_store_buf(V (&rv)[8], unsigned char* base,
                                                 float inv) {
 #pragma unroll
   for (int e = 0; e < NCH; ++e) {
-    const int off = plane_off(e * Q + cq, pg);
+    const int off = wg_off(e * Q + cq, pg);
     u32x4 H, M, L;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -195,7 +195,7 @@ __device__ __forceinline__ void split_store8h(f32x2v (&rv)[8], uint32_t okmask, 
   }
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
-    const int off = plane_off(e * Q2 + cq, pg);
+    const int off = wg_off(e * Q2 + cq, pg);
     u32x4 H, M, L;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -338,14 +338,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
 #pragma unroll
   for (int a = 0; a < MB; ++a)
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) fa_off[a][kk] = plane_off(wm * WM + a * 32 + li, 2 * kk + lh);
+    for (int kk = 0; kk < 2; ++kk) fa_off[a][kk] = wg_off(wm * WM + a * 32 + li, 2 * kk + lh);
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
     // im2col LDS row e * QB + q holds channel 4q + e of the k range (staging permutation).  Matrix wave wn takes q in
     // [32 wn, 32 wn + 32) of ALL four e-blocks as its NB = 4 column blocks: lane li then owns the four CONSECUTIVE
     // k columns 4 (32 wn + li) + {0..3} across its blocks, i.e. one 16-byte store per accumulator row.
-    for (int kk = 0; kk < 2; ++kk) fb_off[b][kk] = 3 * BM * kRowBytes + plane_off(b * QB + wn * 32 + li, 2 * kk + lh);
+    for (int kk = 0; kk < 2; ++kk) fb_off[b][kk] = 3 * BM * kRowBytes + wg_off(b * QB + wn * 32 + li, 2 * kk + lh);
 
   auto half_step = [&](const unsigned char* S, int kk) {
     bf16x8 fa[MB][3], fb[NB][3];

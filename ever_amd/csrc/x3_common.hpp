@@ -92,5 +92,16 @@ __device__ __forceinline__ OpScale op_scale(uint32_t absmax_bits) {
 // byte offset of 16-byte chunk c16 (0..3) of row `row` inside one plane; the XOR spreads the
 // ds_read_b128 / ds_write_b128 of 16 consecutive rows over 16 distinct 16-byte slots of a 256-byte bank row
 __device__ __forceinline__ int plane_off(int row, int c16) { return row * kRowBytes + ((c16 ^ ((row >> 2) & 3)) << 4); }
+// The weight-gradient kernels' form: their staging waves write 16 bytes per lane with CONSECUTIVE LANES ON CONSECUTIVE
+// ROWS, and ds_write_b128 is served in groups of 8 contiguous lanes against 32 banks (a 128-byte window, guide table):
+// under plane_off rows r and r + 2 of a group land on the same banks (PMC: SQ_LDS_BANK_CONFLICT = half the LDS cycles of
+// the staging waves).  XOR-ing with ((row >> 1) ^ (row >> 2)) & 3 gives the 4 even and the 4 odd rows of every 8-row
+// group four different slots each, and still spreads the ds_read_b128 lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}
+// over 16 distinct 16-byte slots of a 256-byte bank row (exhaustive check: tools/probes/lds_swizzle.py).  Measured:
+// neutral in time (3x3x256 @128^2 1288 -> 1285 us) — a 2-way store conflict costs 16 LDS cycles against the 13 the
+// VGPR -> LDS transfer of a ds_write_b128 takes anyway; kept because it is the layout the counters call clean.
+__device__ __forceinline__ int wg_off(int row, int c16) {
+  return row * kRowBytes + ((c16 ^ (((row >> 1) ^ (row >> 2)) & 3)) << 4);
+}
 
 }  // namespace evk
