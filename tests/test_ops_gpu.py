@@ -404,6 +404,8 @@ def test_stem_space_to_depth_conv_matches_torch(cuda, c, h, w, nchw):
     images, sizes that are not multiples of the tiles."""
     from ever_amd.hip import functional as HF
     import ever_amd as er
+    if HF.get_conv_math() == 'f32':
+        pytest.skip('the space-to-depth stem belongs to the split arithmetics (EVK_CONV_MATH=f32 keeps the fp32 kernel)')
     torch.manual_seed(c * 100 + h)
     conv = er.module.Conv2d(c, 64, 7, 2, 3, bias=False).to(cuda)
     x = torch.randn(2, c, h, w)
