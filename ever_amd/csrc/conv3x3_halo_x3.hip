@@ -25,8 +25,12 @@ constexpr int kPW = 16;                        // output patch width; height PH 
 // halo row pitch in slots: 32 (>= 18, multiple of 16: every 16-lane group of a ds_read_b128 covers 16 distinct row
 // residues) for the 8-row patch; 18 for the 16-row patch, whose halo would not fit twice otherwise (2 of 16 lanes
 // of a read group then share a slot: +1 LDS cycle on a path that is not the bottleneck)
-template <int PH> struct HaloGeom {
-  static constexpr int kHP = PH == 8 ? 32 : 18;
+// PL = LDS planes per operand: 2 under the f16x2 arithmetic (its third plane does not exist), else 3.  With two planes
+// the 16-row patch affords pitch 32 as well: at pitch 18 EVERY fragment read is 2-way bank-conflicted for the lane
+// groups ds_read_b128 is really served in ({0-3,12-15,20-27} / {4-11,16-19,28-31}, not 16 contiguous lanes; PMC: a third
+// of the kernel's LDS cycles; exhaustive check in the round-2 notes), at pitch 32 none is.
+template <int PH, int PL = 3> struct HaloGeom {
+  static constexpr int kHP = (PH == 8 || PL == 2) ? 32 : 18;
   static constexpr int kHSlots = (PH + 2) * kHP;
   static constexpr int kHaloPix = (PH + 2) * (kPW + 2);
 };
@@ -37,9 +41,11 @@ __device__ __forceinline__ int half_off(int row, int c16) { return row * kRB + (
 
 template <int BN, int PH, int NP>
 __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p, int tiles_y, int tiles_x) {
-  constexpr int kPH = PH, kHP = HaloGeom<PH>::kHP, kHSlots = HaloGeom<PH>::kHSlots, kHaloPix = HaloGeom<PH>::kHaloPix;
-  constexpr int kAStage = 3 * kHSlots * kRB;          // 30720 B (PH 8) / 31104 B (PH 16)
-  constexpr int kBStage = 3 * 3 * BN * kRB;           // 36864 B at BN = 128
+  constexpr int PL = NP == 2 ? 2 : 3;
+  using Geo = HaloGeom<PH, PL>;
+  constexpr int kPH = PH, kHP = Geo::kHP, kHSlots = Geo::kHSlots, kHaloPix = Geo::kHaloPix;
+  constexpr int kAStage = PL * kHSlots * kRB;         // three planes: 30720 B (PH 8) / 31104 B (PH 16); two: 20480 / 36864
+  constexpr int kBStage = 3 * PL * BN * kRB;          // 36864 B at BN = 128 (24576 with two planes)
   constexpr int WMR = PH * kPW / 2;                   // rows per matrix wave (2 waves along M)
   constexpr int WN = BN / 2, NB = WN / 32, MB = WMR / 32;
   constexpr int AI = (kHaloPix * 4 + 255) / 256;      // halo items per staging thread
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
       int co = n0 + row;
       co = co < p.Cd ? co : p.Cd - 1;
       b_src[i] = (int)(pt * plane_stride + (size_t)jx * tap_stride + (size_t)co * kCh + half * 8);
-      b_lds[i] = (jx * 3 + pt) * BN * kRB + half_off(row, half);
+      b_lds[i] = (jx * PL + (pt < PL ? pt : 0)) * BN * kRB + half_off(row, half);
     }
     f32x4 ra[AI];
     u32x4 rbv[BI];
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
       for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int pt = 0; pt < NP; ++pt)
-          fbv[b][pt] = *reinterpret_cast<const bf16x8*>(B + (jx * 3 + pt) * BN * kRB + fb[b]);
+          fbv[b][pt] = *reinterpret_cast<const bf16x8*>(B + (jx * PL + pt) * BN * kRB + fb[b]);
 #pragma unroll
       for (int t6 = 0; t6 < X3Prod<NP>::N; ++t6)
 #pragma unroll
@@ -272,7 +278,8 @@ static int launch_halo_np(IGemmArgs& a, hipStream_t stream) {
   const int tiles_y = a.Hm / PH, tiles_x = a.Wm / kPW;
   a.tiles_m = a.N * tiles_y * tiles_x;
   bn_stats_setup(a, PH * kPW, BN, 2, a.tiles_m);   // two row waves per patch; the ring (>= 100 KB) is the scratch
-  const size_t lds = (size_t)2 * (3 * HaloGeom<PH>::kHSlots * kRB) + (size_t)2 * (3 * 3 * BN * kRB);
+  constexpr int PL = NP == 2 ? 2 : 3;
+  const size_t lds = (size_t)2 * (PL * HaloGeom<PH, PL>::kHSlots * kRB) + (size_t)2 * (3 * PL * BN * kRB);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_x3_kernel<BN, PH, NP>),
