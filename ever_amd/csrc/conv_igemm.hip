@@ -454,8 +454,12 @@ static int conv_dgrad_any(const evk_conv_desc* d, const float* dy, const float* 
   bool all_covered = true;
   for (int cy = 0; cy < sh; ++cy) all_covered = all_covered && plan_axis(cy, d->pad_h, d->dil_h, sh, d->kh).nt > 0;
   for (int cx = 0; cx < sw; ++cx) all_covered = all_covered && plan_axis(cx, d->pad_w, d->dil_w, sw, d->kw).nt > 0;
-  EVK_REQUIRE(accum != dx, EVK_E_INVALID, "conv2d_dgrad: accum must not alias dx");
-  if (!all_covered) {  // pixels no tap reaches: dx = 0 (+ accum)
+  // accum == dx (split kernels only): accumulate in place — every epilogue thread reads the accum quads of its row block
+  // before it stores the same addresses (igemm_store_rows), and pixels no tap reaches already hold their value.  The
+  // strided 1x1 shortcut of a residual block uses this: its data gradient touches one pixel in four of a tensor the
+  // main branch's data gradient has just written, so the 268 MB fill / copy below disappears.
+  EVK_REQUIRE(accum != dx || wt3, EVK_E_INVALID, "conv2d_dgrad: accum must not alias dx in the fp32 kernels");
+  if (!all_covered && accum != dx) {  // pixels no tap reaches: dx = 0 (+ accum)
     const size_t bytes = (size_t)d->N * d->H * d->W * d->Cin * sizeof(float);
     hipError_t e = accum ? hipMemcpyAsync(dx, accum, bytes, hipMemcpyDeviceToDevice, st) : hipMemsetAsync(dx, 0, bytes, st);
     if (e != hipSuccess) { set_error("conv2d_dgrad fill: %s", hipGetErrorString(e)); return EVK_E_LAUNCH; }

@@ -344,9 +344,17 @@ def _conv_forward(x, weight, bias, stride, padding, dilation, relu, want_stats=F
     return y, cs
 
 
-def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None):
+def _sparse_dgrad(cs):
+    """True when the data gradient of this convolution reaches only some pixels of x (kernel smaller than the stride:
+    the 1x1 / stride-2 shortcut of a residual block) and runs on the plane kernels, which accumulate in place."""
+    d = cs.desc
+    return (_planes_math() and (d.kh < d.stride_h or d.kw < d.stride_w) and d.Cin % 8 == 0 and d.Cout % 8 == 0
+            and cs.cin == d.Cin)
+
+
+def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False):
     """(dx, dw, db) of one convolution.  `accum` (a tensor of x's shape or None) is added to dx inside
-    the data-gradient epilogue: dx = conv_transpose(dy, w) + accum."""
+    the data-gradient epilogue: dx = conv_transpose(dy, w) + accum; with `inplace` (plane kernels only) dx IS accum."""
     d, xk, w_ohwi = cs.desc, cs.xk, cs.w_ohwi
     dev = dy.device
     st = _stream()
@@ -384,7 +392,7 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None):
         if accum is not None:
             accum = as_nhwc(accum, 'conv2d.backward.accum')
             acc_ptr = accum.data_ptr()
-        dx = empty_nhwc(n, cin, d.H, d.W, dev)
+        dx = accum if (inplace and accum is not None) else empty_nhwc(n, cin, d.H, d.W, dev)
         dybits = absmax_bits(dyk, st) if wabs_ptr is not None else None
         sp = timing.span('conv_igemm', cs.flops, cs.abytes, cs.scope)
         if wabs_ptr is not None:
@@ -591,6 +599,14 @@ class _ConvForkFn(Function):
                 slot_g = None
         if ctx.cs_short is None:
             acc = dshort  # gradient of the identity shortcut
+        elif dshort is not None and dy is not None and need_dx and _sparse_dgrad(ctx.cs_short):
+            # strided 1x1 shortcut: the main branch's (dense) data gradient first, the shortcut's one-pixel-in-four
+            # contribution accumulated into it in place — no zero fill / copy of the whole tensor for the other three
+            dx, dw, db = _conv_backward(ctx.cs_main, dy, True, ctx.needs_input_grad[1],
+                                        ctx.cs_main.has_bias and ctx.needs_input_grad[3], accum=slot_g)
+            dx, dws, dbs = _conv_backward(ctx.cs_short, dshort, True, ctx.needs_input_grad[2],
+                                          ctx.cs_short.has_bias and ctx.needs_input_grad[4], accum=dx, inplace=True)
+            return dx, dw, dws, db, dbs, None, None, None, None
         elif dshort is not None:
             acc, dws, dbs = _conv_backward(ctx.cs_short, dshort, need_dx, ctx.needs_input_grad[2],
                                            ctx.cs_short.has_bias and ctx.needs_input_grad[4], accum=slot_g)
