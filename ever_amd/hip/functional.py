@@ -755,7 +755,7 @@ class _StemConvFn(Function):
     weight on every call (12 KB), the products and their sum are the ones of the 7x7 form.  No gradient to the image."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, want_stats=False):
         n, c, h, w = x.shape
         cout = weight.shape[0]
         dev, st = x.device, _stream()
@@ -775,8 +775,14 @@ class _StemConvFn(Function):
         nbytes = 4.0 * (x.numel() + y.numel() + weight.numel())
         sp = timing.span('conv_igemm', flops, nbytes)
         if wabs_ptr is not None:
+            # BatchNorm statistics of the stem's output from the epilogue as well (the largest map of the network)
+            parts, cap, nparts = None, 0, ctypes.c_int32(0)
+            if want_stats and _BN_EPILOGUE and cout % 4 == 0:
+                cap = int(_C.load().evk_conv2d_stats_max_parts(ctypes.byref(d)))
+                parts = torch.empty((cap * 3 * cout,), device=dev, dtype=torch.float32)
             _C.call('evk_conv2d_fwd_f16x2', ctypes.byref(d), xs.data_ptr(), xbits.data_ptr(), pl_ptr, wabs_ptr, None, None,
-                    y.data_ptr(), 0, None, 0, ctypes.byref(ctypes.c_int32(0)), st)
+                    y.data_ptr(), 0, _ptr(parts), cap, ctypes.byref(nparts), st)
+            _BN_HANDOFF[0] = (parts, int(nparts.value)) if nparts.value > 0 else None
         elif _CONV_MATH == 'bf16':
             _C.call('evk_conv2d_fwd_bf16', ctypes.byref(d), xs.data_ptr(), pl_ptr, None, y.data_ptr(), 0, None, 0,
                     ctypes.byref(ctypes.c_int32(0)), st)
@@ -814,7 +820,7 @@ class _StemConvFn(Function):
             sp.stop()
         dw7 = torch.empty((d.Cout, 7, 7, c), device=dev, dtype=torch.float32)
         _C.call('evk_stem_s2d_weight_bwd', dw4.data_ptr(), dw7.data_ptr(), d.Cout, c, st)
-        return None, dw7.permute(0, 3, 1, 2)                     # logical OIHW over OHWI memory, as the parameter
+        return None, dw7.permute(0, 3, 1, 2), None               # logical OIHW over OHWI memory, as the parameter
 
 
 def stem_conv_applicable(x, conv):
@@ -827,9 +833,12 @@ def stem_conv_applicable(x, conv):
             and os.environ.get('EVK_STEM_S2D', '1') != '0')
 
 
-def stem_conv7x7s2(x, weight):
+def stem_conv7x7s2(x, weight, bn_stats=False):
     _require_cuda(x, 'stem_conv7x7s2')
-    return _StemConvFn.apply(x, weight)
+    _BN_HANDOFF[0] = None
+    y = _StemConvFn.apply(x, weight, bool(bn_stats))
+    parts, _BN_HANDOFF[0] = _BN_HANDOFF[0], None
+    return _attach_parts(y, parts)
 
 
 # ------------------------------------------------------------------------------------ batch norm

@@ -175,7 +175,7 @@ class ResNet(nn.Module):
             return self.stem(x)
         if HF.stem_conv_applicable(x, self.conv1) and not _use_folded(self.conv1, self.bn1):
             # 7x7 / stride 2 on a 3- or 4-band image: space-to-depth form on the split-MFMA kernels (csrc/stem_s2d.hip)
-            return self.bn1(HF.stem_conv7x7s2(x, self.conv1.weight), relu=True)
+            return self.bn1(HF.stem_conv7x7s2(x, self.conv1.weight, bn_stats=_takes_epilogue_stats(self.bn1)), relu=True)
         return conv_bn(self.conv1, self.bn1, x, relu=True)
 
     def forward(self, x):

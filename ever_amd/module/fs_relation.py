@@ -36,7 +36,9 @@ def _content_and_reencoded(content_encoders, feature_reencoders, features):
                     and isinstance(fr, nn.Sequential) and len(ce) > 0 and len(fr) > 0
                     and isinstance(ce[0], Conv2d) and isinstance(fr[0], Conv2d))
         if pairable:
-            yc, yf = HF.conv2d_fork(f, ce[0], fr[0])
+            from .fold import _takes_epilogue_stats
+            want = tuple(len(seq) > 1 and isinstance(seq[1], BatchNorm2d) and _takes_epilogue_stats(seq[1]) for seq in (ce, fr))
+            yc, yf = HF.conv2d_fork(f, ce[0], fr[0], bn_stats=want)
             contents.append(run_sequence(list(ce)[1:], yc))
             feats.append(run_sequence(list(fr)[1:], yf))
         else:
