@@ -54,6 +54,7 @@ SIGNATURES = {
     'evk_conv2d_dgrad_bf16': (c_int, [_DP, P, P, P, P, P]),
     'evk_conv2d_wgrad_bf16': (c_int, [_DP, P, P, P, P, P, c_size_t, P]),
     'evk_conv2d_dgrad_x3': (c_int, [_DP, P, P, P, P, P]),
+    'evk_absmax_words': (c_size_t, []),
     'evk_absmax_workspace_bytes': (c_size_t, []),
     'evk_absmax': (c_int, [P, c_i64, P, P, P]),
     'evk_absmax_multi': (c_int, [P, P, c_i32, P, P]),

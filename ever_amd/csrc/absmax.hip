@@ -1,12 +1,13 @@
 // max |x| of a tensor as the bit image of a non-negative float (unsigned order = float order), left in device memory:
 // the per-tensor operand scale of the f16x2 convolution arithmetic (x3_common.hpp: op_scale).  No reference call site —
 // operand preparation of this engine's arithmetic, like the weight planes.  HBM-bound: one read pass.
-//   evk_absmax        one tensor; partial maxima per workgroup, folded by the LAST-ARRIVING workgroup (no second launch,
-//                     no pre-zeroed output; the caller's workspace holds the partials and a ticket counter that must be
+//   evk_absmax        one tensor -> an ACTIVATION scale buffer of evk_absmax_words() words (slot 0 = the maximum, the other
+//                     slots zero: x3_common.hpp act_absmax); partial maxima per workgroup, folded by the LAST-ARRIVING
+//                     workgroup (no second launch, no pre-zeroed output; the caller's workspace holds the partials and a ticket counter that must be
 //                     zero before the first call and is left zero by every call — calls on ONE stream only)
 //   evk_absmax_multi  n tensors in one launch (the convolution weights, once per optimiser step): atomic max into a
 //                     zeroed output array
-#include "common.hpp"
+#include "x3_common.hpp"
 
 namespace evk {
 
@@ -56,10 +57,8 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
   for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) t = max(t, __builtin_nontemporal_load(ws + b));
   __syncthreads();   // block_max's shared array is reused
   t = block_max(t);
-  if (threadIdx.x == 0) {
-    out[0] = t;
-    ws[kAbsBlocks] = 0;   // ready for the next call on this stream
-  }
+  if (threadIdx.x < kAmaxSlots) out[threadIdx.x * kAmaxStride] = threadIdx.x == 0 ? t : 0u;   // slot 0; the others empty
+  if (threadIdx.x == 0) ws[kAbsBlocks] = 0;   // ready for the next call on this stream
 }
 
 __global__ __launch_bounds__(256) void absmax_multi_kernel(const float* const* __restrict__ ptrs,
@@ -84,6 +83,7 @@ __global__ __launch_bounds__(256) void absmax_multi_kernel(const float* const* _
 
 using namespace evk;
 
+extern "C" size_t evk_absmax_words(void) { return (size_t)kAmaxWords; }
 extern "C" size_t evk_absmax_workspace_bytes(void) { return (size_t)(kAbsBlocks + 1) * sizeof(uint32_t); }
 
 extern "C" int evk_absmax(const float* x, int64_t n, uint32_t* out_bits, void* workspace, void* stream) {

@@ -4,12 +4,17 @@
 // fpn.py:163-167.  HBM-bound: every kernel streams [rows][C] with 16-byte accesses, a workgroup's
 // row range is one contiguous span.  Statistics are reduced in two stages (fp32 partials per
 // workgroup, fp64 finalisation) so results do not depend on the launch grid.
-#include "common.hpp"
+#include "x3_common.hpp"
 #include <stdlib.h>
 
 namespace evk {
 
 constexpr int kMaxStatBlocks = 2048;
+
+// the slots of an output's operand-scale buffer start empty (block_absmax below fills them)
+__device__ __forceinline__ void zero_amax(uint32_t* __restrict__ amax) {   // by workgroup 0 of the finalisation kernels
+  if (amax && blockIdx.x == 0 && threadIdx.x < kAmaxSlots) amax[threadIdx.x * kAmaxStride] = 0;
+}
 
 struct BnPlan {
   int nblk;
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __rest
                                                              float* __restrict__ save_invstd,
                                                              float* __restrict__ scale_shift,
                                                              uint32_t* __restrict__ amax) {
-  if (amax && blockIdx.x == 0 && threadIdx.x == 0) *amax = 0;   // the apply pass accumulates max|y| into it
+  zero_amax(amax);   // the apply pass accumulates max|y| into its slots
   int c;
   double s, q;
   if (!reduce_partials(partial, nblk, C, c, s, q)) return;
@@ -158,7 +163,7 @@ __global__ void bn_eval_coef_kernel(const float* __restrict__ gamma, const float
                                     float* __restrict__ scale_shift, float* __restrict__ save_mean,
                                     float* __restrict__ save_invstd, uint32_t* __restrict__ amax) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (amax && c == 0) *amax = 0;
+  zero_amax(amax);
   if (c >= C) return;
   const float invstd = (float)(1.0 / sqrt((double)rv[c] + (double)eps));
   if (save_mean) save_mean[c] = rm[c];
@@ -179,38 +184,27 @@ __device__ __forceinline__ int chunk_of(size_t blk_base, int c4) {
   return r >= c4 ? r - c4 : r;
 }
 
-// max|v| over a workgroup's 16-byte elements -> amax_partial[blockIdx.x] (bit image; the f16x2 convolution arithmetic's
-// operand scale of the tensor being written, csrc/absmax.hip), folded into one word by absmax_fold_kernel right after.
-// Plain stores only: an atomic (or even a guarded read) of ONE word from every workgroup of a 268 MB map is a
-// same-address hot spot across the eight XCDs — measured 0.4 TB/s for the whole pass instead of 4.6.
-__device__ __forceinline__ void block_absmax(const f32x4 v, bool valid, uint32_t* __restrict__ amax_partial) {
+// max|v| over a workgroup's 16-byte elements into the output's operand-scale buffer (bit image; the f16x2 convolution
+// arithmetic's scale of the tensor being written, x3_common.hpp act_absmax): ONE atomic max per workgroup on slot
+// (workgroup & 63), the slots a cache line apart and zeroed by the finalisation kernel launched just before.  Measured:
+// free (BatchNorm family 4.16 -> 4.13 TB/s).  What was not: an atomic or a guarded read of ONE word from every wave, and
+// a last-arriver fold with a device-scope fence per workgroup (0.4 TB/s each); per-workgroup words + a fold launch worked
+// but cost 136 launches of 5.7 us per step.
+__device__ __forceinline__ void block_absmax(const f32x4 v, bool valid, uint32_t* __restrict__ amax) {
   __shared__ uint32_t red[4];
   uint32_t m = 0;
   if (valid) {
     m = __builtin_bit_cast(uint32_t, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-    const uint32_t nan_or = ((__builtin_bit_cast(uint32_t, v.x) | __builtin_bit_cast(uint32_t, v.y) |
-                              __builtin_bit_cast(uint32_t, v.z) | __builtin_bit_cast(uint32_t, v.w)) & 0x7fffffffu);
-    if (nan_or > 0x7f800000u && (v.x != v.x || v.y != v.y || v.z != v.z || v.w != v.w)) m = 0x7fc00000u;  // keep NaNs visible
+    if (v.x != v.x || v.y != v.y || v.z != v.z || v.w != v.w) m = 0x7fc00000u;   // fmaxf drops NaNs: keep them visible
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) amax_partial[blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
-}
-// out (zeroed by the finalisation kernel launched before the apply pass) = max over the workgroups' words
-__global__ __launch_bounds__(256) void absmax_fold_kernel(const uint32_t* __restrict__ partial, size_t n,
-                                                          uint32_t* __restrict__ out) {
-  uint32_t m = 0;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = max(m, partial[i]);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
-}
-static int launch_absmax_fold(const uint32_t* partial, size_t n, uint32_t* out, hipStream_t st) {
-  const unsigned blocks = (unsigned)((n + 4095) / 4096 > 64 ? 64 : (n + 4095) / 4096);
-  hipLaunchKernelGGL(absmax_fold_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, partial, n, out);
-  return check_launch("absmax_fold");
+  if (threadIdx.x == 0) {
+    const uint32_t t = max(max(red[0], red[1]), max(red[2], red[3]));
+    if (t) atomicMax(&amax[(blockIdx.x & (kAmaxSlots - 1)) * kAmaxStride], t);
+  }
 }
 
 // y = act(x*scale + shift [+ residual]).
@@ -337,7 +331,7 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            float* __restrict__ coef, int train,
                                                            uint32_t* __restrict__ amax) {
-  if (amax && blockIdx.x == 0 && threadIdx.x == 0) *amax = 0;   // stage 3 accumulates max|dx| into it
+  zero_amax(amax);   // stage 3 accumulates max|dx| into its slots
   int c;
   double s, q;
   if (!reduce_partials(partial, nblk, C, c, s, q)) return;
@@ -403,7 +397,7 @@ __global__ __launch_bounds__(256) void bn_parts_final_kernel(const float* __rest
                                                              float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                                              float* __restrict__ scale_shift,
                                                              uint32_t* __restrict__ amax) {
-  if (amax && blockIdx.x == 0 && threadIdx.x == 0) *amax = 0;   // the apply pass accumulates max|y| into it
+  zero_amax(amax);   // the apply pass accumulates max|y| into its slots
   // With a common pivot p (the first record's mean) the merge of all records is three plain sums,
   //   N = sum n_i,  A = sum n_i (mean_i - p),  B = sum [M2_i + n_i (mean_i - p)^2]:  mean = p + A/N,  M2 = B - A^2/N
   // (Chan's pairwise formula telescoped; no division inside the loop, no order dependence beyond the fixed one below).
@@ -471,13 +465,9 @@ using namespace evk;
 
 extern "C" size_t evk_bn_workspace_bytes(int64_t rows, int32_t C) {
   if (rows <= 0 || C <= 0) return 0;
-  // statistics partials + per-channel vectors + one word per workgroup of the apply pass (fused max|output|)
-  return ((size_t)kMaxStatBlocks * 2 * C + 8 * (size_t)C + ((size_t)rows * C / 4 + 255) / 256 + 64) * sizeof(float);
+  return ((size_t)kMaxStatBlocks * 2 * C + 8 * (size_t)C) * sizeof(float);
 }
 
-static inline uint32_t* amax_words(void* workspace, int32_t C) {
-  return reinterpret_cast<uint32_t*>((float*)workspace + (size_t)kMaxStatBlocks * 2 * C + 8 * (size_t)C);
-}
 
 extern "C" int evk_bn_fwd_train(const float* x, const float* residual, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, float momentum, float eps, float* y,
@@ -504,10 +494,8 @@ extern "C" int evk_bn_fwd_train(const float* x, const float* residual, const flo
   if (rc) return rc;
   const size_t n4 = (size_t)rows * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, x, residual,
-                     scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, y_absmax ? amax_words(workspace, C) : nullptr);
-  rc = check_launch("bn_apply");
-  if (rc || !y_absmax) return rc;
-  return launch_absmax_fold(amax_words(workspace, C), oneshot_grid(n4), y_absmax, st);
+                     scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, y_absmax);
+  return check_launch("bn_apply");
 }
 
 extern "C" int evk_bn_fwd_train_parts(const float* x, const float* residual, const float* gamma, const float* beta,
@@ -529,10 +517,8 @@ extern "C" int evk_bn_fwd_train_parts(const float* x, const float* residual, con
   if (rc) return rc;
   const size_t n4 = (size_t)rows * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, x, residual,
-                     scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, y_absmax ? amax_words(workspace, C) : nullptr);
-  rc = check_launch("bn_apply");
-  if (rc || !y_absmax) return rc;
-  return launch_absmax_fold(amax_words(workspace, C), oneshot_grid(n4), y_absmax, st);
+                     scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, y_absmax);
+  return check_launch("bn_apply");
 }
 
 extern "C" int evk_bn_fwd_eval(const float* x, const float* residual, const float* gamma, const float* beta,
@@ -542,8 +528,8 @@ extern "C" int evk_bn_fwd_eval(const float* x, const float* residual, const floa
   EVK_REQUIRE(x && y && running_mean && running_var, EVK_E_INVALID, "bn_fwd_eval: null pointer");
   EVK_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 2048, EVK_E_UNSUPPORTED, "bn_fwd_eval: rows=%lld C=%d",
               (long long)rows, C);
-  EVK_REQUIRE(workspace && workspace_bytes >= (y_absmax ? evk_bn_workspace_bytes(rows, C) : 2 * (size_t)C * sizeof(float)),
-              EVK_E_WORKSPACE, "bn_fwd_eval: workspace too small");
+  EVK_REQUIRE(workspace && workspace_bytes >= 2 * (size_t)C * sizeof(float), EVK_E_WORKSPACE,
+              "bn_fwd_eval: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   float* scale_shift = (float*)workspace;
   hipLaunchKernelGGL(bn_eval_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, st, gamma, beta, running_mean,
@@ -552,10 +538,8 @@ extern "C" int evk_bn_fwd_eval(const float* x, const float* residual, const floa
   if (rc) return rc;
   const size_t n4 = (size_t)rows * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, x, residual,
-                     scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, y_absmax ? amax_words(workspace, C) : nullptr);
-  rc = check_launch("bn_apply");
-  if (rc || !y_absmax) return rc;
-  return launch_absmax_fold(amax_words(workspace, C), oneshot_grid(n4), y_absmax, st);
+                     scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, y_absmax);
+  return check_launch("bn_apply");
 }
 
 extern "C" int evk_bn_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
@@ -588,11 +572,8 @@ extern "C" int evk_bn_bwd(const float* dy, const float* x, const float* y, const
   const float* gsrc = d_residual ? d_residual : dy;
   const int relu3 = d_residual ? 0 : relu;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, gsrc, x, y,
-                     save_mean, save_invstd, coef, gamma, beta, dx, n4, C, relu3,
-                     dx_absmax ? amax_words(workspace, C) : nullptr);
-  rc = check_launch("bn_bwd_apply");
-  if (rc || !dx_absmax) return rc;
-  return launch_absmax_fold(amax_words(workspace, C), oneshot_grid(n4), dx_absmax, st);
+                     save_mean, save_invstd, coef, gamma, beta, dx, n4, C, relu3, dx_absmax);
+  return check_launch("bn_bwd_apply");
 }
 
 // ------------------------------------------------------------------------------------------------

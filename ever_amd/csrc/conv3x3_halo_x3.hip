@@ -106,7 +106,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
     f32x4 ra[AI];
     u32x4 rbv[BI];
     float a_inv = 1.f;   // f16x2: 1 / activation scale
-    if constexpr (NP == 2) a_inv = op_scale(*p.a_scale).inv;
+    if constexpr (NP == 2) a_inv = op_scale(act_absmax(p.a_scale)).inv;
     auto load_a = [&](int c) {
 #pragma unroll
       for (int i = 0; i < AI; ++i) ra[i] = *reinterpret_cast<const f32x4*>(p.src + a_src[i] + (a_ok[i] ? c * kCh : 0));
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
     __syncthreads();
   }
 
-  if constexpr (NP == 2) igemm_scale_acc<MB, NB>(acc, op_scale(*p.a_scale).s * op_scale(*p.w_scale).s);
+  if constexpr (NP == 2) igemm_scale_acc<MB, NB>(acc, op_scale(act_absmax(p.a_scale)).s * op_scale(*p.w_scale).s);
   if (p.bn_part) {
     // BatchNorm statistics of the output from the epilogue: the loop ended on a barrier of all eight waves and the
     // staging waves have nothing left to write, so the LDS is free to park the tile (igemm_common.hpp)

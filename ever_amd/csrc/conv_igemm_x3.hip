@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(const IGemmArgs p) {
   uint32_t okmask = 0;
   float a_inv = 1.f, out_scale = 1.f;   // f16x2: 1 / activation scale; activation scale x weight scale
   if constexpr (NP == 2) {
-    const OpScale sa = op_scale(*p.a_scale), sw = op_scale(*p.w_scale);
+    const OpScale sa = op_scale(act_absmax(p.a_scale)), sw = op_scale(*p.w_scale);
     a_inv = sa.inv;
     out_scale = sa.s * sw.s;
   }

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws_kernel(const IGemmArgs p)
     u32x4 rbv[2][BR][3];
     uint32_t okmask[2] = {0, 0};
     float a_inv = 1.f;   // f16x2: 1 / activation scale
-    if constexpr (NP == 2) a_inv = op_scale(*p.a_scale).inv;
+    if constexpr (NP == 2) a_inv = op_scale(act_absmax(p.a_scale)).inv;
 
     auto load_tiles = [&](auto SET) {
       constexpr int s = decltype(SET)::value;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws_kernel(const IGemmArgs p)
       fb_off[b][kk] = 3 * BM * kRowBytes + plane_off(wn * WN + b * 32 + li, 2 * kk + lh);
 
   float out_scale = 1.f;   // f16x2: activation scale x weight scale
-  if constexpr (NP == 2) out_scale = op_scale(*p.a_scale).s * op_scale(*p.w_scale).s;
+  if constexpr (NP == 2) out_scale = op_scale(act_absmax(p.a_scale)).s * op_scale(*p.w_scale).s;
   bf16x8 fa[2][MB][3], fb[2][NB][3];  // fragment registers, double buffered across the two k-halves
   auto read_frags = [&](const unsigned char* S, int kk, int slot) {
 #pragma unroll

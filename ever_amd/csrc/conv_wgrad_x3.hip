@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const WGradArgs p) {
   uint32_t okmask = 0;
   float st_inv = 1.f, out_scale = 1.f;   // f16x2: 1 / scale of the operand this thread stages; product of both scales
   if constexpr (NP == 2) {
-    const OpScale sx = op_scale(*p.x_scale), sd = op_scale(*p.dy_scale);
+    const OpScale sx = op_scale(act_absmax(p.x_scale)), sd = op_scale(act_absmax(p.dy_scale));
     st_inv = roleA ? sd.inv : sx.inv;
     out_scale = sx.s * sd.s;
   }

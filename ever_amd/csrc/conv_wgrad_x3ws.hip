@@ -265,8 +265,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
     const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.M * p.Cout * 4, 0x00020000);
     float x_inv = 1.f, dy_inv = 1.f;   // f16x2: 1 / operand scales
     if constexpr (NP == 2) {
-      x_inv = op_scale(*p.x_scale).inv;
-      dy_inv = op_scale(*p.dy_scale).inv;
+      x_inv = op_scale(act_absmax(p.x_scale)).inv;
+      dy_inv = op_scale(act_absmax(p.dy_scale)).inv;
     }
 
     auto load = [&](auto SET, int kt) {
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
   }
 
   if constexpr (NP == 2) {   // f16x2: back to the operands' units
-    const float sc = op_scale(*p.x_scale).s * op_scale(*p.dy_scale).s;
+    const float sc = op_scale(act_absmax(p.x_scale)).s * op_scale(act_absmax(p.dy_scale)).s;
 #pragma unroll
     for (int a = 0; a < MB; ++a)
 #pragma unroll

@@ -75,6 +75,18 @@ __device__ __forceinline__ f32x16 mfma_np(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// An ACTIVATION operand's max|x| lives in kAmaxSlots words spaced one cache line apart (evk_absmax fills slot 0 and zeroes
+// the rest; the BatchNorm apply passes raise slot (workgroup & 63) with one atomic per workgroup — 64 addresses on 64
+// lines take a 268 MB map's 65 K atomics without a measurable cost, where ONE hot word serialised the eight XCDs).  A
+// wave reads one slot per lane and folds them; every wave of a kernel gets the same value.  Weights keep a single word.
+constexpr int kAmaxSlots = 64, kAmaxStride = 32, kAmaxWords = kAmaxSlots * kAmaxStride;
+__device__ __forceinline__ uint32_t act_absmax(const uint32_t* __restrict__ slots) {
+  uint32_t m = slots[(threadIdx.x & 63) * kAmaxStride];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  return m;
+}
+
 // Operand scale of the f16x2 arithmetic from the bit image of max|x| (what evk_absmax leaves in device memory):
 // s = 2^(E - 13) with E the biased exponent, clamped to the normal range; zero / non-finite tensors use s = 1.
 struct OpScale { float inv, s; };

@@ -74,21 +74,36 @@ def _inherit_amax(out, src):
     return out
 
 
+_AMAX_WORDS = [0]
+
+
+def _amax_buf(dev):
+    """An activation scale buffer (64 slots of partial max|x| bit images, include/ever_hip.h: evk_absmax)."""
+    if not _AMAX_WORDS[0]:
+        _AMAX_WORDS[0] = int(_C.load().evk_absmax_words())
+    return torch.empty((_AMAX_WORDS[0],), device=dev, dtype=torch.int32)
+
+
+def absmax_value(bits):
+    """The bit image of max|x| held by an activation scale buffer (tests, tools): the maximum of its slots."""
+    n = bits.numel() // 64
+    return int(bits.view(64, n)[:, 0].max().item())
+
+
 def _amax_out(dev):
-    """A device word for a producer kernel to leave max|output| in, or None when no consumer will want it."""
-    return torch.empty((1,), device=dev, dtype=torch.int32) if (_FUSED_AMAX and _f16x2()) else None
+    """A scale buffer for a producer kernel to leave max|output| in, or None when no consumer will want it."""
+    return _amax_buf(dev) if (_FUSED_AMAX and _f16x2()) else None
 
 
 def absmax_bits(t, st):
-    """int32[1] device tensor holding the bit image of max|t| (the f16x2 operand scale derives from it inside the
-    kernels).  Cached on the tensor object: the forward's scale of x serves the weight gradient, the scale of dy serves
+    """Activation scale buffer of t (the f16x2 operand scale derives from the maximum of its slots inside the kernels).  Cached on the tensor object: the forward's scale of x serves the weight gradient, the scale of dy serves
     data and weight gradient, a block input serves both convolutions that read it."""
     hit = getattr(t, '_evk_amax', None)
     if hit is not None and hit[0] == t._version and hit[1] == t.data_ptr():
         absmax_stats['hits'] += 1
         return hit[2]
     absmax_stats['standalone'] += 1
-    bits = torch.empty((1,), device=t.device, dtype=torch.int32)
+    bits = _amax_buf(t.device)
     sp = timing.span('absmax', 0.0, 4.0 * t.numel())
     _C.call('evk_absmax', t.data_ptr(), t.numel(), bits.data_ptr(), weight_planes.absmax_workspace(t.device, st).data_ptr(), st)
     if sp is not None:
@@ -109,7 +124,7 @@ def _weight_planes(weight, w_dense, w_ptr, d, for_dgrad, st, dev):
         return (hit[0], hit[1], None) if h2 else (hit, None, None)
     planes = workspace(dev, _C.load().evk_conv2d_split_weight_bytes(ctypes.byref(d), for_dgrad))
     if h2:
-        wb = torch.empty((1,), device=dev, dtype=torch.int32)
+        wb = _amax_buf(dev)          # (slot 0 = the maximum: a valid single word for the kernels' w_absmax)
         nel = d.Cout * d.kh * d.kw * d.Cin
         _C.call('evk_absmax', w_ptr, nel, wb.data_ptr(), weight_planes.absmax_workspace(dev, st).data_ptr(), st)
         _C.call('evk_conv2d_split_weight_f16x2', ctypes.byref(d), w_ptr, for_dgrad, planes.data_ptr(), wb.data_ptr(), st)

@@ -233,7 +233,8 @@ def planes_for(weight, w_dense, d, for_dgrad, stream, f16x2=False):
         e.jobs = [jobs[i] for i in range(n)]
         if kind == 'h':
             wabs_ptr = _wabs_for(weight.device).data_ptr() + 4 * e.slot
-            _C.call('evk_absmax', e.ptr, e.numel, wabs_ptr, absmax_workspace(weight.device, stream).data_ptr(), stream)
+            one = torch.tensor([e.ptr, e.numel], dtype=torch.int64, device=weight.device)   # one-entry (pointer, size) table
+            _C.call('evk_absmax_multi', one.data_ptr(), one.data_ptr() + 8, 1, wabs_ptr, stream)
             _C.call('evk_conv2d_split_weight_f16x2', ctypes.byref(d), e.ptr, for_dgrad, e.planes.data_ptr(), wabs_ptr, stream)
         else:
             _C.call('evk_conv2d_split_weight', ctypes.byref(d), e.ptr, for_dgrad, e.planes.data_ptr(), stream)

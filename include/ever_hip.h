@@ -133,10 +133,15 @@ int evk_conv2d_wgrad_bf16(const evk_conv_desc* d, const float* x, const float* d
  * l*wh + h*wl + h*wh on v_mfma_f32_32x32x16_f16 (dropped: l*wl <= 2^-22 |x*w|), accumulated in fp32 and multiplied by
  * the two scales at the end.  Same call sites as the x3 forms (nn.Conv2d at _resnets.py:21-29,149, fpn.py:23-37,
  * fs_relation.py:23-53), same plane buffers (planes 0 and 1 are used), half the matrix work.
- *   evk_absmax:        bit image of max|x| (a non-negative float read as uint32) -> *out_bits (device); `workspace` =
+ *   An ACTIVATION's scale source is a device buffer of evk_absmax_words() uint32: 64 slots one cache line apart, each
+ *   the bit image of a partial max|x| (a non-negative float read as uint32); consumers take the maximum of the slots.
+ *   evk_absmax:        fills such a buffer from a tensor (slot 0 = max|x|, the others zero); `workspace` =
  *                      evk_absmax_workspace_bytes() bytes, ZERO before the first call, private to one stream
- *   evk_absmax_multi:  the same for n tensors in one launch (the weights, once per optimiser step)
- *   *_absmax arguments below are such device words; the kernels derive s = 2^(exponent - 13) from them. */
+ *   the BatchNorm calls fill one for their output as a by-product (y_absmax / dx_absmax arguments)
+ *   evk_absmax_multi:  ONE word per tensor for n tensors in one launch (the weights, once per optimiser step)
+ *   x_absmax / dy_absmax arguments below are activation buffers, w_absmax a single word; the kernels derive
+ *   s = 2^(exponent - 13) from them. */
+size_t evk_absmax_words(void);
 size_t evk_absmax_workspace_bytes(void);
 int evk_absmax(const float* x, int64_t n, uint32_t* out_bits, void* workspace, void* stream);
 int evk_absmax_multi(const float* const* ptrs_dev, const int64_t* sizes_dev, int32_t n_tensors, uint32_t* out_bits,
@@ -236,9 +241,10 @@ int evk_bn_fwd_train(const float* x, const float* residual, const float* gamma, 
                      float* running_mean, float* running_var, float momentum, float eps,
                      float* y, float* save_mean, float* save_invstd, int64_t rows, int32_t C,
                      uint32_t flags, void* workspace, size_t workspace_bytes, uint32_t* y_absmax, void* stream);
-/* y_absmax / dx_absmax (may be NULL) in the four calls of this section: the apply pass also leaves the bit image of
- * max|output| in that device word (what evk_absmax would compute) — the tensor is the next convolution's operand and
- * the f16x2 arithmetic needs its scale; producing it here saves that tensor one read pass. */
+/* y_absmax / dx_absmax (may be NULL) in the four calls of this section: an activation scale buffer of
+ * evk_absmax_words() uint32 (see evk_absmax) that the apply pass fills with the bit images of max|output| as a
+ * by-product — the tensor is the next convolution's operand and the f16x2 arithmetic needs its scale; producing it here
+ * saves that tensor one read pass. */
 /* Eval forward (running statistics): y = act((x-rm)/sqrt(rv+eps)*gamma+beta [+ residual]). */
 /* evk_bn_fwd_train with the statistics pass replaced by the merge (Chan, fp64, fixed order) of the (count, mean, M2)
  * records a convolution epilogue wrote (evk_conv2d_fwd_x3_stats): one pass over x less per layer. */

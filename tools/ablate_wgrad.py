@@ -19,12 +19,12 @@ for (h, c) in ((128, 256), (64, 256), (32, 256)):
     d = _C.ConvDesc(16, h, h, c, h, h, c, 3, 3, 1, 1, 1, 1, 1, 1)
     x = torch.randn(16, h, h, c, device=dev); dy = torch.randn(16, h, h, c, device=dev)
     dw = torch.empty(c, 3, 3, c, device=dev)
-    bits = torch.zeros(2, dtype=torch.int32, device=dev)
-    _C.call('evk_absmax', x.data_ptr(), x.numel(), bits[0:1].data_ptr(), aws.data_ptr(), st)
-    _C.call('evk_absmax', dy.data_ptr(), dy.numel(), bits[1:2].data_ptr(), aws.data_ptr(), st)
+    nw = int(lib.evk_absmax_words()); bits = [torch.zeros(nw, dtype=torch.int32, device=dev) for _ in range(2)]
+    _C.call('evk_absmax', x.data_ptr(), x.numel(), bits[0].data_ptr(), aws.data_ptr(), st)
+    _C.call('evk_absmax', dy.data_ptr(), dy.numel(), bits[1].data_ptr(), aws.data_ptr(), st)
     wsb = lib.evk_conv2d_wgrad_x3_workspace_bytes(ctypes.byref(d)); wsp = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    th = timeit(lambda: _C.call('evk_conv2d_wgrad_f16x2', ctypes.byref(d), x.data_ptr(), bits[0:1].data_ptr(), dy.data_ptr(),
-                                bits[1:2].data_ptr(), dw.data_ptr(), None, wsp.data_ptr(), wsb, st))
+    th = timeit(lambda: _C.call('evk_conv2d_wgrad_f16x2', ctypes.byref(d), x.data_ptr(), bits[0].data_ptr(), dy.data_ptr(),
+                                bits[1].data_ptr(), dw.data_ptr(), None, wsp.data_ptr(), wsb, st))
     t3 = timeit(lambda: _C.call('evk_conv2d_wgrad_x3', ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None,
                                 wsp.data_ptr(), wsb, st))
     out.append(f'{c}@{h}: f16x2 {th:7.1f} us  bf16x3 {t3:7.1f} us')

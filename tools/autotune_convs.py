@@ -81,25 +81,25 @@ def main():
         dy = torch.randn(n, ho, wo, cout, generator=g).to(dev)
         for_dgrad = 1 if kind.startswith('dgrad') else 0
         planes = torch.empty(lib.evk_conv2d_split_weight_bytes(ctypes.byref(d), for_dgrad), dtype=torch.uint8, device=dev)
-        bits = torch.zeros(4, dtype=torch.int32, device=dev)
+        nw = int(lib.evk_absmax_words()); bits = [torch.zeros(nw, dtype=torch.int32, device=dev) for _ in range(2)]
         aws = torch.zeros(lib.evk_absmax_workspace_bytes(), dtype=torch.uint8, device=dev)
         src = dy if for_dgrad else x
-        _C.call('evk_absmax', src.data_ptr(), src.numel(), bits[0:1].data_ptr(), aws.data_ptr(), st)
-        _C.call('evk_absmax', wt.data_ptr(), wt.numel(), bits[1:2].data_ptr(), aws.data_ptr(), st)
-        _C.call('evk_conv2d_split_weight_f16x2', ctypes.byref(d), wt.data_ptr(), for_dgrad, planes.data_ptr(), bits[1:2].data_ptr(), st)
+        _C.call('evk_absmax', src.data_ptr(), src.numel(), bits[0].data_ptr(), aws.data_ptr(), st)
+        _C.call('evk_absmax', wt.data_ptr(), wt.numel(), bits[1].data_ptr(), aws.data_ptr(), st)
+        _C.call('evk_conv2d_split_weight_f16x2', ctypes.byref(d), wt.data_ptr(), for_dgrad, planes.data_ptr(), bits[1].data_ptr(), st)
         npart = ctypes.c_int32(0)
         if kind in ('fwd', 'fwd_stats'):
             out = torch.empty(n, ho, wo, cout, device=dev)
             cap = int(lib.evk_conv2d_stats_max_parts(ctypes.byref(d))) if kind == 'fwd_stats' else 0
             parts = torch.empty(max(cap, 1) * 3 * cout, device=dev)
-            fn = lambda: _C.call('evk_conv2d_fwd_f16x2', ctypes.byref(d), x.data_ptr(), bits[0:1].data_ptr(), planes.data_ptr(),
-                                 bits[1:2].data_ptr(), None, None, out.data_ptr(), 0, parts.data_ptr() if cap else None, cap,
+            fn = lambda: _C.call('evk_conv2d_fwd_f16x2', ctypes.byref(d), x.data_ptr(), bits[0].data_ptr(), planes.data_ptr(),
+                                 bits[1].data_ptr(), None, None, out.data_ptr(), 0, parts.data_ptr() if cap else None, cap,
                                  ctypes.byref(npart), st)
         else:
             out = torch.empty(n, h, w, cin, device=dev)
             acc = torch.randn(n, h, w, cin, device=dev) if kind == 'dgrad_accum' else None
-            fn = lambda: _C.call('evk_conv2d_dgrad_f16x2', ctypes.byref(d), dy.data_ptr(), bits[0:1].data_ptr(), planes.data_ptr(),
-                                 bits[1:2].data_ptr(), acc.data_ptr() if acc is not None else None, out.data_ptr(), st)
+            fn = lambda: _C.call('evk_conv2d_dgrad_f16x2', ctypes.byref(d), dy.data_ptr(), bits[0].data_ptr(), planes.data_ptr(),
+                                 bits[1].data_ptr(), acc.data_ptr() if acc is not None else None, out.data_ptr(), st)
         gf = 2.0 * n * ho * wo * cout * cin * kh * kw / 1e9
         iters = 20 if gf < 50 else 8
         os.environ['EVK_X3_FORCE'] = ''

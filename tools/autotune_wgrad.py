@@ -76,16 +76,16 @@ def main():
         dw = torch.empty(cout, kh, kw, cin, device=dev)
         gf = 2.0 * n * ho * wo * cout * cin * kh * kw / 1e9
         iters = 20 if gf < 50 else 8
-        bits = torch.zeros(2, dtype=torch.int32, device=dev)
+        nw = int(lib.evk_absmax_words()); bits = [torch.zeros(nw, dtype=torch.int32, device=dev) for _ in range(2)]
         aws = torch.zeros(lib.evk_absmax_workspace_bytes(), dtype=torch.uint8, device=dev)
-        _C.call('evk_absmax', x.data_ptr(), x.numel(), bits[0:1].data_ptr(), aws.data_ptr(), st)
-        _C.call('evk_absmax', dy.data_ptr(), dy.numel(), bits[1:2].data_ptr(), aws.data_ptr(), st)
+        _C.call('evk_absmax', x.data_ptr(), x.numel(), bits[0].data_ptr(), aws.data_ptr(), st)
+        _C.call('evk_absmax', dy.data_ptr(), dy.numel(), bits[1].data_ptr(), aws.data_ptr(), st)
 
         def run():
             wsb = lib.evk_conv2d_wgrad_x3_workspace_bytes(ctypes.byref(d))
             wsp = torch.empty(wsb, dtype=torch.uint8, device=dev)
-            fn = lambda: _C.call('evk_conv2d_wgrad_f16x2', ctypes.byref(d), x.data_ptr(), bits[0:1].data_ptr(), dy.data_ptr(),
-                                 bits[1:2].data_ptr(), dw.data_ptr(), None, wsp.data_ptr(), wsb, st)
+            fn = lambda: _C.call('evk_conv2d_wgrad_f16x2', ctypes.byref(d), x.data_ptr(), bits[0].data_ptr(), dy.data_ptr(),
+                                 bits[1].data_ptr(), dw.data_ptr(), None, wsp.data_ptr(), wsb, st)
             return timeit(fn, iters)
         setk(None)
         run()

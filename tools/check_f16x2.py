@@ -61,14 +61,15 @@ def main():
         pf3 = torch.empty(lib.evk_conv2d_split_weight_bytes(ctypes.byref(d), 0), dtype=torch.uint8, device=dev)
         pd3 = torch.empty(lib.evk_conv2d_split_weight_bytes(ctypes.byref(d), 1), dtype=torch.uint8, device=dev)
         pfh, pdh = torch.empty_like(pf3), torch.empty_like(pd3)
-        bits = torch.zeros(4, dtype=torch.int32, device=dev)   # [x, w, dy]
-        bx, bw, bdy = bits[0:1], bits[1:2], bits[2:3]
+        nw = int(lib.evk_absmax_words())
+        bx, bw, bdy = (torch.zeros(nw, dtype=torch.int32, device=dev) for _ in range(3))   # slot 0 = the maximum
         _C.call('evk_absmax', x.data_ptr(), x.numel(), bx.data_ptr(), aws.data_ptr(), st)
         _C.call('evk_absmax', wt.data_ptr(), wt.numel(), bw.data_ptr(), aws.data_ptr(), st)
         _C.call('evk_absmax', dy.data_ptr(), dy.numel(), bdy.data_ptr(), aws.data_ptr(), st)
         torch.cuda.synchronize()
         ref_bits = [int(t.abs().max().view(torch.int32)) for t in (x, wt, dy)]
-        assert [int(v) for v in bits[:3]] == ref_bits, (bits, ref_bits)
+        got = [int(b.view(64, nw // 64)[:, 0].max()) for b in (bx, bw, bdy)]
+        assert got == ref_bits, (got, ref_bits)
         _C.call('evk_conv2d_split_weight', ctypes.byref(d), wt.data_ptr(), 0, pf3.data_ptr(), st)
         _C.call('evk_conv2d_split_weight', ctypes.byref(d), wt.data_ptr(), 1, pd3.data_ptr(), st)
         _C.call('evk_conv2d_split_weight_f16x2', ctypes.byref(d), wt.data_ptr(), 0, pfh.data_ptr(), bw.data_ptr(), st)
