@@ -235,13 +235,15 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
     bn_part_write<WN, 2>(p, st, (n * tiles_y + ty) * tiles_x + tx, n0, wm, wn, lh * 32 + li, xch);
     return;
   }
+  AmaxAcc amax_l{0u, p.out_amax != nullptr};
 #pragma unroll
   for (int a = 0; a < MB; ++a) {
     const int m = wm * WMR + a * 32 + li;
     const int gy = Y0 + (m >> 4), gx = X0 + (m & 15);
     const size_t roff = (((size_t)n * p.Hd + (size_t)(gy * p.dsh + p.doy)) * p.Wd + (size_t)(gx * p.dsw + p.dox)) * p.Cd;
-    igemm_store_rows<NB, WN>(p, acc[a], roff, n0, wn, lh);
+    igemm_store_rows<NB, WN>(p, acc[a], roff, n0, wn, lh, amax_l);
   }
+  if (p.out_amax) amax_commit(p.out_amax, amax_l.m);
 }
 
 // does the halo kernel take this launch?  (also decides the layout evk_conv2d_split_weight produces)

@@ -349,7 +349,7 @@ static inline int kpad32(int k) { return (k + 31) & ~31; }
 static int conv_fwd_any(const evk_conv_desc* d, const float* x, const float* w, const uint16_t* w3, const float* bias,
                         float* y, uint32_t flags, void* stream, const float* residual = nullptr,
                         float* bn_parts = nullptr, int32_t bn_cap = 0, int32_t* nparts = nullptr, int planes = 3,
-                        const uint32_t* a_scale = nullptr, const uint32_t* w_scale = nullptr) {
+                        const uint32_t* a_scale = nullptr, const uint32_t* w_scale = nullptr, uint32_t* out_amax = nullptr) {
   int rc = check_desc(d);
   if (rc) return rc;
   EVK_REQUIRE(x && (w || w3) && y, EVK_E_INVALID, "conv2d_fwd: null pointer");
@@ -368,6 +368,7 @@ static int conv_fwd_any(const evk_conv_desc* d, const float* x, const float* w, 
   a.Kpad = kpad32(a.Ktot);
   a.planes = planes;
   a.a_scale = a_scale; a.w_scale = w_scale;
+  a.out_amax = out_amax;
   a.bn_want = (bn_parts && w3 && d->Cout % 4 == 0) ? 1 : 0;
   a.bn_buf = bn_parts;
   a.bn_cap = bn_cap;
@@ -423,10 +424,11 @@ extern "C" int evk_conv2d_fwd_bf16(const evk_conv_desc* d, const float* x, const
 // evk_conv2d_split_weight_f16x2 / evk_conv2d_split_multi_f16x2).  residual, bn_parts, nparts may be null.
 extern "C" int evk_conv2d_fwd_f16x2(const evk_conv_desc* d, const float* x, const uint32_t* x_absmax, const void* wsplit,
                                     const uint32_t* w_absmax, const float* bias, const float* residual, float* y,
-                                    uint32_t flags, float* bn_parts, int32_t bn_capacity, int32_t* nparts, void* stream) {
+                                    uint32_t flags, float* bn_parts, int32_t bn_capacity, int32_t* nparts,
+                                    uint32_t* y_absmax, void* stream) {
   EVK_REQUIRE(wsplit && x_absmax && w_absmax, EVK_E_INVALID, "conv2d_fwd_f16x2: null weight planes / scales");
   return conv_fwd_any(d, x, nullptr, reinterpret_cast<const uint16_t*>(wsplit), bias, y, flags, stream, residual, bn_parts,
-                      bn_capacity, nparts, 2, x_absmax, w_absmax);
+                      bn_capacity, nparts, 2, x_absmax, w_absmax, y_absmax);
 }
 
 // y = act(conv(x, w) + bias + residual): the inference form of a ResNet block's last convolution once its
@@ -443,7 +445,7 @@ extern "C" int evk_conv2d_fwd_x3_res(const evk_conv_desc* d, const float* x, con
 
 static int conv_dgrad_any(const evk_conv_desc* d, const float* dy, const float* wt, const uint16_t* wt3,
                           const float* accum, float* dx, void* stream, int planes = 3,
-                          const uint32_t* a_scale = nullptr, const uint32_t* w_scale = nullptr) {
+                          const uint32_t* a_scale = nullptr, const uint32_t* w_scale = nullptr, uint32_t* out_amax = nullptr) {
   int rc = check_desc(d);
   if (rc) return rc;
   EVK_REQUIRE(dy && (wt || wt3) && dx, EVK_E_INVALID, "conv2d_dgrad: null pointer");
@@ -477,6 +479,7 @@ static int conv_dgrad_any(const evk_conv_desc* d, const float* dy, const float* 
         IGemmArgs a{};
         a.planes = planes;
         a.a_scale = a_scale; a.w_scale = w_scale;
+        a.out_amax = out_amax;
         a.src = dy; a.wgt = wt ? wt + woff : nullptr; a.wgt3 = wt3 ? wt3 + woff3 : nullptr;
         a.bias = nullptr; a.accum = accum; a.dst = dx;
         a.N = d->N; a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Cout;
@@ -513,10 +516,10 @@ extern "C" int evk_conv2d_dgrad_bf16(const evk_conv_desc* d, const float* dy, co
 
 extern "C" int evk_conv2d_dgrad_f16x2(const evk_conv_desc* d, const float* dy, const uint32_t* dy_absmax,
                                       const void* wsplit_t, const uint32_t* w_absmax, const float* accum, float* dx,
-                                      void* stream) {
+                                      uint32_t* dx_absmax, void* stream) {
   EVK_REQUIRE(wsplit_t && dy_absmax && w_absmax, EVK_E_INVALID, "conv2d_dgrad_f16x2: null weight planes / scales");
   return conv_dgrad_any(d, dy, nullptr, reinterpret_cast<const uint16_t*>(wsplit_t), accum, dx, stream, 2, dy_absmax,
-                        w_absmax);
+                        w_absmax, dx_absmax);
 }
 
 extern "C" int evk_conv2d_dgrad_x3(const evk_conv_desc* d, const float* dy, const void* wsplit_t, const float* accum,

@@ -232,7 +232,9 @@ __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(const IGemmArgs p) {
     igemm_epilogue_stats<MB, NB, WM, WN, WAVES_M, WAVES_N>(p, acc, m0, n0, wm, wn, li, lh, reinterpret_cast<float*>(smem3));
     return;
   }
-  igemm_epilogue<MB, NB, WM, WN>(p, acc, m0, n0, wm, wn, li, lh);
+  AmaxAcc amax_l{0u, p.out_amax != nullptr};
+  igemm_epilogue<MB, NB, WM, WN>(p, acc, m0, n0, wm, wn, li, lh, amax_l);
+  if (p.out_amax) amax_commit(p.out_amax, amax_l.m);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NBUF, int NP>

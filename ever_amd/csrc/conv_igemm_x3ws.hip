@@ -247,6 +247,7 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws_kernel(const IGemmArgs p)
 
   __syncthreads();
   int g = 0;
+  AmaxAcc amax_l{0u, p.out_amax != nullptr};
   for (int i = 0; i < my_tiles; ++i) {
 #pragma unroll
     for (int a = 0; a < MB; ++a)
@@ -272,8 +273,10 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws_kernel(const IGemmArgs p)
                                                              li, lh, reinterpret_cast<float*>(smem3 + p.bn_scratch_off));
       continue;
     }
-    igemm_epilogue<MB, NB, WM, WN>(p, acc, (bid / p.tiles_n) * BM, (bid % p.tiles_n) * BN, wm, wn, li, lh);
+    igemm_epilogue<MB, NB, WM, WN>(p, acc, (bid / p.tiles_n) * BM, (bid % p.tiles_n) * BN, wm, wn, li, lh,
+                                   amax_l);
   }
+  if (p.out_amax) amax_commit(p.out_amax, amax_l.m);   // once per wave, over all the tiles of this workgroup
 }
 
 // EVK_X3_WS_PERSIST: 1 (default) persistent workgroups, and the wave-specialised form also for short reductions;

@@ -27,6 +27,8 @@ struct IGemmArgs {
                             // 2: 2-term fp16 split of scaled operands, three products (*_f16x2 entry points)
   const uint32_t* a_scale;  // planes == 2: bit image of max|src| (evk_absmax) and of max|weight| (the planes' producer)
   const uint32_t* w_scale;
+  uint32_t* out_amax;       // optional: the output's operand-scale buffer (64 slots, x3_common.hpp act_absmax), raised with
+                            // one atomic max per wave from the epilogue — the output is a later convolution's operand
   // BatchNorm statistics of the OUTPUT from the epilogue (forward convolutions followed by a training-mode BatchNorm):
   // bn_part[part][3][Cd] = (count, mean, M2 = sum (y - mean)^2) of the rows of row-part `part`; nullptr = off.
   // Written by igemm_store_rows_stats / bn_part_write; merged (Chan) by evk_bn_fwd_train_parts.
@@ -52,9 +54,28 @@ __device__ __forceinline__ void igemm_scale_acc(f32x16 (&acc)[MB][NB], float s) 
 // ONE pixel (column lane&31) and, per accumulator quad r4, FOUR consecutive output channels
 // co = 8*r4 + 4*(lane>>5) + {0..3}: one 16-byte store per quad (4x fewer store instructions than the
 // row-per-register layout; the small-K 1x1 convolutions are store-issue bound).
+// running max of |v| as a bit image (integer order = float order for non-negative floats; NaNs stay visible as > inf)
+// (the accumulator is passed by reference with a separate on/off flag: a pointer that may be null pins it to scratch)
+struct AmaxAcc {
+  uint32_t m;
+  bool on;
+};
+__device__ __forceinline__ void amax_one(AmaxAcc& am, float s) {
+  if (am.on) am.m = max(am.m, __builtin_bit_cast(uint32_t, s) & 0x7fffffffu);
+}
+__device__ __forceinline__ void amax_quad(AmaxAcc& am, const f32x4 v) {
+  amax_one(am, v.x); amax_one(am, v.y); amax_one(am, v.z); amax_one(am, v.w);
+}
+// one atomic max per wave into slot (workgroup & 63) of the output's operand-scale buffer (64 slots, 32 words apart)
+__device__ __forceinline__ void amax_commit(uint32_t* __restrict__ slots, uint32_t m) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(&slots[(blockIdx.x & 63) * 32], m);
+}
+
 template <int NB, int WN>
 __device__ __forceinline__ void igemm_store_rows(const IGemmArgs& p, f32x16 (&accrow)[NB], size_t roff, int n0, int wn,
-                                                 int lh) {
+                                                 int lh, AmaxAcc& am) {
   const bool vec = (p.Cd & 3) == 0 && n0 + wn * WN + NB * 32 <= p.Cd;   // whole block inside the tensor, 16-byte rows
   if (vec) {
     // gfx9 has ONE in-order vmcnt for loads and stores: a bias / accumulate load issued after a store is only
@@ -83,6 +104,7 @@ __device__ __forceinline__ void igemm_store_rows(const IGemmArgs& p, f32x16 (&ac
         if (has_b || has_a) v += add[b][r4];
         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         *reinterpret_cast<f32x4*>(p.dst + roff + col) = v;
+        amax_quad(am, v);
       }
     return;
   }
@@ -97,6 +119,7 @@ __device__ __forceinline__ void igemm_store_rows(const IGemmArgs& p, f32x16 (&ac
         if (p.accum) v += *reinterpret_cast<const f32x4*>(p.accum + roff + col);
         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         *reinterpret_cast<f32x4*>(p.dst + roff + col) = v;
+        amax_quad(am, v);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -106,16 +129,24 @@ __device__ __forceinline__ void igemm_store_rows(const IGemmArgs& p, f32x16 (&ac
             if (p.accum) s += p.accum[roff + col + e];
             if (p.relu) s = fmaxf(s, 0.f);
             p.dst[roff + col + e] = s;
+            amax_one(am, s);
           }
       }
     }
   }
 }
 
+template <int NB, int WN>
+__device__ __forceinline__ void igemm_store_rows(const IGemmArgs& p, f32x16 (&accrow)[NB], size_t roff, int n0, int wn,
+                                                 int lh) {
+  AmaxAcc off{0u, false};
+  igemm_store_rows<NB, WN>(p, accrow, roff, n0, wn, lh, off);
+}
+
 // Epilogue shared by the row-linear kernels (the C/D fragment layout does not depend on the input dtype).
 template <int MB, int NB, int WM, int WN>
 __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)[MB][NB], int m0, int n0, int wm,
-                                               int wn, int li, int lh) {
+                                               int wn, int li, int lh, AmaxAcc& am) {
 #pragma unroll
   for (int a = 0; a < MB; ++a) {
     const int row = m0 + wm * WM + a * 32 + li;
@@ -131,10 +162,17 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
       const int gx = rem - gy * p.Wm;
       roff = (((size_t)n * p.Hd + (size_t)(gy * p.dsh + p.doy)) * p.Wd + (size_t)(gx * p.dsw + p.dox)) * p.Cd;
     }
-    igemm_store_rows<NB, WN>(p, acc[a], roff, n0, wn, lh);
+    igemm_store_rows<NB, WN>(p, acc[a], roff, n0, wn, lh, am);
   }
 }
 
+
+template <int MB, int NB, int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)[MB][NB], int m0, int n0, int wm,
+                                               int wn, int li, int lh) {
+  AmaxAcc off{0u, false};
+  igemm_epilogue<MB, NB, WM, WN>(p, acc, m0, n0, wm, wn, li, lh, off);
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Epilogue THROUGH LDS with BatchNorm partial statistics.  A 32-row accumulator block is parked in a wave-private LDS

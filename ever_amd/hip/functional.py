@@ -90,6 +90,25 @@ def absmax_value(bits):
     return int(bits.view(64, n)[:, 0].max().item())
 
 
+_ZERO_POOL = {}
+
+
+def _amax_zeroed(dev):
+    """A scale buffer whose slots are zero (for producers that only RAISE slots: the convolution epilogues), or None.
+    Buffers are cut from a pool zeroed 256 at a time: one fill launch per 256 convolution outputs."""
+    if not (_FUSED_AMAX and _f16x2()):
+        return None
+    if not _AMAX_WORDS[0]:
+        _AMAX_WORDS[0] = int(_C.load().evk_absmax_words())
+    nw = _AMAX_WORDS[0]
+    pool = _ZERO_POOL.get(dev)
+    if pool is None or pool[1] >= pool[0].shape[0]:
+        pool = _ZERO_POOL[dev] = [torch.zeros((256, nw), device=dev, dtype=torch.int32), 0]
+    buf = pool[0][pool[1]]
+    pool[1] += 1
+    return buf
+
+
 def _amax_out(dev):
     """A scale buffer for a producer kernel to leave max|output| in, or None when no consumer will want it."""
     return _amax_buf(dev) if (_FUSED_AMAX and _f16x2()) else None
@@ -333,8 +352,12 @@ def _conv_forward(x, weight, bias, stride, padding, dilation, relu, want_stats=F
             cap = int(_C.load().evk_conv2d_stats_max_parts(ctypes.byref(d)))
             parts = torch.empty((cap * 3 * cout,), device=dev, dtype=torch.float32)
         if wabs_ptr is not None:
+            # an output that no BatchNorm will normalise is (mostly) another convolution's operand: its scale from here
+            ybits = None if stats else _amax_zeroed(dev)
             _C.call('evk_conv2d_fwd_f16x2', ctypes.byref(d), x_ptr, xbits.data_ptr(), pl_ptr, wabs_ptr, _ptr(bias), None,
-                    y.data_ptr(), 1 if relu else 0, _ptr(parts), cap, ctypes.byref(nparts), st)
+                    y.data_ptr(), 1 if relu else 0, _ptr(parts), cap, ctypes.byref(nparts), _ptr(ybits), st)
+            if ybits is not None:
+                _note_amax(y, ybits)
         elif _CONV_MATH == 'bf16':
             _C.call('evk_conv2d_fwd_bf16', ctypes.byref(d), x_ptr, pl_ptr, _ptr(bias), y.data_ptr(), 1 if relu else 0,
                     _ptr(parts), cap, ctypes.byref(nparts), st)
@@ -411,8 +434,13 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False)
         dybits = absmax_bits(dyk, st) if wabs_ptr is not None else None
         sp = timing.span('conv_igemm', cs.flops, cs.abytes, cs.scope)
         if wabs_ptr is not None:
+            # in place: the slots the main branch's launch raised stay (an upper bound is all a scale needs)
+            hit = getattr(dx, '_evk_amax', None) if inplace else None
+            dxbits = hit[2] if hit is not None else _amax_zeroed(dev)
             _C.call('evk_conv2d_dgrad_f16x2', ctypes.byref(dk), dy_ptr, dybits.data_ptr(), pl_ptr, wabs_ptr, acc_ptr,
-                    dx.data_ptr(), st)
+                    dx.data_ptr(), _ptr(dxbits), st)
+            if dxbits is not None:
+                _note_amax(dx, dxbits)
         else:
             _C.call(_entry('evk_conv2d_dgrad_x3'), ctypes.byref(dk), dy_ptr, pl_ptr, acc_ptr, dx.data_ptr(), st)
         if sp is not None:
@@ -796,7 +824,7 @@ class _StemConvFn(Function):
                 cap = int(_C.load().evk_conv2d_stats_max_parts(ctypes.byref(d)))
                 parts = torch.empty((cap * 3 * cout,), device=dev, dtype=torch.float32)
             _C.call('evk_conv2d_fwd_f16x2', ctypes.byref(d), xs.data_ptr(), xbits.data_ptr(), pl_ptr, wabs_ptr, None, None,
-                    y.data_ptr(), 0, _ptr(parts), cap, ctypes.byref(nparts), st)
+                    y.data_ptr(), 0, _ptr(parts), cap, ctypes.byref(nparts), None, st)
             _BN_HANDOFF[0] = (parts, int(nparts.value)) if nparts.value > 0 else None
         elif _CONV_MATH == 'bf16':
             _C.call('evk_conv2d_fwd_bf16', ctypes.byref(d), xs.data_ptr(), pl_ptr, None, y.data_ptr(), 0, None, 0,

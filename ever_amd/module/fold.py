@@ -164,7 +164,7 @@ def folded_conv2d(x, conv, residual=None, relu=False):
         if h2:
             xbits = HF.absmax_bits(x, st)
             _C.call('evk_conv2d_fwd_f16x2', ctypes.byref(d), x_ptr, xbits.data_ptr(), f.planes.data_ptr(), f.wbits.data_ptr(),
-                    f.bias.data_ptr(), res_ptr, y.data_ptr(), flags, None, 0, ctypes.byref(ctypes.c_int32(0)), st)
+                    f.bias.data_ptr(), res_ptr, y.data_ptr(), flags, None, 0, ctypes.byref(ctypes.c_int32(0)), None, st)
         else:
             _C.call('evk_conv2d_fwd_x3_res', ctypes.byref(d), x_ptr, f.planes.data_ptr(), f.bias.data_ptr(), res_ptr,
                     y.data_ptr(), flags, st)

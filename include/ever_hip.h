@@ -151,12 +151,15 @@ int evk_conv2d_split_weight_f16x2(const evk_conv_desc* d, const float* w, int32_
 /* job.arg[11] = index of the job's weight in absmax_dev */
 int evk_conv2d_split_multi_f16x2(const evk_split_job* jobs_dev, const int32_t* block_map_dev, int32_t nblocks,
                                  const uint32_t* absmax_dev, void* stream);
-/* residual, bn_parts (+ nparts) may be NULL; with bn_parts the epilogue also emits the BatchNorm records (fwd_x3_stats) */
+/* residual, bn_parts (+ nparts) may be NULL; with bn_parts the epilogue also emits the BatchNorm records (fwd_x3_stats).
+ * y_absmax / dx_absmax (may be NULL): an activation scale buffer whose slots are ZERO on entry; the epilogue raises them
+ * to max|output| (the output is a later convolution's operand: saves its evk_absmax pass).  accum may alias dx. */
 int evk_conv2d_fwd_f16x2(const evk_conv_desc* d, const float* x, const uint32_t* x_absmax, const void* wsplit,
                          const uint32_t* w_absmax, const float* bias, const float* residual, float* y, uint32_t flags,
-                         float* bn_parts, int32_t bn_capacity, int32_t* nparts /* host */, void* stream);
+                         float* bn_parts, int32_t bn_capacity, int32_t* nparts /* host */, uint32_t* y_absmax,
+                         void* stream);
 int evk_conv2d_dgrad_f16x2(const evk_conv_desc* d, const float* dy, const uint32_t* dy_absmax, const void* wsplit_t,
-                           const uint32_t* w_absmax, const float* accum, float* dx, void* stream);
+                           const uint32_t* w_absmax, const float* accum, float* dx, uint32_t* dx_absmax, void* stream);
 int evk_conv2d_wgrad_f16x2(const evk_conv_desc* d, const float* x, const uint32_t* x_absmax, const float* dy,
                            const uint32_t* dy_absmax, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
                            void* stream);

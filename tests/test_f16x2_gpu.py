@@ -234,3 +234,41 @@ def test_weight_gradient_3x3_wide_rows(cuda, case):
     err = ((wg.grad.cpu().double() - w64.grad).abs().max() / w64.grad.abs().max()).item()
     print('dw relative error vs fp64:', err)
     assert err < 5e-6, err
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 16, 16, 256, 1, 1, 0, True), (2, 64, 128, 128, 64, 3, 1, 1, False),
+                                   (4, 256, 32, 32, 512, 1, 1, 0, False), (2, 128, 16, 16, 128, 3, 2, 1, True),
+                                   (2, 256, 64, 64, 128, 1, 2, 0, False)])
+def test_scales_from_the_convolution_epilogues(cuda, shape):
+    """A convolution output that no BatchNorm normalises carries max|y| from the forward epilogue and its input gradient
+    max|dx| from the data-gradient epilogue (all residue classes of a strided one): equal to the tensors' true maxima."""
+    from ever_amd.hip import functional as F
+    n, cin, h, w, cout, k, s, p, bias = shape
+    g = torch.Generator().manual_seed(cin + cout + k + s)
+    prev = F.set_conv_math('f16x2')
+    try:
+        x = (torch.randn(n, cin, h, w, generator=g) * 3).to(cuda).requires_grad_()
+        wt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(cuda).contiguous(memory_format=torch.channels_last)
+        b = torch.randn(cout, generator=g).to(cuda) if bias else None
+        seen = {}
+
+        class Probe(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, t):
+                return t.view_as(t)
+
+            @staticmethod
+            def backward(ctx, gt):
+                seen['dx'] = gt
+                return gt
+        y = F.conv2d(Probe.apply(x), wt, b, stride=s, padding=p)
+        hit = getattr(y, '_evk_amax', None)
+        assert hit is not None
+        y.backward(torch.randn(y.shape, generator=g).to(cuda) * 1e-4)
+        torch.cuda.synchronize()
+        assert F.absmax_value(hit[2]) == _bits(y)
+        hit = getattr(seen['dx'], '_evk_amax', None)
+        assert hit is not None
+        assert F.absmax_value(hit[2]) == _bits(seen['dx'])
+    finally:
+        F.set_conv_math(prev)

@@ -94,12 +94,12 @@ def main():
             parts = torch.empty(max(cap, 1) * 3 * cout, device=dev)
             fn = lambda: _C.call('evk_conv2d_fwd_f16x2', ctypes.byref(d), x.data_ptr(), bits[0].data_ptr(), planes.data_ptr(),
                                  bits[1].data_ptr(), None, None, out.data_ptr(), 0, parts.data_ptr() if cap else None, cap,
-                                 ctypes.byref(npart), st)
+                                 ctypes.byref(npart), None, st)
         else:
             out = torch.empty(n, h, w, cin, device=dev)
             acc = torch.randn(n, h, w, cin, device=dev) if kind == 'dgrad_accum' else None
             fn = lambda: _C.call('evk_conv2d_dgrad_f16x2', ctypes.byref(d), dy.data_ptr(), bits[0].data_ptr(), planes.data_ptr(),
-                                 bits[1].data_ptr(), acc.data_ptr() if acc is not None else None, out.data_ptr(), st)
+                                 bits[1].data_ptr(), acc.data_ptr() if acc is not None else None, out.data_ptr(), None, st)
         gf = 2.0 * n * ho * wo * cout * cin * kh * kw / 1e9
         iters = 20 if gf < 50 else 8
         os.environ['EVK_X3_FORCE'] = ''

@@ -77,10 +77,10 @@ def main():
         zero = ctypes.c_int32(0)
         f3 = lambda: _C.call('evk_conv2d_fwd_x3', ctypes.byref(d), x.data_ptr(), pf3.data_ptr(), None, y3.data_ptr(), 0, st)
         fh = lambda: _C.call('evk_conv2d_fwd_f16x2', ctypes.byref(d), x.data_ptr(), bx.data_ptr(), pfh.data_ptr(), bw.data_ptr(),
-                             None, None, yh.data_ptr(), 0, None, 0, ctypes.byref(zero), st)
+                             None, None, yh.data_ptr(), 0, None, 0, ctypes.byref(zero), None, st)
         g3 = lambda: _C.call('evk_conv2d_dgrad_x3', ctypes.byref(d), dy.data_ptr(), pd3.data_ptr(), None, dx3.data_ptr(), st)
         gh = lambda: _C.call('evk_conv2d_dgrad_f16x2', ctypes.byref(d), dy.data_ptr(), bdy.data_ptr(), pdh.data_ptr(), bw.data_ptr(),
-                             None, dxh.data_ptr(), st)
+                             None, dxh.data_ptr(), None, st)
         dw3, dwh = torch.empty_like(wt), torch.empty_like(wt)
         wsb = lib.evk_conv2d_wgrad_x3_workspace_bytes(ctypes.byref(d))
         wsp = torch.empty(wsb, dtype=torch.uint8, device=dev)
