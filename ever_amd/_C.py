@@ -97,7 +97,7 @@ SIGNATURES = {
     'evk_gelu_bwd': (c_int, [P, P, P, c_i64, P]),
     'evk_maxpool3x3s2_fwd': (c_int, [P, P, P, c_i32, c_i32, c_i32, c_i32, P]),
     'evk_maxpool3x3s2_bwd': (c_int, [P, P, P, c_i32, c_i32, c_i32, c_i32, P]),
-    'evk_upsample_nearest2x_add_fwd': (c_int, [P, P, P, c_i32, c_i32, c_i32, c_i32, P]),
+    'evk_upsample_nearest2x_add_fwd': (c_int, [P, P, P, c_i32, c_i32, c_i32, c_i32, P, P]),
     'evk_upsample_nearest2x_bwd': (c_int, [P, P, c_i32, c_i32, c_i32, c_i32, P]),
     'evk_upsample_bilinear_fwd': (c_int, [P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, P]),
     'evk_upsample_bilinear_bwd': (c_int, [P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, P]),
@@ -106,7 +106,7 @@ SIGNATURES = {
     'evk_relation_fwd': (c_int, [P, P, P, P, P, c_i32, c_i32, c_i32, P]),
     'evk_relation_workspace_bytes': (c_size_t, [c_i32, c_i32, c_i32]),
     'evk_relation_bwd': (c_int, [P, P, P, P, P, P, P, P, c_i32, c_i32, c_i32, P, c_size_t, P]),
-    'evk_mean4_fwd': (c_int, [P, P, P, P, P, c_i64, P]),
+    'evk_mean4_fwd': (c_int, [P, P, P, P, P, c_i64, P, P]),
     'evk_loss_stats_doubles': (c_i64, [c_i32]),
     'evk_bce_fwd': (c_int, [P, P, c_i64, c_i64, c_f32, P, P, P]),
     'evk_bce_bwd': (c_int, [P, P, c_i64, c_i64, c_f32, P, P, P, c_i32, P]),

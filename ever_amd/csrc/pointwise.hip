@@ -8,6 +8,19 @@
 
 namespace evk {
 
+// max|v| of what a workgroup wrote into slot (workgroup & 63) of the output's operand-scale buffer (64 slots 32 words
+// apart, zero on entry; include/ever_hip.h: evk_absmax) — one atomic per wave, as the BatchNorm and convolution epilogues
+__device__ __forceinline__ uint32_t abs4_bits(uint32_t m, const f32x4 v) {
+  m = max(m, __builtin_bit_cast(uint32_t, v.x) & 0x7fffffffu); m = max(m, __builtin_bit_cast(uint32_t, v.y) & 0x7fffffffu);
+  m = max(m, __builtin_bit_cast(uint32_t, v.z) & 0x7fffffffu); m = max(m, __builtin_bit_cast(uint32_t, v.w) & 0x7fffffffu);
+  return m;
+}
+__device__ __forceinline__ void commit_absmax(uint32_t* __restrict__ slots, uint32_t m) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(&slots[(blockIdx.x & 63) * 32], m);
+}
+
 // One element per thread (the grid-stride loops below then run once): resident workgroups sweep one contiguous
 // window of HBM in dispatch order, 6.1 TB/s for 1R+1W on 268 MB against 5.1 for 4096 grid-striding workgroups
 // (tools/probes/copy_patterns.hip).
@@ -68,14 +81,19 @@ __global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, co
 
 __global__ __launch_bounds__(256) void mean4_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                     const float* __restrict__ c, const float* __restrict__ d,
-                                                    float* __restrict__ o, size_t n4) {
+                                                    float* __restrict__ o, size_t n4, uint32_t* __restrict__ amax) {
   const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
   const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
   const f32x4* c4 = reinterpret_cast<const f32x4*>(c);
   const f32x4* d4 = reinterpret_cast<const f32x4*>(d);
   f32x4* o4 = reinterpret_cast<f32x4*>(o);
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
-    o4[i] = (((a4[i] + b4[i]) + c4[i]) + d4[i]) * 0.25f;  // same association as python sum(list)/4
+  uint32_t m = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 v = (((a4[i] + b4[i]) + c4[i]) + d4[i]) * 0.25f;  // same association as python sum(list)/4
+    o4[i] = v;
+    m = abs4_bits(m, v);
+  }
+  if (amax) commit_absmax(amax, m);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -201,10 +219,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void nearest2x_add_kernel(const float* __restrict__ top,
                                                             const float* __restrict__ lateral,
-                                                            float* __restrict__ out, int N, int H, int W, int C) {
+                                                            float* __restrict__ out, int N, int H, int W, int C,
+                                                            uint32_t* __restrict__ amax) {
   const int c4 = C >> 2;
   const int Ht = H >> 1, Wt = W >> 1;
   const size_t total = (size_t)N * H * W * c4;
+  uint32_t m = 0;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int cb = (int)(i % c4);
     size_t pix = i / c4;
@@ -214,8 +234,11 @@ __global__ __launch_bounds__(256) void nearest2x_add_kernel(const float* __restr
     const int n = (int)(pix / H);
     const f32x4 t = *reinterpret_cast<const f32x4*>(top + (((size_t)n * Ht + (y >> 1)) * Wt + (x >> 1)) * C + cb * 4);
     const f32x4 l = *reinterpret_cast<const f32x4*>(lateral + i * 4);
-    *reinterpret_cast<f32x4*>(out + i * 4) = l + t;
+    const f32x4 v = l + t;
+    *reinterpret_cast<f32x4*>(out + i * 4) = v;
+    m = abs4_bits(m, v);
   }
+  if (amax) commit_absmax(amax, m);
 }
 __global__ __launch_bounds__(256) void nearest2x_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dtop,
                                                             int N, int H, int W, int C) {
@@ -607,10 +630,10 @@ extern "C" int evk_gelu_bwd(const float* dy, const float* x, float* dx, int64_t 
   EW_LAUNCH(6, dy, x, dx, n, 0.f, "gelu_bwd");
 }
 extern "C" int evk_mean4_fwd(const float* a, const float* b, const float* c, const float* d, float* out, int64_t n,
-                             void* stream) {
+                             uint32_t* out_absmax, void* stream) {
   EVK_REQUIRE(a && b && c && d && out && n > 0 && n % 4 == 0, EVK_E_INVALID, "mean4: bad argument");
   hipLaunchKernelGGL(mean4_kernel, dim3(grid_for((size_t)n / 4)), dim3(256), 0, (hipStream_t)stream, a, b, c, d, out,
-                     (size_t)n / 4);
+                     (size_t)n / 4, out_absmax);
   return check_launch("mean4");
 }
 
@@ -661,11 +684,11 @@ extern "C" int evk_maxpool3x3s2_bwd(const float* dy, const uint8_t* code, float*
 }
 
 extern "C" int evk_upsample_nearest2x_add_fwd(const float* top, const float* lateral, float* out, int32_t N, int32_t H,
-                                              int32_t W, int32_t C, void* stream) {
+                                              int32_t W, int32_t C, uint32_t* out_absmax, void* stream) {
   EVK_REQUIRE(top && lateral && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && H % 2 == 0 && W % 2 == 0,
               EVK_E_INVALID, "nearest2x_add: bad argument (H,W must be even, C %% 4 == 0)");
   hipLaunchKernelGGL(nearest2x_add_kernel, dim3(grid_for((size_t)N * H * W * (C / 4))), dim3(256), 0,
-                     (hipStream_t)stream, top, lateral, out, N, H, W, C);
+                     (hipStream_t)stream, top, lateral, out, N, H, W, C, out_absmax);
   return check_launch("nearest2x_add");
 }
 extern "C" int evk_upsample_nearest2x_bwd(const float* dout, float* dtop, int32_t N, int32_t H, int32_t W, int32_t C,

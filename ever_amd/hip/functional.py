@@ -1073,8 +1073,11 @@ class _Nearest2xAddFn(Function):
     def forward(ctx, top, lateral):
         n, c, h, w = lateral.shape
         out = empty_nhwc(n, c, h, w, lateral.device)
+        bits = _amax_zeroed(lateral.device)      # the sum is the FPN output convolution's operand
         _C.call('evk_upsample_nearest2x_add_fwd', top.data_ptr(), lateral.data_ptr(), out.data_ptr(), n, h, w, c,
-                _stream())
+                _ptr(bits), _stream())
+        if bits is not None:
+            _note_amax(out, bits)
         ctx.shape = (n, c, h, w)
         return out
 
@@ -1201,8 +1204,11 @@ class _Mean4Fn(Function):
     @staticmethod
     def forward(ctx, a, b, c, d):
         out = torch.empty_like(a)
+        bits = _amax_zeroed(a.device)            # the mean is the classifier convolution's operand
         _C.call('evk_mean4_fwd', a.data_ptr(), b.data_ptr(), c.data_ptr(), d.data_ptr(), out.data_ptr(), a.numel(),
-                _stream())
+                _ptr(bits), _stream())
+        if bits is not None:
+            _note_amax(out, bits)
         return out
 
     @staticmethod

@@ -291,8 +291,9 @@ int evk_maxpool3x3s2_bwd(const float* dy, const uint8_t* code, float* dx, int32_
 
 /* F.interpolate(scale_factor=2, mode="nearest") + lateral add — fpn.py:100-105.
  * out[n,y,x,:] = lateral[n,y,x,:] + top[n,y/2,x/2,:];  top is [N,H/2,W/2,C]. */
+/* out_absmax (may be NULL) here and in evk_mean4_fwd: an activation scale buffer, zero on entry, raised to max|out| */
 int evk_upsample_nearest2x_add_fwd(const float* top, const float* lateral, float* out, int32_t N,
-                                   int32_t H, int32_t W, int32_t C, void* stream);
+                                   int32_t H, int32_t W, int32_t C, uint32_t* out_absmax, void* stream);
 /* adjoint wrt `top`: dtop[n,y,x,:] = sum of the 2x2 block of dout. (d lateral = dout.) */
 int evk_upsample_nearest2x_bwd(const float* dout, float* dtop, int32_t N, int32_t H, int32_t W,
                                int32_t C, void* stream);
@@ -321,7 +322,7 @@ int evk_relation_bwd(const float* dout, const float* scene, const float* content
 
 /* `sum(list)/len(list)` over 4 decoder branches — fpn.py:189. */
 int evk_mean4_fwd(const float* a, const float* b, const float* c, const float* d, float* out,
-                  int64_t n, void* stream);
+                  int64_t n, uint32_t* out_absmax, void* stream);
 
 /* ------------------------------------------------------------------ pixel losses ----------- */
 /* Labels are int64 [N*H*W]; ignore_index pixels are dropped from every sum (the reference

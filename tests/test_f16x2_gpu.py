@@ -272,3 +272,23 @@ def test_scales_from_the_convolution_epilogues(cuda, shape):
         assert F.absmax_value(hit[2]) == _bits(seen['dx'])
     finally:
         F.set_conv_math(prev)
+
+
+def test_scales_from_nearest_add_and_mean4(cuda):
+    """the FPN top-down sum and the decoder's mean of four leave max|out| for the convolution that reads them"""
+    from ever_amd.hip import functional as F
+    prev = F.set_conv_math('f16x2')
+    try:
+        g = torch.Generator().manual_seed(12)
+        top = F.as_nhwc((torch.randn(2, 64, 9, 7, generator=g) * 2).to(cuda), 't')
+        lat = F.as_nhwc(torch.randn(2, 64, 18, 14, generator=g).to(cuda), 't')
+        out = F.upsample_nearest2x_add(top, lat)
+        parts = [F.as_nhwc((torch.randn(3, 32, 10, 6, generator=g) * (k + 1)).to(cuda), 't') for k in range(4)]
+        mean = F.mean4(*parts)
+        torch.cuda.synchronize()
+        for t in (out, mean):
+            hit = getattr(t, '_evk_amax', None)
+            assert hit is not None
+            assert F.absmax_value(hit[2]) == _bits(t)
+    finally:
+        F.set_conv_math(prev)
