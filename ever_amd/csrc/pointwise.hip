@@ -11,8 +11,10 @@ namespace evk {
 // max|v| of what a workgroup wrote into slot (workgroup & 63) of the output's operand-scale buffer (64 slots 32 words
 // apart, zero on entry; include/ever_hip.h: evk_absmax) — one atomic per wave, as the BatchNorm and convolution epilogues
 __device__ __forceinline__ uint32_t abs4_bits(uint32_t m, const f32x4 v) {
-  m = max(m, __builtin_bit_cast(uint32_t, v.x) & 0x7fffffffu); m = max(m, __builtin_bit_cast(uint32_t, v.y) & 0x7fffffffu);
-  m = max(m, __builtin_bit_cast(uint32_t, v.z) & 0x7fffffffu); m = max(m, __builtin_bit_cast(uint32_t, v.w) & 0x7fffffffu);
+  // by value into floats first: __builtin_bit_cast on a vector-element lvalue (v.y) reads element 0 with this compiler
+  const float x = v.x, y = v.y, z = v.z, w = v.w;
+  m = max(m, __float_as_uint(x) & 0x7fffffffu); m = max(m, __float_as_uint(y) & 0x7fffffffu);
+  m = max(m, __float_as_uint(z) & 0x7fffffffu); m = max(m, __float_as_uint(w) & 0x7fffffffu);
   return m;
 }
 __device__ __forceinline__ void commit_absmax(uint32_t* __restrict__ slots, uint32_t m) {
