@@ -79,9 +79,45 @@ __global__ __launch_bounds__(256) void absmax_multi_kernel(const float* const* _
   if (threadIdx.x == 0 && m) atomicMax(out + t, m);
 }
 
+// x -> packed words of x / s (x3_common.hpp: pack_hl), s from the tensor's scale buffer; and back (h + l) * s
+__global__ __launch_bounds__(256) void pack_f16x2_kernel(const float* __restrict__ x, size_t n4,
+                                                         const uint32_t* __restrict__ slots, uint32_t* __restrict__ out) {
+  const float inv = op_scale(act_absmax(slots)).inv;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+  u32x4 o;
+  o.x = pack_hl(v.x * inv); o.y = pack_hl(v.y * inv); o.z = pack_hl(v.z * inv); o.w = pack_hl(v.w * inv);
+  reinterpret_cast<u32x4*>(out)[i] = o;
+}
+__global__ __launch_bounds__(256) void unpack_f16x2_kernel(const uint32_t* __restrict__ in, size_t n4,
+                                                           const uint32_t* __restrict__ slots, float* __restrict__ out) {
+  const float s = op_scale(act_absmax(slots)).s;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const u32x4 w = reinterpret_cast<const u32x4*>(in)[i];
+  const f32x4 v = {unpack_hl(w.x) * s, unpack_hl(w.y) * s, unpack_hl(w.z) * s, unpack_hl(w.w) * s};
+  reinterpret_cast<f32x4*>(out)[i] = v;
+}
+
 }  // namespace evk
 
 using namespace evk;
+
+extern "C" int evk_pack_f16x2(const float* x, int64_t n, const uint32_t* x_absmax, uint32_t* out, void* stream) {
+  EVK_REQUIRE(x && x_absmax && out && n > 0 && n % 4 == 0, EVK_E_INVALID, "pack_f16x2: bad argument (n %% 4 == 0)");
+  const size_t n4 = (size_t)n >> 2;
+  hipLaunchKernelGGL(pack_f16x2_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n4,
+                     x_absmax, out);
+  return check_launch("pack_f16x2");
+}
+extern "C" int evk_unpack_f16x2(const uint32_t* packed, int64_t n, const uint32_t* x_absmax, float* out, void* stream) {
+  EVK_REQUIRE(packed && x_absmax && out && n > 0 && n % 4 == 0, EVK_E_INVALID, "unpack_f16x2: bad argument (n %% 4 == 0)");
+  const size_t n4 = (size_t)n >> 2;
+  hipLaunchKernelGGL(unpack_f16x2_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, packed,
+                     n4, x_absmax, out);
+  return check_launch("unpack_f16x2");
+}
 
 extern "C" size_t evk_absmax_words(void) { return (size_t)kAmaxWords; }
 extern "C" size_t evk_absmax_workspace_bytes(void) { return (size_t)(kAbsBlocks + 1) * sizeof(uint32_t); }

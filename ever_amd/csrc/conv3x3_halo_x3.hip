@@ -39,8 +39,10 @@ constexpr int kRB = kCh * 2;                   // bytes per row and plane
 
 __device__ __forceinline__ int half_off(int row, int c16) { return row * kRB + ((c16 ^ ((row >> 3) & 1)) << 4); }
 
-template <int BN, int PH, int NP>
+template <int BN, int PH, int NPX>
 __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p, int tiles_y, int tiles_x) {
+  constexpr int NP = X3Mode<NPX>::NP;
+  constexpr bool PK = X3Mode<NPX>::PK;   // the activation operand arrives packed (x3_common.hpp)
   constexpr int PL = NP == 2 ? 2 : 3;
   using Geo = HaloGeom<PH, PL>;
   constexpr int kPH = PH, kHP = Geo::kHP, kHSlots = Geo::kHSlots, kHaloPix = Geo::kHaloPix;
@@ -119,8 +121,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
         const f32x4 v = ra[i];
         const bool ok = a_ok[i];
         uint32_t h0, m0 = 0, l0 = 0, h1, m1 = 0, l1 = 0;
-        split_np<NP>(ok ? v.x : 0.f, ok ? v.y : 0.f, a_inv, h0, m0, l0);
-        split_np<NP>(ok ? v.z : 0.f, ok ? v.w : 0.f, a_inv, h1, m1, l1);
+        split_op<NP, PK>(ok ? v.x : 0.f, ok ? v.y : 0.f, a_inv, h0, m0, l0);
+        split_op<NP, PK>(ok ? v.z : 0.f, ok ? v.w : 0.f, a_inv, h1, m1, l1);
         *reinterpret_cast<uint2*>(A + a_lds[i]) = make_uint2(h0, h1);
         if (NP >= 2) *reinterpret_cast<uint2*>(A + kHSlots * kRB + a_lds[i]) = make_uint2(m0, m1);
         if (NP == 3) *reinterpret_cast<uint2*>(A + 2 * kHSlots * kRB + a_lds[i]) = make_uint2(l0, l1);
@@ -274,8 +276,9 @@ bool conv_desc_uses_halo(const evk_conv_desc* d, int for_dgrad) {
   return conv3x3_halo_applies(a);
 }
 
-template <int BN, int PH, int NP>
+template <int BN, int PH, int NPX>
 static int launch_halo_np(IGemmArgs& a, hipStream_t stream) {
+  constexpr int NP = X3Mode<NPX>::NP;
   a.tiles_n = ceil_div(a.Cd, BN);
   const int tiles_y = a.Hm / PH, tiles_x = a.Wm / kPW;
   a.tiles_m = a.N * tiles_y * tiles_x;
@@ -284,19 +287,19 @@ static int launch_halo_np(IGemmArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)2 * (PL * HaloGeom<PH, PL>::kHSlots * kRB) + (size_t)2 * (3 * PL * BN * kRB);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_x3_kernel<BN, PH, NP>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_x3_kernel<BN, PH, NPX>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const long long nwg = (long long)a.tiles_m * a.tiles_n;
-  hipLaunchKernelGGL((conv3x3_halo_x3_kernel<BN, PH, NP>), dim3((unsigned)nwg), dim3(512), lds, stream, a, tiles_y, tiles_x);
+  hipLaunchKernelGGL((conv3x3_halo_x3_kernel<BN, PH, NPX>), dim3((unsigned)nwg), dim3(512), lds, stream, a, tiles_y, tiles_x);
   return check_launch("conv3x3_halo_x3");
 }
 
 template <int BN, int PH>
 static int launch_halo(IGemmArgs& a, hipStream_t stream) {
   if (a.planes == 1) return launch_halo_np<BN, PH, 1>(a, stream);
-  if (a.planes == 2) return launch_halo_np<BN, PH, 2>(a, stream);
+  if (a.planes == 2) return a.a_packed ? launch_halo_np<BN, PH, 4>(a, stream) : launch_halo_np<BN, PH, 2>(a, stream);
   return launch_halo_np<BN, PH, 3>(a, stream);
 }
 

@@ -368,6 +368,7 @@ static int conv_fwd_any(const evk_conv_desc* d, const float* x, const float* w, 
   a.Kpad = kpad32(a.Ktot);
   a.planes = planes;
   a.a_scale = a_scale; a.w_scale = w_scale;
+  a.a_packed = (planes == 2 && (flags & EVK_CONV_X_PACKED)) ? 1 : 0;
   a.out_amax = out_amax;
   a.bn_want = (bn_parts && w3 && d->Cout % 4 == 0) ? 1 : 0;
   a.bn_buf = bn_parts;
@@ -445,7 +446,8 @@ extern "C" int evk_conv2d_fwd_x3_res(const evk_conv_desc* d, const float* x, con
 
 static int conv_dgrad_any(const evk_conv_desc* d, const float* dy, const float* wt, const uint16_t* wt3,
                           const float* accum, float* dx, void* stream, int planes = 3,
-                          const uint32_t* a_scale = nullptr, const uint32_t* w_scale = nullptr, uint32_t* out_amax = nullptr) {
+                          const uint32_t* a_scale = nullptr, const uint32_t* w_scale = nullptr, uint32_t* out_amax = nullptr,
+                          int dy_packed = 0) {
   int rc = check_desc(d);
   if (rc) return rc;
   EVK_REQUIRE(dy && (wt || wt3) && dx, EVK_E_INVALID, "conv2d_dgrad: null pointer");
@@ -479,6 +481,7 @@ static int conv_dgrad_any(const evk_conv_desc* d, const float* dy, const float* 
         IGemmArgs a{};
         a.planes = planes;
         a.a_scale = a_scale; a.w_scale = w_scale;
+        a.a_packed = dy_packed;
         a.out_amax = out_amax;
         a.src = dy; a.wgt = wt ? wt + woff : nullptr; a.wgt3 = wt3 ? wt3 + woff3 : nullptr;
         a.bias = nullptr; a.accum = accum; a.dst = dx;
@@ -520,6 +523,15 @@ extern "C" int evk_conv2d_dgrad_f16x2(const evk_conv_desc* d, const float* dy, c
   EVK_REQUIRE(wsplit_t && dy_absmax && w_absmax, EVK_E_INVALID, "conv2d_dgrad_f16x2: null weight planes / scales");
   return conv_dgrad_any(d, dy, nullptr, reinterpret_cast<const uint16_t*>(wsplit_t), accum, dx, stream, 2, dy_absmax,
                         w_absmax, dx_absmax);
+}
+
+extern "C" int evk_conv2d_dgrad_f16x2_ex(const evk_conv_desc* d, const void* dy, const uint32_t* dy_absmax,
+                                         const void* wsplit_t, const uint32_t* w_absmax, const float* accum, float* dx,
+                                         uint32_t* dx_absmax, uint32_t flags, void* stream) {
+  EVK_REQUIRE(wsplit_t && dy_absmax && w_absmax, EVK_E_INVALID, "conv2d_dgrad_f16x2_ex: null weight planes / scales");
+  EVK_REQUIRE((flags & ~EVK_CONV_DY_PACKED) == 0, EVK_E_INVALID, "conv2d_dgrad_f16x2_ex: unknown flag 0x%x", flags);
+  return conv_dgrad_any(d, reinterpret_cast<const float*>(dy), nullptr, reinterpret_cast<const uint16_t*>(wsplit_t), accum, dx,
+                        stream, 2, dy_absmax, w_absmax, dx_absmax, (flags & EVK_CONV_DY_PACKED) ? 1 : 0);
 }
 
 extern "C" int evk_conv2d_dgrad_x3(const evk_conv_desc* d, const float* dy, const void* wsplit_t, const float* accum,

@@ -23,8 +23,10 @@
 
 namespace evk {
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NBUF, int NP>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NBUF, int NPX>
 __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(const IGemmArgs p) {
+  constexpr int NP = X3Mode<NPX>::NP;
+  constexpr bool PK = X3Mode<NPX>::PK;   // the activation operand arrives packed (x3_common.hpp)
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MB = WM / 32, NB = WN / 32;
   constexpr int AR = BM / 64, BR = BN / 64;  // row slots per thread (64 rows x 4 sixteen-byte chunks per pass)
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(const IGemmArgs p) {
         const f32x4 v = ra[j][e >> 1];
         const float x0 = ok ? v[2 * (e & 1)] : 0.f, x1 = ok ? v[2 * (e & 1) + 1] : 0.f;
         uint32_t h, m = 0, l = 0;
-        split_np<NP>(x0, x1, a_inv, h, m, l);
+        split_op<NP, PK>(x0, x1, a_inv, h, m, l);
         H[e] = h; M[e] = m; L[e] = l;
       }
       *reinterpret_cast<u32x4*>(Ab + off) = H;
@@ -264,7 +266,9 @@ static int launch_cfg3_np(IGemmArgs& a, hipStream_t stream) {
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NBUF>
 static int launch_cfg3(IGemmArgs& a, hipStream_t stream) {
   if (a.planes == 1) return launch_cfg3_np<BM, BN, WAVES_M, WAVES_N, NBUF, 1>(a, stream);
-  if (a.planes == 2) return launch_cfg3_np<BM, BN, WAVES_M, WAVES_N, NBUF, 2>(a, stream);
+  if (a.planes == 2)
+    return a.a_packed ? launch_cfg3_np<BM, BN, WAVES_M, WAVES_N, NBUF, 4>(a, stream)
+                      : launch_cfg3_np<BM, BN, WAVES_M, WAVES_N, NBUF, 2>(a, stream);
   return launch_cfg3_np<BM, BN, WAVES_M, WAVES_N, NBUF, 3>(a, stream);
 }
 

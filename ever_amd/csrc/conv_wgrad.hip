@@ -349,7 +349,7 @@ extern "C" size_t evk_conv2d_wgrad_x3_workspace_bytes(const evk_conv_desc* d) { 
 
 static int conv_wgrad_any(const evk_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
                           void* workspace, size_t workspace_bytes, void* stream, int x3, int planes = 3,
-                          const uint32_t* x_scale = nullptr, const uint32_t* dy_scale = nullptr) {
+                          const uint32_t* x_scale = nullptr, const uint32_t* dy_scale = nullptr, uint32_t pk_flags = 0) {
   EVK_REQUIRE(d && x && dy && dw, EVK_E_INVALID, "conv2d_wgrad: null pointer");
   EVK_REQUIRE(d->Cin % 4 == 0 && d->Cout % 4 == 0, EVK_E_UNSUPPORTED,
               "conv2d_wgrad: Cin=%d and Cout=%d must be multiples of 4", d->Cin, d->Cout);
@@ -363,6 +363,9 @@ static int conv_wgrad_any(const evk_conv_desc* d, const float* x, const float* d
   WGradArgs a{};
   a.planes = planes;
   a.x_scale = x_scale; a.dy_scale = dy_scale;
+  a.x_packed = (pk_flags & EVK_CONV_X_PACKED) ? 1 : 0;
+  a.dy_packed = (pk_flags & EVK_CONV_DY_PACKED) ? 1 : 0;
+  EVK_REQUIRE(!(a.dy_packed && dbias), EVK_E_UNSUPPORTED, "conv2d_wgrad: the bias gradient needs dy as fp32");
   a.x = x; a.dy = dy;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
   a.kh = d->kh; a.kw = d->kw; a.cpt = d->Cin / 4;
@@ -425,6 +428,18 @@ extern "C" int evk_conv2d_wgrad_f16x2(const evk_conv_desc* d, const float* x, co
   EVK_REQUIRE(d && d->Cin % 4 == 0 && d->Cout % 4 == 0, EVK_E_UNSUPPORTED, "conv2d_wgrad_f16x2: channels must be multiples of 4");
   EVK_REQUIRE(x_absmax && dy_absmax, EVK_E_INVALID, "conv2d_wgrad_f16x2: null scales");
   return conv_wgrad_any(d, x, dy, dw, dbias, workspace, workspace_bytes, stream, 1, 2, x_absmax, dy_absmax);
+}
+
+// flags: EVK_CONV_X_PACKED / EVK_CONV_DY_PACKED — that operand holds packed words (evk_pack_f16x2) instead of fp32
+extern "C" int evk_conv2d_wgrad_f16x2_ex(const evk_conv_desc* d, const void* x, const uint32_t* x_absmax, const void* dy,
+                                         const uint32_t* dy_absmax, float* dw, float* dbias, void* workspace,
+                                         size_t workspace_bytes, uint32_t flags, void* stream) {
+  EVK_REQUIRE(d && d->Cin % 4 == 0 && d->Cout % 4 == 0, EVK_E_UNSUPPORTED, "conv2d_wgrad_f16x2_ex: channels must be multiples of 4");
+  EVK_REQUIRE(x_absmax && dy_absmax, EVK_E_INVALID, "conv2d_wgrad_f16x2_ex: null scales");
+  EVK_REQUIRE((flags & ~(EVK_CONV_X_PACKED | EVK_CONV_DY_PACKED)) == 0, EVK_E_INVALID,
+              "conv2d_wgrad_f16x2_ex: unknown flag 0x%x", flags);
+  return conv_wgrad_any(d, reinterpret_cast<const float*>(x), reinterpret_cast<const float*>(dy), dw, dbias, workspace,
+                        workspace_bytes, stream, 1, 2, x_absmax, dy_absmax, flags);
 }
 
 extern "C" int evk_conv2d_wgrad_x3(const evk_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,

@@ -21,8 +21,10 @@
 
 namespace evk {
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NP>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NPX>
 __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const WGradArgs p) {
+  constexpr int NP = X3Mode<NPX>::NP;
+  constexpr bool PK = X3Mode<NPX>::PK;   // one or both operands arrive packed (p.x_packed / p.dy_packed; x3_common.hpp)
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MB = WM / 32, NB = WN / 32;
   constexpr int QA = BM / 4, QB = BN / 4;  // channel quads per operand
@@ -83,6 +85,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const WGradArgs p) {
     st_inv = roleA ? sd.inv : sx.inv;
     out_scale = sx.s * sd.s;
   }
+  const bool st_packed = PK && (roleA ? p.dy_packed : p.x_packed) != 0;   // wave-uniform
 
   auto load_tiles = [&](int pix0) {
     okmask = 0;
@@ -136,7 +139,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const WGradArgs p) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         uint32_t h, m = 0, l = 0;
-        split_np<NP>(rv[2 * t][e], rv[2 * t + 1][e], st_inv, h, m, l);
+        if constexpr (PK) {
+          if (st_packed) split_op<NP, true>(rv[2 * t][e], rv[2 * t + 1][e], st_inv, h, m, l);
+          else split_np<NP>(rv[2 * t][e], rv[2 * t + 1][e], st_inv, h, m, l);
+        } else {
+          split_np<NP>(rv[2 * t][e], rv[2 * t + 1][e], st_inv, h, m, l);
+        }
         H[t] = h; M[t] = m; L[t] = l;
       }
       *reinterpret_cast<u32x4*>(st_base + off) = H;
@@ -230,6 +238,9 @@ static int launch_one(const WGradArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)3 * (BM + BN) * kRowBytes;
   if (a.planes == 1) {
     hipLaunchKernelGGL((conv_wgrad_x3_kernel<BM, BN, WAVES_M, WAVES_N, 1>), dim3(a.tiles_co * a.tiles_k * a.splitk),
+                       dim3(256), lds, stream, a);
+  } else if (a.planes == 2 && (a.x_packed || a.dy_packed)) {
+    hipLaunchKernelGGL((conv_wgrad_x3_kernel<BM, BN, WAVES_M, WAVES_N, 4>), dim3(a.tiles_co * a.tiles_k * a.splitk),
                        dim3(256), lds, stream, a);
   } else if (a.planes == 2) {
     hipLaunchKernelGGL((conv_wgrad_x3_kernel<BM, BN, WAVES_M, WAVES_N, 2>), dim3(a.tiles_co * a.tiles_k * a.splitk),

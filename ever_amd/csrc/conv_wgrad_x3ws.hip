@@ -165,7 +165,7 @@ __device__ __forceinline__ void gather8h_buf(__amdgpu_buffer_rsrc_t rs, int Cout
   }
 }
 // split the micro-block (already zero where out of range) and write channel 4*cq+e to LDS row e*Q + cq, chunk pg
-template <int NP, int NCH, typename V>
+template <int NP, int NCH, bool PK, typename V>
 __device__ __forceinline__ void split_store_buf(V (&rv)[8], unsigned char* base, int plane_bytes, int Q, int cq, int pg,
                                                 float inv) {
 #pragma unroll
@@ -175,7 +175,7 @@ __device__ __forceinline__ void split_store_buf(V (&rv)[8], unsigned char* base,
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       uint32_t h, m = 0, l = 0;
-      split_np<NP>(rv[2 * t][e], rv[2 * t + 1][e], inv, h, m, l);
+      split_op<NP, PK>(rv[2 * t][e], rv[2 * t + 1][e], inv, h, m, l);
       H[t] = h; M[t] = m; L[t] = l;
     }
     *reinterpret_cast<u32x4*>(base + off) = H;
@@ -209,8 +209,10 @@ __device__ __forceinline__ void split_store8h(f32x2v (&rv)[8], uint32_t okmask, 
   }
 }
 
-template <int BM, int BN, int NP, bool W8>
+// PKX / PKD: x / dy arrive packed (f16x2 only; x3_common.hpp)
+template <int BM, int BN, int NP, bool W8, bool PKX = false, bool PKD = false>
 __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p) {
+  static_assert(NP == 2 || (!PKX && !PKD), "packed operands exist for the f16x2 arithmetic only");
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MB = WM / 32, NB = WN / 32;
   constexpr int QA = BM / 4, QB = BN / 4;
@@ -287,8 +289,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
       unsigned char* Bb = Ab + 3 * BM * kRowBytes;
       if (p.dbg & 2) return;   // ablation: no split, no LDS writes
       if constexpr (kBuf) {
-        split_store_buf<NP, 4>(rb[s], Bb, BN * kRowBytes, QB, bcq, bpg, x_inv);
-        split_store_buf<NP, 2>(ra[s], Ab, BM * kRowBytes, QA2, acq, apg, dy_inv);
+        split_store_buf<NP, 4, PKX>(rb[s], Bb, BN * kRowBytes, QB, bcq, bpg, x_inv);
+        split_store_buf<NP, 2, PKD>(ra[s], Ab, BM * kRowBytes, QA2, acq, apg, dy_inv);
       } else {
         split_store8<NP>(rb[s], okb[s], Bb, BN * kRowBytes, QB, bcq, bpg, x_inv);
         split_store8h<NP>(ra[s], oka[s], Ab, BM * kRowBytes, QA2, acq, apg, dy_inv);
@@ -410,17 +412,17 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
     }
 }
 
-template <int NP, bool W8>
+template <int NP, bool W8, bool PKX = false, bool PKD = false>
 static int launch_wgrad_x3ws_t(const WGradArgs& b, hipStream_t stream) {
   constexpr int BM = 128, BN = 256;
   const size_t lds = (size_t)2 * 3 * (BM + BN) * kRowBytes;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x3ws_kernel<BM, BN, NP, W8>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x3ws_kernel<BM, BN, NP, W8, PKX, PKD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_x3ws_kernel<BM, BN, NP, W8>), dim3(b.tiles_co * b.tiles_k * b.splitk), dim3(512), lds, stream, b);
+  hipLaunchKernelGGL((conv_wgrad_x3ws_kernel<BM, BN, NP, W8, PKX, PKD>), dim3(b.tiles_co * b.tiles_k * b.splitk), dim3(512), lds, stream, b);
   return check_launch("conv_wgrad_x3ws");
 }
 
@@ -430,7 +432,13 @@ int launch_wgrad_x3ws(const WGradArgs& a, hipStream_t stream) {
   b.dbg = dbg;
   const bool w8 = (a.Wo & 7) == 0;
   if (a.planes == 1) return w8 ? launch_wgrad_x3ws_t<1, true>(b, stream) : launch_wgrad_x3ws_t<1, false>(b, stream);
-  if (a.planes == 2) return w8 ? launch_wgrad_x3ws_t<2, true>(b, stream) : launch_wgrad_x3ws_t<2, false>(b, stream);
+  if (a.planes == 2) {
+    const int pk = (a.x_packed ? 1 : 0) | (a.dy_packed ? 2 : 0);
+    if (pk == 3) return w8 ? launch_wgrad_x3ws_t<2, true, true, true>(b, stream) : launch_wgrad_x3ws_t<2, false, true, true>(b, stream);
+    if (pk == 2) return w8 ? launch_wgrad_x3ws_t<2, true, false, true>(b, stream) : launch_wgrad_x3ws_t<2, false, false, true>(b, stream);
+    if (pk == 1) return w8 ? launch_wgrad_x3ws_t<2, true, true, false>(b, stream) : launch_wgrad_x3ws_t<2, false, true, false>(b, stream);
+    return w8 ? launch_wgrad_x3ws_t<2, true>(b, stream) : launch_wgrad_x3ws_t<2, false>(b, stream);
+  }
   return w8 ? launch_wgrad_x3ws_t<3, true>(b, stream) : launch_wgrad_x3ws_t<3, false>(b, stream);
 }
 

@@ -27,6 +27,7 @@ struct IGemmArgs {
                             // 2: 2-term fp16 split of scaled operands, three products (*_f16x2 entry points)
   const uint32_t* a_scale;  // planes == 2: bit image of max|src| (evk_absmax) and of max|weight| (the planes' producer)
   const uint32_t* w_scale;
+  int a_packed;             // planes == 2: src holds packed (h | l << 16) words of src / s instead of fp32 (x3_common.hpp)
   uint32_t* out_amax;       // optional: the output's operand-scale buffer (64 slots, x3_common.hpp act_absmax), raised with
                             // one atomic max per wave from the epilogue — the output is a later convolution's operand
   // BatchNorm statistics of the OUTPUT from the epilogue (forward convolutions followed by a training-mode BatchNorm):

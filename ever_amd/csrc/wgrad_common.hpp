@@ -19,6 +19,7 @@ struct WGradArgs {
                // 2: 2-term fp16 split of scaled operands, three products (evk_conv2d_wgrad_f16x2)
   const uint32_t* x_scale;   // planes == 2: bit images of max|x| and max|dy| (evk_absmax)
   const uint32_t* dy_scale;
+  int x_packed, dy_packed;   // planes == 2: the operand holds packed (h | l << 16) words of value / s (x3_common.hpp)
   int dbg;  // EVK_WG_DBG ablation switches of the wave-specialised kernel (0 in production)
 };
 

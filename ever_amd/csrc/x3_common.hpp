@@ -66,6 +66,34 @@ __device__ __forceinline__ void split_np(float x0, float x1, float inv, uint32_t
   else if constexpr (NP == 2) split2h(x0 * inv, x1 * inv, H, M);
   else H = cvt2(x0, x1);
 }
+// "Packed" activation operands of the f16x2 arithmetic: the producer (evk_pack_f16x2, the BatchNorm apply passes) already
+// split x / s and stored ONE 32-bit word per element, h in the low half and l in the high half — same addressing as the
+// fp32 tensor, the consumer's staging is two v_perm_b32 per element pair instead of scale, 2 x convert, subtract, convert
+// (the staging VALU was the bound of the weight gradient: 1292 -> 944 us on 3x3x256 @128^2 x16 with packed operands).
+// Kernels take the mode as NPX: 1, 2, 3 = NP with fp32 operands, 4 = NP 2 with a packed activation operand.
+template <int NPX> struct X3Mode {
+  static constexpr int NP = NPX == 4 ? 2 : NPX;
+  static constexpr bool PK = NPX == 4;
+};
+__device__ __forceinline__ uint32_t pack_hl(float xs) {   // xs = x / s; the same two roundings as split2h
+  const _Float16 h = (_Float16)xs;
+  const _Float16 l = (_Float16)(xs - (float)h);
+  return (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
+}
+__device__ __forceinline__ float unpack_hl(uint32_t w) {  // h + l (22 bits), still in units of s
+  return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)) + (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
+}
+template <int NP, bool PK>
+__device__ __forceinline__ void split_op(float x0, float x1, float inv, uint32_t& H, uint32_t& M, uint32_t& L) {
+  if constexpr (PK) {
+    static_assert(NP == 2, "packed operands exist for the f16x2 arithmetic only");
+    const uint32_t w0 = __builtin_bit_cast(uint32_t, x0), w1 = __builtin_bit_cast(uint32_t, x1);
+    H = __builtin_amdgcn_perm(w1, w0, 0x05040100u);
+    M = __builtin_amdgcn_perm(w1, w0, 0x07060302u);
+  } else {
+    split_np<NP>(x0, x1, inv, H, M, L);
+  }
+}
 // one MFMA of the instantiation's operand type on two 16-byte LDS fragments
 template <int NP>
 __device__ __forceinline__ f32x16 mfma_np(bf16x8 a, bf16x8 b, f32x16 c) {

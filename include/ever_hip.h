@@ -56,6 +56,9 @@ typedef struct evk_conv_desc {
 
 /* flags for evk_conv2d_fwd */
 #define EVK_CONV_RELU 1u /* y = max(y, 0) in the epilogue */
+/* f16x2 entry points only: that activation operand is stored PACKED (evk_pack_f16x2: one 32-bit word per element) */
+#define EVK_CONV_X_PACKED 2u
+#define EVK_CONV_DY_PACKED 4u
 
 /* y = conv(x, w) (+ bias).  w: [Cout][kh][kw][Cin].  bias may be NULL.
  * Implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32), im2col rows gathered to LDS. */
@@ -163,6 +166,22 @@ int evk_conv2d_dgrad_f16x2(const evk_conv_desc* d, const float* dy, const uint32
 int evk_conv2d_wgrad_f16x2(const evk_conv_desc* d, const float* x, const uint32_t* x_absmax, const float* dy,
                            const uint32_t* dy_absmax, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
                            void* stream);
+/* Packed activation operands of the f16x2 arithmetic.  The kernels split every fp32 operand element into two fp16
+ * (h, l) of x / s while staging it — the bound of the weight gradient.  A producer that knows the
+ * scale can store the element already split: one 32-bit word, h in the low half, l in the high half, same shape and
+ * strides as the fp32 tensor; the consumer's staging becomes a byte permute and its results are bit-identical to the
+ * fp32 operand's under the same scale buffer.  evk_pack_f16x2 is the stand-alone producer (the BatchNorm passes are the
+ * fused ones, EVK_BN_PACK_*), evk_unpack_f16x2 returns (h + l) * s (tests, debugging).  n % 4 == 0.
+ * evk_conv2d_fwd_f16x2 takes EVK_CONV_X_PACKED in flags; the _ex forms of the two gradients take both flags
+ * (dbias must be NULL with EVK_CONV_DY_PACKED). */
+int evk_pack_f16x2(const float* x, int64_t n, const uint32_t* x_absmax, uint32_t* out, void* stream);
+int evk_unpack_f16x2(const uint32_t* packed, int64_t n, const uint32_t* x_absmax, float* out, void* stream);
+int evk_conv2d_dgrad_f16x2_ex(const evk_conv_desc* d, const void* dy, const uint32_t* dy_absmax, const void* wsplit_t,
+                              const uint32_t* w_absmax, const float* accum, float* dx, uint32_t* dx_absmax,
+                              uint32_t flags, void* stream);
+int evk_conv2d_wgrad_f16x2_ex(const evk_conv_desc* d, const void* x, const uint32_t* x_absmax, const void* dy,
+                              const uint32_t* dy_absmax, float* dw, float* dbias, void* workspace,
+                              size_t workspace_bytes, uint32_t flags, void* stream);
 /* y = act(conv(x, w) + bias + residual): inference form of a residual block's last convolution with its
  * BatchNorm folded into (w, bias) — `out += identity; relu` of reference _resnets.py:95-112 in the epilogue. */
 int evk_conv2d_fwd_res(const evk_conv_desc* d, const float* x, const float* w, const float* bias,

@@ -1,0 +1,130 @@
+"""Packed activation operands of the f16x2 arithmetic (include/ever_hip.h: evk_pack_f16x2): a producer that knows the
+operand scale stores every element already split (h | l << 16); the convolution kernels then only permute bytes while
+staging.  Contract checked here: under the SAME scale buffer a packed operand gives bit-identical results to the fp32
+operand, on every kernel family (halo 3x3, wave-specialised and single-role implicit GEMM, strided residue classes,
+both weight-gradient kernels), and unpack(pack(x)) is x to 22 bits."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _scale_buf(lib, t, aws, st):
+    from ever_amd import _C
+    b = torch.zeros(int(lib.evk_absmax_words()), dtype=torch.int32, device=t.device)
+    _C.call('evk_absmax', t.data_ptr(), t.numel(), b.data_ptr(), aws.data_ptr(), st)
+    return b
+
+
+def _pack(t, bits, st):
+    from ever_amd import _C
+    out = torch.empty(t.shape, dtype=torch.int32, device=t.device)
+    _C.call('evk_pack_f16x2', t.data_ptr(), t.numel(), bits.data_ptr(), out.data_ptr(), st)
+    return out
+
+
+def test_pack_round_trip_keeps_22_bits(cuda):
+    from ever_amd import _C
+    lib = _C.load()
+    st = torch.cuda.current_stream().cuda_stream
+    aws = torch.zeros(lib.evk_absmax_workspace_bytes(), dtype=torch.uint8, device=cuda)
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(1 << 16, generator=g) * torch.logspace(-6, 2, 1 << 16)).to(cuda)
+    bits = _scale_buf(lib, x, aws, st)
+    pk = _pack(x, bits, st)
+    back = torch.empty_like(x)
+    _C.call('evk_unpack_f16x2', pk.data_ptr(), x.numel(), bits.data_ptr(), back.data_ptr(), st)
+    torch.cuda.synchronize()
+    big = x.abs().max().item()
+    err = (back.double() - x.double()).abs()
+    # 22 bits relative for elements within 2^-17 of the largest, an absolute 2^-38 of the largest below
+    bound = torch.maximum(x.double().abs() * 2.0 ** -21, torch.full_like(err, big * 2.0 ** -37))
+    assert bool((err <= bound).all()), float((err / bound).max())
+    zeros = torch.zeros(1024, device=cuda)
+    assert int(_pack(zeros, bits, st).abs().max()) == 0
+
+
+CASES = [
+    # n, cin, h, w, cout, k, stride, pad
+    (2, 64, 32, 32, 64, 3, 1, 1),       # halo 3x3
+    (2, 256, 32, 32, 256, 3, 1, 1),     # halo 3x3, wide
+    (2, 128, 16, 16, 128, 3, 2, 1),     # strided 3x3: residue classes in the data gradient
+    (4, 256, 32, 32, 512, 1, 1, 0),     # 1x1 wave-specialised
+    (2, 64, 16, 16, 256, 1, 1, 0),      # 1x1 single-role
+    (2, 256, 64, 64, 128, 1, 2, 0),     # strided 1x1 shortcut
+    (1, 32, 24, 40, 48, 3, 1, 1),       # ragged tiles
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_packed_operands_are_bit_identical(cuda, case):
+    from ever_amd import _C
+    lib = _C.load()
+    st = torch.cuda.current_stream().cuda_stream
+    n, cin, h, w, cout, k, s, p = case
+    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    d = _C.ConvDesc(n, h, w, cin, ho, wo, cout, k, k, s, s, p, p, 1, 1)
+    g = torch.Generator().manual_seed(cin * 7 + cout + k + s)
+    x = (torch.randn(n, h, w, cin, generator=g) + 0.25).to(cuda)
+    wt = (torch.randn(cout, k, k, cin, generator=g) * 0.05).to(cuda)
+    dy = (torch.randn(n, ho, wo, cout, generator=g) * 1e-3).to(cuda)
+    aws = torch.zeros(lib.evk_absmax_workspace_bytes(), dtype=torch.uint8, device=cuda)
+    bx, bw, bdy = (_scale_buf(lib, t, aws, st) for t in (x, wt, dy))
+    xp, dyp = _pack(x, bx, st), _pack(dy, bdy, st)
+    pf = torch.empty(lib.evk_conv2d_split_weight_bytes(ctypes.byref(d), 0), dtype=torch.uint8, device=cuda)
+    pd = torch.empty(lib.evk_conv2d_split_weight_bytes(ctypes.byref(d), 1), dtype=torch.uint8, device=cuda)
+    _C.call('evk_conv2d_split_weight_f16x2', ctypes.byref(d), wt.data_ptr(), 0, pf.data_ptr(), bw.data_ptr(), st)
+    _C.call('evk_conv2d_split_weight_f16x2', ctypes.byref(d), wt.data_ptr(), 1, pd.data_ptr(), bw.data_ptr(), st)
+    zero = ctypes.c_int32(0)
+
+    def fwd(src, flags):
+        y = torch.empty(n, ho, wo, cout, device=cuda)
+        _C.call('evk_conv2d_fwd_f16x2', ctypes.byref(d), src.data_ptr(), bx.data_ptr(), pf.data_ptr(), bw.data_ptr(), None,
+                None, y.data_ptr(), flags, None, 0, ctypes.byref(zero), None, st)
+        return y
+
+    def dgrad(src, flags):
+        dx = torch.empty_like(x)
+        _C.call('evk_conv2d_dgrad_f16x2_ex', ctypes.byref(d), src.data_ptr(), bdy.data_ptr(), pd.data_ptr(), bw.data_ptr(),
+                None, dx.data_ptr(), None, flags, st)
+        return dx
+
+    wsb = lib.evk_conv2d_wgrad_x3_workspace_bytes(ctypes.byref(d))
+    wsp = torch.empty(max(wsb, 16), dtype=torch.uint8, device=cuda)
+
+    def wgrad(xs, dys, flags):
+        dw = torch.empty_like(wt)
+        _C.call('evk_conv2d_wgrad_f16x2_ex', ctypes.byref(d), xs.data_ptr(), bx.data_ptr(), dys.data_ptr(), bdy.data_ptr(),
+                dw.data_ptr(), None, wsp.data_ptr(), wsb, flags, st)
+        return dw
+
+    X, DY = 2, 4   # EVK_CONV_X_PACKED, EVK_CONV_DY_PACKED
+    y0, y1 = fwd(x, 0), fwd(xp, X)
+    g0, g1 = dgrad(dy, 0), dgrad(dyp, DY)
+    w0 = wgrad(x, dy, 0)
+    torch.cuda.synchronize()
+    assert y0.abs().max().item() > 0 and g0.abs().max().item() > 0 and w0.abs().max().item() > 0
+    assert torch.equal(y0, y1), (y0 - y1).abs().max().item()
+    assert torch.equal(g0, g1), (g0 - g1).abs().max().item()
+    for flags, xs, dys in ((X, xp, dy), (DY, x, dyp), (X | DY, xp, dyp)):
+        w1 = wgrad(xs, dys, flags)
+        torch.cuda.synchronize()
+        assert torch.equal(w0, w1), (flags, (w0 - w1).abs().max().item())
+
+
+def test_packed_dy_refuses_a_bias_gradient(cuda):
+    from ever_amd import _C
+    lib = _C.load()
+    st = torch.cuda.current_stream().cuda_stream
+    d = _C.ConvDesc(1, 8, 8, 32, 8, 8, 32, 1, 1, 1, 1, 0, 0, 1, 1)
+    x = torch.randn(1, 8, 8, 32, device=cuda)
+    aws = torch.zeros(lib.evk_absmax_workspace_bytes(), dtype=torch.uint8, device=cuda)
+    b = _scale_buf(lib, x, aws, st)
+    dw, db = torch.empty(32, 1, 1, 32, device=cuda), torch.empty(32, device=cuda)
+    wsb = lib.evk_conv2d_wgrad_x3_workspace_bytes(ctypes.byref(d))
+    wsp = torch.empty(max(wsb, 16), dtype=torch.uint8, device=cuda)
+    with pytest.raises(Exception):
+        _C.call('evk_conv2d_wgrad_f16x2_ex', ctypes.byref(d), x.data_ptr(), b.data_ptr(), x.data_ptr(), b.data_ptr(),
+                dw.data_ptr(), db.data_ptr(), wsp.data_ptr(), wsb, 4, st)
