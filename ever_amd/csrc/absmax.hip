@@ -86,9 +86,7 @@ __global__ __launch_bounds__(256) void pack_f16x2_kernel(const float* __restrict
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
-  u32x4 o;
-  o.x = pack_hl(v.x * inv); o.y = pack_hl(v.y * inv); o.z = pack_hl(v.z * inv); o.w = pack_hl(v.w * inv);
-  reinterpret_cast<u32x4*>(out)[i] = o;
+  reinterpret_cast<u32x4*>(out)[i] = pack_hl4(v, inv);
 }
 __global__ __launch_bounds__(256) void unpack_f16x2_kernel(const uint32_t* __restrict__ in, size_t n4,
                                                            const uint32_t* __restrict__ slots, float* __restrict__ out) {

@@ -213,6 +213,9 @@ __device__ __forceinline__ void block_absmax(const f32x4 v, bool valid, uint32_t
 // (tools/probes/copy_patterns.hip) — the resident workgroups then sweep one contiguous window of HBM in dispatch
 // order instead of 2048 x 4 scattered pages.  scale/shift (2C floats) come from L1/L2, not LDS: staging them
 // per workgroup would cost more than the 4 KB a workgroup streams.
+// PK: y is written as packed words of y / s (x3_common.hpp: pack_hl), s from the bound the finalisation left in slot 0
+// of `amax` — the tensor is the next convolution's operand and nothing else.
+template <bool PK = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ residual,
                                                        const float* __restrict__ scale_shift, float* __restrict__ y,
                                                        size_t n4, int C, int relu, uint32_t* __restrict__ amax) {
@@ -220,6 +223,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   const size_t i = base + threadIdx.x;
   const bool valid = i < n4;
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  float pk_inv = 1.f;
+  if constexpr (PK) pk_inv = op_scale(amax[0]).inv;
   if (valid) {
     const int c4 = C >> 2;
     const int cb = chunk_of(base, c4);
@@ -230,13 +235,21 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     if (relu) {
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
-    reinterpret_cast<f32x4*>(y)[i] = v;
+    if constexpr (PK) {
+      reinterpret_cast<u32x4*>(y)[i] = pack_hl4(v, pk_inv);
+    } else {
+      reinterpret_cast<f32x4*>(y)[i] = v;
+    }
   }
-  if (amax) block_absmax(v, valid, amax);   // all lanes of the workgroup arrive here together
+  if constexpr (!PK)
+    if (amax) block_absmax(v, valid, amax);   // all lanes of the workgroup arrive here together
 }
 
 // Backward stage 1: g = dy * (y > 0) ; partial[blk][0][C] = sum g, [1][C] = sum g * xhat.
 // Optionally writes g to d_residual.
+// PK (dx will be written packed, EVK_BN_PACK_DX): also pmax[blk][0][C] = max |g|, [1][C] = max |xhat| — what the
+// finalisation needs to bound |dx| per channel BEFORE the apply pass writes it under that scale.
+template <bool PK>
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ y,
                                                              const float* __restrict__ mean,
@@ -245,7 +258,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
                                                              const float* __restrict__ beta,
                                                              float* __restrict__ d_residual,
                                                              float* __restrict__ partial, int64_t rows, int C,
-                                                             int64_t rows_per_blk, int tpc, int rl, int relu) {
+                                                             int64_t rows_per_blk, int tpc, int rl, int relu,
+                                                             float* __restrict__ pmax) {
   // relu: 0 none, 1 mask from the saved output y, 2 mask recomputed from x (no residual: the
   // forward's pre-activation is x*sc+sh with the same sc/sh arithmetic as bn_stats_final_kernel)
   __shared__ f32x4 red[2][256];
@@ -265,6 +279,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
       sh = b4 - mu * sc;
     }
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    f32x4 gm = {0.f, 0.f, 0.f, 0.f}, xm = {0.f, 0.f, 0.f, 0.f};
     if (tr < rl) {
       auto one = [&](const f32x4 gin, const f32x4 xv, const f32x4 yin, size_t off) {
         f32x4 g = gin;
@@ -275,7 +290,14 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
         }
         if (d_residual) *reinterpret_cast<f32x4*>(d_residual + off) = g;
         s += g;
-        q += g * ((xv - mu) * is);
+        const f32x4 xh = (xv - mu) * is;
+        q += g * xh;
+        if constexpr (PK) {
+          gm.x = fmaxf(gm.x, fabsf(g.x)); gm.y = fmaxf(gm.y, fabsf(g.y));
+          gm.z = fmaxf(gm.z, fabsf(g.z)); gm.w = fmaxf(gm.w, fabsf(g.w));
+          xm.x = fmaxf(xm.x, fabsf(xh.x)); xm.y = fmaxf(xm.y, fabsf(xh.y));
+          xm.z = fmaxf(xm.z, fabsf(xh.z)); xm.w = fmaxf(xm.w, fabsf(xh.w));
+        }
       };
       const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
       int64_t r = r0 + tr;
@@ -321,6 +343,22 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
       *reinterpret_cast<f32x4*>(o + C + cb * 4) = q;
     }
     __syncthreads();
+    if constexpr (PK) {
+      red[0][threadIdx.x] = gm;
+      red[1][threadIdx.x] = xm;
+      __syncthreads();
+      if (tr == 0) {
+        for (int k = 1; k < rl; ++k) {
+          const f32x4 a = red[0][k * tpc + tc], b = red[1][k * tpc + tc];
+          gm.x = fmaxf(gm.x, a.x); gm.y = fmaxf(gm.y, a.y); gm.z = fmaxf(gm.z, a.z); gm.w = fmaxf(gm.w, a.w);
+          xm.x = fmaxf(xm.x, b.x); xm.y = fmaxf(xm.y, b.y); xm.z = fmaxf(xm.z, b.z); xm.w = fmaxf(xm.w, b.w);
+        }
+        float* o = pmax + (size_t)blockIdx.x * 2 * C;
+        *reinterpret_cast<f32x4*>(o + cb * 4) = gm;
+        *reinterpret_cast<f32x4*>(o + C + cb * 4) = xm;
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -330,21 +368,56 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
                                                            const float* __restrict__ invstd,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            float* __restrict__ coef, int train,
-                                                           uint32_t* __restrict__ amax) {
-  zero_amax(amax);   // stage 3 accumulates max|dx| into its slots
+                                                           uint32_t* __restrict__ amax,
+                                                           const float* __restrict__ pmax) {
+  // pmax == nullptr: stage 3 accumulates max|dx| into the slots (zeroed here).  pmax != nullptr (packed dx): the slots
+  // arrive ZERO and every workgroup raises one of them to a bound of its channels' |dx| before stage 3 starts:
+  //   |dx_c| = |k0 (g - k1 - xhat k2)| <= |k0| (max|g_c| + |k1| + max|xhat_c| |k2|)
+  // (tight to a factor of ~2; an upper bound is all a scale needs, x3_common.hpp).
+  if (!pmax) zero_amax(amax);
+  float gmax = 0.f, xmax = 0.f;
+  if (pmax) {
+    __shared__ float mred[2][kFinLanes][kFinCh];
+    const int tc = threadIdx.x % kFinCh, tl = threadIdx.x / kFinCh;
+    const int cc = blockIdx.x * kFinCh + tc;
+    if (cc < C)
+      for (int b = tl; b < nblk; b += kFinLanes) {
+        gmax = fmaxf(gmax, pmax[(size_t)b * 2 * C + cc]);
+        xmax = fmaxf(xmax, pmax[(size_t)b * 2 * C + C + cc]);
+      }
+    mred[0][tl][tc] = gmax;
+    mred[1][tl][tc] = xmax;
+    __syncthreads();
+    if (tl == 0)
+      for (int k = 1; k < kFinLanes; ++k) {
+        gmax = fmaxf(gmax, mred[0][k][tc]);
+        xmax = fmaxf(xmax, mred[1][k][tc]);
+      }
+  }
   int c;
   double s, q;
   if (!reduce_partials(partial, nblk, C, c, s, q)) return;
   if (dbeta) dbeta[c] = (float)s;
   if (dgamma) dgamma[c] = (float)q;
   const float g = gamma ? gamma[c] : 1.f;
-  coef[c] = g * invstd[c];
-  coef[C + c] = train ? (float)(s * inv_rows) : 0.f;
-  coef[2 * C + c] = train ? (float)(q * inv_rows) : 0.f;
+  const float k0 = g * invstd[c], k1 = train ? (float)(s * inv_rows) : 0.f, k2 = train ? (float)(q * inv_rows) : 0.f;
+  coef[c] = k0;
+  coef[C + c] = k1;
+  coef[2 * C + c] = k2;
+  if (pmax) {
+    const float bound = fabsf(k0) * (gmax + fabsf(k1) + xmax * fabsf(k2));
+    uint32_t bits = __builtin_bit_cast(uint32_t, bound);
+    if (bound != bound) bits = 0x7fc00000u;
+    // slot 0 only (C / 8 workgroups in this launch: nothing to spread), so that the apply pass — one 16-byte element
+    // per thread — reads ONE word instead of folding 64 cache lines per wave (measured: the fold cost the pass 5 %)
+    if (bits) atomicMax(&amax[0], bits);
+  }
 }
 
 // dx = coef0 * (g - coef1 - xhat*coef2); one 16-byte element per thread (see bn_apply_kernel), the per-channel
-// vectors read through L1.
+// vectors read through L1.  PK: dx is written as packed words of dx / s (x3_common.hpp: pack_hl), s from the bound the
+// finalisation left in `amax` — the tensor is the producing convolution's dy operand and nothing else.
+template <bool PK>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
@@ -356,6 +429,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   const size_t i = base + threadIdx.x;
   const bool valid = i < n4;
   f32x4 out = {0.f, 0.f, 0.f, 0.f};
+  float pk_inv = 1.f;
+  if constexpr (PK) pk_inv = op_scale(amax[0]).inv;   // the finalisation's bound lives in slot 0 alone
   if (valid) {
     const int c4 = C >> 2;
     const int c = chunk_of(base, c4);
@@ -381,9 +456,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
     const f32x4 xh = (xv - mu) * is;
     out = k0 * (g - k1 - xh * k2);
-    reinterpret_cast<f32x4*>(dx)[i] = out;
+    if constexpr (PK) {
+      reinterpret_cast<u32x4*>(dx)[i] = pack_hl4(out, pk_inv);
+    } else {
+      reinterpret_cast<f32x4*>(dx)[i] = out;
+    }
   }
-  if (amax) block_absmax(out, valid, amax);   // all lanes of the workgroup arrive here together
+  if constexpr (!PK)
+    if (amax) block_absmax(out, valid, amax);   // all lanes of the workgroup arrive here together
 }
 
 // Statistics that arrive as per-row-part records (count, mean, M2) from the producing convolution's epilogue
@@ -396,8 +476,14 @@ __global__ __launch_bounds__(256) void bn_parts_final_kernel(const float* __rest
                                                              float* __restrict__ running_var, float momentum, float eps,
                                                              float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                                              float* __restrict__ scale_shift,
-                                                             uint32_t* __restrict__ amax) {
-  zero_amax(amax);   // the apply pass accumulates max|y| into its slots
+                                                             uint32_t* __restrict__ amax, int pack) {
+  // pack == 0: the apply pass accumulates max|y| into the slots (zeroed here).  pack != 0 (y will be written packed,
+  // EVK_BN_PACK_Y): the slots arrive ZERO and slot 0 is raised HERE to a bound of |y|, from the records alone: a row of
+  // record i deviates from the record's mean by at most sqrt(M2_i) (one term of the sum), so
+  //   |x - mean_c| <= E_c + |pivot - mean_c|,  E_c = max_i (sqrt(M2_i) + |mean_i - pivot|),  |y_c| <= |sc| (..) + |beta|
+  // — about 2-3x the true maximum at 64..256 rows per record; an upper bound is all a scale needs (x3_common.hpp).
+  if (!pack) zero_amax(amax);
+  float E = 0.f;
   // With a common pivot p (the first record's mean) the merge of all records is three plain sums,
   //   N = sum n_i,  A = sum n_i (mean_i - p),  B = sum [M2_i + n_i (mean_i - p)^2]:  mean = p + A/N,  M2 = B - A^2/N
   // (Chan's pairwise formula telescoped; no division inside the loop, no order dependence beyond the fixed one below).
@@ -422,6 +508,11 @@ __global__ __launch_bounds__(256) void bn_parts_final_kernel(const float* __rest
       A += ((double)n0 * d0 + (double)n1 * d1) + ((double)n2 * d2 + (double)n3 * d3);
       B += (((double)q0 + (double)n0 * d0 * d0) + ((double)q1 + (double)n1 * d1 * d1)) +
            (((double)q2 + (double)n2 * d2 * d2) + ((double)q3 + (double)n3 * d3 * d3));
+      if (pack) {
+        const float e0 = n0 > 0.f ? sqrtf(q0) + fabsf((float)d0) : 0.f, e1 = n1 > 0.f ? sqrtf(q1) + fabsf((float)d1) : 0.f;
+        const float e2 = n2 > 0.f ? sqrtf(q2) + fabsf((float)d2) : 0.f, e3 = n3 > 0.f ? sqrtf(q3) + fabsf((float)d3) : 0.f;
+        E = fmaxf(E, fmaxf(fmaxf(e0, e1), fmaxf(e2, e3)));
+      }
     }
     for (; b < nparts; b += kFinLanes) {
       const float* r0 = r + (size_t)b * st;
@@ -429,8 +520,11 @@ __global__ __launch_bounds__(256) void bn_parts_final_kernel(const float* __rest
       N += n0;
       A += n0 * d0;
       B += (double)r0[2 * C] + n0 * d0 * d0;
+      if (pack && n0 > 0.0) E = fmaxf(E, sqrtf(r0[2 * C]) + fabsf((float)d0));
     }
   }
+  __shared__ float ered[kFinLanes][kFinCh];
+  if (pack) ered[tl][tc] = E;
   red[0][tl][tc] = N;
   red[1][tl][tc] = A;
   red[2][tl][tc] = B;
@@ -455,6 +549,13 @@ __global__ __launch_bounds__(256) void bn_parts_final_kernel(const float* __rest
   const float sc = g * invstd;
   scale_shift[c] = sc;
   scale_shift[C + c] = bb - meanf * sc;
+  if (pack) {
+    for (int k = 1; k < kFinLanes; ++k) E = fmaxf(E, ered[k][tc]);
+    const float bound = fabsf(sc) * (E * 1.001f + fabsf((float)(piv - mean))) + fabsf(bb);
+    uint32_t bits = __builtin_bit_cast(uint32_t, bound);
+    if (bound != bound) bits = 0x7fc00000u;
+    if (bits) atomicMax(&amax[0], bits);   // slot 0 alone: the apply pass reads one word (see bn_bwd_final_kernel)
+  }
 }
 
 static unsigned oneshot_grid(size_t n4) { return (unsigned)((n4 + 255) / 256); }
@@ -465,7 +566,8 @@ using namespace evk;
 
 extern "C" size_t evk_bn_workspace_bytes(int64_t rows, int32_t C) {
   if (rows <= 0 || C <= 0) return 0;
-  return ((size_t)kMaxStatBlocks * 2 * C + 8 * (size_t)C) * sizeof(float);
+  // partial sums [blocks][2][C], 8 C of coefficients, per-block maxima [blocks][2][C] (packed outputs)
+  return ((size_t)kMaxStatBlocks * 4 * C + 8 * (size_t)C) * sizeof(float);
 }
 
 
@@ -493,7 +595,7 @@ extern "C" int evk_bn_fwd_train(const float* x, const float* residual, const flo
   rc = check_launch("bn_stats_final");
   if (rc) return rc;
   const size_t n4 = (size_t)rows * C / 4;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, x, residual,
+  hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(oneshot_grid(n4)), dim3(256), 0, st, x, residual,
                      scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, y_absmax);
   return check_launch("bn_apply");
 }
@@ -508,16 +610,23 @@ extern "C" int evk_bn_fwd_train_parts(const float* x, const float* residual, con
               (long long)rows, C);
   EVK_REQUIRE(workspace && workspace_bytes >= evk_bn_workspace_bytes(rows, C), EVK_E_WORKSPACE,
               "bn_fwd_train_parts: workspace too small");
+  const bool pack = (flags & EVK_BN_PACK_Y) != 0;
+  EVK_REQUIRE(!pack || (y_absmax && !residual), EVK_E_INVALID,
+              "bn_fwd_train_parts: EVK_BN_PACK_Y needs y_absmax (slots zero on entry) and no residual");
   hipStream_t st = (hipStream_t)stream;
   float* scale_shift = (float*)workspace + (size_t)kMaxStatBlocks * 2 * C;
   hipLaunchKernelGGL(bn_parts_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, parts, nparts, C,
                      (double)rows, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
-                     scale_shift, y_absmax);
+                     scale_shift, y_absmax, pack ? 1 : 0);
   int rc = check_launch("bn_parts_final");
   if (rc) return rc;
   const size_t n4 = (size_t)rows * C / 4;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, x, residual,
-                     scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, y_absmax);
+  if (pack)
+    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(oneshot_grid(n4)), dim3(256), 0, st, x, residual,
+                       scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, y_absmax);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(oneshot_grid(n4)), dim3(256), 0, st, x, residual,
+                       scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, y_absmax);
   return check_launch("bn_apply");
 }
 
@@ -537,7 +646,7 @@ extern "C" int evk_bn_fwd_eval(const float* x, const float* residual, const floa
   int rc = check_launch("bn_eval_coef");
   if (rc) return rc;
   const size_t n4 = (size_t)rows * C / 4;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, x, residual,
+  hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(oneshot_grid(n4)), dim3(256), 0, st, x, residual,
                      scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, y_absmax);
   return check_launch("bn_apply");
 }
@@ -559,20 +668,32 @@ extern "C" int evk_bn_bwd(const float* dy, const float* x, const float* y, const
   const BnPlan pl = bn_plan(rows, C);
   float* partial = (float*)workspace;
   float* coef = partial + (size_t)kMaxStatBlocks * 2 * C;
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(pl.nblk), dim3(256), 0, st, dy, x, y, save_mean, save_invstd,
-                     gamma, beta, d_residual, partial, rows, C, pl.rows_per_blk, pl.tpc, pl.rl, relu);
+  const bool pack = (flags & EVK_BN_PACK_DX) != 0;
+  EVK_REQUIRE(!pack || dx_absmax, EVK_E_INVALID, "bn_bwd: EVK_BN_PACK_DX needs dx_absmax (slots zero on entry)");
+  float* pmax = pack ? coef + 8 * (size_t)C : nullptr;
+  if (pack)
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(pl.nblk), dim3(256), 0, st, dy, x, y, save_mean, save_invstd,
+                       gamma, beta, d_residual, partial, rows, C, pl.rows_per_blk, pl.tpc, pl.rl, relu, pmax);
+  else
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(pl.nblk), dim3(256), 0, st, dy, x, y, save_mean, save_invstd,
+                       gamma, beta, d_residual, partial, rows, C, pl.rows_per_blk, pl.tpc, pl.rl, relu, pmax);
   int rc = check_launch("bn_bwd_partial");
   if (rc) return rc;
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, partial, pl.nblk, C,
-                     1.0 / (double)rows, gamma, save_invstd, dgamma, dbeta, coef, train ? 1 : 0, dx_absmax);
+                     1.0 / (double)rows, gamma, save_invstd, dgamma, dbeta, coef, train ? 1 : 0, dx_absmax,
+                     (const float*)pmax);
   rc = check_launch("bn_bwd_final");
   if (rc) return rc;
   const size_t n4 = (size_t)rows * C / 4;
   // when d_residual holds g already, stage 3 can read it instead of re-masking dy
   const float* gsrc = d_residual ? d_residual : dy;
   const int relu3 = d_residual ? 0 : relu;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, gsrc, x, y,
-                     save_mean, save_invstd, coef, gamma, beta, dx, n4, C, relu3, dx_absmax);
+  if (pack)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(oneshot_grid(n4)), dim3(256), 0, st, gsrc, x, y,
+                       save_mean, save_invstd, coef, gamma, beta, dx, n4, C, relu3, dx_absmax);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(oneshot_grid(n4)), dim3(256), 0, st, gsrc, x, y,
+                       save_mean, save_invstd, coef, gamma, beta, dx, n4, C, relu3, dx_absmax);
   return check_launch("bn_bwd_apply");
 }
 
@@ -656,7 +777,7 @@ extern "C" int evk_bn_apply_stats(const float* x, const float* residual, const f
   hipLaunchKernelGGL(bn_coef_from_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, st, gamma, beta, mean, invstd, C,
                      scale_shift);
   const size_t n4 = (size_t)rows * C / 4;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, x, residual,
+  hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(oneshot_grid(n4)), dim3(256), 0, st, x, residual,
                      (const float*)scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, (uint32_t*)nullptr);
   return check_launch("bn_apply_stats");
 }
@@ -673,8 +794,8 @@ extern "C" int evk_bn_bwd_local_sums(const float* dy, const float* x, const floa
   hipStream_t st = (hipStream_t)stream;
   const BnPlan pl = bn_plan(rows, C);
   float* partial = (float*)workspace;
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(pl.nblk), dim3(256), 0, st, dy, x, y, mean, invstd, gamma, beta,
-                     d_residual, partial, rows, C, pl.rows_per_blk, pl.tpc, pl.rl, relu);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(pl.nblk), dim3(256), 0, st, dy, x, y, mean, invstd, gamma, beta,
+                     d_residual, partial, rows, C, pl.rows_per_blk, pl.tpc, pl.rl, relu, (float*)nullptr);
   hipLaunchKernelGGL(bn_bwd_sums_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, (const float*)partial,
                      pl.nblk, C, sums);
   return check_launch("bn_bwd_local_sums");
@@ -692,7 +813,7 @@ extern "C" int evk_bn_bwd_apply_sums(const float* dy, const float* x, const floa
   float* coef = (float*)workspace;
   hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, st, gamma, invstd, mean_g, mean_gx, C, coef);
   const size_t n4 = (size_t)rows * C / 4;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, dy, x, y, mean,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(oneshot_grid(n4)), dim3(256), 0, st, dy, x, y, mean,
                      invstd, (const float*)coef, gamma, beta, dx, n4, C, relu, (uint32_t*)nullptr);
   return check_launch("bn_bwd_apply_sums");
 }

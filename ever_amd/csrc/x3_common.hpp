@@ -80,6 +80,20 @@ __device__ __forceinline__ uint32_t pack_hl(float xs) {   // xs = x / s; the sam
   const _Float16 l = (_Float16)(xs - (float)h);
   return (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
 }
+// two elements at once: the pair split of the kernels (packed converts), then one byte permute per word
+__device__ __forceinline__ void pack_hl2(float xs0, float xs1, uint32_t& w0, uint32_t& w1) {
+  uint32_t H, L;
+  split2h(xs0, xs1, H, L);
+  w0 = __builtin_amdgcn_perm(L, H, 0x05040100u);
+  w1 = __builtin_amdgcn_perm(L, H, 0x07060302u);
+}
+__device__ __forceinline__ u32x4 pack_hl4(const f32x4 v, float inv) {
+  u32x4 w;
+  uint32_t a, b;
+  pack_hl2(v.x * inv, v.y * inv, a, b); w.x = a; w.y = b;
+  pack_hl2(v.z * inv, v.w * inv, a, b); w.z = a; w.w = b;
+  return w;
+}
 __device__ __forceinline__ float unpack_hl(uint32_t w) {  // h + l (22 bits), still in units of s
   return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)) + (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
 }

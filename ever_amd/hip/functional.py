@@ -51,7 +51,7 @@ def _f16x2():
     return _CONV_MATH == 'f16x2'
 
 
-absmax_stats = {'hits': 0, 'standalone': 0, 'fused': 0}   # where the operand scales came from (tools / tests)
+absmax_stats = {'hits': 0, 'standalone': 0, 'fused': 0, 'packed': 0}   # where the operand scales came from (tools / tests)
 _FUSED_AMAX = os.environ.get('EVK_FUSED_ABSMAX', '1') != '0'
 
 
@@ -171,6 +171,22 @@ def get_conv_math():
 
 # BatchNorm statistics from the producing convolution's epilogue (EVK_BN_EPILOGUE=0: BatchNorm's own statistics pass)
 _BN_EPILOGUE = os.environ.get('EVK_BN_EPILOGUE', '1') != '0'
+# f16x2: activations that only convolutions read are stored already split ("packed", include/ever_hip.h:
+# evk_pack_f16x2) by the BatchNorm pass that writes them (EVK_PACKED=0: fp32 everywhere, split while staging)
+_PACKED = os.environ.get('EVK_PACKED', '1') != '0'
+
+
+def _mark_packed(t, bits):
+    """`t` holds packed words of t / s (s from `bits`), not fp32: only the f16x2 convolution kernels may read it."""
+    _note_amax(t, bits)
+    t._evk_packed = (t._version, t.data_ptr())
+    absmax_stats['packed'] += 1
+    return t
+
+
+def _is_packed(t):
+    hit = getattr(t, '_evk_packed', None)
+    return hit is not None and hit[0] == t._version and hit[1] == t.data_ptr()
 
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
@@ -329,6 +345,10 @@ def _conv_forward(x, weight, bias, stride, padding, dilation, relu, want_stats=F
         xk = x
         x_ptr, w_ptr = x.data_ptr(), w_ohwi.data_ptr()
     d = _conv_desc(n, h, w, cin_p, cout, kh, kw, stride, padding, dilation)
+    x_pk = _is_packed(x)        # written packed by the BatchNorm pass before this convolution (EVK_BN_PACK_Y)
+    if x_pk and not (_f16x2() and cin_p == cin and cin % 8 == 0 and n * d.Ho * d.Wo > 32):
+        raise HipPathError('conv2d: a packed activation reached a convolution that cannot read it '
+                           f'(math {_CONV_MATH}, Cin {cin}, {n * d.Ho * d.Wo} output rows)')
     y = empty_nhwc(n, cout, d.Ho, d.Wo, dev)
     cs = _ConvState()
     cs.scope = timing.current_scope()
@@ -355,7 +375,8 @@ def _conv_forward(x, weight, bias, stride, padding, dilation, relu, want_stats=F
             # an output that no BatchNorm will normalise is (mostly) another convolution's operand: its scale from here
             ybits = None if stats else _amax_zeroed(dev)
             _C.call('evk_conv2d_fwd_f16x2', ctypes.byref(d), x_ptr, xbits.data_ptr(), pl_ptr, wabs_ptr, _ptr(bias), None,
-                    y.data_ptr(), 1 if relu else 0, _ptr(parts), cap, ctypes.byref(nparts), _ptr(ybits), st)
+                    y.data_ptr(), (1 if relu else 0) | (2 if x_pk else 0), _ptr(parts), cap, ctypes.byref(nparts),
+                    _ptr(ybits), st)
             if ybits is not None:
                 _note_amax(y, ybits)
         elif _CONV_MATH == 'bf16':
@@ -368,7 +389,10 @@ def _conv_forward(x, weight, bias, stride, padding, dilation, relu, want_stats=F
             _C.call('evk_conv2d_fwd_x3', ctypes.byref(d), x_ptr, pl_ptr, _ptr(bias), y.data_ptr(),
                     1 if relu else 0, st)
         if nparts.value > 0:
-            bn_parts = (parts, int(nparts.value))
+            # third field: this convolution's backward takes its dy packed (the BatchNorm that consumes the records is
+            # the ONLY reader of y — conv2d(bn_stats=True)'s contract — so its dx has no other reader either)
+            bn_parts = (parts, int(nparts.value),
+                        _PACKED and wabs_ptr is not None and bias is None and cout % 8 == 0)
     else:
         sp = timing.span('conv_igemm_f32', cs.flops, cs.abytes)
         _C.call('evk_conv2d_fwd', ctypes.byref(d), x_ptr, w_ptr, _ptr(bias), y.data_ptr(), 1 if relu else 0, st)
@@ -399,6 +423,9 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False)
     n, cin_p, cout, kh, kw = d.N, d.Cin, d.Cout, d.kh, d.kw
     cin = cs.cin
     dy = as_nhwc(dy, 'conv2d.backward')
+    dy_pk = _is_packed(dy)      # written packed by the BatchNorm backward that follows this convolution
+    if dy_pk and (cs.relu or need_db or not _f16x2() or d.Cout % 8 or cs.cin != d.Cin):
+        raise HipPathError('conv2d.backward: a packed output gradient reached a convolution that cannot read it')
     if cs.relu:
         g = torch.empty_like(dy)
         _C.call('evk_relu_bwd', dy.data_ptr(), cs.y.data_ptr(), g.data_ptr(), dy.numel(), st)
@@ -437,8 +464,8 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False)
             # in place: the slots the main branch's launch raised stay (an upper bound is all a scale needs)
             hit = getattr(dx, '_evk_amax', None) if inplace else None
             dxbits = hit[2] if hit is not None else _amax_zeroed(dev)
-            _C.call('evk_conv2d_dgrad_f16x2', ctypes.byref(dk), dy_ptr, dybits.data_ptr(), pl_ptr, wabs_ptr, acc_ptr,
-                    dx.data_ptr(), _ptr(dxbits), st)
+            _C.call('evk_conv2d_dgrad_f16x2_ex', ctypes.byref(dk), dy_ptr, dybits.data_ptr(), pl_ptr, wabs_ptr, acc_ptr,
+                    dx.data_ptr(), _ptr(dxbits), 4 if dy_pk else 0, st)
             if dxbits is not None:
                 _note_amax(dx, dxbits)
         else:
@@ -485,8 +512,8 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False)
             xbits, dybits = absmax_bits(xk, st), absmax_bits(dyk, st)
         sp = timing.span('conv_wgrad' if x3 else 'conv_wgrad_f32', cs.flops, cs.abytes, cs.scope)
         if h2:
-            _C.call('evk_conv2d_wgrad_f16x2', ctypes.byref(dk), xk.data_ptr(), xbits.data_ptr(), dy_ptr, dybits.data_ptr(),
-                    dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes, st)
+            _C.call('evk_conv2d_wgrad_f16x2_ex', ctypes.byref(dk), xk.data_ptr(), xbits.data_ptr(), dy_ptr, dybits.data_ptr(),
+                    dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes, (2 if _is_packed(xk) else 0) | (4 if dy_pk else 0), st)
         else:
             _C.call(_entry('evk_conv2d_wgrad_x3') if x3 else 'evk_conv2d_wgrad', ctypes.byref(dk), xk.data_ptr(), dy_ptr,
                     dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes, st)
@@ -893,7 +920,8 @@ class _BatchNormActFn(Function):
     """
 
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu, parts=None):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu, parts=None,
+                pack_out=False):
         n, c, h, w = x.shape
         rows = n * h * w
         dev = x.device
@@ -905,7 +933,14 @@ class _BatchNormActFn(Function):
         save_mean = torch.empty((c,), device=dev, dtype=torch.float32)
         save_invstd = torch.empty((c,), device=dev, dtype=torch.float32)
         flags = 1 if relu else 0
-        abits = _amax_out(dev)
+        # pack_out: y is one convolution's operand and nothing else — written packed, its scale bounded from the
+        # statistics records before the apply pass (EVK_BN_PACK_Y); rows: that convolution must be on the plane kernels
+        pack = bool(pack_out and _PACKED and _f16x2() and training and parts is not None and residual is None
+                    and c % 8 == 0 and rows >= 256)
+        abits = _amax_zeroed(dev) if pack else _amax_out(dev)
+        pack = pack and abits is not None
+        if pack:
+            flags |= 4
         # algorithmic bytes (fp32): statistics read + apply read/write (+ residual read)
         nb = 4.0 * x.numel() * ((3 if training else 2) + (1 if residual is not None else 0))
         if training and parts is not None:
@@ -923,8 +958,9 @@ class _BatchNormActFn(Function):
                     running_var.data_ptr(), float(eps), y.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(),
                     rows, c, flags, ws.data_ptr(), ws_bytes, _ptr(abits), st)
         global _AMAX_HANDOFF
-        _AMAX_HANDOFF = abits
+        _AMAX_HANDOFF = (abits, pack)
         ctx.training = training
+        ctx.pack_dx = bool(parts is not None and len(parts) > 2 and parts[2])
         ctx.relu = relu
         ctx.has_res = residual is not None
         # the ReLU mask is recomputed from x in backward unless a residual was added (then y is needed)
@@ -952,19 +988,29 @@ class _BatchNormActFn(Function):
         dbeta = torch.empty((c,), device=dev, dtype=torch.float32) if has_affine else None
         # reduce pass reads dy, x (+y mask); apply pass reads g, x and writes dx (+ the residual gradient write)
         nb = 4.0 * x.numel() * (5 + (1 if y is not None else 0) + (1 if need_res else 0))
-        abits = _amax_out(dev)
+        # dx is the producing convolution's dy (data and weight gradient operand) — and, when that convolution said so
+        # in forward, nothing else: written packed under a scale bounded before the apply pass (EVK_BN_PACK_DX)
+        pack = ctx.pack_dx and _f16x2()
+        abits = _amax_zeroed(dev) if pack else _amax_out(dev)
+        pack = pack and abits is not None
         _timed_call('bn', nb, 'evk_bn_bwd', dy.data_ptr(), x.data_ptr(), _ptr(y), _ptr(weight), _ptr(bias), save_mean.data_ptr(),
                 save_invstd.data_ptr(), dx.data_ptr(), _ptr(dres), _ptr(dgamma), _ptr(dbeta), rows, c,
-                1 if ctx.relu else 0, 1 if ctx.training else 0, ws.data_ptr(), ws_bytes, _ptr(abits), st)
-        if abits is not None:
-            _note_amax(dx, abits)       # dx is the producing convolution's dy (data and weight gradient operand)
+                (1 if ctx.relu else 0) | (2 if pack else 0), 1 if ctx.training else 0, ws.data_ptr(), ws_bytes,
+                _ptr(abits), st)
+        if pack:
+            _mark_packed(dx, abits)
+        elif abits is not None:
+            _note_amax(dx, abits)
         if ctx.has_res and not need_res:
             dres = None
         return (dx, dres, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
-def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentum, eps, residual=None, relu=False):
+def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentum, eps, residual=None, relu=False,
+                   pack_out=False):
+    """pack_out: the caller guarantees that ONE convolution of this package (forward + weight gradient) is the only
+    reader of the result; under the f16x2 arithmetic it is then stored packed (include/ever_hip.h: EVK_BN_PACK_Y)."""
     _require_cuda(x, 'batch_norm')
     x = as_nhwc(x, 'batch_norm')
     if x.shape[1] % 4 != 0:
@@ -978,9 +1024,13 @@ def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentu
     global _AMAX_HANDOFF
     _AMAX_HANDOFF = None
     y = _BatchNormActFn.apply(x, residual, weight, bias, running_mean, running_var, bool(use_batch_stats),
-                              0.0 if momentum is None else momentum, eps, bool(relu), parts)
-    if _AMAX_HANDOFF is not None:       # the apply pass left max|y| in this word: y is the next convolution's operand
-        _note_amax(y, _AMAX_HANDOFF)
+                              0.0 if momentum is None else momentum, eps, bool(relu), parts, bool(pack_out))
+    if _AMAX_HANDOFF is not None:       # the pass left max|y| (or its bound) there: y is the next convolution's operand
+        abits, packed = _AMAX_HANDOFF
+        if packed:
+            _mark_packed(y, abits)
+        elif abits is not None:
+            _note_amax(y, abits)
         _AMAX_HANDOFF = None
     return y
 

@@ -71,7 +71,7 @@ class BasicBlock(nn.Module):
             out = conv_bn(self.conv1, self.bn1, x, relu=True)
             return conv_bn(self.conv2, self.bn2, out, residual=shortcut, relu=True)
         h, shortcut = _fork(self, x)
-        out = self.bn1(h, relu=True)
+        out = self.bn1(h, relu=True, conv_only=True)       # read by conv2 alone
         return conv_bn(self.conv2, self.bn2, out, residual=shortcut, relu=True)
 
 
@@ -100,8 +100,8 @@ class Bottleneck(nn.Module):
             out = conv_bn(self.conv2, self.bn2, out, relu=True)
             return conv_bn(self.conv3, self.bn3, out, residual=shortcut, relu=True)
         h, shortcut = _fork(self, x)
-        out = self.bn1(h, relu=True)
-        out = conv_bn(self.conv2, self.bn2, out, relu=True)
+        out = self.bn1(h, relu=True, conv_only=True)       # read by conv2 alone
+        out = conv_bn(self.conv2, self.bn2, out, relu=True, conv_only=True)   # ... and this by conv3 alone
         return conv_bn(self.conv3, self.bn3, out, residual=shortcut, relu=True)
 
 

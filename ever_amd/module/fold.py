@@ -117,11 +117,12 @@ def _takes_epilogue_stats(bn):
     return type(bn) is BatchNorm2d and (bn.training or bn.running_mean is None)
 
 
-def conv_bn(conv, bn, x, residual=None, relu=False):
-    """bn(conv(x)) (+ residual) (ReLU): one folded convolution at inference, conv + fused BatchNorm pass otherwise."""
+def conv_bn(conv, bn, x, residual=None, relu=False, conv_only=False):
+    """bn(conv(x)) (+ residual) (ReLU): one folded convolution at inference, conv + fused BatchNorm pass otherwise.
+    conv_only: see layers.BatchNorm2d.forward."""
     if _use_folded(conv, bn):
         return folded_conv2d(x, conv, residual=residual, relu=relu)
-    return bn(conv(x, bn_stats=_takes_epilogue_stats(bn)), residual=residual, relu=relu)
+    return bn(conv(x, bn_stats=_takes_epilogue_stats(bn)), residual=residual, relu=relu, conv_only=conv_only)
 
 
 def folded_conv2d(x, conv, residual=None, relu=False):

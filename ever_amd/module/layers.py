@@ -60,7 +60,10 @@ def _check_conv(m):
 class BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d with optional fused residual add and ReLU (one apply pass over HBM)."""
 
-    def forward(self, x, residual=None, relu=False):
+    def forward(self, x, residual=None, relu=False, conv_only=False):
+        """conv_only: the result is read by ONE convolution of this package (and that convolution's weight gradient) and
+        by nothing else — under the f16x2 arithmetic the pass may then store it already split ("packed",
+        hip/functional.py:batch_norm_act); any other reader would see raw words."""
         if self.momentum is None:
             raise NotImplementedError('ever_amd BatchNorm2d: cumulative moving average (momentum=None) unsupported')
         training = self.training or (self.running_mean is None)
@@ -71,7 +74,7 @@ class BatchNorm2d(nn.BatchNorm2d):
         rm = self.running_mean if (not self.training or self.track_running_stats) else None
         rv = self.running_var if (not self.training or self.track_running_stats) else None
         return HF.batch_norm_act(x, self.weight, self.bias, rm, rv, training, self.momentum, self.eps,
-                                 residual=residual, relu=relu)
+                                 residual=residual, relu=relu, pack_out=conv_only)
 
 
     def flush_num_batches_tracked(self):

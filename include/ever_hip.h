@@ -258,6 +258,15 @@ int evk_nhwc_to_nchw(const float* src, float* dst, int32_t N, int32_t C, int32_t
  * momentum update, as torch), y = act(gamma * (x-mean)*invstd + beta [+ residual]).
  * save_mean / save_invstd: [C] outputs kept for backward. */
 #define EVK_BN_RELU 1u
+/* evk_bn_bwd only: dx is written PACKED (evk_pack_f16x2's format) instead of fp32 — it is the producing convolution's dy
+ * operand (EVK_CONV_DY_PACKED) and nothing else.  dx_absmax is required and its slots must be ZERO on entry: the
+ * finalisation raises them to a per-channel bound of |dx| (from max|g|, max|xhat| gathered by the reduce pass) before the
+ * apply pass writes dx under that scale; the bound is within ~2x of max|dx| (an upper bound is all a scale needs). */
+#define EVK_BN_PACK_DX 2u
+/* evk_bn_fwd_train_parts only, residual == NULL: y is written PACKED — it is the next convolution's operand
+ * (EVK_CONV_X_PACKED in its forward and weight gradient) and nothing else.  y_absmax as for EVK_BN_PACK_DX: zero on entry,
+ * slot 0 raised by the finalisation to a bound of |y| derived from the statistics records (2-3x the true maximum). */
+#define EVK_BN_PACK_Y 4u
 size_t evk_bn_workspace_bytes(int64_t rows, int32_t C);
 int evk_bn_fwd_train(const float* x, const float* residual, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, float momentum, float eps,

@@ -128,3 +128,64 @@ def test_packed_dy_refuses_a_bias_gradient(cuda):
     with pytest.raises(Exception):
         _C.call('evk_conv2d_wgrad_f16x2_ex', ctypes.byref(d), x.data_ptr(), b.data_ptr(), x.data_ptr(), b.data_ptr(),
                 dw.data_ptr(), db.data_ptr(), wsp.data_ptr(), wsb, 4, st)
+
+
+def _chain(F, x, ws, bns, pack):
+    """conv -> BN -> ReLU three times (3x3, 1x1, strided 3x3), as the residual blocks chain them"""
+    prev = F._PACKED
+    F._PACKED = pack
+    try:
+        cfgs = ((1, 1), (1, 0), (2, 1))
+        h = x
+        for i, (w, (gm, bt), (s, p)) in enumerate(zip(ws, bns, cfgs)):
+            h = F.conv2d(h, w, None, stride=s, padding=p, bn_stats=True)
+            # the first two results are read by the next convolution alone: stored packed (EVK_BN_PACK_Y)
+            h = F.batch_norm_act(h, gm, bt, None, None, True, 0.1, 1e-5, relu=True, pack_out=i < 2)
+        loss = (h * h).sum()
+        grads = torch.autograd.grad(loss, [x] + list(ws) + [t for pr in bns for t in pr])
+        return loss.detach(), [g.detach().clone() for g in grads]
+    finally:
+        F._PACKED = prev
+
+
+def test_batchnorm_passes_hand_the_convolutions_packed_operands(cuda):
+    """dx of a BatchNorm that follows a convolution is written packed (EVK_BN_PACK_DX) and read packed by that
+    convolution's two gradients; the output of a BatchNorm that only a convolution reads is written packed
+    (EVK_BN_PACK_Y) and read packed by its forward and weight gradient: same loss, gradients equal to the fp32-operand
+    run within the f16x2 tolerance, and both within it of a float64 reference."""
+    from ever_amd.hip import functional as F
+    import torch.nn.functional as TF
+    prev = F.set_conv_math('f16x2')
+    try:
+        g = torch.Generator().manual_seed(21)
+        x = torch.randn(4, 64, 32, 32, generator=g).to(cuda).requires_grad_()
+        shapes = ((64, 64, 3), (128, 64, 1), (128, 128, 3))
+        ws = [(torch.randn(o, i, k, k, generator=g) / (i * k * k) ** 0.5).to(cuda)
+              .contiguous(memory_format=torch.channels_last).requires_grad_() for o, i, k in shapes]
+        bns = [((torch.rand(o, generator=g) + 0.5).to(cuda).requires_grad_(),
+                (torch.randn(o, generator=g) * 0.1).to(cuda).requires_grad_()) for o, _, _ in shapes]
+        F.absmax_stats.update(hits=0, standalone=0, fused=0, packed=0)
+        l1, g1 = _chain(F, x, ws, bns, True)
+        assert F.absmax_stats['packed'] == 5, F.absmax_stats    # three dx, two y
+        seen = F.absmax_stats['packed']
+        l0, g0 = _chain(F, x, ws, bns, False)
+        assert F.absmax_stats['packed'] == seen
+        # float64 reference
+        xd = x.detach().double().cpu().requires_grad_()
+        wd = [w.detach().double().cpu().requires_grad_() for w in ws]
+        bd = [(a.detach().double().cpu().requires_grad_(), b.detach().double().cpu().requires_grad_()) for a, b in bns]
+        h = xd
+        for w, (gm, bt), (s, p) in zip(wd, bd, ((1, 1), (1, 0), (2, 1))):
+            h = TF.relu(TF.batch_norm(TF.conv2d(h, w, None, s, p), None, None, gm, bt, True, 0.1, 1e-5))
+        lr = (h * h).sum()
+        gr = torch.autograd.grad(lr, [xd] + wd + [t for pr in bd for t in pr])
+        torch.cuda.synchronize()
+        assert abs(l1.item() - lr.item()) <= 2e-6 * abs(lr.item())
+        for a, b, r in zip(g1, g0, gr):
+            scale = r.abs().max().item()
+            ea = (a.double().cpu() - r).abs().max().item() / scale
+            eb = (b.double().cpu() - r).abs().max().item() / scale
+            assert ea < 2e-5 and eb < 2e-5, (ea, eb)
+            assert ea < 4 * eb + 1e-6, (ea, eb)     # packing (a bounded, slightly loose scale) costs no accuracy
+    finally:
+        F.set_conv_math(prev)
