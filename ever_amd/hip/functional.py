@@ -184,6 +184,21 @@ def _mark_packed(t, bits):
     return t
 
 
+def _wgrad_pack_pays(flops, x_elems, dy_elems):
+    """A stand-alone evk_pack_f16x2 pass over the weight gradient's fp32 operand(s) first?  Measured (3x3x256 @128^2
+    x16): both operands packed 1292 -> 944 us, i.e. ~27 % of a kernel that runs at ~260 TFLOP/s; a pass moves 8 bytes
+    per element at ~5 TB/s.  Pays for the 3x3 convolutions of the FPN / decoder, not for 1x1 ones."""
+    if x_elems + dy_elems == 0:
+        return False
+    if os.environ.get('EVK_WGRAD_PACK', '1') == '0':
+        return False
+    t_kernel = flops / 2.6e14
+    t_pack = 8.0 * (x_elems + dy_elems) / 5.0e12 + 4e-6 * ((x_elems > 0) + (dy_elems > 0))
+    # the im2col operand is two thirds of the staging work (256 of the 384 rows of a 128 x 256 tile)
+    gain = (0.18 if x_elems else 0.0) + (0.09 if dy_elems else 0.0)
+    return gain * t_kernel - t_pack > 0.08 * t_kernel
+
+
 def _is_packed(t):
     hit = getattr(t, '_evk_packed', None)
     return hit is not None and hit[0] == t._version and hit[1] == t.data_ptr()
@@ -508,12 +523,28 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False)
         dwk = torch.empty((cout_p, taps, cin_p), device=dev, dtype=torch.float32)
         dbk = torch.empty((cout_p,), device=dev, dtype=torch.float32) if need_db else None
         h2 = x3 and _f16x2()
-        if h2:
-            xbits, dybits = absmax_bits(xk, st), absmax_bits(dyk, st)
         sp = timing.span('conv_wgrad' if x3 else 'conv_wgrad_f32', cs.flops, cs.abytes, cs.scope)
         if h2:
-            _C.call('evk_conv2d_wgrad_f16x2_ex', ctypes.byref(dk), xk.data_ptr(), xbits.data_ptr(), dy_ptr, dybits.data_ptr(),
-                    dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes, (2 if _is_packed(xk) else 0) | (4 if dy_pk else 0), st)
+            xbits, dybits = absmax_bits(xk, st), absmax_bits(dyk, st)
+            x_pk = _is_packed(xk)
+            xw_ptr, dyw_ptr, _tmp = xk.data_ptr(), dy_ptr, None
+            if _PACKED and not need_db and cout_p == cout and _wgrad_pack_pays(cs.flops, 0 if x_pk else xk.numel(),
+                                                                             0 if dy_pk else dyk.numel()):
+                # the kernel's bound is the split of its operands while staging (each element is staged by many
+                # workgroups): where the matrix work per byte is high, one streaming pass that stores them split first
+                _tmp = []
+                if not x_pk:
+                    xp = torch.empty_like(xk)
+                    _C.call('evk_pack_f16x2', xk.data_ptr(), xk.numel(), xbits.data_ptr(), xp.data_ptr(), st)
+                    xw_ptr, x_pk = xp.data_ptr(), True
+                    _tmp.append(xp)
+                if not dy_pk:
+                    dp = torch.empty_like(dyk)
+                    _C.call('evk_pack_f16x2', dy_ptr, dyk.numel(), dybits.data_ptr(), dp.data_ptr(), st)
+                    dyw_ptr, dy_pk = dp.data_ptr(), True
+                    _tmp.append(dp)
+            _C.call('evk_conv2d_wgrad_f16x2_ex', ctypes.byref(dk), xw_ptr, xbits.data_ptr(), dyw_ptr, dybits.data_ptr(),
+                    dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes, (2 if x_pk else 0) | (4 if dy_pk else 0), st)
         else:
             _C.call(_entry('evk_conv2d_wgrad_x3') if x3 else 'evk_conv2d_wgrad', ctypes.byref(dk), xk.data_ptr(), dy_ptr,
                     dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes, st)
