@@ -380,11 +380,23 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
     __shared__ float mred[2][kFinLanes][kFinCh];
     const int tc = threadIdx.x % kFinCh, tl = threadIdx.x / kFinCh;
     const int cc = blockIdx.x * kFinCh + tc;
-    if (cc < C)
-      for (int b = tl; b < nblk; b += kFinLanes) {
-        gmax = fmaxf(gmax, pmax[(size_t)b * 2 * C + cc]);
-        xmax = fmaxf(xmax, pmax[(size_t)b * 2 * C + C + cc]);
+    if (cc < C) {
+      const float* pm = pmax + cc;
+      const size_t st = (size_t)2 * C;
+      int b = tl;
+      for (; b + 3 * kFinLanes < nblk; b += 4 * kFinLanes) {   // eight independent loads in flight per lane
+        const float g0 = pm[b * st], g1 = pm[(b + kFinLanes) * st], g2 = pm[(b + 2 * kFinLanes) * st],
+                    g3 = pm[(b + 3 * kFinLanes) * st];
+        const float x0 = pm[b * st + C], x1 = pm[(b + kFinLanes) * st + C], x2 = pm[(b + 2 * kFinLanes) * st + C],
+                    x3 = pm[(b + 3 * kFinLanes) * st + C];
+        gmax = fmaxf(gmax, fmaxf(fmaxf(g0, g1), fmaxf(g2, g3)));
+        xmax = fmaxf(xmax, fmaxf(fmaxf(x0, x1), fmaxf(x2, x3)));
       }
+      for (; b < nblk; b += kFinLanes) {
+        gmax = fmaxf(gmax, pm[b * st]);
+        xmax = fmaxf(xmax, pm[b * st + C]);
+      }
+    }
     mred[0][tl][tc] = gmax;
     mred[1][tl][tc] = xmax;
     __syncthreads();

@@ -7,7 +7,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o r -- python $R/bench.py
 cd $R
 python bench.py > $O/bench.log 2>&1
 tail -1 $O/bench.log > $O/bench.json
-tail -1 $O/bench_under_rocprof.log > $O/bench_under_rocprof.json
+grep "^{\"metric\"" $O/bench_under_rocprof.log | tail -1 > $O/bench_under_rocprof.json
 python tools/rocpd_summary.py $(ls $O/stats/*.db | head -1) $O/kernel_stats
 python tools/traffic_from_pmc.py $(ls $O/fetch/*.db | head -1) $(ls $O/write/*.db | head -1) $O/traffic.json
 rm -rf $O/fetch $O/write   # keep the merged-back payload small; the stats db stays
