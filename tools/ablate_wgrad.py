@@ -27,5 +27,16 @@ for (h, c) in ((128, 256), (64, 256), (32, 256)):
                                 bits[1].data_ptr(), dw.data_ptr(), None, wsp.data_ptr(), wsb, st))
     t3 = timeit(lambda: _C.call('evk_conv2d_wgrad_x3', ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None,
                                 wsp.data_ptr(), wsb, st))
-    out.append(f'{c}@{h}: f16x2 {th:7.1f} us  bf16x3 {t3:7.1f} us')
+    # both operands packed (evk_pack_f16x2): EVK_WG_BIG=1 routes these to the 256x256 kernel
+    xp, dyp = torch.empty_like(x), torch.empty_like(dy)
+    _C.call('evk_pack_f16x2', x.data_ptr(), x.numel(), bits[0].data_ptr(), xp.data_ptr(), st)
+    _C.call('evk_pack_f16x2', dy.data_ptr(), dy.numel(), bits[1].data_ptr(), dyp.data_ptr(), st)
+    ref = dw.clone()
+    _C.call('evk_conv2d_wgrad_f16x2', ctypes.byref(d), x.data_ptr(), bits[0].data_ptr(), dy.data_ptr(), bits[1].data_ptr(),
+            ref.data_ptr(), None, wsp.data_ptr(), wsb, st)
+    tp = timeit(lambda: _C.call('evk_conv2d_wgrad_f16x2_ex', ctypes.byref(d), xp.data_ptr(), bits[0].data_ptr(), dyp.data_ptr(),
+                                bits[1].data_ptr(), dw.data_ptr(), None, wsp.data_ptr(), wsb, 6, st))
+    torch.cuda.synchronize()
+    err = ((dw - ref).abs().max() / ref.abs().max()).item()
+    out.append(f'{c}@{h}: f16x2 {th:7.1f} us  packed {tp:7.1f} us (rel diff {err:.1e})  bf16x3 {t3:7.1f} us')
 print('EVK_WG_DBG=' + os.environ.get('EVK_WG_DBG', '0'), ' | '.join(out))
