@@ -176,6 +176,13 @@ _BN_EPILOGUE = os.environ.get('EVK_BN_EPILOGUE', '1') != '0'
 _PACKED = os.environ.get('EVK_PACKED', '1') != '0'
 
 
+def _collectives_in_flight():
+    """RCCL kernels may share the device with the backward (gradient buckets reduced while it runs): the one-launch
+    BatchNorm backward, whose grid has to be resident as a whole, is not used then (EVK_BN_NO_FUSE)."""
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 def _mark_packed(t, bits):
     """`t` holds packed words of t / s (s from `bits`), not fp32: only the f16x2 convolution kernels may read it."""
     _note_amax(t, bits)
@@ -1026,8 +1033,8 @@ class _BatchNormActFn(Function):
         pack = pack and abits is not None
         _timed_call('bn', nb, 'evk_bn_bwd', dy.data_ptr(), x.data_ptr(), _ptr(y), _ptr(weight), _ptr(bias), save_mean.data_ptr(),
                 save_invstd.data_ptr(), dx.data_ptr(), _ptr(dres), _ptr(dgamma), _ptr(dbeta), rows, c,
-                (1 if ctx.relu else 0) | (2 if pack else 0), 1 if ctx.training else 0, ws.data_ptr(), ws_bytes,
-                _ptr(abits), st)
+                (1 if ctx.relu else 0) | (2 if pack else 0) | (8 if _collectives_in_flight() else 0),
+                1 if ctx.training else 0, ws.data_ptr(), ws_bytes, _ptr(abits), st)
         if pack:
             _mark_packed(dx, abits)
         elif abits is not None:

@@ -267,6 +267,11 @@ int evk_nhwc_to_nchw(const float* src, float* dst, int32_t N, int32_t C, int32_t
  * (EVK_CONV_X_PACKED in its forward and weight gradient) and nothing else.  y_absmax as for EVK_BN_PACK_DX: zero on entry,
  * slot 0 raised by the finalisation to a bound of |y| derived from the statistics records (2-3x the true maximum). */
 #define EVK_BN_PACK_Y 4u
+/* evk_bn_bwd runs maps of up to 33.5 MB as ONE launch whose workgroups meet at two grid-wide barriers (dy and x stay in
+ * registers in between: 3 tensor transfers instead of 5).  Its grid (<= 256 workgroups that each fill a CU) must become
+ * resident as a whole; a caller that keeps other long-running kernels on the device (RCCL collectives overlapping the
+ * backward) passes EVK_BN_NO_FUSE and gets the three-launch form. */
+#define EVK_BN_NO_FUSE 8u
 size_t evk_bn_workspace_bytes(int64_t rows, int32_t C);
 int evk_bn_fwd_train(const float* x, const float* residual, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, float momentum, float eps,
