@@ -191,13 +191,19 @@ def main():
     timer = None if args.no_kernel_timer else timing.KernelTimer()
     sampled = 0
     t0 = time.perf_counter()
+    marks = []
     for i in range(args.steps):
+        marks.append(time.perf_counter())
         if timer is not None and i % 4 == 0:
             with timer:
                 step()
             sampled += 1
         else:
             step()
+    enqueued = time.perf_counter() - t0      # host time to enqueue the K steps (no synchronisation inside the loop)
+    if os.environ.get('EVK_BENCH_MARKS'):
+        marks.append(time.perf_counter())
+        print('host ms per step:', [round((b - a) * 1e3, 1) for a, b in zip(marks, marks[1:])], file=sys.stderr)
     fence()
     elapsed = time.perf_counter() - t0
     if use_ddp:
@@ -211,6 +217,7 @@ def main():
         line = {
             'metric': '512x512 tiles/sec fwd+bwd, FarSeg-R50', 'value': round(tiles_s, 2), 'unit': 'tiles/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
+            'host_enqueue_ms_per_step': round(enqueued / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if conv_math == 'bf16' else 'f32', 'data': 'synthetic',
             'config': {'workload': 'FarSeg ResNet-50 FPN (FarSegHead defaults, BCE+dice), 3-band 512x512, '
