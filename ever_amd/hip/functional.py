@@ -191,6 +191,10 @@ def _mark_packed(t, bits):
     return t
 
 
+_WGRAD_PACK_MARGIN = float(os.environ.get('EVK_WGRAD_PACK_MARGIN', '0.0'))
+_WGRAD_PACK_GAIN = float(os.environ.get('EVK_WGRAD_PACK_GAIN', '1.0'))
+
+
 def _wgrad_pack_pays(flops, x_elems, dy_elems):
     """A stand-alone evk_pack_f16x2 pass over the weight gradient's fp32 operand(s) first?  Measured (3x3x256 @128^2
     x16): both operands packed 1292 -> 944 us, i.e. ~27 % of a kernel that runs at ~260 TFLOP/s; a pass moves 8 bytes
@@ -202,8 +206,8 @@ def _wgrad_pack_pays(flops, x_elems, dy_elems):
     t_kernel = flops / 2.6e14
     t_pack = 8.0 * (x_elems + dy_elems) / 5.0e12 + 4e-6 * ((x_elems > 0) + (dy_elems > 0))
     # the im2col operand is two thirds of the staging work (256 of the 384 rows of a 128 x 256 tile)
-    gain = (0.18 if x_elems else 0.0) + (0.09 if dy_elems else 0.0)
-    return gain * t_kernel - t_pack > 0.08 * t_kernel
+    gain = _WGRAD_PACK_GAIN * ((0.18 if x_elems else 0.0) + (0.09 if dy_elems else 0.0))
+    return gain * t_kernel - t_pack > _WGRAD_PACK_MARGIN * t_kernel
 
 
 def _is_packed(t):
