@@ -6,6 +6,8 @@
 // workgroup, fp64 finalisation) so results do not depend on the launch grid.
 #include "x3_common.hpp"
 #include <stdlib.h>
+#include <mutex>
+#include <unordered_map>
 
 namespace evk {
 
