@@ -891,9 +891,7 @@ static FusedPlan fused_plan(int64_t rows, int C) {
   if (p.cpw > 32) { p.nwg = 0; return p; }
   return p;
 }
-// the barrier word of a stream (device memory owned by the library, zero at first use, never reset)
-#include <mutex>
-#include <unordered_map>
+// the barrier words of a stream (device memory owned by the library, zero at first use, never reset)
 struct FusedCounter { uint32_t* words; uint32_t group[8]; uint32_t top; };   // values once all enqueued launches ran
 // reserve the arrivals of one launch (two barriers of nwg workgroups) on the stream's words
 static uint32_t* fused_counter(hipStream_t st, int nwg, BarrierTargets* t1, BarrierTargets* t2) {
