@@ -875,12 +875,19 @@ static FusedPlan fused_plan(int64_t rows, int C) {
   if (!on || c4 > kFusedThreads || kFusedThreads % c4 != 0) return p;
   p.tpc = c4;
   p.rl = kFusedThreads / c4;
+  // every workgroup must be resident at the barriers and one fills a CU: never more workgroups than the device has CUs
+  static const int ncu = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return n < 256 ? n : 256;
+  }();
   const int64_t cap = (int64_t)kFusedRows * p.rl;              // rows one workgroup can hold
   int64_t nwg = (rows + cap - 1) / cap;
-  if (nwg > 256) return p;
-  // spread over the chip: as many workgroups as give each at least one full row-lane set, up to 256
+  if (nwg > ncu) return p;
+  // spread over the chip: as many workgroups as give each at least one full row-lane set, up to the CU count
   int64_t want = (rows + p.rl - 1) / p.rl;
-  if (want > 256) want = 256;
+  if (want > ncu) want = ncu;
   if (nwg < want) nwg = want;
   int64_t rpw = (rows + nwg - 1) / nwg;
   rpw = ((rpw + p.rl - 1) / p.rl) * p.rl;
