@@ -9,7 +9,7 @@ import sqlite3
 import sys
 
 
-def main(db_path, out):
+def main(db_path, out, steps=25):
     db = sqlite3.connect(db_path)
     rows = db.execute('select name, count(*), sum(duration), avg(duration), min(duration), max(duration) '
                       'from kernels group by name order by sum(duration) desc').fetchall()
@@ -23,20 +23,24 @@ def main(db_path, out):
                         round(100.0 * s / total, 2)])
     fams = [('conv_igemm (forward + data gradient: conv3x3_halo_x3 / conv_igemm_x3ws / conv_igemm_x3 / conv_igemm kernels)', ('conv_igemm', 'conv3x3_halo')),
             ('conv_wgrad (conv_wgrad_x3ws / conv_wgrad_x3 / conv_wgrad kernels)', ('conv_wgrad',)),
-            ('BatchNorm (bn_* kernels)', ('bn_',))]
+            ('conv_wgrad as bench.py brackets it (one span per C-ABI call: + splitk_reduce, colsum_*, pack_f16x2 kernels; '
+             '"launches" = weight-gradient kernels)', ('conv_wgrad', 'splitk_reduce', 'colsum_', 'pack_f16x2')),
+            ('BatchNorm (bn_* kernels; bench.py times C-ABI calls of 2-3 kernels each)', ('bn_',))]
     fam_rows = []
     for label, pats in fams:
         sel = [r for r in rows if any(p in r[0] for p in pats)]
         if sel:
-            calls, tot = sum(r[1] for r in sel), sum(r[2] for r in sel)
+            calls, tot = sum(r[1] for r in sel if pats[0] in r[0] or len(pats) < 3), sum(r[2] for r in sel)
             fam_rows.append((label, calls, tot, tot / calls))
     with open(out + '.md', 'w') as f:
         f.write(f'# rocprofv3 --kernel-trace --stats summary\n\nsource: `{db_path}`; {sum(r[1] for r in rows)} '
                 f'dispatches, {total / 1e6:.1f} ms of kernel time over a {(span[1] - span[0]) / 1e6:.1f} ms window\n\n')
-        f.write('Kernel families as bench.py times them with HIP events (its `avg_launch_us` is per launch of the family):\n\n'
-                '| family | launches | total ms | avg us per launch | % |\n|---|---:|---:|---:|---:|\n')
+        f.write('Kernel families as bench.py times them with HIP events.  Its `avg_launch_us` is per C-ABI CALL (a strided data '
+                'gradient is up to four kernels, a weight gradient carries its split-K reduce / column sums / pack passes), so compare '
+                f'`avg_launch_us x launches_per_step` with the ms-per-step column ({steps} steps in this run):\n\n'
+                '| family | launches | total ms | avg us per launch | ms per step | % |\n|---|---:|---:|---:|---:|---:|\n')
         for label, calls, tot, avg in fam_rows:
-            f.write(f'| {label} | {calls} | {tot / 1e6:.2f} | {avg / 1e3:.1f} | {100.0 * tot / total:.2f} |\n')
+            f.write(f'| {label} | {calls} | {tot / 1e6:.2f} | {avg / 1e3:.1f} | {tot / 1e6 / steps:.2f} | {100.0 * tot / total:.2f} |\n')
         f.write('\n| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---:|---:|---:|---:|---:|---:|\n')
         for n, c, s, a, mn, mx in rows:
             f.write(f'| `{n[:110]}` | {c} | {s / 1e6:.2f} | {a / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} | '
@@ -45,4 +49,4 @@ def main(db_path, out):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 25)
