@@ -189,3 +189,75 @@ def test_batchnorm_passes_hand_the_convolutions_packed_operands(cuda):
             assert ea < 4 * eb + 1e-6, (ea, eb)     # packing (a bounded, slightly loose scale) costs no accuracy
     finally:
         F.set_conv_math(prev)
+
+
+@pytest.mark.parametrize('scale', [3e-2, 1.0, 1e10])   # (below ~1e-2 the BatchNorm eps dominates the variance: ill-conditioned)
+def test_packed_batchnorm_chain_is_scale_invariant(cuda, scale):
+    """the bounds the BatchNorm passes pack under come from statistics records / per-channel maxima: any magnitude of
+    the network input must give the same relative accuracy (BatchNorm itself removes the scale after the first layer)"""
+    from ever_amd.hip import functional as F
+    prev = F.set_conv_math('f16x2')
+    try:
+        g = torch.Generator().manual_seed(33)
+        x0 = torch.randn(2, 64, 32, 32, generator=g)
+        shapes = ((64, 64, 3), (128, 64, 1), (128, 128, 3))
+        ws = [(torch.randn(o, i, k, k, generator=g) / (i * k * k) ** 0.5).to(cuda)
+              .contiguous(memory_format=torch.channels_last).requires_grad_() for o, i, k in shapes]
+        bns = [((torch.rand(o, generator=g) + 0.5).to(cuda).requires_grad_(),
+                (torch.randn(o, generator=g) * 0.1).to(cuda).requires_grad_()) for o, _, _ in shapes]
+        x1 = (x0 * scale).to(cuda).requires_grad_()
+        l1, g1 = _chain(F, x1, ws, bns, True)
+        l0, g0 = _chain(F, x1, ws, bns, False)
+        torch.cuda.synchronize()
+        assert torch.isfinite(l1) and abs(l1.item() - l0.item()) <= 5e-6 * abs(l0.item())
+        for a, b in zip(g1[1:], g0[1:]):          # weight / BatchNorm gradients (the input gradient scales with 1 / scale)
+            ref = b.abs().max().item()
+            assert torch.isfinite(a).all()
+            assert (a - b).abs().max().item() <= 4e-5 * ref + 1e-30
+    finally:
+        F.set_conv_math(prev)
+
+
+def test_packed_batchnorm_all_zero_input(cuda):
+    """zero statistics records bound the output by |beta| alone; with beta = 0 the bound is 0 and the packed tensor exact
+    zeros (scale 1)"""
+    from ever_amd.hip import functional as F
+    prev = F.set_conv_math('f16x2')
+    try:
+        x = torch.zeros(2, 64, 16, 16, device=cuda, requires_grad=True)
+        w = torch.randn(64, 64, 3, 3, device=cuda).contiguous(memory_format=torch.channels_last).requires_grad_()
+        w2 = torch.randn(64, 64, 1, 1, device=cuda).contiguous(memory_format=torch.channels_last).requires_grad_()
+        for beta in (0.0, 0.25):
+            gm = torch.ones(64, device=cuda, requires_grad=True)
+            bt = torch.full((64,), beta, device=cuda, requires_grad=True)
+            h = F.conv2d(x, w, None, stride=1, padding=1, bn_stats=True)
+            h = F.batch_norm_act(h, gm, bt, None, None, True, 0.1, 1e-5, relu=True, pack_out=True)
+            assert F._is_packed(h)
+            y = F.conv2d(h, w2, None)
+            torch.cuda.synchronize()
+            ref = torch.nn.functional.conv2d(torch.full((2, 64, 16, 16), beta, device=cuda), w2.detach())
+            assert torch.allclose(y, ref, rtol=1e-5, atol=1e-6), (y - ref).abs().max().item()
+            y.sum().backward()
+            torch.cuda.synchronize()
+            assert torch.isfinite(w.grad).all() and torch.isfinite(w2.grad).all()
+    finally:
+        F.set_conv_math(prev)
+
+
+def test_a_packed_tensor_is_refused_by_readers_that_cannot_take_it(cuda):
+    """a packed activation must never be read as fp32: convolutions outside the f16x2 plane kernels raise"""
+    from ever_amd.hip import functional as F
+    prev = F.set_conv_math('f16x2')
+    try:
+        x = torch.randn(2, 64, 16, 16, device=cuda)
+        w = torch.randn(64, 64, 3, 3, device=cuda).contiguous(memory_format=torch.channels_last)
+        gm, bt = torch.ones(64, device=cuda), torch.zeros(64, device=cuda)
+        with torch.no_grad():
+            h = F.conv2d(x, w, None, stride=1, padding=1, bn_stats=True)
+            h = F.batch_norm_act(h, gm, bt, None, None, True, 0.1, 1e-5, relu=True, pack_out=True)
+            assert F._is_packed(h)
+            F.set_conv_math('bf16x3')
+            with pytest.raises(F.HipPathError):
+                F.conv2d(h, w, None, padding=1)
+    finally:
+        F.set_conv_math(prev)
