@@ -91,6 +91,9 @@ SIGNATURES = {
     'evk_bn_fwd_train': (c_int, [P, P, P, P, P, P, c_f32, c_f32, P, P, P, c_i64, c_i32, c_u32, P, c_size_t, P, P]),
     'evk_bn_fwd_train_parts': (c_int, [P, P, P, P, P, P, c_f32, c_f32, P, P, P, c_i64, c_i32, c_u32, P, c_i32, P, c_size_t, P, P]),
     'evk_bn_fwd_eval': (c_int, [P, P, P, P, P, P, c_f32, P, P, P, c_i64, c_i32, c_u32, P, c_size_t, P, P]),
+    'evk_bn_relu_pool_fwd_train_parts': (c_int, [P, P, P, P, P, c_f32, c_f32, P, P, P, P, c_i32, c_i32, c_i32, c_i32, P, c_i32,
+                                                 P, c_size_t, P, P]),
+    'evk_bn_relu_pool_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, P, c_size_t, P, P]),
     'evk_bn_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_i64, c_i32, c_u32, c_i32, P, c_size_t, P, P]),
     'evk_relu_fwd': (c_int, [P, P, c_i64, P]),
     'evk_relu_bwd': (c_int, [P, P, P, c_i64, P]),

@@ -573,6 +573,178 @@ __global__ __launch_bounds__(256) void bn_parts_final_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// The stem's BatchNorm + ReLU + MaxPool2d(3, 2, 1) as ONE pass each way (reference _resnets.py:150-153: bn1, relu,
+// maxpool on the 7x7 convolution's output, a quarter-resolution consumer of a full-resolution tensor).  Separate
+// kernels wrote and re-read the normalised 268 MB map forward, and scattered the pooled gradient into a 268 MB map
+// for the BatchNorm backward to read twice.  Here the forward reads the convolution output once and writes the pooled
+// map + the winning tap of every window (the codes of maxpool_fwd_kernel: first maximum in scan order, NaN wins); the
+// backward's two passes rebuild g = dz * (z > 0) on the fly — an input pixel is tap (iy - 2oy + 1, ix - 2ox + 1) of at
+// most 2 x 2 windows: g = sum of their dp where that tap won — from the 67 MB pooled gradient and the 17 MB codes.
+__global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ scale_shift,
+                                                               float* __restrict__ y, uint8_t* __restrict__ code, int N,
+                                                               int H, int W, int C, int Ho, int Wo,
+                                                               uint32_t* __restrict__ amax) {
+  const int c4 = C >> 2;
+  const uint32_t total = (uint32_t)N * Ho * Wo * c4;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const bool valid = i < total;
+  f32x4 best = {0.f, 0.f, 0.f, 0.f};
+  if (valid) {
+    const int cb = (int)(i % (uint32_t)c4);
+    uint32_t pix = i / (uint32_t)c4;
+    const int ox = (int)(pix % (uint32_t)Wo);
+    pix /= (uint32_t)Wo;
+    const int oy = (int)(pix % (uint32_t)Ho);
+    const int n = (int)(pix / (uint32_t)Ho);
+    const f32x4 sc = reinterpret_cast<const f32x4*>(scale_shift)[cb];
+    const f32x4 sh = reinterpret_cast<const f32x4*>(scale_shift + C)[cb];
+    int bx = 0, by = 0, bz = 0, bw = 0;
+    bool first = true;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 - 1 + kx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)n * H + iy) * W + ix) * C + cb * 4) * sc + sh;
+        v.x = v.x != v.x ? v.x : fmaxf(v.x, 0.f); v.y = v.y != v.y ? v.y : fmaxf(v.y, 0.f);   // relu keeps NaN visible
+        v.z = v.z != v.z ? v.z : fmaxf(v.z, 0.f); v.w = v.w != v.w ? v.w : fmaxf(v.w, 0.f);
+        const int t = ky * 3 + kx;
+        if (first) {
+          best = v; bx = by = bz = bw = t; first = false;
+        } else {
+          if (v.x > best.x || v.x != v.x) { best.x = v.x; bx = t; }
+          if (v.y > best.y || v.y != v.y) { best.y = v.y; by = t; }
+          if (v.z > best.z || v.z != v.z) { best.z = v.z; bz = t; }
+          if (v.w > best.w || v.w != v.w) { best.w = v.w; bw = t; }
+        }
+      }
+    }
+    const size_t o = (((size_t)n * Ho + oy) * Wo + ox) * C + cb * 4;
+    *reinterpret_cast<f32x4*>(y + o) = best;
+    *reinterpret_cast<uint32_t*>(code + o) = (uint32_t)bx | ((uint32_t)by << 8) | ((uint32_t)bz << 16) | ((uint32_t)bw << 24);
+  }
+  if (amax) block_absmax(best, valid, amax);
+}
+
+// dz of input pixel (n, iy, ix), channel chunk cb: the pooled gradient of the windows this pixel won
+__device__ __forceinline__ f32x4 pool_gather(const float* __restrict__ dp, const uint8_t* __restrict__ code, int n, int iy,
+                                             int ix, int Ho, int Wo, int C, int cb) {
+  f32x4 g = {0.f, 0.f, 0.f, 0.f};
+  const int oy_lo = iy >> 1, oy_hi = min(Ho - 1, (iy + 1) >> 1);
+  const int ox_lo = ix >> 1, ox_hi = min(Wo - 1, (ix + 1) >> 1);
+  for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+    const int ky = iy - 2 * oy + 1;
+    if ((unsigned)ky > 2u) continue;
+    for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+      const int kx = ix - 2 * ox + 1;
+      if ((unsigned)kx > 2u) continue;
+      const uint32_t t = (uint32_t)(ky * 3 + kx);
+      const size_t o = (((size_t)n * Ho + oy) * Wo + ox) * C + cb * 4;
+      const uint32_t cw = *reinterpret_cast<const uint32_t*>(code + o);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(dp + o);
+      g.x += (cw & 0xffu) == t ? d.x : 0.f;
+      g.y += ((cw >> 8) & 0xffu) == t ? d.y : 0.f;
+      g.z += ((cw >> 16) & 0xffu) == t ? d.z : 0.f;
+      g.w += (cw >> 24) == t ? d.w : 0.f;
+    }
+  }
+  return g;
+}
+
+// stage 1 of the backward (as bn_bwd_partial_kernel, ReLU mask recomputed from x): partial[blk][0][C] = sum g,
+// [1][C] = sum g * xhat
+__global__ __launch_bounds__(256) void bn_pool_bwd_partial_kernel(const float* __restrict__ dp,
+                                                                  const uint8_t* __restrict__ code,
+                                                                  const float* __restrict__ x,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta,
+                                                                  float* __restrict__ partial, int rows, int H, int W,
+                                                                  int C, int Ho, int Wo, int rows_per_blk, int tpc, int rl) {
+  __shared__ f32x4 red[2][256];
+  const int c4 = C >> 2;
+  const int tc = threadIdx.x % tpc, tr = threadIdx.x / tpc;
+  const int r0 = blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
+  const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+  for (int cb = tc; cb < c4; cb += tpc) {
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + cb * 4);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + cb * 4);
+    const f32x4 sc = (gamma ? *reinterpret_cast<const f32x4*>(gamma + cb * 4) : one) * is;
+    const f32x4 sh = (beta ? *reinterpret_cast<const f32x4*>(beta + cb * 4) : zero) - mu * sc;
+    f32x4 s = zero, q = zero;
+    if (tr < rl)
+      for (int r = r0 + tr; r < r1; r += rl) {
+        const int n = r / (H * W), rem = r - n * H * W;
+        const int iy = rem / W, ix = rem - iy * W;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)r * C + cb * 4);
+        f32x4 g = pool_gather(dp, code, n, iy, ix, Ho, Wo, C, cb);
+        const f32x4 yy = xv * sc + sh;
+        g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+        g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+        s += g;
+        q += g * ((xv - mu) * is);
+      }
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = q;
+    __syncthreads();
+    if (tr == 0) {
+      for (int k = 1; k < rl; ++k) {
+        s += red[0][k * tpc + tc];
+        q += red[1][k * tpc + tc];
+      }
+      float* o = partial + (size_t)blockIdx.x * 2 * C;
+      *reinterpret_cast<f32x4*>(o + cb * 4) = s;
+      *reinterpret_cast<f32x4*>(o + C + cb * 4) = q;
+    }
+    __syncthreads();
+  }
+}
+
+// stage 3: dx = coef0 * (g - coef1 - xhat * coef2), one 16-byte element per thread
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* __restrict__ dp,
+                                                                const uint8_t* __restrict__ code,
+                                                                const float* __restrict__ x,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ coef,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ dx,
+                                                                uint32_t n4, int H, int W, int C, int Ho, int Wo,
+                                                                uint32_t* __restrict__ amax) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const bool valid = i < n4;
+  f32x4 out = {0.f, 0.f, 0.f, 0.f};
+  if (valid) {
+    const int c4 = C >> 2;
+    const int cb = (int)(i % (uint32_t)c4);
+    const int r = (int)(i / (uint32_t)c4);
+    const int n = r / (H * W), rem = r - n * H * W;
+    const int iy = rem / W, ix = rem - iy * W;
+    const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, z4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 k0 = reinterpret_cast<const f32x4*>(coef)[cb];
+    const f32x4 k1 = reinterpret_cast<const f32x4*>(coef + C)[cb];
+    const f32x4 k2 = reinterpret_cast<const f32x4*>(coef + 2 * C)[cb];
+    const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[cb];
+    const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[cb];
+    const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+    f32x4 g = pool_gather(dp, code, n, iy, ix, Ho, Wo, C, cb);
+    const f32x4 sc = (gamma ? reinterpret_cast<const f32x4*>(gamma)[cb] : one4) * is;
+    const f32x4 sh = (beta ? reinterpret_cast<const f32x4*>(beta)[cb] : z4) - mu * sc;
+    const f32x4 yy = xv * sc + sh;
+    g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+    g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+    out = k0 * (g - k1 - ((xv - mu) * is) * k2);
+    reinterpret_cast<f32x4*>(dx)[i] = out;
+  }
+  if (amax) block_absmax(out, valid, amax);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Backward of SMALL maps in ONE launch (tensors up to 33.5 MB: layer 3 / 4 of the encoder, the coarse pyramid levels).
 // The three-launch form above reads dy and x twice (5 tensor-sized transfers) and its launches cost more than its
 // bytes there: 16.8 MB maps ran at 2.3 TB/s.  Here every thread keeps its slice of g = dy * mask and x in REGISTERS
@@ -842,6 +1014,64 @@ extern "C" int evk_bn_fwd_train_parts(const float* x, const float* residual, con
     hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(oneshot_grid(n4)), dim3(256), 0, st, x, residual,
                        scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, y_absmax);
   return check_launch("bn_apply");
+}
+
+// BatchNorm (batch statistics from the convolution epilogue's records) + ReLU + MaxPool2d(3, 2, 1): x [N,H,W,C] ->
+// y [N,Ho,Wo,C], code [N,Ho,Wo,C] uint8 (winning tap of each window), Ho = (H - 1) / 2 + 1
+extern "C" int evk_bn_relu_pool_fwd_train_parts(const float* x, const float* gamma, const float* beta, float* running_mean,
+                                                float* running_var, float momentum, float eps, float* y, uint8_t* code,
+                                                float* save_mean, float* save_invstd, int32_t N, int32_t H, int32_t W,
+                                                int32_t C, const float* parts, int32_t nparts, void* workspace,
+                                                size_t workspace_bytes, uint32_t* y_absmax, void* stream) {
+  EVK_REQUIRE(x && y && code && save_mean && save_invstd && parts && nparts > 0, EVK_E_INVALID, "bn_relu_pool_fwd: bad argument");
+  const int64_t rows = (int64_t)N * H * W;
+  EVK_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 2048 && rows * (C / 4) < 0x7fffffffLL, EVK_E_UNSUPPORTED,
+              "bn_relu_pool_fwd: N=%d H=%d W=%d C=%d", N, H, W, C);
+  EVK_REQUIRE(workspace && workspace_bytes >= evk_bn_workspace_bytes(rows, C), EVK_E_WORKSPACE,
+              "bn_relu_pool_fwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* scale_shift = (float*)workspace + (size_t)kMaxStatBlocks * 2 * C;
+  hipLaunchKernelGGL(bn_parts_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, parts, nparts, C,
+                     (double)rows, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
+                     scale_shift, y_absmax, 0);
+  int rc = check_launch("bn_parts_final");
+  if (rc) return rc;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const size_t total = (size_t)N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(oneshot_grid(total)), dim3(256), 0, st, x, (const float*)scale_shift, y,
+                     code, N, H, W, C, Ho, Wo, y_absmax);
+  return check_launch("bn_relu_pool_fwd");
+}
+
+// its backward: dp [N,Ho,Wo,C] -> dx [N,H,W,C] (gradient of the convolution output), dgamma, dbeta
+extern "C" int evk_bn_relu_pool_bwd(const float* dp, const uint8_t* code, const float* x, const float* gamma,
+                                    const float* beta, const float* save_mean, const float* save_invstd, float* dx,
+                                    float* dgamma, float* dbeta, int32_t N, int32_t H, int32_t W, int32_t C, int32_t train,
+                                    void* workspace, size_t workspace_bytes, uint32_t* dx_absmax, void* stream) {
+  EVK_REQUIRE(dp && code && x && save_mean && save_invstd && dx, EVK_E_INVALID, "bn_relu_pool_bwd: null pointer");
+  const int64_t rows = (int64_t)N * H * W;
+  EVK_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 2048 && rows * (C / 4) < 0x7fffffffLL, EVK_E_UNSUPPORTED,
+              "bn_relu_pool_bwd: N=%d H=%d W=%d C=%d", N, H, W, C);
+  EVK_REQUIRE(workspace && workspace_bytes >= evk_bn_workspace_bytes(rows, C), EVK_E_WORKSPACE,
+              "bn_relu_pool_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const BnPlan pl = bn_plan(rows, C);
+  float* partial = (float*)workspace;
+  float* coef = partial + (size_t)kMaxStatBlocks * 2 * C;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  hipLaunchKernelGGL(bn_pool_bwd_partial_kernel, dim3(pl.nblk), dim3(256), 0, st, dp, code, x, save_mean, save_invstd, gamma,
+                     beta, partial, (int)rows, H, W, C, Ho, Wo, (int)pl.rows_per_blk, pl.tpc, pl.rl);
+  int rc = check_launch("bn_pool_bwd_partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, (const float*)partial, pl.nblk, C,
+                     1.0 / (double)rows, gamma, save_invstd, dgamma, dbeta, coef, train ? 1 : 0, dx_absmax,
+                     (const float*)nullptr);
+  rc = check_launch("bn_bwd_final");
+  if (rc) return rc;
+  const uint32_t n4 = (uint32_t)(rows * (C / 4));
+  hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, dp, code, x, save_mean, save_invstd,
+                     (const float*)coef, gamma, beta, dx, n4, H, W, C, Ho, Wo, dx_absmax);
+  return check_launch("bn_pool_bwd_apply");
 }
 
 extern "C" int evk_bn_fwd_eval(const float* x, const float* residual, const float* gamma, const float* beta,

@@ -1100,6 +1100,83 @@ def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentu
 _AMAX_HANDOFF = None
 
 
+class _BnReluPoolFn(Function):
+    """The stem's BatchNorm (batch statistics from the convolution epilogue's records) + ReLU + MaxPool2d(3, 2, 1) as
+    one pass each way (csrc/bn.hip: bn_relu_pool_fwd_kernel): the normalised full-resolution map and its gradient are
+    never written.  Replaces bn1 / relu / maxpool of reference ever/module/_resnets.py:150-153."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, parts):
+        n, c, h, w = x.shape
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        dev, st = x.device, _stream()
+        ws_bytes = _C.load().evk_bn_workspace_bytes(n * h * w, c)
+        ws = workspace(dev, ws_bytes)
+        y = empty_nhwc(n, c, ho, wo, dev)
+        code = torch.empty((n, ho, wo, c), device=dev, dtype=torch.uint8)
+        save_mean = torch.empty((c,), device=dev, dtype=torch.float32)
+        save_invstd = torch.empty((c,), device=dev, dtype=torch.float32)
+        abits = _amax_out(dev)
+        # algorithmic bytes: read x, write the pooled map and the codes
+        nb = 4.0 * x.numel() + 5.0 * y.numel()
+        _timed_call('bn', nb, 'evk_bn_relu_pool_fwd_train_parts', x.data_ptr(), _ptr(weight), _ptr(bias), _ptr(running_mean),
+                    _ptr(running_var), float(momentum), float(eps), y.data_ptr(), code.data_ptr(), save_mean.data_ptr(),
+                    save_invstd.data_ptr(), n, h, w, c, parts[0].data_ptr(), parts[1], ws.data_ptr(), ws_bytes, _ptr(abits), st)
+        global _AMAX_HANDOFF
+        _AMAX_HANDOFF = (abits, False)
+        ctx.save_for_backward(x, weight, bias, save_mean, save_invstd, code)
+        ctx.mark_non_differentiable(*[t for t in (running_mean, running_var) if t is not None])
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dp):
+        x, weight, bias, save_mean, save_invstd, code = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dev, st = x.device, _stream()
+        dp = as_nhwc(dp, 'bn_relu_pool.backward')
+        ws_bytes = _C.load().evk_bn_workspace_bytes(n * h * w, c)
+        ws = workspace(dev, ws_bytes)
+        dx = torch.empty_like(x)
+        has_affine = weight is not None
+        dgamma = torch.empty((c,), device=dev, dtype=torch.float32) if has_affine else None
+        dbeta = torch.empty((c,), device=dev, dtype=torch.float32) if has_affine else None
+        abits = _amax_out(dev)
+        # both passes read x, the pooled gradient and the codes; the apply pass writes dx
+        nb = 4.0 * x.numel() * 3 + 2 * 5.0 * dp.numel()
+        _timed_call('bn', nb, 'evk_bn_relu_pool_bwd', dp.data_ptr(), code.data_ptr(), x.data_ptr(), _ptr(weight), _ptr(bias),
+                    save_mean.data_ptr(), save_invstd.data_ptr(), dx.data_ptr(), _ptr(dgamma), _ptr(dbeta), n, h, w, c, 1,
+                    ws.data_ptr(), ws_bytes, _ptr(abits), st)
+        if abits is not None:
+            _note_amax(dx, abits)
+        return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
+                None, None, None, None, None)
+
+
+_STEM_POOL = os.environ.get('EVK_STEM_POOL', '1') != '0'
+
+
+def batch_norm_relu_max_pool(x, weight, bias, running_mean, running_var, momentum, eps):
+    """max_pool3x3s2(relu(batch_norm(x))) in training mode.  One fused pass each way when x carries the statistics
+    records of the convolution that produced it (conv2d / stem_conv7x7s2 with bn_stats=True); the two separate passes
+    otherwise (EVK_STEM_POOL=0 forces them)."""
+    _require_cuda(x, 'batch_norm_relu_max_pool')
+    x = as_nhwc(x, 'batch_norm_relu_max_pool')
+    parts = getattr(x, '_evk_bn_parts', None)
+    n, c, h, w = x.shape
+    if parts is None or not _STEM_POOL or c % 4 or n * h * w * (c // 4) >= 2 ** 31:
+        return max_pool3x3s2(batch_norm_act(x, weight, bias, running_mean, running_var, True, momentum, eps, relu=True))
+    del x._evk_bn_parts
+    global _AMAX_HANDOFF
+    _AMAX_HANDOFF = None
+    y = _BnReluPoolFn.apply(x, weight, bias, running_mean, running_var, 0.0 if momentum is None else momentum, eps, parts)
+    if _AMAX_HANDOFF is not None:
+        if _AMAX_HANDOFF[0] is not None:
+            _note_amax(y, _AMAX_HANDOFF[0])
+        _AMAX_HANDOFF = None
+    return y
+
+
 # ------------------------------------------------------------------------------------ pointwise
 class _ReluFn(Function):
     @staticmethod

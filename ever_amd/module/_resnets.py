@@ -178,8 +178,16 @@ class ResNet(nn.Module):
             return self.bn1(HF.stem_conv7x7s2(x, self.conv1.weight, bn_stats=_takes_epilogue_stats(self.bn1)), relu=True)
         return conv_bn(self.conv1, self.bn1, x, relu=True)
 
+    def stem_pool_forward(self, x):
+        """maxpool(stem_forward(x)); BatchNorm + ReLU + max-pool as one pass each way where the 7x7 stem runs in its
+        space-to-depth form under a training-mode BatchNorm2d (hip/functional.py:batch_norm_relu_max_pool)."""
+        if (not self.deep_stem and type(self.maxpool) is MaxPool2d and _takes_epilogue_stats(self.bn1)
+                and HF.stem_conv_applicable(x, self.conv1) and not _use_folded(self.conv1, self.bn1)):
+            return self.bn1.forward_relu_pool(HF.stem_conv7x7s2(x, self.conv1.weight, bn_stats=True))
+        return self.maxpool(self.stem_forward(x))
+
     def forward(self, x):
-        x = self.maxpool(self.stem_forward(x))
+        x = self.stem_pool_forward(x)
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         x = self.avgpool(x)
         return self.fc(x.reshape(x.size(0), -1))

@@ -77,6 +77,18 @@ class BatchNorm2d(nn.BatchNorm2d):
                                  residual=residual, relu=relu, pack_out=conv_only)
 
 
+    def forward_relu_pool(self, x):
+        """max_pool3x3s2(relu(self(x))): the ResNet stem's tail; fused into one pass each way in training mode
+        (hip/functional.py:batch_norm_relu_max_pool)."""
+        training = self.training or (self.running_mean is None)
+        if not training or self.momentum is None:
+            return HF.max_pool3x3s2(self.forward(x, relu=True))
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self._nbt_pending = getattr(self, '_nbt_pending', 0) + 1
+        rm = self.running_mean if self.track_running_stats else None
+        rv = self.running_var if self.track_running_stats else None
+        return HF.batch_norm_relu_max_pool(x, self.weight, self.bias, rm, rv, self.momentum, self.eps)
+
     def flush_num_batches_tracked(self):
         pending = getattr(self, '_nbt_pending', 0)
         if pending and self.num_batches_tracked is not None:

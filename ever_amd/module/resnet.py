@@ -112,7 +112,7 @@ class ResNetEncoder(ERModule):
     def forward(self, inputs):
         x = inputs
         r = self.resnet
-        x = r.maxpool(r.stem_forward(x))
+        x = r.stem_pool_forward(x)
         wcp = self.config.with_cp
         # A stage output feeds the next stage AND (later) the caller.  With gradient slots the caller's gradient is
         # added inside the next stage's first data-gradient launch (hip/functional.py:GradSlot) instead of by an

@@ -289,6 +289,20 @@ int evk_bn_fwd_train_parts(const float* x, const float* residual, const float* g
                            float* save_mean, float* save_invstd, int64_t rows, int32_t C, uint32_t flags,
                            const float* parts, int32_t nparts, void* workspace, size_t workspace_bytes,
                            uint32_t* y_absmax, void* stream);
+/* The stem: BatchNorm (batch statistics from the convolution epilogue's records, as evk_bn_fwd_train_parts) + ReLU +
+ * MaxPool2d(3, 2, 1) in one pass each way — reference _resnets.py:150-153 (bn1, relu, maxpool).  x [N,H,W,C] ->
+ * y [N,Ho,Wo,C] and code [N,Ho,Wo,C] uint8 (winning tap ky*3+kx of each window, first maximum in scan order, as
+ * evk_maxpool3x3s2_fwd), Ho = (H-1)/2+1.  The backward rebuilds dz * (z > 0) from the pooled gradient dp and the
+ * codes inside its two passes: the normalised full-resolution map and its gradient are never written. */
+int evk_bn_relu_pool_fwd_train_parts(const float* x, const float* gamma, const float* beta, float* running_mean,
+                                     float* running_var, float momentum, float eps, float* y, uint8_t* code,
+                                     float* save_mean, float* save_invstd, int32_t N, int32_t H, int32_t W, int32_t C,
+                                     const float* parts, int32_t nparts, void* workspace, size_t workspace_bytes,
+                                     uint32_t* y_absmax, void* stream);
+int evk_bn_relu_pool_bwd(const float* dp, const uint8_t* code, const float* x, const float* gamma, const float* beta,
+                         const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta,
+                         int32_t N, int32_t H, int32_t W, int32_t C, int32_t train, void* workspace,
+                         size_t workspace_bytes, uint32_t* dx_absmax, void* stream);
 int evk_bn_fwd_eval(const float* x, const float* residual, const float* gamma, const float* beta,
                     const float* running_mean, const float* running_var, float eps, float* y,
                     float* save_mean /* may be NULL */, float* save_invstd /* may be NULL */,

@@ -483,3 +483,49 @@ def test_batchnorm_statistics_from_the_conv_epilogue(cuda, case):
     assert err < 1e-4, err
     assert float((outs[0][5].cpu().double() - ref_b.running_mean).abs().max()) < 1e-5
     assert float((outs[0][6].cpu().double() - ref_b.running_var).abs().max()) < 1e-5 * float(ref_b.running_var.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 32, 48), (1, 64, 30, 34), (3, 32, 16, 16)])
+def test_stem_batchnorm_relu_maxpool_fused_equals_separate_passes(cuda, shape):
+    """BatchNorm + ReLU + MaxPool2d(3, 2, 1) of the stem as one pass each way (csrc/bn.hip) against the separate passes
+    and against torch in float64: pooled map, the gradient of the convolution output, dgamma, dbeta."""
+    from ever_amd.hip import functional as F
+    import torch.nn.functional as TF
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(h * w + c)
+    img = torch.randn(n, 3, 2 * h, 2 * w, generator=g).to(cuda)
+    wt = (torch.randn(c, 3, 7, 7, generator=g) * 0.1).to(cuda).contiguous(memory_format=torch.channels_last).requires_grad_()
+    gamma = (torch.rand(c, generator=g) + 0.5).to(cuda).requires_grad_()
+    beta = (torch.randn(c, generator=g) * 0.3).to(cuda).requires_grad_()
+    dp = torch.randn(n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1, generator=g).to(cuda)
+
+    def run(fused):
+        prev = F._STEM_POOL
+        F._STEM_POOL = fused
+        try:
+            rm, rv = torch.zeros(c, device=cuda), torch.ones(c, device=cuda)
+            y = F.stem_conv7x7s2(img, wt, bn_stats=True)
+            # (no records from the epilogue at 32 channels: batch_norm_relu_max_pool then runs the separate passes itself)
+            assert c < 64 or getattr(y, '_evk_bn_parts', None) is not None
+            out = F.batch_norm_relu_max_pool(y, gamma, beta, rm, rv, 0.1, 1e-5)
+            grads = torch.autograd.grad(out, [wt, gamma, beta], dp)
+            return out.detach(), [t.detach().clone() for t in grads], rm, rv
+        finally:
+            F._STEM_POOL = prev
+
+    o1, g1, rm1, rv1 = run(True)
+    o0, g0, rm0, rv0 = run(False)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o0)
+    assert torch.equal(rm1, rm0) and torch.equal(rv1, rv0)
+    for a, b in zip(g1, g0):
+        assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item() + 1e-12
+    # float64 reference
+    imgd = img.double().cpu()
+    wd, gd, bd = (t.detach().double().cpu().requires_grad_() for t in (wt, gamma, beta))
+    yd = TF.conv2d(imgd, wd, None, 2, 3)
+    od = TF.max_pool2d(TF.relu(TF.batch_norm(yd, None, None, gd, bd, True, 0.1, 1e-5)), 3, 2, 1)
+    gr = torch.autograd.grad(od, [wd, gd, bd], dp.double().cpu())
+    assert (o1.double().cpu() - od).abs().max().item() < 2e-5 * od.abs().max().item()
+    for a, r in zip(g1, gr):
+        assert (a.double().cpu() - r).abs().max().item() < 5e-5 * r.abs().max().item() + 1e-9
