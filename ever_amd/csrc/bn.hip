@@ -655,6 +655,145 @@ __device__ __forceinline__ f32x4 pool_gather(const float* __restrict__ dp, const
   return g;
 }
 
+// Even H and W (every stem this network sees): a thread takes a 2 x 2 input QUAD (2k + {0,1}, 2l + {0,1}).  Its four
+// pixels are taps of the same four windows (k, l), (k, l+1), (k+1, l), (k+1, l+1) — tap 4 / 5,3 / 7,1 / 8,6,2,0 — so four
+// window look-ups serve four pixels instead of nine (pool_gather per pixel: 1 + 2 + 2 + 4).
+struct PoolQuad { f32x4 g[4]; };   // dz of (2k,2l), (2k,2l+1), (2k+1,2l), (2k+1,2l+1)
+__device__ __forceinline__ PoolQuad pool_gather_quad(const float* __restrict__ dp, const uint8_t* __restrict__ code, int n,
+                                                     int k, int l, int Ho, int Wo, int C, int cb) {
+  PoolQuad q;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  q.g[0] = q.g[1] = q.g[2] = q.g[3] = z;
+  // tap of window (k + a, l + b) that each quad pixel is; 255 = not in that window
+  constexpr uint32_t kTap[2][2][4] = {{{4u, 5u, 7u, 8u}, {255u, 3u, 255u, 6u}}, {{255u, 255u, 1u, 2u}, {255u, 255u, 255u, 0u}}};
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    if (k + a >= Ho) continue;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      if (l + b >= Wo) continue;
+      const size_t o = (((size_t)n * Ho + k + a) * Wo + l + b) * C + cb * 4;
+      const uint32_t cw = *reinterpret_cast<const uint32_t*>(code + o);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(dp + o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t t = kTap[a][b][e];
+        if (t == 255u) continue;
+        q.g[e].x += (cw & 0xffu) == t ? d.x : 0.f;
+        q.g[e].y += ((cw >> 8) & 0xffu) == t ? d.y : 0.f;
+        q.g[e].z += ((cw >> 16) & 0xffu) == t ? d.z : 0.f;
+        q.g[e].w += (cw >> 24) == t ? d.w : 0.f;
+      }
+    }
+  }
+  return q;
+}
+
+// quad forms of the two passes below (H, W even): rows -> quads; the sums run over the same elements, in quad order
+__global__ __launch_bounds__(256) void bn_pool_bwd_partial_quad_kernel(const float* __restrict__ dp,
+                                                                       const uint8_t* __restrict__ code,
+                                                                       const float* __restrict__ x,
+                                                                       const float* __restrict__ mean,
+                                                                       const float* __restrict__ invstd,
+                                                                       const float* __restrict__ gamma,
+                                                                       const float* __restrict__ beta,
+                                                                       float* __restrict__ partial, int quads, int H, int W,
+                                                                       int C, int Ho, int Wo, int quads_per_blk, int tpc,
+                                                                       int rl) {
+  __shared__ f32x4 red[2][256];
+  const int c4 = C >> 2;
+  const int tc = threadIdx.x % tpc, tr = threadIdx.x / tpc;
+  const int q0 = blockIdx.x * quads_per_blk, q1 = min(quads, q0 + quads_per_blk);
+  const int Hq = H >> 1, Wq = W >> 1;
+  const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+  for (int cb = tc; cb < c4; cb += tpc) {
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + cb * 4);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + cb * 4);
+    const f32x4 sc = (gamma ? *reinterpret_cast<const f32x4*>(gamma + cb * 4) : one) * is;
+    const f32x4 sh = (beta ? *reinterpret_cast<const f32x4*>(beta + cb * 4) : zero) - mu * sc;
+    f32x4 s = zero, q = zero;
+    if (tr < rl)
+      for (int qi = q0 + tr; qi < q1; qi += rl) {
+        const int n = qi / (Hq * Wq), rem = qi - n * Hq * Wq;
+        const int k = rem / Wq, l = rem - k * Wq;
+        const PoolQuad pq = pool_gather_quad(dp, code, n, k, l, Ho, Wo, C, cb);
+        const float* xb = x + (((size_t)n * H + 2 * k) * W + 2 * l) * C + cb * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + ((size_t)(e >> 1) * W + (e & 1)) * C);
+          f32x4 g = pq.g[e];
+          const f32x4 yy = xv * sc + sh;
+          g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+          g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+          s += g;
+          q += g * ((xv - mu) * is);
+        }
+      }
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = q;
+    __syncthreads();
+    if (tr == 0) {
+      for (int kk = 1; kk < rl; ++kk) {
+        s += red[0][kk * tpc + tc];
+        q += red[1][kk * tpc + tc];
+      }
+      float* o = partial + (size_t)blockIdx.x * 2 * C;
+      *reinterpret_cast<f32x4*>(o + cb * 4) = s;
+      *reinterpret_cast<f32x4*>(o + C + cb * 4) = q;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_quad_kernel(const float* __restrict__ dp,
+                                                                     const uint8_t* __restrict__ code,
+                                                                     const float* __restrict__ x,
+                                                                     const float* __restrict__ mean,
+                                                                     const float* __restrict__ invstd,
+                                                                     const float* __restrict__ coef,
+                                                                     const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta, float* __restrict__ dx,
+                                                                     uint32_t nq4, int H, int W, int C, int Ho, int Wo,
+                                                                     uint32_t* __restrict__ amax) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const bool valid = i < nq4;
+  f32x4 mx = {0.f, 0.f, 0.f, 0.f};
+  bool nan = false;
+  if (valid) {
+    const int c4 = C >> 2, Hq = H >> 1, Wq = W >> 1;
+    const int cb = (int)(i % (uint32_t)c4);
+    const int qi = (int)(i / (uint32_t)c4);
+    const int n = qi / (Hq * Wq), rem = qi - n * Hq * Wq;
+    const int k = rem / Wq, l = rem - k * Wq;
+    const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, z4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 k0 = reinterpret_cast<const f32x4*>(coef)[cb];
+    const f32x4 k1 = reinterpret_cast<const f32x4*>(coef + C)[cb];
+    const f32x4 k2 = reinterpret_cast<const f32x4*>(coef + 2 * C)[cb];
+    const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[cb];
+    const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[cb];
+    const f32x4 sc = (gamma ? reinterpret_cast<const f32x4*>(gamma)[cb] : one4) * is;
+    const f32x4 sh = (beta ? reinterpret_cast<const f32x4*>(beta)[cb] : z4) - mu * sc;
+    const PoolQuad pq = pool_gather_quad(dp, code, n, k, l, Ho, Wo, C, cb);
+    const size_t base = (((size_t)n * H + 2 * k) * W + 2 * l) * C + cb * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const size_t off = base + ((size_t)(e >> 1) * W + (e & 1)) * C;
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
+      f32x4 g = pq.g[e];
+      const f32x4 yy = xv * sc + sh;
+      g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+      g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+      const f32x4 out = k0 * (g - k1 - ((xv - mu) * is) * k2);
+      *reinterpret_cast<f32x4*>(dx + off) = out;
+      mx.x = fmaxf(mx.x, fabsf(out.x)); mx.y = fmaxf(mx.y, fabsf(out.y));
+      mx.z = fmaxf(mx.z, fabsf(out.z)); mx.w = fmaxf(mx.w, fabsf(out.w));
+      nan = nan || out.x != out.x || out.y != out.y || out.z != out.z || out.w != out.w;
+    }
+    if (nan) mx.x = __builtin_nanf("");   // fmaxf drops NaNs: keep them visible in the scale slots (block_absmax tests v)
+  }
+  if (amax) block_absmax(mx, valid, amax);
+}
+
 // stage 1 of the backward (as bn_bwd_partial_kernel, ReLU mask recomputed from x): partial[blk][0][C] = sum g,
 // [1][C] = sum g * xhat
 __global__ __launch_bounds__(256) void bn_pool_bwd_partial_kernel(const float* __restrict__ dp,
@@ -1059,18 +1198,32 @@ extern "C" int evk_bn_relu_pool_bwd(const float* dp, const uint8_t* code, const 
   float* partial = (float*)workspace;
   float* coef = partial + (size_t)kMaxStatBlocks * 2 * C;
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  hipLaunchKernelGGL(bn_pool_bwd_partial_kernel, dim3(pl.nblk), dim3(256), 0, st, dp, code, x, save_mean, save_invstd, gamma,
-                     beta, partial, (int)rows, H, W, C, Ho, Wo, (int)pl.rows_per_blk, pl.tpc, pl.rl);
+  const bool quad = (H % 2 == 0) && (W % 2 == 0);
+  // quads in place of rows, as many workgroups as the row plan (a quad is four rows' worth of elements)
+  const int quads = (int)(rows / 4);
+  int qpb = (quads + pl.nblk - 1) / pl.nblk;
+  qpb = ((qpb + pl.rl - 1) / pl.rl) * pl.rl;
+  const int nblk = quad ? (quads + qpb - 1) / qpb : pl.nblk;
+  if (quad)
+    hipLaunchKernelGGL(bn_pool_bwd_partial_quad_kernel, dim3(nblk), dim3(256), 0, st, dp, code, x, save_mean, save_invstd,
+                       gamma, beta, partial, quads, H, W, C, Ho, Wo, qpb, pl.tpc, pl.rl);
+  else
+    hipLaunchKernelGGL(bn_pool_bwd_partial_kernel, dim3(pl.nblk), dim3(256), 0, st, dp, code, x, save_mean, save_invstd, gamma,
+                       beta, partial, (int)rows, H, W, C, Ho, Wo, (int)pl.rows_per_blk, pl.tpc, pl.rl);
   int rc = check_launch("bn_pool_bwd_partial");
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, (const float*)partial, pl.nblk, C,
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, (const float*)partial, nblk, C,
                      1.0 / (double)rows, gamma, save_invstd, dgamma, dbeta, coef, train ? 1 : 0, dx_absmax,
                      (const float*)nullptr);
   rc = check_launch("bn_bwd_final");
   if (rc) return rc;
   const uint32_t n4 = (uint32_t)(rows * (C / 4));
-  hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, dp, code, x, save_mean, save_invstd,
-                     (const float*)coef, gamma, beta, dx, n4, H, W, C, Ho, Wo, dx_absmax);
+  if (quad)
+    hipLaunchKernelGGL(bn_pool_bwd_apply_quad_kernel, dim3(oneshot_grid(n4 / 4)), dim3(256), 0, st, dp, code, x, save_mean,
+                       save_invstd, (const float*)coef, gamma, beta, dx, n4 / 4, H, W, C, Ho, Wo, dx_absmax);
+  else
+    hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, st, dp, code, x, save_mean, save_invstd,
+                       (const float*)coef, gamma, beta, dx, n4, H, W, C, Ho, Wo, dx_absmax);
   return check_launch("bn_pool_bwd_apply");
 }
 
