@@ -364,11 +364,16 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
 // and L2-resident — made the kernel L2->L1 bound: 90 us for the 64^2 -> 128^2 x 256 maps against 38 us for its
 // 268 MB of stores alone (tools/probes/upsample_probe.hip).
 constexpr int kTileR = 4, kTileC = 16;
+// LPP lanes per pixel: 64 (C > 128), or 32 — the decoder's 128-channel maps fill only half a wave per pixel, so a wave
+// takes two pixels side by side there (the per-pixel arithmetic is then per half-wave, on the vector unit)
+template <int LPP>
 __global__ __launch_bounds__(256) void bilinear_fwd_tile_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                 int Hi, int Wi, int Ho, int Wo, int C, float sy,
                                                                 float sx, int patch_cols) {
   extern __shared__ __attribute__((aligned(16))) float patch[];  // [rows][patch_cols][C]
+  constexpr int PPW = 64 / LPP;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int sub = lane / LPP, cl = (lane % LPP) * 4;
   const int n = blockIdx.z, oy0 = blockIdx.y * kTileR, ox0 = blockIdx.x * kTileC;
   const int oy_last = min(oy0 + kTileR, Ho) - 1, ox_last = min(ox0 + kTileC, Wo) - 1;
   int ylo, yhi, xlo, xhi, t0;
@@ -379,11 +384,11 @@ __global__ __launch_bounds__(256) void bilinear_fwd_tile_kernel(const float* __r
   bl_coord(ox_last, sx, Wi, t0, xhi, f0, f1);
   const int pr = yhi - ylo + 1, pc = xhi - xlo + 1;  // pc <= patch_cols by the host's bound
   const float* b = x + (size_t)n * Hi * Wi * C;
-  for (int q = wave; q < pr * pc; q += 4) {
+  for (int q = wave * PPW + sub; q < pr * pc; q += 4 * PPW) {
     const int r = q / pc, c = q - r * pc;
     const float* src = b + ((size_t)(ylo + r) * Wi + (xlo + c)) * C;
     float* dst = patch + (size_t)(r * patch_cols + c) * C;
-    for (int k = lane * 4; k < C; k += 256) *reinterpret_cast<f32x4*>(dst + k) = *reinterpret_cast<const f32x4*>(src + k);
+    for (int k = cl; k < C; k += LPP * 4) *reinterpret_cast<f32x4*>(dst + k) = *reinterpret_cast<const f32x4*>(src + k);
   }
   __syncthreads();
   // wave w: output row oy0 + w (kTileR == 4 waves), all kTileC columns
@@ -395,12 +400,12 @@ __global__ __launch_bounds__(256) void bilinear_fwd_tile_kernel(const float* __r
   const float* r0 = patch + (size_t)(y0 - ylo) * patch_cols * C;
   const float* r1 = patch + (size_t)(y1 - ylo) * patch_cols * C;
   float* o = y + (((size_t)n * Ho + oy) * Wo + ox0) * C;
-  for (int j = 0; j <= ox_last - ox0; ++j) {
+  for (int j = sub; j <= ox_last - ox0; j += PPW) {
     int x0, x1;
     float wx0, wx1;
     bl_coord(ox0 + j, sx, Wi, x0, x1, wx0, wx1);
     const int c0 = (x0 - xlo) * C, c1 = (x1 - xlo) * C;
-    for (int k = lane * 4; k < C; k += 256) {
+    for (int k = cl; k < C; k += LPP * 4) {
       const f32x4 v00 = *reinterpret_cast<const f32x4*>(r0 + c0 + k), v01 = *reinterpret_cast<const f32x4*>(r0 + c1 + k);
       const f32x4 v10 = *reinterpret_cast<const f32x4*>(r1 + c0 + k), v11 = *reinterpret_cast<const f32x4*>(r1 + c1 + k);
       *reinterpret_cast<f32x4*>(o + (size_t)j * C + k) = hy0 * (wx0 * v00 + wx1 * v01) + hy1 * (wx0 * v10 + wx1 * v11);
@@ -715,12 +720,19 @@ extern "C" int evk_upsample_bilinear_fwd(const float* x, float* y, int32_t N, in
   if (C % 4 == 0 && C >= 128 && patch_bytes <= 64 * 1024 && N <= 65535 && (Ho + kTileR - 1) / kTileR <= 65535) {
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bilinear_fwd_tile_kernel),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bilinear_fwd_tile_kernel<64>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bilinear_fwd_tile_kernel<32>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
       attr_set = true;
     }
-    hipLaunchKernelGGL(bilinear_fwd_tile_kernel, dim3((Wo + kTileC - 1) / kTileC, (Ho + kTileR - 1) / kTileR, N),
-                       dim3(256), patch_bytes, (hipStream_t)stream, x, y, Hi, Wi, Ho, Wo, C, sy, sx, pcol);
+    const dim3 grid((Wo + kTileC - 1) / kTileC, (Ho + kTileR - 1) / kTileR, N);
+    if (C <= 128)
+      hipLaunchKernelGGL(bilinear_fwd_tile_kernel<32>, grid, dim3(256), patch_bytes, (hipStream_t)stream, x, y, Hi, Wi, Ho, Wo,
+                         C, sy, sx, pcol);
+    else
+      hipLaunchKernelGGL(bilinear_fwd_tile_kernel<64>, grid, dim3(256), patch_bytes, (hipStream_t)stream, x, y, Hi, Wi, Ho, Wo,
+                         C, sy, sx, pcol);
   }
   else if (C % 4 == 0)
     hipLaunchKernelGGL(bilinear_fwd_kernel<4>, dim3(grid_for((size_t)N * Ho * Wo * (C / 4))), dim3(256), 0,

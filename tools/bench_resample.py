@@ -11,7 +11,7 @@ def ev(fn, it=10):
     for _ in range(it): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / it * 1e-3
-for (n, c, h, w, sc) in [(16, 256, 64, 64, 2), (16, 256, 32, 32, 2), (16, 256, 16, 16, 2), (16, 1, 128, 128, 4)]:
+for (n, c, h, w, sc) in [(16, 128, 64, 64, 2), (16, 128, 32, 32, 2), (16, 128, 16, 16, 2), (16, 256, 64, 64, 2), (16, 256, 32, 32, 2), (16, 256, 16, 16, 2), (16, 1, 128, 128, 4)]:
     x = F.empty_nhwc(n, c, h, w, dev).normal_().requires_grad_()
     y = F.upsample_bilinear(x, sc)
     dy = torch.randn_like(y)
