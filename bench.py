@@ -56,7 +56,51 @@ def parse():
                         'MFMA products, fp32 grade; bf16x3 = 3-term bf16 split, 6 products, fp32 grade; f32 = exact fp32 '
                         'MFMA; bf16 = plain bf16 operands, the --mixed_precision bf16 mode: NOT the headline configuration)')
     p.add_argument('--no-kernel-timer', action='store_true')
+    p.add_argument('--config', choices=['c2', 'c3', 'c4', 'c5'], default='c2',
+                   help='BASELINE.json configs[1..4] at N = 1 (per-GPU size): c2 = the headline (default, the only one the '
+                        'driver times); c3 = FarSeg++ R50 4-band 1024x1024 batch 8; c4 = ChangeStar (FarSeg-R50 + ChangeMixin) '
+                        '2 x (3x512x512) batch 8; c5 = FreeNet 200-band 610x340 scene (padded to 616x344), batch 1')
     return p.parse_args()
+
+
+def make_workload(er, cfg, dev, batch, rank):
+    """(model, args of model(*args), unit name, units per step, metric, workload text, GFLOP fwd+bwd per unit or None)"""
+    import torch
+    g = torch.Generator(device=dev)
+    g.manual_seed(2333 + rank)
+    if cfg == 'c2':
+        x, y = make_batch(dev, batch, rank)
+        return (er.module.FarSeg(dict()), (x, y), 'tiles/s', batch, '512x512 tiles/sec fwd+bwd, FarSeg-R50',
+                f'FarSeg ResNet-50 FPN (FarSegHead defaults, BCE+dice), 3-band 512x512, batch {batch}/GPU, fwd+bwd+SGD step, '
+                'inputs resident in HBM', GF_FWD_BWD_PER_TILE, [BANDS, TILE, TILE])
+    if cfg == 'c3':
+        b = 8 if batch == BATCH else batch
+        x = torch.randn(b, 4, 1024, 1024, device=dev, generator=g)
+        y = (torch.rand(b, 1024, 1024, device=dev, generator=g) < 0.3).long()
+        y[:, :8, :8] = 255
+        return (er.module.FarSegPP(dict(encoder=dict(in_channels=4))), (x, y), 'tiles/s', b,
+                '1024x1024 tiles/sec fwd+bwd, FarSeg++-R50',
+                f'FarSeg++ ResNet-50 (FSRelationV2 head, BCE+dice), 4-band 1024x1024, batch {b}/GPU, fwd+bwd+SGD step, inputs '
+                'resident in HBM (BASELINE.json configs[2] at its per-GPU size)', None, [4, 1024, 1024])
+    if cfg == 'c4':
+        b = 8 if batch == BATCH else batch
+        x = torch.randn(b, 6, TILE, TILE, device=dev, generator=g)
+        y = dict(cls=(torch.rand(b, TILE, TILE, device=dev, generator=g) < 0.3).long(),
+                 cls2=(torch.rand(b, TILE, TILE, device=dev, generator=g) < 0.3).long())
+        y['change'] = (y['cls'] != y['cls2']).long()
+        y['change'][:, :8, :8] = 255
+        return (er.module.ChangeStarFarSeg(dict()), (x, y), 'pairs/s', b,
+                'bitemporal 512x512 tile pairs/sec fwd+bwd, ChangeStar(FarSeg-R50)',
+                f'ChangeStar (FarSeg-R50 + ChangeMixin; semantic BCE+dice on both dates, change BCE on both orders), bitemporal '
+                f'2 x (3x512x512), batch {b} pairs/GPU, fwd+bwd+SGD step, inputs resident in HBM (BASELINE.json configs[3] at its '
+                'per-GPU size)', None, [6, TILE, TILE])
+    from ever_amd.module.freenet import divisible_pad
+    x = divisible_pad(torch.randn(1, 200, 610, 340, device=dev, generator=g), 8)
+    y = divisible_pad(torch.randint(0, 17, (1, 610, 340), device=dev, generator=g).float(), 8).long()
+    return (er.module.FreeNet(dict()), (x, y), 'scenes/s', 1, '200-band 610x340 scenes/sec fwd+bwd, FreeNet',
+            'FreeNet patch-free hyperspectral model (GroupNorm conv blocks, nearest top-down, CE on labelled pixels), one '
+            '200-band 610x340 scene padded to 616x344, fwd+bwd+SGD step, input resident in HBM (BASELINE.json configs[4])',
+            None, [200, 616, 344])
 
 
 def make_batch(dev, batch, rank):
@@ -159,7 +203,9 @@ def main():
     _C.load()
 
     torch.manual_seed(2333)
-    model = er.module.FarSeg(dict()).to(dev).train()      # R50 encoder + FarSegHead reference defaults
+    model, inputs, unit, units_per_step, metric, workload, gf_per_unit, tile_shape = make_workload(er, args.config, dev,
+                                                                                                  args.batch, rank)
+    model = model.to(dev).train()      # c2: R50 encoder + FarSegHead reference defaults
     ddp = model
     if use_ddp:
         if args.ddp == 'flat':   # the trainer's default exchange: one pack launch + one RCCL all-reduce per 64 MB bucket
@@ -169,10 +215,9 @@ def main():
             ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
                                                             bucket_cap_mb=64, gradient_as_bucket_view=True)
     opt = er.opt.FusedSGD(model.parameters(), lr=0.007, momentum=0.9, weight_decay=1e-4)
-    x, y = make_batch(dev, args.batch, rank)
 
     def step():
-        out = ddp(x, y)
+        out = ddp(*inputs)
         sum(v for k, v in out.items() if k.endswith('loss')).backward()
         opt.step()
         opt.zero_grad(set_to_none=True)
@@ -213,16 +258,15 @@ def main():
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        tiles_s = world * args.batch * args.steps / elapsed
+        tiles_s = world * units_per_step * args.steps / elapsed
         line = {
-            'metric': '512x512 tiles/sec fwd+bwd, FarSeg-R50', 'value': round(tiles_s, 2), 'unit': 'tiles/s',
+            'metric': metric, 'value': round(tiles_s, 3 if tiles_s < 100 else 2), 'unit': unit,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
             'host_enqueue_ms_per_step': round(enqueued / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if conv_math == 'bf16' else 'f32', 'data': 'synthetic',
-            'config': {'workload': 'FarSeg ResNet-50 FPN (FarSegHead defaults, BCE+dice), 3-band 512x512, '
-                                   f'batch {args.batch}/GPU, fwd+bwd+SGD step, inputs resident in HBM',
-                       'global_batch': world * args.batch, 'tile': [BANDS, TILE, TILE],
+            'config': {'workload': workload,
+                       'global_batch': world * units_per_step, 'tile': tile_shape,
                        'parallelism': f'dp{world}' if world > 1 else 'single',
                        'arithmetic': ('fp32 in / fp32 accumulate / fp32 out; conv operands divided by a per-tensor power of two '
                                       'and split into 2 fp16 terms (22-bit operands), 3 fp16-MFMA partial products each '
@@ -232,9 +276,10 @@ def main():
                              '6 bf16-MFMA partial products each (error < 2^-24 per product)') if conv_math == 'bf16x3'
                        else ('fp32 tensors; conv operands rounded to bf16 once, 1 bf16-MFMA product, fp32 accumulate '
                              '(--mixed_precision bf16; BatchNorm, resampling, losses fp32)') if conv_math == 'bf16'
-                       else 'fp32 MFMA (exact fmaf chain)',
-                       'whole_model_tflops': round(tiles_s * GF_FWD_BWD_PER_TILE / 1e3 / world, 2)},
+                       else 'fp32 MFMA (exact fmaf chain)'},
         }
+        if gf_per_unit is not None:
+            line['config']['whole_model_tflops'] = round(tiles_s * gf_per_unit / 1e3 / world, 2)
         if use_ddp:
             line['config']['gradient_exchange'] = ('FlatGradDDP: 64 MB buckets, one pack launch + one RCCL all-reduce per bucket'
                                                    if args.ddp == 'flat' else 'torch DistributedDataParallel') + \
@@ -248,11 +293,28 @@ def main():
             peak = PEAK_BF16_MFMA_TFLOPS / passes if x3 else PEAK_FP32_MFMA_TFLOPS
             peak_note = (f'dense bf16/fp16 MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} TF / {passes} partial product(s) per product'
                          if x3 else 'dense f32-input MFMA peak (v_mfma_f32_32x32x2_f32)')
+            convs = [fam[k] for k in ('conv_igemm', 'conv_wgrad', 'conv_igemm_f32', 'conv_wgrad_f32') if k in fam]
+            if convs:   # algorithmic convolution work of one step as the spans saw it (forward + both gradients)
+                line['config']['conv_gflop_per_step'] = round(sum(c['flops'] for c in convs) / max(1, sampled) / 1e9, 1)
+                line['config']['conv_ms_per_step'] = round(sum(c['seconds'] for c in convs) / max(1, sampled) * 1e3, 3)
+            if args.config == 'c5':
+                # BASELINE.json configs[4] "channel-heavy implicit-GEMM stress": the Cin = 200 first convolution alone
+                # (forward + weight gradient; the image needs no data gradient)
+                f200 = 2.0 * 616 * 344 * 96 * 200 * 9
+                recs = [r for r in timer.records if abs(r[1] - f200) < 1.0]
+                if recs:
+                    sec = sum(r[3].elapsed_time(r[4]) for r in recs) * 1e-3
+                    ach = f200 * len(recs) / sec / 1e12
+                    line['roofline_cin200'] = {'bound': 'mfma', 'kernel': 'first convolution, 3x3, Cin 200 -> 96 @616x344 '
+                                               '(forward + weight gradient launches)', 'achieved': round(ach, 2),
+                                               'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                                               'launches_per_step': len(recs) // max(1, sampled),
+                                               'avg_launch_us': round(sec / len(recs) * 1e6, 2)}
             ig = fam.get('conv_igemm' if x3 else 'conv_igemm_f32')
             if ig:
                 ach = ig['flops'] / ig['seconds'] / 1e12
                 # the committed PMC passes were collected under the default arithmetic
-                traffic, traffic_file = pmc_traffic('conv_igemm') if conv_math == 'f16x2' else (None, None)
+                traffic, traffic_file = pmc_traffic('conv_igemm') if (conv_math == 'f16x2' and args.config == 'c2') else (None, None)
                 line['roofline'] = {
                     'bound': 'mfma',
                     'kernel': ('evk::conv3x3_halo_x3_kernel / conv_igemm_x3ws_kernel / conv_igemm_x3_kernel' if x3
@@ -267,7 +329,7 @@ def main():
             wg = fam.get('conv_wgrad' if x3 else 'conv_wgrad_f32')
             if wg:
                 ach = wg['flops'] / wg['seconds'] / 1e12
-                wtraffic, _ = pmc_traffic('conv_wgrad') if conv_math == 'f16x2' else (None, None)
+                wtraffic, _ = pmc_traffic('conv_wgrad') if (conv_math == 'f16x2' and args.config == 'c2') else (None, None)
                 line['roofline_wgrad'] = {'bound': 'mfma',
                                           'kernel': ('evk::conv_wgrad_x3ws_kernel / conv_wgrad_x3_kernel' if x3 else
                                                      'evk::conv_wgrad_kernel') + ' (+split-K reduce)',

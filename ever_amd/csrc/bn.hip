@@ -913,18 +913,39 @@ __device__ __forceinline__ f32x4 ld_agent4(const float* p) {
 }
 // Two-level arrival: workgroup b adds to the word of group b % 8 (8 words on 8 cache lines — same-address atomics are
 // served one per ~20 ns, 256 arrivals on ONE word cost the 5 us the first form of the barrier showed), the last
-// arrival of a group adds to the top word, everybody polls the top word.  All words only ever increase; the host
-// passes what each will read when this launch's arrivals are complete (launches of a stream are ordered).
-struct BarrierTargets { uint32_t group[8]; uint32_t top; };
+// arrival of a group adds to the top word, the last group bumps a GENERATION word that everybody polls.  The barrier
+// is self-resetting: the last arriver of a level zeroes that level's word before it passes the arrival on, so the words
+// hold no history — nothing is reserved on the host (a failed launch cannot desynchronise later ones, and a captured
+// launch replays correctly).  A workgroup reads the generation BEFORE it arrives: it cannot advance until it has.
+// The spin is bounded: a grid that is not resident as a whole (another barrier kernel of another process sharing the
+// device) traps after a few seconds instead of hanging the GPU.
 constexpr int kBarStride = 32;   // words between the counters (128 bytes)
-__device__ __forceinline__ void grid_barrier(uint32_t* __restrict__ words, uint32_t group_target, uint32_t top_target) {
+constexpr int kBarWords = 10 * kBarStride;
+constexpr uint32_t kBarSpinLimit = 1u << 23;
+__device__ __forceinline__ void grid_barrier(uint32_t* __restrict__ words, int nwg) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's agent-scope stores have been performed
   __syncthreads();
   if (threadIdx.x == 0) {
-    const uint32_t old = __hip_atomic_fetch_add(&words[(blockIdx.x & 7) * kBarStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old + 1u == group_target) __hip_atomic_fetch_add(&words[8 * kBarStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while ((int32_t)(__hip_atomic_load(&words[8 * kBarStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - top_target) < 0)
+    const int g = blockIdx.x & 7;
+    const uint32_t members = (uint32_t)((nwg - g + 7) / 8), ngroups = (uint32_t)(nwg < 8 ? nwg : 8);
+    uint32_t* gen = &words[9 * kBarStride];
+    const uint32_t my_gen = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t old = __hip_atomic_fetch_add(&words[g * kBarStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1u == members) {
+      (void)__hip_atomic_exchange(&words[g * kBarStride], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the reset is performed before the arrival moves up
+      const uint32_t t = __hip_atomic_fetch_add(&words[8 * kBarStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t + 1u == ngroups) {
+        (void)__hip_atomic_exchange(&words[8 * kBarStride], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    uint32_t spins = 0;
+    while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_gen) {
       __builtin_amdgcn_s_sleep(1);
+      if (++spins > kBarSpinLimit) __builtin_trap();
+    }
   }
   __syncthreads();
 }
@@ -936,8 +957,7 @@ __global__ __launch_bounds__(kFusedThreads) void bn_bwd_fused_kernel(
     const float* __restrict__ beta, float* __restrict__ dx, float* __restrict__ d_residual,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ partial, float* __restrict__ coef,
     float* __restrict__ pmax, int64_t rows, int C, int rows_per_wg, int tpc, int rl, int cpw, int relu, int train,
-    double inv_rows, uint32_t* __restrict__ amax, uint32_t* __restrict__ counter, const BarrierTargets bt1,
-    const BarrierTargets bt2) {
+    double inv_rows, uint32_t* __restrict__ amax, uint32_t* __restrict__ counter) {
   __shared__ f32x4 red[2][kFusedThreads];
   const int nwg = gridDim.x;
   const int tc = threadIdx.x % tpc, tr = threadIdx.x / tpc;   // tpc = C / 4: one channel chunk per thread
@@ -1010,7 +1030,7 @@ __global__ __launch_bounds__(kFusedThreads) void bn_bwd_fused_kernel(
   }
   if (!PK && amax && blockIdx.x == 0 && threadIdx.x < kAmaxSlots)
     __hip_atomic_store(&amax[threadIdx.x * kAmaxStride], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  grid_barrier(counter, bt1.group[blockIdx.x & 7], bt1.top);
+  grid_barrier(counter, nwg);
 
   // ---- phase 2: channels [blockIdx * cpw, +cpw), one 32-lane group per channel (cpw <= 32)
   {
@@ -1053,7 +1073,7 @@ __global__ __launch_bounds__(kFusedThreads) void bn_bwd_fused_kernel(
       }
     }
   }
-  grid_barrier(counter, bt2.group[blockIdx.x & 7], bt2.top);
+  grid_barrier(counter, nwg);
 
   // ---- phase 3
   const f32x4 k0 = ld_agent4(coef + tc * 4), k1 = ld_agent4(coef + C + tc * 4), k2 = ld_agent4(coef + 2 * C + tc * 4);
@@ -1281,38 +1301,24 @@ static FusedPlan fused_plan(int64_t rows, int C) {
   if (p.cpw > 32) { p.nwg = 0; return p; }
   return p;
 }
-// the barrier words of a stream (device memory owned by the library, zero at first use, never reset)
-struct FusedCounter { uint32_t* words; uint32_t group[8]; uint32_t top; };   // values once all enqueued launches ran
-// reserve the arrivals of one launch (two barriers of nwg workgroups) on the stream's words
-static uint32_t* fused_counter(hipStream_t st, int nwg, BarrierTargets* t1, BarrierTargets* t2) {
+// The barrier words of a device (device memory owned by the library, zeroed once; the barrier resets itself).  The
+// kernel's grid must be resident as a whole, so two such grids must never run concurrently: the one-launch form is given
+// to ONE stream per device (the first that asks); any other stream gets nullptr = the three-launch form.
+static uint32_t* fused_counter(hipStream_t st) {
+  struct Entry { hipStream_t stream; uint32_t* words; };
   static std::mutex mu;
-  static std::unordered_map<hipStream_t, FusedCounter> words;
+  static std::unordered_map<int, Entry> by_dev;
   std::lock_guard<std::mutex> lock(mu);
   int dev = 0;
   (void)hipGetDevice(&dev);
-  hipStream_t key = (hipStream_t)((uintptr_t)st ^ ((uintptr_t)(dev + 1) << 56));
-  auto it = words.find(key);
-  if (it == words.end()) {
+  auto it = by_dev.find(dev);
+  if (it == by_dev.end()) {
     uint32_t* w = nullptr;
-    const size_t bytes = (size_t)9 * kBarStride * sizeof(uint32_t);
+    const size_t bytes = (size_t)kBarWords * sizeof(uint32_t);
     if (hipMalloc((void**)&w, bytes) != hipSuccess || hipMemset(w, 0, bytes) != hipSuccess) return nullptr;
-    FusedCounter fc{};
-    fc.words = w;
-    it = words.emplace(key, fc).first;
+    it = by_dev.emplace(dev, Entry{st, w}).first;
   }
-  FusedCounter& fc = it->second;
-  for (BarrierTargets* t : {t1, t2}) {
-    int groups = 0;
-    for (int g = 0; g < 8; ++g) {
-      const int members = nwg > g ? (nwg - g + 7) / 8 : 0;
-      fc.group[g] += (uint32_t)members;
-      t->group[g] = fc.group[g];
-      groups += members > 0;
-    }
-    fc.top += (uint32_t)groups;
-    t->top = fc.top;
-  }
-  return fc.words;
+  return it->second.stream == st ? it->second.words : nullptr;
 }
 
 extern "C" int evk_bn_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
@@ -1338,17 +1344,19 @@ extern "C" int evk_bn_bwd(const float* dy, const float* x, const float* y, const
   FusedPlan fp = fused_plan(rows, C);
   if (flags & EVK_BN_NO_FUSE) fp.nwg = 0;
   if (fp.nwg > 0) {
-    BarrierTargets bt1, bt2;
-    uint32_t* counter = fused_counter(st, fp.nwg, &bt1, &bt2);
-    EVK_REQUIRE(counter, EVK_E_LAUNCH, "bn_bwd: could not allocate the barrier word");
+    uint32_t* counter = fused_counter(st);
+    if (!counter) fp.nwg = 0;   // another stream of this device owns the one-launch form
+  }
+  if (fp.nwg > 0) {
+    uint32_t* counter = fused_counter(st);
     if (pack)
       hipLaunchKernelGGL(bn_bwd_fused_kernel<true>, dim3(fp.nwg), dim3(kFusedThreads), 0, st, dy, x, y, save_mean,
                          save_invstd, gamma, beta, dx, d_residual, dgamma, dbeta, partial, coef, pmax, rows, C,
-                         fp.rows_per_wg, fp.tpc, fp.rl, fp.cpw, relu, train ? 1 : 0, 1.0 / (double)rows, dx_absmax, counter, bt1, bt2);
+                         fp.rows_per_wg, fp.tpc, fp.rl, fp.cpw, relu, train ? 1 : 0, 1.0 / (double)rows, dx_absmax, counter);
     else
       hipLaunchKernelGGL(bn_bwd_fused_kernel<false>, dim3(fp.nwg), dim3(kFusedThreads), 0, st, dy, x, y, save_mean,
                          save_invstd, gamma, beta, dx, d_residual, dgamma, dbeta, partial, coef, pmax, rows, C,
-                         fp.rows_per_wg, fp.tpc, fp.rl, fp.cpw, relu, train ? 1 : 0, 1.0 / (double)rows, dx_absmax, counter, bt1, bt2);
+                         fp.rows_per_wg, fp.tpc, fp.rl, fp.cpw, relu, train ? 1 : 0, 1.0 / (double)rows, dx_absmax, counter);
     return check_launch("bn_bwd_fused");
   }
   if (pack)

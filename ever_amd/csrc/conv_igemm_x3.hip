@@ -296,10 +296,12 @@ int launch_igemm_x3(IGemmArgs& a, hipStream_t stream) {
       if (!strcmp(f, "c64x64")) return launch_cfg3<64, 64, 2, 2, 1>(a, stream);
     }
   }
+#ifdef EVK_WITH_X3DMA   // experimental/conv_igemm_x3dma.hip, `make EXPERIMENTAL=1` only
   {
     const int rc = launch_igemm_x3dma(a, stream);  // LDS-DMA form for the one-tap (1x1) convolutions
     if (rc != 1) return rc;
   }
+#endif
   {
     const int rc = launch_igemm_x3ws(a, stream);  // wave-specialised form for the large layers
     if (rc != 1) return rc;

@@ -16,8 +16,8 @@
 // EXPERIMENTAL (off by default, EVK_X3_DMA=1): correct (tests/test_dma_gpu.py) and at parity with the register-staged
 // kernels; the measured breakdown (compute ~145 us + unhidden DMA wait ~55 us + store burst ~58 us on 256->256 @128^2)
 // says these layers need their three parts OVERLAPPED, not any one of them made faster.
-#include "igemm_common.hpp"
-#include "x3_common.hpp"
+#include "../igemm_common.hpp"
+#include "../x3_common.hpp"
 #include <stdlib.h>
 
 namespace evk {

@@ -214,6 +214,33 @@ def _is_packed(t):
     hit = getattr(t, '_evk_packed', None)
     return hit is not None and hit[0] == t._version and hit[1] == t.data_ptr()
 
+
+_top_saved_hooks = getattr(torch._C._autograd, '_top_saved_tensors_default_hooks', None)
+
+
+def observers_active():
+    """True when something other than this package's own kernels may get to see an activation between its producer and
+    its consumer: saved-tensor hooks (non-reentrant checkpointing, save_on_cpu: the unpack hook returns a NEW tensor
+    object, which would not carry the `_evk_packed` mark) or global module forward hooks.  Packed tensors are raw words
+    marked only by a Python attribute, so nothing is stored packed while an observer is installed; per-module
+    hooks are checked by the layers (module/layers.py)."""
+    if _top_saved_hooks is not None and _top_saved_hooks(True) is not None:
+        return True
+    from torch.nn.modules import module as _m
+    return bool(_m._global_forward_hooks or _m._global_forward_pre_hooks or _m._global_forward_hooks_always_called)
+
+
+def unpacked(t):
+    """`t` as fp32 values: itself unless it holds packed f16x2 words, then (h + l) * s by evk_unpack_f16x2.  For readers
+    outside the f16x2 convolution kernels (folded inference convolutions, debugging)."""
+    if not _is_packed(t):
+        return t
+    bits = t._evk_amax[2]
+    out = torch.empty_like(t)
+    _C.call('evk_unpack_f16x2', t.data_ptr(), t.numel(), bits.data_ptr(), out.data_ptr(), _stream())
+    _note_amax(out, bits)
+    return out
+
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
 
@@ -427,7 +454,7 @@ def _conv_forward(x, weight, bias, stride, padding, dilation, relu, want_stats=F
             # third field: this convolution's backward takes its dy packed (the BatchNorm that consumes the records is
             # the ONLY reader of y — conv2d(bn_stats=True)'s contract — so its dx has no other reader either)
             bn_parts = (parts, int(nparts.value),
-                        _PACKED and wabs_ptr is not None and bias is None and cout % 8 == 0)
+                        _PACKED and wabs_ptr is not None and bias is None and cout % 8 == 0 and not observers_active())
     else:
         sp = timing.span('conv_igemm_f32', cs.flops, cs.abytes)
         _C.call('evk_conv2d_fwd', ctypes.byref(d), x_ptr, w_ptr, _ptr(bias), y.data_ptr(), 1 if relu else 0, st)
@@ -998,7 +1025,7 @@ class _BatchNormActFn(Function):
         # pack_out: y is one convolution's operand and nothing else — written packed, its scale bounded from the
         # statistics records before the apply pass (EVK_BN_PACK_Y); rows: that convolution must be on the plane kernels
         pack = bool(pack_out and _PACKED and _f16x2() and training and parts is not None and residual is None
-                    and c % 8 == 0 and rows >= 256)
+                    and c % 8 == 0 and rows >= 256 and not observers_active())
         abits = _amax_zeroed(dev) if pack else _amax_out(dev)
         pack = pack and abits is not None
         if pack:
@@ -1085,6 +1112,8 @@ def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentu
         del x._evk_bn_parts
     global _AMAX_HANDOFF
     _AMAX_HANDOFF = None
+    if use_batch_stats and running_mean is not None:
+        weight_planes.note_running_stats_changed()
     y = _BatchNormActFn.apply(x, residual, weight, bias, running_mean, running_var, bool(use_batch_stats),
                               0.0 if momentum is None else momentum, eps, bool(relu), parts, bool(pack_out))
     if _AMAX_HANDOFF is not None:       # the pass left max|y| (or its bound) there: y is the next convolution's operand
@@ -1169,6 +1198,8 @@ def batch_norm_relu_max_pool(x, weight, bias, running_mean, running_var, momentu
     del x._evk_bn_parts
     global _AMAX_HANDOFF
     _AMAX_HANDOFF = None
+    if running_mean is not None:
+        weight_planes.note_running_stats_changed()
     y = _BnReluPoolFn.apply(x, weight, bias, running_mean, running_var, 0.0 if momentum is None else momentum, eps, parts)
     if _AMAX_HANDOFF is not None:
         if _AMAX_HANDOFF[0] is not None:

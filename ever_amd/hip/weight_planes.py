@@ -80,6 +80,16 @@ def enabled():
     return _ENABLED
 
 
+_stats_epoch = 0
+
+
+def note_running_stats_changed():
+    """A training-mode BatchNorm kernel updated running_mean / running_var through raw pointers (no autograd version
+    bump): whatever was derived from them — folded inference weights (module/fold.py) — is stale."""
+    global _stats_epoch
+    _stats_epoch += 1
+
+
 def note_weights_changed():
     """Parameters were written behind autograd's back (raw-pointer kernels): every cached plane is stale."""
     global _epoch

@@ -27,7 +27,7 @@ def _stamp(conv, bn):
     ERModule.apply_gradients).  A folded pair whose stamp no longer matches is re-derived before use."""
     from ..hip import weight_planes
     ts = (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
-    return tuple(-1 if t is None else (t.data_ptr(), t._version) for t in ts) + (weight_planes._epoch,)
+    return tuple(-1 if t is None else (t.data_ptr(), t._version) for t in ts) + (weight_planes._epoch, weight_planes._stats_epoch)
 
 
 def _fold_pair(conv, bn):
@@ -127,7 +127,8 @@ def conv_bn(conv, bn, x, residual=None, relu=False, conv_only=False):
 
 def folded_conv2d(x, conv, residual=None, relu=False):
     f = conv._folded
-    x = HF.as_nhwc(x, 'folded conv')
+    # (a training-mode BatchNorm in front of a folded pair may have stored its result packed: ADVICE r2)
+    x = HF.unpacked(HF.as_nhwc(x, 'folded conv'))
     n, cin, h, w = x.shape
     if cin != f.cin:
         raise ValueError(f'folded conv: input has {cin} channels, expected {f.cin}')

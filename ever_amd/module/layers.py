@@ -28,8 +28,12 @@ class Conv2d(nn.Conv2d):
 
     def forward(self, x, relu=False, bn_stats=False):
         """bn_stats: a training-mode BatchNorm consumes the result next (hip/functional.py:conv2d)"""
-        return HF.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, relu=relu,
-                         bn_stats=bn_stats)
+        y = HF.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, relu=relu,
+                      bn_stats=bn_stats)
+        if self._forward_hooks and getattr(y, '_evk_bn_parts', None) is not None and len(y._evk_bn_parts) > 2:
+            # a forward hook may hang a tensor hook on y: its gradient (the BatchNorm's dx) must then stay fp32
+            y._evk_bn_parts = y._evk_bn_parts[:2] + (False,)
+        return y
 
 
 class ConvTranspose2d(nn.ConvTranspose2d):
@@ -73,6 +77,8 @@ class BatchNorm2d(nn.BatchNorm2d):
             self._nbt_pending = getattr(self, '_nbt_pending', 0) + 1
         rm = self.running_mean if (not self.training or self.track_running_stats) else None
         rv = self.running_var if (not self.training or self.track_running_stats) else None
+        # a forward hook on this module would be handed the packed words: store fp32 then
+        conv_only = conv_only and not self._forward_hooks
         return HF.batch_norm_act(x, self.weight, self.bias, rm, rv, training, self.momentum, self.eps,
                                  residual=residual, relu=relu, pack_out=conv_only)
 

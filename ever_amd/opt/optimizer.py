@@ -48,6 +48,12 @@ class FusedSGD(SGD):
         self.last_grad_norm = norm       # device scalar: no host sync on the critical path
         self._clip = coef                # applied inside the SGD kernel
 
+    def _clip_unfused(self, params):
+        """A group that takes torch's own step (amsgrad, maximize, non-fp32 ...) never sees the coefficient the fused
+        kernels multiply in: scale its gradients here, so that `grad_clip` holds for every group."""
+        if self._clip is not None:
+            torch._foreach_mul_([p.grad for p in params], self._clip.to(params[0].grad.dtype))
+
     @staticmethod
     def _dense(t):
         return t.is_contiguous() or (t.dim() == 4 and t.permute(0, 2, 3, 1).is_contiguous())
@@ -119,6 +125,7 @@ class FusedSGD(SGD):
                 continue
             if not (params[0].is_cuda and all(p.dtype == torch.float32 for p in params)) or group.get('maximize'):
                 # CPU plumbing path (BASELINE config 1): exactly torch.optim.SGD
+                self._clip_unfused(params)
                 saved = self.param_groups
                 self.param_groups = [group]
                 try:
@@ -152,6 +159,7 @@ class _FusedAdamMixin:
         self.last_grad_norm = None
 
     fused_clip = FusedSGD.fused_clip
+    _clip_unfused = FusedSGD._clip_unfused
     _table = FusedSGD._table
     _dense = staticmethod(FusedSGD._dense)
     _same_layout = staticmethod(FusedSGD._same_layout)
@@ -172,6 +180,7 @@ class _FusedAdamMixin:
             if not params:
                 continue
             if not self._fused_ok(group, params):
+                self._clip_unfused(params)
                 saved = self.param_groups
                 self.param_groups = [group]
                 try:
@@ -194,8 +203,10 @@ class _FusedAdamMixin:
                 st['step'] += 1
                 by_step.setdefault(float(st['step']), []).append(p)
             beta1, beta2 = group['betas']
-            for step, ps in by_step.items():
-                dev, slot = ps[0].device, (gi, step if len(by_step) > 1 else 0)
+            # tables are keyed by the bucket's ORDINAL, not by the step value: with mixed step counts the values change
+            # every iteration and a value key would allocate five pinned + device tables per bucket per step, forever
+            for bi, (step, ps) in enumerate(sorted(by_step.items())):
+                dev, slot = ps[0].device, (gi, bi)
                 pt = self._table((slot, 'p'), ps, dev)
                 nt = self._table((slot, 'n'), ps, dev, sizes=True)
                 gt = self._table((slot, 'g'), [p.grad for p in ps], dev)

@@ -239,3 +239,13 @@ def test_folded_batchnorm_inference_matches_unfolded_and_reference(cuda, conv_ma
     m.train()                                                # training is untouched by the folded copies
     lg = m.head(m.en(x))
     assert _rel_err(lg.detach().cpu().contiguous().numpy(), gold['logits']) < 5e-2  # second step: statistics moved on
+    # that training-mode forward moved the running statistics through raw pointers, with no optimiser step
+    # ("precise BN" re-calibration): the folded copies must notice and fold again from the new statistics
+    m.eval()
+    with torch.no_grad():
+        refolded = m.head(m.en(x)).cpu().contiguous().numpy()
+        from ever_amd.module.fold import unfold_batchnorm
+        unfold_batchnorm(m)
+        plain2 = m.head(m.en(x)).cpu().contiguous().numpy()
+    assert _rel_err(plain2, plain) > 1e-4                     # the statistics did move
+    assert _rel_err(refolded, plain2) < 2e-5, _rel_err(refolded, plain2)

@@ -261,3 +261,63 @@ def test_a_packed_tensor_is_refused_by_readers_that_cannot_take_it(cuda):
                 F.conv2d(h, w, None, padding=1)
     finally:
         F.set_conv_math(prev)
+
+
+def test_nothing_is_stored_packed_while_an_observer_is_installed(cuda):
+    """packed words are marked by a Python attribute on the tensor object only.  Saved-tensor hooks hand the
+    backward NEW tensor objects (non-reentrant checkpointing, save_on_cpu), module forward hooks show intermediate
+    activations to user code: while either is installed the BatchNorm passes store fp32 — same results as without, and no
+    packed tensor is produced."""
+    from ever_amd.hip import functional as F
+    prev = F.set_conv_math('f16x2')
+    try:
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(2, 64, 32, 32, generator=g).to(cuda).requires_grad_()
+        shapes = ((64, 64, 3), (128, 64, 1), (128, 128, 3))
+        ws = [(torch.randn(o, i, k, k, generator=g) / (i * k * k) ** 0.5).to(cuda)
+              .contiguous(memory_format=torch.channels_last).requires_grad_() for o, i, k in shapes]
+        bns = [((torch.rand(o, generator=g) + 0.5).to(cuda).requires_grad_(),
+                (torch.randn(o, generator=g) * 0.1).to(cuda).requires_grad_()) for o, _, _ in shapes]
+        l0, g0 = _chain(F, x, ws, bns, False)
+        F.absmax_stats.update(hits=0, standalone=0, fused=0, packed=0)
+        copies = []
+
+        def pack_hook(t):
+            copies.append(1)
+            return t.clone()          # a new tensor object with new memory, as an offloading hook would return
+
+        with torch.autograd.graph.saved_tensors_hooks(pack_hook, lambda t: t):
+            l1, g1 = _chain(F, x, ws, bns, True)
+        assert copies and F.absmax_stats['packed'] == 0, F.absmax_stats
+        torch.cuda.synchronize()
+        assert abs(l1.item() - l0.item()) <= 1e-6 * abs(l0.item())
+        for a, b in zip(g1, g0):
+            assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+        # ... and the packed path is back once the hooks are gone
+        _chain(F, x, ws, bns, True)
+        assert F.absmax_stats['packed'] == 5
+    finally:
+        F.set_conv_math(prev)
+
+
+def test_a_folded_convolution_unpacks_a_packed_input(cuda):
+    """a training-mode BatchNorm in front of a folded conv+BN pair (mixed train / eval sub-modules) may hand it packed
+    words: module/fold.py reads them through evk_unpack_f16x2 instead of as fp32"""
+    from ever_amd.hip import functional as F
+    prev = F.set_conv_math('f16x2')
+    try:
+        x = torch.randn(2, 64, 16, 16, device=cuda)
+        w = torch.randn(64, 64, 3, 3, device=cuda).contiguous(memory_format=torch.channels_last)
+        gm, bt = torch.ones(64, device=cuda), torch.zeros(64, device=cuda)
+        with torch.no_grad():
+            h = F.conv2d(x, w, None, stride=1, padding=1, bn_stats=True)
+            hp = F.batch_norm_act(h, gm, bt, None, None, True, 0.1, 1e-5, relu=True, pack_out=True)
+            h = F.conv2d(x, w, None, stride=1, padding=1, bn_stats=True)
+            hf = F.batch_norm_act(h, gm, bt, None, None, True, 0.1, 1e-5, relu=True, pack_out=False)
+            assert F._is_packed(hp) and not F._is_packed(hf)
+            up = F.unpacked(hp)
+            assert not F._is_packed(up)
+            torch.cuda.synchronize()
+            assert (up - hf).abs().max().item() <= 2.0 ** -20 * hf.abs().max().item()
+    finally:
+        F.set_conv_math(prev)

@@ -55,6 +55,37 @@ def test_fused_adam_and_adamw_match_torch(cuda, decoupled):
         assert oc.state[p]['exp_avg'].stride() == p.stride()
 
 
+def test_grad_clip_reaches_groups_that_take_torchs_own_step(cuda):
+    """fused_clip only leaves a coefficient for the fused kernels; a group the fused step cannot take
+    (amsgrad=True here) must still train on clipped gradients, also when it sits beside a fused group, and the table cache
+    must not grow when parameters of one group are at different step counts."""
+    import ever_amd as er
+    torch.manual_seed(3)
+    mk = lambda: [torch.randn(s, device=cuda) for s in ((32, 8, 3, 3), (32,), (17, 5))]
+    base_a, base_b = mk(), mk()
+    a1 = [p.clone().requires_grad_() for p in base_a]; a2 = [p.clone().requires_grad_() for p in base_b]
+    b1 = [p.clone().requires_grad_() for p in base_a]; b2 = [p.clone().requires_grad_() for p in base_b]
+    groups = lambda x, y: [dict(params=x, amsgrad=True), dict(params=y)]
+    oa = er.opt.FusedAdam(groups(a1, a2), lr=0.01, betas=(0.9, 0.99))
+    ob = torch.optim.Adam(groups(b1, b2), lr=0.01, betas=(0.9, 0.99))
+    for step in range(6):
+        for k, (p, q) in enumerate(zip(a1 + a2, b1 + b2)):
+            if step == 2 and k == 4:
+                p.grad = q.grad = None          # mixed step counts inside the fused group from here on
+                continue
+            g = 10.0 * torch.randn_like(q)
+            p.grad, q.grad = g.clone(), g.clone()
+        oa.fused_clip(max_norm=1.0)
+        torch.nn.utils.clip_grad_norm_([q for q in b1 + b2 if q.grad is not None], max_norm=1.0)
+        oa.step()
+        ob.step()
+        for p, q in zip(a1 + a2, b1 + b2):
+            assert torch.allclose(p, q, rtol=2e-5, atol=2e-6), (step, tuple(p.shape), float((p - q).abs().max()))
+        if step == 3:       # two step-count buckets in the fused group since this step
+            n_tabs = len(oa._tabs)
+    assert len(oa._tabs) == n_tabs, 'optimizer pointer tables keep growing with mixed step counts'
+
+
 def test_fused_sgd_matches_torch_sgd(cuda):
     import ever_amd as er
     torch.manual_seed(0)
