@@ -65,6 +65,8 @@ SIGNATURES = {
     'evk_conv2d_wgrad_f16x2': (c_int, [_DP, P, P, P, P, P, P, P, c_size_t, P]),
     'evk_pack_f16x2': (c_int, [P, c_i64, P, P, P]),
     'evk_unpack_f16x2': (c_int, [P, c_i64, P, P, P]),
+    'evk_pack_planar_f16x2': (c_int, [P, c_i64, P, P, P]),
+    'evk_unpack_planar_f16x2': (c_int, [P, c_i64, P, P, P]),
     'evk_conv2d_dgrad_f16x2_ex': (c_int, [_DP, P, P, P, P, P, P, P, c_u32, P]),
     'evk_conv2d_wgrad_f16x2_ex': (c_int, [_DP, P, P, P, P, P, P, P, c_size_t, c_u32, P]),
     'evk_conv_transpose2d_fwd': (c_int, [_DP, P, P, P, P, P]),

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
   }
 }
 
-WGradPlan plan_wgrad(const evk_conv_desc* d, int x3, int planes) {
+WGradPlan plan_wgrad(const evk_conv_desc* d, int x3, int planes, int tr) {
   WGradPlan pl;
   const int Ktot = d->kh * d->kw * d->Cin;
   const int M = d->N * d->Ho * d->Wo;
@@ -280,6 +280,7 @@ WGradPlan plan_wgrad(const evk_conv_desc* d, int x3, int planes) {
   const bool fits32 = (long long)d->N * d->H * d->W * d->Cin * 4 < 0x7fffffffLL &&
                       (long long)d->N * d->Ho * d->Wo * d->Cout * 4 < 0x7fffffffLL;
   pl.ws = (x3 && ws_mode && d->Cout >= 128 && Ktot >= 256 && fits32) ? 1 : 0;
+  if (tr) { pl.ws = 1; pl.bm = 128; }
   if (pl.ws) pl.bn = 256;
   pl.tiles_co = ceil_div(d->Cout, pl.bm);
   pl.tiles_k = ceil_div(Ktot, pl.bn);
@@ -338,7 +339,8 @@ static size_t wgrad_ws_bytes(const evk_conv_desc* d, int x3) {
   if (!d) return 0;
   const WGradPlan pl = plan_wgrad(d, x3), pl2 = plan_wgrad(d, x3, 2);   // the f16x2 plan may split differently
   const size_t Ktot = (size_t)d->kh * d->kw * d->Cin;
-  const int sk = pl.splitk > pl2.splitk ? pl.splitk : pl2.splitk;
+  int sk = pl.splitk > pl2.splitk ? pl.splitk : pl2.splitk;
+  if (x3) { const int sk3 = plan_wgrad(d, x3, 2, 1).splitk; sk = sk > sk3 ? sk : sk3; }   // ... and the planar kernel's
   size_t a = sk > 1 ? (size_t)sk * d->Cout * Ktot * sizeof(float) : 0;
   size_t b = (size_t)colsum_blocks((int64_t)d->N * d->Ho * d->Wo) * d->Cout * sizeof(float);
   return (a > b ? a : b) + 256;
@@ -359,9 +361,13 @@ static int conv_wgrad_any(const evk_conv_desc* d, const float* x, const float* d
                   (long long)d->N * d->Ho * d->Wo * d->Cout < 0x7fffffffLL,
               EVK_E_UNSUPPORTED, "conv2d_wgrad: tensors of 2^31 or more elements are not supported");
   hipStream_t st = (hipStream_t)stream;
-  const WGradPlan pl = plan_wgrad(d, x3, planes);
+  const int planar = (pk_flags & (EVK_CONV_X_PLANAR | EVK_CONV_DY_PLANAR)) ? 1 : 0;
+  EVK_REQUIRE(!planar || ((pk_flags & EVK_CONV_X_PLANAR) && (pk_flags & EVK_CONV_DY_PLANAR) && planes == 2 && !dbias),
+              EVK_E_UNSUPPORTED, "conv2d_wgrad: planar operands come in pairs (x and dy), f16x2 only, no bias gradient");
+  const WGradPlan pl = plan_wgrad(d, x3, planes, planar);
   WGradArgs a{};
   a.planes = planes;
+  a.planar = planar;
   a.x_scale = x_scale; a.dy_scale = dy_scale;
   a.x_packed = (pk_flags & EVK_CONV_X_PACKED) ? 1 : 0;
   a.dy_packed = (pk_flags & EVK_CONV_DY_PACKED) ? 1 : 0;
@@ -377,7 +383,11 @@ static int conv_wgrad_any(const evk_conv_desc* d, const float* x, const float* d
   a.fd_w = make_fastdiv((uint32_t)d->Wo);
   a.out = pl.splitk > 1 ? (float*)workspace : dw;
   int rc;
-  if (x3) rc = launch_wgrad_x3(a, pl, st);
+  if (planar) {
+    EVK_REQUIRE(wgrad_tr_applicable(a), EVK_E_UNSUPPORTED, "conv2d_wgrad: planar operands need Cin %% 32 == 0 and Cout %% 32 == 0 "
+                "(Cin=%d Cout=%d) and tensors below 2 GiB", d->Cin, d->Cout);
+    rc = launch_wgrad_tr(a, st);
+  } else if (x3) rc = launch_wgrad_x3(a, pl, st);
   else if (pl.bm == 128 && pl.bn == 128) rc = launch_wgrad<128, 128, 2, 2>(a, st);
   else if (pl.bm == 64 && pl.bn == 128) rc = launch_wgrad<64, 128, 2, 2>(a, st);
   else if (pl.bm == 128 && pl.bn == 64) rc = launch_wgrad<128, 64, 2, 2>(a, st);
@@ -436,7 +446,7 @@ extern "C" int evk_conv2d_wgrad_f16x2_ex(const evk_conv_desc* d, const void* x, 
                                          size_t workspace_bytes, uint32_t flags, void* stream) {
   EVK_REQUIRE(d && d->Cin % 4 == 0 && d->Cout % 4 == 0, EVK_E_UNSUPPORTED, "conv2d_wgrad_f16x2_ex: channels must be multiples of 4");
   EVK_REQUIRE(x_absmax && dy_absmax, EVK_E_INVALID, "conv2d_wgrad_f16x2_ex: null scales");
-  EVK_REQUIRE((flags & ~(EVK_CONV_X_PACKED | EVK_CONV_DY_PACKED)) == 0, EVK_E_INVALID,
+  EVK_REQUIRE((flags & ~(EVK_CONV_X_PACKED | EVK_CONV_DY_PACKED | EVK_CONV_X_PLANAR | EVK_CONV_DY_PLANAR)) == 0, EVK_E_INVALID,
               "conv2d_wgrad_f16x2_ex: unknown flag 0x%x", flags);
   return conv_wgrad_any(d, reinterpret_cast<const float*>(x), reinterpret_cast<const float*>(dy), dw, dbias, workspace,
                         workspace_bytes, stream, 1, 2, x_absmax, dy_absmax, flags);

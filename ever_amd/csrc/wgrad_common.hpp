@@ -20,6 +20,7 @@ struct WGradArgs {
   const uint32_t* x_scale;   // planes == 2: bit images of max|x| and max|dy| (evk_absmax)
   const uint32_t* dy_scale;
   int x_packed, dy_packed;   // planes == 2: the operand holds packed (h | l << 16) words of value / s (x3_common.hpp)
+  int planar;                // planes == 2: BOTH operands are planar fp16 pairs (conv_wgrad_tr.hip)
   int dbg;  // EVK_WG_DBG ablation switches of the wave-specialised kernel (0 in production)
 };
 
@@ -30,8 +31,11 @@ struct WGradPlan {
   int ws;  // 1: wave-specialised 128x256 kernel (conv_wgrad_x3ws.hip)
 };
 // x3 = 1: plan for the bf16-split kernel (different LDS footprint => different residency)
-WGradPlan plan_wgrad(const evk_conv_desc* d, int x3, int planes = 3);
+// tr = 1: the planar-operand kernel (conv_wgrad_tr.hip): always the 128 x 256 tile, one workgroup per CU
+WGradPlan plan_wgrad(const evk_conv_desc* d, int x3, int planes = 3, int tr = 0);
 int launch_wgrad_x3(const WGradArgs& a, const WGradPlan& pl, hipStream_t stream);
 int launch_wgrad_x3ws(const WGradArgs& a, hipStream_t stream);
+bool wgrad_tr_applicable(const WGradArgs& a);
+int launch_wgrad_tr(const WGradArgs& a, hipStream_t stream);
 
 }  // namespace evk

@@ -59,6 +59,12 @@ typedef struct evk_conv_desc {
 /* f16x2 entry points only: that activation operand is stored PACKED (evk_pack_f16x2: one 32-bit word per element) */
 #define EVK_CONV_X_PACKED 2u
 #define EVK_CONV_DY_PACKED 4u
+/* PLANAR operands of the f16x2 arithmetic (round 3): the same (h, l) pair of value / s, stored as two fp16 planes —
+ * H[M][C] followed by L[M][C] in one allocation of the fp32 tensor's size (evk_pack_planar_f16x2).  The weight gradient
+ * then stages nothing: both operands go global -> LDS by DMA and the fragments come from transposing LDS reads
+ * (csrc/conv_wgrad_tr.hip).  Needs both flags, Cin % 32 == 0, Cout % 32 == 0, dbias == NULL. */
+#define EVK_CONV_X_PLANAR 8u
+#define EVK_CONV_DY_PLANAR 16u
 
 /* y = conv(x, w) (+ bias).  w: [Cout][kh][kw][Cin].  bias may be NULL.
  * Implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32), im2col rows gathered to LDS. */
@@ -176,6 +182,10 @@ int evk_conv2d_wgrad_f16x2(const evk_conv_desc* d, const float* x, const uint32_
  * (dbias must be NULL with EVK_CONV_DY_PACKED). */
 int evk_pack_f16x2(const float* x, int64_t n, const uint32_t* x_absmax, uint32_t* out, void* stream);
 int evk_unpack_f16x2(const uint32_t* packed, int64_t n, const uint32_t* x_absmax, float* out, void* stream);
+/* planar form (EVK_CONV_*_PLANAR): n % 8 == 0; `out` / `planar` hold n fp16 of h followed by n fp16 of l (4 n bytes).
+ * Replaces nothing in the reference: operand preparation of this build's arithmetic, as evk_pack_f16x2. */
+int evk_pack_planar_f16x2(const float* x, int64_t n, const uint32_t* x_absmax, void* out, void* stream);
+int evk_unpack_planar_f16x2(const void* planar, int64_t n, const uint32_t* x_absmax, float* out, void* stream);
 int evk_conv2d_dgrad_f16x2_ex(const evk_conv_desc* d, const void* dy, const uint32_t* dy_absmax, const void* wsplit_t,
                               const uint32_t* w_absmax, const float* accum, float* dx, uint32_t* dx_absmax,
                               uint32_t flags, void* stream);
