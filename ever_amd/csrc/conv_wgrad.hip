@@ -283,7 +283,7 @@ WGradPlan plan_wgrad(const evk_conv_desc* d, int x3, int planes, int tr) {
   if (tr) { pl.ws = 1; pl.bm = 128; }
   if (pl.ws) pl.bn = 256;
   pl.tiles_co = ceil_div(d->Cout, pl.bm);
-  pl.tiles_k = ceil_div(Ktot, pl.bn);
+  pl.tiles_k = tr == 2 ? d->Cin / 64 : ceil_div(Ktot, pl.bn);
   const int tiles = pl.tiles_co * pl.tiles_k;
   // Split the pixel reduction so that the grid fills WHOLE rounds of the machine: slots = 256 CUs x
   // resident workgroups per CU (LDS-limited: 64 KB tiles -> 2, 48 KB -> 3, 32 KB -> 4).  A grid of
@@ -340,7 +340,9 @@ static size_t wgrad_ws_bytes(const evk_conv_desc* d, int x3) {
   const WGradPlan pl = plan_wgrad(d, x3), pl2 = plan_wgrad(d, x3, 2);   // the f16x2 plan may split differently
   const size_t Ktot = (size_t)d->kh * d->kw * d->Cin;
   int sk = pl.splitk > pl2.splitk ? pl.splitk : pl2.splitk;
-  if (x3) { const int sk3 = plan_wgrad(d, x3, 2, 1).splitk; sk = sk > sk3 ? sk : sk3; }   // ... and the planar kernel's
+  if (x3 && d->Cin % 64 == 0) {   // ... and the planar kernels'
+    for (int tr = 1; tr <= 2; ++tr) { const int sk3 = plan_wgrad(d, x3, 2, tr).splitk; sk = sk > sk3 ? sk : sk3; }
+  }
   size_t a = sk > 1 ? (size_t)sk * d->Cout * Ktot * sizeof(float) : 0;
   size_t b = (size_t)colsum_blocks((int64_t)d->N * d->Ho * d->Wo) * d->Cout * sizeof(float);
   return (a > b ? a : b) + 256;
@@ -364,7 +366,8 @@ static int conv_wgrad_any(const evk_conv_desc* d, const float* x, const float* d
   const int planar = (pk_flags & (EVK_CONV_X_PLANAR | EVK_CONV_DY_PLANAR)) ? 1 : 0;
   EVK_REQUIRE(!planar || ((pk_flags & EVK_CONV_X_PLANAR) && (pk_flags & EVK_CONV_DY_PLANAR) && planes == 2 && !dbias),
               EVK_E_UNSUPPORTED, "conv2d_wgrad: planar operands come in pairs (x and dy), f16x2 only, no bias gradient");
-  const WGradPlan pl = plan_wgrad(d, x3, planes, planar);
+  const int nine = planar && wgrad_tr_nine_tap(d) ? 1 : 0;
+  const WGradPlan pl = plan_wgrad(d, x3, planes, planar ? 1 + nine : 0);
   WGradArgs a{};
   a.planes = planes;
   a.planar = planar;
@@ -384,9 +387,9 @@ static int conv_wgrad_any(const evk_conv_desc* d, const float* x, const float* d
   a.out = pl.splitk > 1 ? (float*)workspace : dw;
   int rc;
   if (planar) {
-    EVK_REQUIRE(wgrad_tr_applicable(a), EVK_E_UNSUPPORTED, "conv2d_wgrad: planar operands need Cin %% 32 == 0 and Cout %% 32 == 0 "
+    EVK_REQUIRE(wgrad_tr_applicable(a), EVK_E_UNSUPPORTED, "conv2d_wgrad: planar operands need Cin %% 64 == 0 and Cout %% 64 == 0 "
                 "(Cin=%d Cout=%d) and tensors below 2 GiB", d->Cin, d->Cout);
-    rc = launch_wgrad_tr(a, st);
+    rc = launch_wgrad_tr(a, nine, st);
   } else if (x3) rc = launch_wgrad_x3(a, pl, st);
   else if (pl.bm == 128 && pl.bn == 128) rc = launch_wgrad<128, 128, 2, 2>(a, st);
   else if (pl.bm == 64 && pl.bn == 128) rc = launch_wgrad<64, 128, 2, 2>(a, st);

@@ -31,11 +31,13 @@ struct WGradPlan {
   int ws;  // 1: wave-specialised 128x256 kernel (conv_wgrad_x3ws.hip)
 };
 // x3 = 1: plan for the bf16-split kernel (different LDS footprint => different residency)
-// tr = 1: the planar-operand kernel (conv_wgrad_tr.hip): always the 128 x 256 tile, one workgroup per CU
+// tr = 1 / 2: the planar-operand kernel (conv_wgrad_tr.hip), one workgroup per CU: 128 x 256 tile / nine-tap form
+// (128 output channels x 9 taps x 64 input channels per tile)
 WGradPlan plan_wgrad(const evk_conv_desc* d, int x3, int planes = 3, int tr = 0);
 int launch_wgrad_x3(const WGradArgs& a, const WGradPlan& pl, hipStream_t stream);
 int launch_wgrad_x3ws(const WGradArgs& a, hipStream_t stream);
 bool wgrad_tr_applicable(const WGradArgs& a);
-int launch_wgrad_tr(const WGradArgs& a, hipStream_t stream);
+bool wgrad_tr_nine_tap(const evk_conv_desc* d);
+int launch_wgrad_tr(const WGradArgs& a, int nine_tap, hipStream_t stream);
 
 }  // namespace evk

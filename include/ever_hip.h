@@ -62,7 +62,7 @@ typedef struct evk_conv_desc {
 /* PLANAR operands of the f16x2 arithmetic (round 3): the same (h, l) pair of value / s, stored as two fp16 planes —
  * H[M][C] followed by L[M][C] in one allocation of the fp32 tensor's size (evk_pack_planar_f16x2).  The weight gradient
  * then stages nothing: both operands go global -> LDS by DMA and the fragments come from transposing LDS reads
- * (csrc/conv_wgrad_tr.hip).  Needs both flags, Cin % 32 == 0, Cout % 32 == 0, dbias == NULL. */
+ * (csrc/conv_wgrad_tr.hip).  Needs both flags, Cin % 64 == 0, Cout % 64 == 0, dbias == NULL. */
 #define EVK_CONV_X_PLANAR 8u
 #define EVK_CONV_DY_PLANAR 16u
 

@@ -21,7 +21,7 @@ SHAPES = [(128, 256, 256, 3, 1), (64, 256, 256, 3, 1), (32, 256, 256, 3, 1), (16
           (32, 1024, 256, 1, 1), (16, 2048, 512, 1, 1), (16, 512, 2048, 1, 1), (128, 256, 256, 1, 1), (64, 128, 128, 3, 1),
           (128, 64, 64, 3, 1), (64, 256, 512, 1, 2), (128, 128, 128, 3, 2)]
 if len(sys.argv) > 1 and sys.argv[1] == 'quick':
-    SHAPES = SHAPES[:3] + [(20, 64, 96, 3, 1), (24, 128, 160, 1, 2)]
+    SHAPES = SHAPES[:3] + [(24, 64, 128, 3, 1), (20, 128, 192, 3, 1), (32, 128, 192, 1, 2)]
 tot_p = tot_t = 0.0
 for (h, cin, cout, k, s) in SHAPES:
     pad = k // 2
