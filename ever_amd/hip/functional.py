@@ -210,6 +210,22 @@ def _wgrad_pack_pays(flops, x_elems, dy_elems):
     return gain * t_kernel - t_pack > _WGRAD_PACK_MARGIN * t_kernel
 
 
+_WGRAD_TR = os.environ.get('EVK_WGRAD_TR', '1') != '0'
+_WGRAD_TR_MIN_HW = int(os.environ.get('EVK_WGRAD_TR_MIN_HW', str(128 * 128)))
+
+
+def _wgrad_planar_pays(d, need_db=False):
+    """The planar-operand weight gradient (csrc/conv_wgrad_tr.hip: DMA + transposing LDS reads, nine-tap halo form) behind
+    a stand-alone planar pack of both operands?  Measured (tools/ab_wgrad_tr.py, 3x3x256 x16): @128^2 966 -> 764 us, @64^2
+    209 -> 200, @32^2 65 -> 72: it pays where the pixel reduction is long — 3x3 / stride 1 / padding 1 on maps of at least
+    EVK_WGRAD_TR_MIN_HW pixels (FarSeg-R50 at 512^2: the FPN and decoder convolutions on the 128^2 maps; at 1024^2 also the
+    256^2 ones), wide enough for its 128 x (9 x 64) tile."""
+    return (_WGRAD_TR and _f16x2() and not need_db and d.kh == 3 and d.kw == 3 and d.stride_h == 1 and d.stride_w == 1
+            and d.pad_h == 1 and d.pad_w == 1 and d.dil_h == 1 and d.dil_w == 1 and d.W % 32 == 0 and d.Cin % 64 == 0
+            and d.Cout % 64 == 0 and d.Cout >= 128 and d.H * d.W >= _WGRAD_TR_MIN_HW
+            and d.N * d.H * d.W * max(d.Cin, d.Cout) * 4 < 2 ** 31)
+
+
 def _is_packed(t):
     hit = getattr(t, '_evk_packed', None)
     return hit is not None and hit[0] == t._version and hit[1] == t.data_ptr()
@@ -453,8 +469,10 @@ def _conv_forward(x, weight, bias, stride, padding, dilation, relu, want_stats=F
         if nparts.value > 0:
             # third field: this convolution's backward takes its dy packed (the BatchNorm that consumes the records is
             # the ONLY reader of y — conv2d(bn_stats=True)'s contract — so its dx has no other reader either)
+            # (the planar weight gradient packs both operands itself: its BatchNorm's dx stays fp32)
             bn_parts = (parts, int(nparts.value),
-                        _PACKED and wabs_ptr is not None and bias is None and cout % 8 == 0 and not observers_active())
+                        _PACKED and wabs_ptr is not None and bias is None and cout % 8 == 0 and not observers_active()
+                        and not _wgrad_planar_pays(d))
     else:
         sp = timing.span('conv_igemm_f32', cs.flops, cs.abytes)
         _C.call('evk_conv2d_fwd', ctypes.byref(d), x_ptr, w_ptr, _ptr(bias), y.data_ptr(), 1 if relu else 0, st)
@@ -575,7 +593,13 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False)
             xbits, dybits = absmax_bits(xk, st), absmax_bits(dyk, st)
             x_pk = _is_packed(xk)
             xw_ptr, dyw_ptr, _tmp = xk.data_ptr(), dy_ptr, None
-            if _PACKED and not need_db and cout_p == cout and _wgrad_pack_pays(cs.flops, 0 if x_pk else xk.numel(),
+            planar = 0
+            if cout_p == cout and cin_p == cin and not x_pk and not dy_pk and _wgrad_planar_pays(dk, need_db):
+                xq, dq = torch.empty_like(xk), torch.empty_like(dyk)
+                _C.call('evk_pack_planar_f16x2', xk.data_ptr(), xk.numel(), xbits.data_ptr(), xq.data_ptr(), st)
+                _C.call('evk_pack_planar_f16x2', dy_ptr, dyk.numel(), dybits.data_ptr(), dq.data_ptr(), st)
+                xw_ptr, dyw_ptr, _tmp, planar = xq.data_ptr(), dq.data_ptr(), [xq, dq], 8 | 16
+            elif _PACKED and not need_db and cout_p == cout and _wgrad_pack_pays(cs.flops, 0 if x_pk else xk.numel(),
                                                                              0 if dy_pk else dyk.numel()):
                 # the kernel's bound is the split of its operands while staging (each element is staged by many
                 # workgroups): where the matrix work per byte is high, one streaming pass that stores them split first
@@ -591,7 +615,8 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False)
                     dyw_ptr, dy_pk = dp.data_ptr(), True
                     _tmp.append(dp)
             _C.call('evk_conv2d_wgrad_f16x2_ex', ctypes.byref(dk), xw_ptr, xbits.data_ptr(), dyw_ptr, dybits.data_ptr(),
-                    dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes, (2 if x_pk else 0) | (4 if dy_pk else 0), st)
+                    dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes,
+                    planar if planar else ((2 if x_pk else 0) | (4 if dy_pk else 0)), st)
         else:
             _C.call(_entry('evk_conv2d_wgrad_x3') if x3 else 'evk_conv2d_wgrad', ctypes.byref(dk), xk.data_ptr(), dy_ptr,
                     dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes, st)
