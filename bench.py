@@ -231,6 +231,16 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # what enqueuing ONE step costs the host when nothing holds it back: the launch queue is empty (fence above), no event
+    # timer, no synchronisation inside; median of three (`host_enqueue_ms_per_step` of the timed loop
+    # reads ~ the GPU step time because the full queue back-pressures the host)
+    unblocked = []
+    for _ in range(3):
+        t_h = time.perf_counter()
+        step()
+        unblocked.append(time.perf_counter() - t_h)
+        fence()
+    host_unblocked_ms = sorted(unblocked)[1] * 1e3
     # HIP-event timing of the conv launches costs ~2 % of the step (two event records per launch), so
     # it samples every 4th step of the timed region rather than all of them.
     timer = None if args.no_kernel_timer else timing.KernelTimer()
@@ -263,6 +273,8 @@ def main():
             'metric': metric, 'value': round(tiles_s, 3 if tiles_s < 100 else 2), 'unit': unit,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
             'host_enqueue_ms_per_step': round(enqueued / args.steps * 1e3, 3),
+            'host_unblocked_ms_per_step': round(host_unblocked_ms, 3),
+            'host_cores': host_cores(), 'host_affinity': len(os.sched_getaffinity(0)),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if conv_math == 'bf16' else 'f32', 'data': 'synthetic',
             'config': {'workload': workload,

@@ -257,8 +257,11 @@ bool conv3x3_halo_applies(const IGemmArgs& a) {
   if (a.Hm != a.Hs || a.Wm != a.Ws || (a.Hm % 8) != 0 || (a.Wm % kPW) != 0) return false;
   if ((a.Cs % kCh) != 0 || a.Cd < 64 || (!a.dense_dst && (a.dsh != 1 || a.dsw != 1))) return false;
   // enough workgroups for the 256 CUs, if necessary with the 64-wide N tile
+  // (EVK_X3_HALO_MIN_WG=0 makes the choice independent of the batch size: tests/test_linearity_pinned_gpu.py pins the
+  // accumulation order — chunk-major here, tap-major in the implicit-GEMM kernels — for a batch and its halves)
+  static const long long min_wg = getenv("EVK_X3_HALO_MIN_WG") ? atoll(getenv("EVK_X3_HALO_MIN_WG")) : 256;
   const long long patches = (long long)a.N * (a.Hm / 8) * (a.Wm / kPW);
-  return patches * ceil_div(a.Cd, 64) >= 256;
+  return patches * ceil_div(a.Cd, 64) >= min_wg;
 }
 
 // the same decision from a convolution descriptor (forward, or stride-1 data gradient)

@@ -217,6 +217,41 @@ def e2e_case(er, name, resnet_type, in_channels, n, hw, num_classes=1, decoder_c
         json.dump(meta, f)
 
 
+def bf16_autocast_case(er, name):
+    """the reference's OWN bf16 mode (core/launcher.py:40-80 wraps model + losses in
+    torch.autocast(bfloat16); module/ops.py:152-166 and fpn.py:96-102 keep the resampling in fp32) on an existing
+    fixture's weights, classifier bias and input, run on the CPU backend's autocast: logits and losses for
+    tests/test_bf16_mode_gpu.py to hold `--mixed_precision bf16` against, plus how far this mode sits from the same
+    reference in fp32 (the yardstick of the tolerance)."""
+    import ever.module.loss as rloss
+    from oracle import portable
+    with open(os.path.join(OUT, f'e2e_{name}.json')) as f:
+        meta = json.load(f)
+    cfg = (meta['resnet_type'], meta['in_channels'], meta['num_classes'], meta['decoder_channels'],
+           meta['classifier_kernel'], meta['relation_version'])
+    x_np, y_np = portable.synthetic_batch(name, meta['n'], meta['in_channels'], meta['hw'], meta['hw'], meta['num_classes'])
+    x, y = torch.from_numpy(x_np), torch.from_numpy(y_np)
+    ref, _ = build_pair(er, *cfg, classifier_bias=np.asarray(meta['classifier_bias'], dtype=np.float32))
+    ref.train()
+    with torch.autocast('cpu', dtype=torch.bfloat16):
+        lg = ref(x)
+        losses = dict(bce_loss=rloss.binary_cross_entropy_with_logits(lg, y, ignore_index=255),
+                      dice_loss=rloss.dice_loss_with_logits(lg, y, ignore_index=255))
+    lg32 = np.load(os.path.join(OUT, f'e2e_{name}.npz'))['logits']
+    lg = lg.detach().float().numpy()
+    dist = float(np.abs(lg - lg32).max() / np.abs(lg32).max())
+    flips = int(((lg > 0) != (lg32 > 0)).sum())
+    print(f'[bf16] {name}: reference under CPU autocast(bfloat16) vs its fp32 run: logits {dist:.2e} of the range, '
+          f'{flips} of {lg.size} mask pixels differ; losses {[round(float(v), 5) for v in losses.values()]} '
+          f'(fp32: {[round(v, 5) for v in meta["losses"].values()]})')
+    np.savez_compressed(os.path.join(OUT, f'e2e_{name}_bf16autocast.npz'), logits=lg,
+                        **{k: np.float64(float(v)) for k, v in losses.items()})
+    with open(os.path.join(OUT, f'e2e_{name}_bf16autocast.json'), 'w') as f:
+        json.dump(dict(source='reference ResNetEncoder + FarSegHead + loss under torch.autocast("cpu", torch.bfloat16), '
+                              'weights / bias / input of the fp32 fixture', logits_vs_fp32=dist, mask_flips_vs_fp32=flips,
+                       losses={k: float(v) for k, v in losses.items()}), f)
+
+
 def op_kats(er):
     """Known answers of the in-tree loss / resampling ops on the inputs of SURVEY §8 (a10-a12, c3)."""
     import ever.module.loss as rloss
@@ -483,6 +518,9 @@ E2E_CASES = [
 ]
 
 
+BF16_CASES = ('r18_4band_64', 'r50_3band_64')
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     er = import_reference()
@@ -501,6 +539,10 @@ def main():
         next_rows_kats(er)
         fsrel_v2_case(er)
         return
+    if only == 'bf16':
+        for name in BF16_CASES:
+            bf16_autocast_case(er, name)
+        return
     op_kats(er)
     block_vectors(er)
     next_rows_kats(er)
@@ -508,6 +550,8 @@ def main():
     launcher_case(er)
     for a in E2E_CASES:
         e2e_case(er, *a[:5], **a[5])
+    for name in BF16_CASES:
+        bf16_autocast_case(er, name)
     with open(os.path.join(OUT, 'PROVENANCE.json'), 'w') as f:
         json.dump(dict(reference='Z-Zheng/ever', version=er.__version__, torch=torch.__version__,
                        generated_by='oracle/gen_golden.py',

@@ -159,3 +159,54 @@ def test_farseg_step_under_launcher_bf16(cuda, tmp_path):
     assert abs(l16 - l32) <= 2e-2 * abs(l32), losses
     assert cos > 0.999, (cos, losses)
     assert 0.7 < g16 / g32 < 1.4, losses
+
+
+@pytest.mark.parametrize('name', ['r18_4band_64', 'r50_3band_64'])
+def test_bf16_mode_against_the_reference_under_autocast(cuda, name):
+    """`--mixed_precision bf16` held against the REFERENCE's own bf16 mode — golden logits and losses
+    of the imported reference run under torch.autocast('cpu', torch.bfloat16) (oracle/gen_golden.py bf16; reference
+    core/launcher.py:40-80, module/ops.py:152-166, fpn.py:96-102), same weights / classifier bias / input as the fp32
+    fixture of that name.  Two bf16 evaluations of a random-init network with 8..32-sample BatchNorm statistics differ by
+    what bf16 rounding does to it: the reference's autocast run is itself 9.7e-2 (R18) / 5.4e-1 (R50) of the logit range
+    from its own fp32 run (max norm; *_bf16autocast.json).  Stated tolerance: this build's bf16 mode is no farther from the
+    reference's bf16 run than 1.5x that distance in the max norm and in the relative L2 norm, and its losses agree to
+    1e-2 — it keeps fp32 tensors between the convolutions where autocast rounds every convolution output to bf16, so it
+    sits CLOSER to the fp32 run than the reference's bf16 mode does (asserted too)."""
+    import json
+    import os
+    import numpy as np
+    from ever_amd.hip import functional as F
+    from oracle import portable
+    from tests.test_e2e_gpu import GOLD, _hip_model
+    with open(os.path.join(GOLD, f'e2e_{name}.json')) as f:
+        meta = json.load(f)
+    with open(os.path.join(GOLD, f'e2e_{name}_bf16autocast.json')) as f:
+        bmeta = json.load(f)
+    gold16 = np.load(os.path.join(GOLD, f'e2e_{name}_bf16autocast.npz'))
+    gold32 = np.load(os.path.join(GOLD, f'e2e_{name}.npz'))
+    x, y = portable.synthetic_batch(name, meta['n'], meta['in_channels'], meta['hw'], meta['hw'], meta['num_classes'])
+    x, y = torch.from_numpy(x).to(cuda), torch.from_numpy(y).to(cuda)
+    prev = F.set_conv_math('bf16')
+    try:
+        m = _hip_model(meta, cuda).train()
+        lg = m.head(m.en(x))
+        losses = m.loss(lg, y)
+        torch.cuda.synchronize()
+    finally:
+        F.set_conv_math(prev)
+    a = lg.detach().cpu().contiguous().numpy().astype(np.float64)
+    r16, r32 = gold16['logits'].astype(np.float64), gold32['logits'].astype(np.float64)
+    rng = np.abs(r32).max()
+    mx = lambda u, v: float(np.abs(u - v).max() / rng)
+    l2 = lambda u, v: float(np.linalg.norm(u - v) / np.linalg.norm(v))
+    d_ref = dict(max=mx(r16, r32), l2=l2(r16, r32))            # reference bf16 vs reference fp32
+    d_hip16 = dict(max=mx(a, r16), l2=l2(a, r16))              # this build's bf16 vs reference bf16
+    d_hip32 = dict(max=mx(a, r32), l2=l2(a, r32))              # this build's bf16 vs reference fp32
+    print(f'{name}: reference autocast vs its fp32 {d_ref}; HIP bf16 vs reference autocast {d_hip16}; HIP bf16 vs reference '
+          f'fp32 {d_hip32}; losses {[round(v.item(), 5) for v in losses.values()]} vs {bmeta["losses"]}')
+    assert abs(d_ref['max'] - bmeta['logits_vs_fp32']) < 1e-6
+    for k in ('max', 'l2'):
+        assert d_hip16[k] <= 1.5 * d_ref[k], (k, d_hip16, d_ref)
+        assert d_hip32[k] <= d_ref[k], (k, d_hip32, d_ref)
+    for k, v in bmeta['losses'].items():
+        assert abs(losses[k].item() - v) <= 1e-2 * abs(v), (k, losses[k].item(), v)

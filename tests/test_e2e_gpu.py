@@ -43,7 +43,7 @@ def _rel_err(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-def _check_masks(lg, ref, num_classes, what, exact=False):
+def _check_masks(lg, ref, num_classes, what, exact=False, pinned=None):
     """Prediction masks (threshold 0 for one logit channel, argmax otherwise).
 
     exact=True (the committed training-mode goldens): BIT-EXACT, zero flipped pixels.  Those fixtures' classifier
@@ -52,7 +52,10 @@ def _check_masks(lg, ref, num_classes, what, exact=False):
     continuous logit field over 1e4..1e5 pixels has tens of pixels inside +-1e-3 of the range, so 'no pixel inside
     the contract margin' is not attainable by choosing inputs; 'no pixel inside the rounding noise' is, and is pinned.
     exact=False (eval-mode logits, live-oracle sizes — no margin was engineered): identical on every pixel the
-    reference decides by more than the contract tolerance (1e-3 of the logit range); flips inside are reported."""
+    reference decides by more than the contract tolerance (1e-3 of the logit range); flips inside are reported.
+    pinned=N: additionally at most N flipped pixels — the count observed on MI355X when the pin was
+    set (round 3: 0 on every deterministic fixture under the default arithmetic), a regression value for the pixels INSIDE
+    the margin."""
     tol = 1e-3 * np.abs(ref).max()
     if num_classes == 1:
         ma, mb = lg > 0, ref > 0
@@ -69,6 +72,8 @@ def _check_masks(lg, ref, num_classes, what, exact=False):
         assert flips == 0, (f'{what}: {flips} mask pixels differ from the reference (smallest reference margin '
                             f'{margin.min() / np.abs(ref).max():.2e} of the logit range)')
     assert flips <= ties, f'{what}: {flips} mask flips but only {ties} pixels within the tie margin'
+    if pinned is not None:
+        assert flips <= pinned, f'{what}: {flips} mask flips inside the tie margin, pinned at {pinned}'
     print(f'{what}: masks identical on {int(decided.sum())}/{decided.size} decided pixels; '
           f'{ties} pixels inside the 1e-3 tie margin, {flips} of them flipped; smallest reference margin '
           f'{margin.min() / np.abs(ref).max():.2e}, largest logit difference {np.abs(lg - ref).max() / np.abs(ref).max():.2e} '
@@ -101,7 +106,9 @@ def test_farseg_matches_reference_golden(cuda, name, conv_math):
     assert _rel_err(lg_np, gold['logits']) < 1e-3, f'logits rel err {_rel_err(lg_np, gold["logits"]):.2e}'
     # bit-exact wherever the fixture's smallest margin is above the rounding noise (every golden but the 131072-pixel
     # gradient fixture, whose widest empty interval is only 6e-5 of the range)
-    _check_masks(lg_np, gold['logits'], meta['num_classes'], name, exact=meta['min_margin_rel'] >= 1e-4)
+    # (the 256^2 fixture: 99 of 131072 pixels inside the margin; flips observed: 0 under f16x2 and f32, 2 under bf16x3)
+    _check_masks(lg_np, gold['logits'], meta['num_classes'], name, exact=meta['min_margin_rel'] >= 1e-4,
+                 pinned={'f16x2': 0, 'bf16x3': 2, 'f32': 0}[conv_math])
     for k, v in meta['losses'].items():
         assert abs(losses[k].item() - v) <= 1e-3 * abs(v), (k, losses[k].item(), v)
     # Gradients.  The backward of a ReLU / max-pool network is DISCONTINUOUS in its activations: a
@@ -159,7 +166,7 @@ def test_farseg_matches_reference_golden(cuda, name, conv_math):
     with torch.no_grad():
         lg_eval = m.head(m.en(x)).cpu().contiguous().numpy()
     assert _rel_err(lg_eval, gold['logits_eval']) < 1e-3
-    _check_masks(lg_eval, gold['logits_eval'], meta['num_classes'], name + ' (eval)')
+    _check_masks(lg_eval, gold['logits_eval'], meta['num_classes'], name + ' (eval)', pinned=0)   # observed 0, all three
 
 
 def test_farseg_matches_oracle_larger_tile(cuda):
@@ -191,7 +198,7 @@ def test_farseg_matches_oracle_larger_tile(cuda):
     sum(out.values()).backward()
     lg = lg.detach().cpu().contiguous().numpy()
     assert _rel_err(lg, logits[torch.float32]) < 1e-3
-    _check_masks(lg, logits[torch.float32], 1, 'oracle256')
+    _check_masks(lg, logits[torch.float32], 1, 'oracle256', pinned=8)   # 217 pixels inside the margin (min 3.8e-6): 4 flipped
     e_hip, e_o32 = _rel_err(lg, logits[torch.float64]), _rel_err(logits[torch.float32], logits[torch.float64])
     print(f'logits vs fp64 truth: HIP {e_hip:.2e}, fp32 oracle {e_o32:.2e}')
     for k, v in losses[torch.float32].items():
@@ -235,7 +242,7 @@ def test_folded_batchnorm_inference_matches_unfolded_and_reference(cuda, conv_ma
         folded = m.head(m.en(x)).cpu().contiguous().numpy()
     assert _rel_err(folded, plain) < 2e-5, _rel_err(folded, plain)
     assert _rel_err(folded, gold['logits_eval']) < 1e-3
-    _check_masks(folded, gold['logits_eval'], meta['num_classes'], name + ' (folded eval)')
+    _check_masks(folded, gold['logits_eval'], meta['num_classes'], name + ' (folded eval)', pinned=0)
     m.train()                                                # training is untouched by the folded copies
     lg = m.head(m.en(x))
     assert _rel_err(lg.detach().cpu().contiguous().numpy(), gold['logits']) < 5e-2  # second step: statistics moved on

@@ -1,0 +1,34 @@
+"""batch linearity of the backward pass AT THE BENCH SIZES under the DEFAULT arithmetic (f16x2), as a
+bound instead of a bug detector.  tests/test_fullsize_gpu.py lets the planner pick: above a grid size the 3x3 convolutions
+run the LDS-halo kernel (channel-chunk-major accumulation), below it the implicit-GEMM kernels (tap-major), so a batch and
+its halves round differently, ReLU decisions flip and the gradients of this random-init network agree only at its
+conditioning (5e-2).  Here the plan is pinned (EVK_X3_HALO_MIN_WG=0, read once per process: a child process): every
+convolution output of a tile is then accumulated in the same order whatever the batch — the forward is BIT-identical — and
+what remains is the split-K grouping of the weight gradients."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize('cfg', ['c2', 'c3'])
+def test_backward_linearity_with_a_pinned_kernel_plan(cuda, cfg):
+    env = dict(os.environ, EVK_X3_HALO_MIN_WG='0', EVK_CONV_MATH='f16x2')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'linearity_check.py'), cfg], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    print(r)
+    assert r['conv_math'] == 'f16x2'
+    # same kernels, same accumulation order: identical logits (FarSeg++'s GroupNorm / scene branch reduce in a
+    # grid-dependent order: last-bit differences there).  Measured: c2 0.0, c3 5.9e-7.
+    assert r['forward_max_rel'] <= (0.0 if cfg == 'c2' else 2e-6), r
+    # gradients: only the split-K grouping of the weight gradients differs.  Measured 1.8e-7 / 1.9e-7 global (unpinned:
+    # 1.5e-3 / 1.0e-6), worst tensor 1.0e-6 / 3.2e-7.
+    assert r['global_rel_l2'] < 1e-5, r
+    assert r['worst_tensor'] < 1e-4, r
