@@ -68,6 +68,7 @@ SIGNATURES = {
     'evk_pack_planar_f16x2': (c_int, [P, c_i64, P, P, P]),
     'evk_unpack_planar_f16x2': (c_int, [P, c_i64, P, P, P]),
     'evk_conv2d_dgrad_f16x2_ex': (c_int, [_DP, P, P, P, P, P, P, P, c_u32, P]),
+    'evk_conv2d_dgrad_f16x2_masked': (c_int, [_DP, P, P, P, P, P, P, P, P, c_u32, P]),
     'evk_conv2d_wgrad_f16x2_ex': (c_int, [_DP, P, P, P, P, P, P, P, c_size_t, c_u32, P]),
     'evk_conv_transpose2d_fwd': (c_int, [_DP, P, P, P, P, P]),
     'evk_conv_transpose2d_fwd_x3': (c_int, [_DP, P, P, P, P, P]),
@@ -92,11 +93,15 @@ SIGNATURES = {
     'evk_bn_workspace_bytes': (c_size_t, [c_i64, c_i32]),
     'evk_bn_fwd_train': (c_int, [P, P, P, P, P, P, c_f32, c_f32, P, P, P, c_i64, c_i32, c_u32, P, c_size_t, P, P]),
     'evk_bn_fwd_train_parts': (c_int, [P, P, P, P, P, P, c_f32, c_f32, P, P, P, c_i64, c_i32, c_u32, P, c_i32, P, c_size_t, P, P]),
+    'evk_bn_fwd_train_parts_bits': (c_int, [P, P, P, P, P, P, c_f32, c_f32, P, P, P, c_i64, c_i32, c_u32, P, c_i32, P, c_size_t, P, P, P]),
+    'evk_relu_bits_bytes': (c_size_t, [c_i64]),
+    'evk_relu_bits_apply': (c_int, [P, P, P, c_i64, P]),
     'evk_bn_fwd_eval': (c_int, [P, P, P, P, P, P, c_f32, P, P, P, c_i64, c_i32, c_u32, P, c_size_t, P, P]),
     'evk_bn_relu_pool_fwd_train_parts': (c_int, [P, P, P, P, P, c_f32, c_f32, P, P, P, P, c_i32, c_i32, c_i32, c_i32, P, c_i32,
                                                  P, c_size_t, P, P]),
     'evk_bn_relu_pool_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, P, c_size_t, P, P]),
     'evk_bn_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_i64, c_i32, c_u32, c_i32, P, c_size_t, P, P]),
+    'evk_bn_bwd_bits': (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_i64, c_i32, c_u32, c_i32, P, c_size_t, P, P, P]),
     'evk_relu_fwd': (c_int, [P, P, c_i64, P]),
     'evk_relu_bwd': (c_int, [P, P, P, c_i64, P]),
     'evk_add': (c_int, [P, P, P, c_i64, P]),

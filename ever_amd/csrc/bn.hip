@@ -220,7 +220,8 @@ __device__ __forceinline__ void block_absmax(const f32x4 v, bool valid, uint32_t
 template <bool PK = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ residual,
                                                        const float* __restrict__ scale_shift, float* __restrict__ y,
-                                                       size_t n4, int C, int relu, uint32_t* __restrict__ amax) {
+                                                       size_t n4, int C, int relu, uint32_t* __restrict__ amax,
+                                                       uint32_t* __restrict__ relu_bits = nullptr) {
   const size_t base = (size_t)blockIdx.x * 256;
   const size_t i = base + threadIdx.x;
   const bool valid = i < n4;
@@ -234,6 +235,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     const f32x4 sh = reinterpret_cast<const f32x4*>(scale_shift + C)[cb];
     v = reinterpret_cast<const f32x4*>(x)[i] * sc + sh;
     if (residual) v += reinterpret_cast<const f32x4*>(residual)[i];
+  }
+  // the backward's mask, one bit per element (common.hpp: relu_bits_*): every lane of the wave takes part (v = 0 where
+  // the element does not exist), i >> 6 is this wave's chunk
+  if (relu_bits) relu_bits_store(relu_bits, i >> 6, v.x > 0.f, v.y > 0.f, v.z > 0.f, v.w > 0.f);
+  if (valid) {
     if (relu) {
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
@@ -261,9 +267,11 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
                                                              float* __restrict__ d_residual,
                                                              float* __restrict__ partial, int64_t rows, int C,
                                                              int64_t rows_per_blk, int tpc, int rl, int relu,
-                                                             float* __restrict__ pmax) {
+                                                             float* __restrict__ pmax,
+                                                             const uint32_t* __restrict__ bits = nullptr) {
   // relu: 0 none, 1 mask from the saved output y, 2 mask recomputed from x (no residual: the
-  // forward's pre-activation is x*sc+sh with the same sc/sh arithmetic as bn_stats_final_kernel)
+  // forward's pre-activation is x*sc+sh with the same sc/sh arithmetic as bn_stats_final_kernel), 3 mask from `bits`
+  // (common.hpp: relu_bits_*: the forward's own bits, or the mask of a gradient that arrives unmasked — EVK_BN_LAZY_RES)
   __shared__ f32x4 red[2][256];
   const int c4 = C >> 2;
   const int tc = threadIdx.x % tpc, tr = threadIdx.x / tpc;
@@ -285,7 +293,9 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     if (tr < rl) {
       auto one = [&](const f32x4 gin, const f32x4 xv, const f32x4 yin, size_t off) {
         f32x4 g = gin;
-        if (relu) {
+        if (relu == 3) {
+          g = relu_bits_mask(g, bits, off >> 2);
+        } else if (relu) {
           const f32x4 yy = (relu == 1) ? yin : xv * sc + sh;
           g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
           g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
@@ -438,7 +448,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ coef,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ dx,
-                                                           size_t n4, int C, int relu, uint32_t* __restrict__ amax) {
+                                                           size_t n4, int C, int relu, uint32_t* __restrict__ amax,
+                                                           const uint32_t* __restrict__ bits = nullptr) {
   const size_t base = (size_t)blockIdx.x * 256;
   const size_t i = base + threadIdx.x;
   const bool valid = i < n4;
@@ -456,7 +467,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[c];
     f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
     const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
-    if (relu) {
+    if (relu == 3) {
+      g = relu_bits_mask(g, bits, i);
+    } else if (relu) {
       f32x4 yy;
       if (relu == 1) {
         yy = reinterpret_cast<const f32x4*>(y)[i];
@@ -957,7 +970,8 @@ __global__ __launch_bounds__(kFusedThreads) void bn_bwd_fused_kernel(
     const float* __restrict__ beta, float* __restrict__ dx, float* __restrict__ d_residual,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ partial, float* __restrict__ coef,
     float* __restrict__ pmax, int64_t rows, int C, int rows_per_wg, int tpc, int rl, int cpw, int relu, int train,
-    double inv_rows, uint32_t* __restrict__ amax, uint32_t* __restrict__ counter) {
+    double inv_rows, uint32_t* __restrict__ amax, uint32_t* __restrict__ counter,
+    const uint32_t* __restrict__ bits) {
   __shared__ f32x4 red[2][kFusedThreads];
   const int nwg = gridDim.x;
   const int tc = threadIdx.x % tpc, tr = threadIdx.x / tpc;   // tpc = C / 4: one channel chunk per thread
@@ -981,7 +995,9 @@ __global__ __launch_bounds__(kFusedThreads) void bn_bwd_fused_kernel(
     const size_t off = ok ? (size_t)r * C + tc * 4 : 0;
     gv[k] = ok ? *reinterpret_cast<const f32x4*>(dy + off) : zero4;
     xv[k] = ok ? *reinterpret_cast<const f32x4*>(x + off) : mu;
-    if (relu) {
+    if (relu == 3) {
+      if (ok) gv[k] = relu_bits_mask(gv[k], bits, off >> 2);
+    } else if (relu) {
       const f32x4 yy = (relu == 1) ? (ok ? *reinterpret_cast<const f32x4*>(y + off) : zero4) : xv[k] * sc + sh;
       gv[k].x = yy.x > 0.f ? gv[k].x : 0.f; gv[k].y = yy.y > 0.f ? gv[k].y : 0.f;
       gv[k].z = yy.z > 0.f ? gv[k].z : 0.f; gv[k].w = yy.w > 0.f ? gv[k].w : 0.f;
@@ -1145,11 +1161,11 @@ extern "C" int evk_bn_fwd_train(const float* x, const float* residual, const flo
   return check_launch("bn_apply");
 }
 
-extern "C" int evk_bn_fwd_train_parts(const float* x, const float* residual, const float* gamma, const float* beta,
-                                      float* running_mean, float* running_var, float momentum, float eps, float* y,
-                                      float* save_mean, float* save_invstd, int64_t rows, int32_t C, uint32_t flags,
-                                      const float* parts, int32_t nparts, void* workspace, size_t workspace_bytes,
-                                      uint32_t* y_absmax, void* stream) {
+extern "C" int evk_bn_fwd_train_parts_bits(const float* x, const float* residual, const float* gamma, const float* beta,
+                                           float* running_mean, float* running_var, float momentum, float eps, float* y,
+                                           float* save_mean, float* save_invstd, int64_t rows, int32_t C, uint32_t flags,
+                                           const float* parts, int32_t nparts, void* workspace, size_t workspace_bytes,
+                                           uint32_t* y_absmax, uint32_t* relu_bits, void* stream) {
   EVK_REQUIRE(x && y && save_mean && save_invstd && parts && nparts > 0, EVK_E_INVALID, "bn_fwd_train_parts: bad argument");
   EVK_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 2048, EVK_E_UNSUPPORTED, "bn_fwd_train_parts: rows=%lld C=%d",
               (long long)rows, C);
@@ -1168,11 +1184,20 @@ extern "C" int evk_bn_fwd_train_parts(const float* x, const float* residual, con
   const size_t n4 = (size_t)rows * C / 4;
   if (pack)
     hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(oneshot_grid(n4)), dim3(256), 0, st, x, residual,
-                       scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, y_absmax);
+                       scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, y_absmax, relu_bits);
   else
     hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(oneshot_grid(n4)), dim3(256), 0, st, x, residual,
-                       scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, y_absmax);
+                       scale_shift, y, n4, C, (flags & EVK_BN_RELU) ? 1 : 0, y_absmax, relu_bits);
   return check_launch("bn_apply");
+}
+extern "C" int evk_bn_fwd_train_parts(const float* x, const float* residual, const float* gamma, const float* beta,
+                                      float* running_mean, float* running_var, float momentum, float eps, float* y,
+                                      float* save_mean, float* save_invstd, int64_t rows, int32_t C, uint32_t flags,
+                                      const float* parts, int32_t nparts, void* workspace, size_t workspace_bytes,
+                                      uint32_t* y_absmax, void* stream) {
+  return evk_bn_fwd_train_parts_bits(x, residual, gamma, beta, running_mean, running_var, momentum, eps, y, save_mean,
+                                     save_invstd, rows, C, flags, parts, nparts, workspace, workspace_bytes, y_absmax, nullptr,
+                                     stream);
 }
 
 // BatchNorm (batch statistics from the convolution epilogue's records) + ReLU + MaxPool2d(3, 2, 1): x [N,H,W,C] ->
@@ -1321,15 +1346,18 @@ static uint32_t* fused_counter(hipStream_t st) {
   return it->second.stream == st ? it->second.words : nullptr;
 }
 
-extern "C" int evk_bn_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
-                          const float* save_mean, const float* save_invstd, float* dx, float* d_residual,
-                          float* dgamma, float* dbeta, int64_t rows, int32_t C, uint32_t flags, int32_t train,
-                          void* workspace, size_t workspace_bytes, uint32_t* dx_absmax, void* stream) {
+extern "C" int evk_bn_bwd_bits(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
+                               const float* save_mean, const float* save_invstd, float* dx, float* d_residual,
+                               float* dgamma, float* dbeta, int64_t rows, int32_t C, uint32_t flags, int32_t train,
+                               void* workspace, size_t workspace_bytes, uint32_t* dx_absmax, const uint32_t* relu_bits,
+                               void* stream) {
   EVK_REQUIRE(dy && x && save_mean && save_invstd && dx, EVK_E_INVALID, "bn_bwd: null pointer");
-  // ReLU mask: from the saved output y when given (needed with a residual), else recomputed from x
-  const int relu = (flags & EVK_BN_RELU) ? (y ? 1 : 2) : 0;
+  // mask of the incoming gradient: the given bits (the forward's ReLU bits, EVK_BN_RELU set — or, without EVK_BN_RELU, the
+  // mask of a gradient that arrives unmasked from a residual block's lazy backward); else from the saved output y when
+  // given (needed with a residual), else recomputed from x
+  const int relu = relu_bits ? 3 : ((flags & EVK_BN_RELU) ? (y ? 1 : 2) : 0);
   EVK_REQUIRE(relu != 2 || !d_residual, EVK_E_INVALID,
-              "bn_bwd: a residual branch needs the forward output y for the ReLU mask");
+              "bn_bwd: a residual branch needs the forward output y (or its ReLU bits) for the mask");
   EVK_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 2048, EVK_E_UNSUPPORTED, "bn_bwd: rows=%lld C=%d",
               (long long)rows, C);
   EVK_REQUIRE(workspace && workspace_bytes >= evk_bn_workspace_bytes(rows, C), EVK_E_WORKSPACE,
@@ -1352,19 +1380,19 @@ extern "C" int evk_bn_bwd(const float* dy, const float* x, const float* y, const
     if (pack)
       hipLaunchKernelGGL(bn_bwd_fused_kernel<true>, dim3(fp.nwg), dim3(kFusedThreads), 0, st, dy, x, y, save_mean,
                          save_invstd, gamma, beta, dx, d_residual, dgamma, dbeta, partial, coef, pmax, rows, C,
-                         fp.rows_per_wg, fp.tpc, fp.rl, fp.cpw, relu, train ? 1 : 0, 1.0 / (double)rows, dx_absmax, counter);
+                         fp.rows_per_wg, fp.tpc, fp.rl, fp.cpw, relu, train ? 1 : 0, 1.0 / (double)rows, dx_absmax, counter, relu_bits);
     else
       hipLaunchKernelGGL(bn_bwd_fused_kernel<false>, dim3(fp.nwg), dim3(kFusedThreads), 0, st, dy, x, y, save_mean,
                          save_invstd, gamma, beta, dx, d_residual, dgamma, dbeta, partial, coef, pmax, rows, C,
-                         fp.rows_per_wg, fp.tpc, fp.rl, fp.cpw, relu, train ? 1 : 0, 1.0 / (double)rows, dx_absmax, counter);
+                         fp.rows_per_wg, fp.tpc, fp.rl, fp.cpw, relu, train ? 1 : 0, 1.0 / (double)rows, dx_absmax, counter, relu_bits);
     return check_launch("bn_bwd_fused");
   }
   if (pack)
     hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(pl.nblk), dim3(256), 0, st, dy, x, y, save_mean, save_invstd,
-                       gamma, beta, d_residual, partial, rows, C, pl.rows_per_blk, pl.tpc, pl.rl, relu, pmax);
+                       gamma, beta, d_residual, partial, rows, C, pl.rows_per_blk, pl.tpc, pl.rl, relu, pmax, relu_bits);
   else
     hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(pl.nblk), dim3(256), 0, st, dy, x, y, save_mean, save_invstd,
-                       gamma, beta, d_residual, partial, rows, C, pl.rows_per_blk, pl.tpc, pl.rl, relu, pmax);
+                       gamma, beta, d_residual, partial, rows, C, pl.rows_per_blk, pl.tpc, pl.rl, relu, pmax, relu_bits);
   int rc = check_launch("bn_bwd_partial");
   if (rc) return rc;
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, partial, pl.nblk, C,
@@ -1378,11 +1406,36 @@ extern "C" int evk_bn_bwd(const float* dy, const float* x, const float* y, const
   const int relu3 = d_residual ? 0 : relu;
   if (pack)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(oneshot_grid(n4)), dim3(256), 0, st, gsrc, x, y,
-                       save_mean, save_invstd, coef, gamma, beta, dx, n4, C, relu3, dx_absmax);
+                       save_mean, save_invstd, coef, gamma, beta, dx, n4, C, relu3, dx_absmax, relu_bits);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(oneshot_grid(n4)), dim3(256), 0, st, gsrc, x, y,
-                       save_mean, save_invstd, coef, gamma, beta, dx, n4, C, relu3, dx_absmax);
+                       save_mean, save_invstd, coef, gamma, beta, dx, n4, C, relu3, dx_absmax, relu_bits);
   return check_launch("bn_bwd_apply");
+}
+
+extern "C" int evk_bn_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
+                          const float* save_mean, const float* save_invstd, float* dx, float* d_residual,
+                          float* dgamma, float* dbeta, int64_t rows, int32_t C, uint32_t flags, int32_t train,
+                          void* workspace, size_t workspace_bytes, uint32_t* dx_absmax, void* stream) {
+  return evk_bn_bwd_bits(dy, x, y, gamma, beta, save_mean, save_invstd, dx, d_residual, dgamma, dbeta, rows, C, flags, train,
+                         workspace, workspace_bytes, dx_absmax, nullptr, stream);
+}
+
+// ---- ReLU bits (common.hpp: relu_bits_*)
+namespace evk {
+__global__ __launch_bounds__(256) void relu_bits_apply_kernel(const float* __restrict__ g, const uint32_t* __restrict__ bits,
+                                                              float* __restrict__ out, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) reinterpret_cast<f32x4*>(out)[i] = relu_bits_mask(reinterpret_cast<const f32x4*>(g)[i], bits, i);
+}
+}  // namespace evk
+extern "C" size_t evk_relu_bits_bytes(int64_t n) { return n > 0 ? relu_bits_words(((size_t)n + 3) / 4) * sizeof(uint32_t) : 0; }
+// out = g where the bit is set, 0 elsewhere (materialises a lazily masked gradient for a reader that cannot take the bits)
+extern "C" int evk_relu_bits_apply(const float* g, const uint32_t* bits, float* out, int64_t n, void* stream) {
+  EVK_REQUIRE(g && bits && out && n > 0 && n % 4 == 0, EVK_E_INVALID, "relu_bits_apply: null pointer or n %% 4 != 0");
+  const size_t n4 = (size_t)n / 4;
+  hipLaunchKernelGGL(relu_bits_apply_kernel, dim3(oneshot_grid(n4)), dim3(256), 0, (hipStream_t)stream, g, bits, out, n4);
+  return check_launch("relu_bits_apply");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -68,4 +68,33 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// ---- ReLU bits of an fp32 tensor: one bit per element ("the activation's output was positive"), written by the
+// BatchNorm + add + ReLU pass of a residual block and read wherever its backward needs the mask — 1/32 of the bytes of the
+// output tensor it replaces there (csrc/bn.hip).  Layout: the tensor is cut into 16-byte elements j (4 floats), 64 of
+// them make a chunk of 8 words: word (j >> 6) * 8 + ((j >> 5) & 1) * 4 + e holds, at bit (j & 31), the bit of float e of
+// element j — so a writer that owns element j = wave-chunk * 64 + lane gets its four words from four wave ballots, and a
+// reader with ANY thread-to-element mapping fetches one aligned 16-byte group and shifts.
+__host__ __device__ inline size_t relu_bits_words(size_t n4) { return ((n4 + 63) / 64) * 8; }
+typedef uint32_t relu_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 relu_bits_mask(f32x4 g, const uint32_t* __restrict__ bits, size_t j) {
+  const relu_u32x4 w = *reinterpret_cast<const relu_u32x4*>(bits + (j >> 6) * 8 + ((j >> 5) & 1) * 4);
+  const uint32_t b = (uint32_t)(j & 31);
+  f32x4 o;
+  o.x = ((w.x >> b) & 1u) ? g.x : 0.f;
+  o.y = ((w.y >> b) & 1u) ? g.y : 0.f;
+  o.z = ((w.z >> b) & 1u) ? g.z : 0.f;
+  o.w = ((w.w >> b) & 1u) ? g.w : 0.f;
+  return o;
+}
+// writer: every lane of the wave calls this with ITS element j = chunk * 64 + lane (inactive elements pass pos = 0 bits)
+__device__ __forceinline__ void relu_bits_store(uint32_t* __restrict__ bits, size_t chunk, bool p0, bool p1, bool p2, bool p3) {
+  const uint64_t b0 = __ballot(p0), b1 = __ballot(p1), b2 = __ballot(p2), b3 = __ballot(p3);
+  const int lane = threadIdx.x & 63;
+  if (lane == 0)
+    *reinterpret_cast<relu_u32x4*>(bits + chunk * 8) = relu_u32x4{(uint32_t)b0, (uint32_t)b1, (uint32_t)b2, (uint32_t)b3};
+  if (lane == 32)
+    *reinterpret_cast<relu_u32x4*>(bits + chunk * 8 + 4) =
+        relu_u32x4{(uint32_t)(b0 >> 32), (uint32_t)(b1 >> 32), (uint32_t)(b2 >> 32), (uint32_t)(b3 >> 32)};
+}
+
 }  // namespace evk

@@ -447,7 +447,7 @@ extern "C" int evk_conv2d_fwd_x3_res(const evk_conv_desc* d, const float* x, con
 static int conv_dgrad_any(const evk_conv_desc* d, const float* dy, const float* wt, const uint16_t* wt3,
                           const float* accum, float* dx, void* stream, int planes = 3,
                           const uint32_t* a_scale = nullptr, const uint32_t* w_scale = nullptr, uint32_t* out_amax = nullptr,
-                          int dy_packed = 0) {
+                          int dy_packed = 0, const uint32_t* accum_bits = nullptr) {
   int rc = check_desc(d);
   if (rc) return rc;
   EVK_REQUIRE(dy && (wt || wt3) && dx, EVK_E_INVALID, "conv2d_dgrad: null pointer");
@@ -485,6 +485,7 @@ static int conv_dgrad_any(const evk_conv_desc* d, const float* dy, const float* 
         a.out_amax = out_amax;
         a.src = dy; a.wgt = wt ? wt + woff : nullptr; a.wgt3 = wt3 ? wt3 + woff3 : nullptr;
         a.bias = nullptr; a.accum = accum; a.dst = dx;
+        a.accum_bits = accum_bits;
         a.N = d->N; a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Cout;
         a.Hm = Hm; a.Wm = Wm; a.Cd = d->Cin;
         a.kh = py.nt; a.kw = px.nt; a.cpt = d->Cout / 4;
@@ -532,6 +533,19 @@ extern "C" int evk_conv2d_dgrad_f16x2_ex(const evk_conv_desc* d, const void* dy,
   EVK_REQUIRE((flags & ~EVK_CONV_DY_PACKED) == 0, EVK_E_INVALID, "conv2d_dgrad_f16x2_ex: unknown flag 0x%x", flags);
   return conv_dgrad_any(d, reinterpret_cast<const float*>(dy), nullptr, reinterpret_cast<const uint16_t*>(wsplit_t), accum, dx,
                         stream, 2, dy_absmax, w_absmax, dx_absmax, (flags & EVK_CONV_DY_PACKED) ? 1 : 0);
+}
+
+// accum_bits: ReLU bits of `accum` (evk_bn_fwd_train_parts_bits): dx = dgrad + (accum where its bit is set).  Stride 1 only.
+extern "C" int evk_conv2d_dgrad_f16x2_masked(const evk_conv_desc* d, const void* dy, const uint32_t* dy_absmax,
+                                             const void* wsplit_t, const uint32_t* w_absmax, const float* accum,
+                                             const uint32_t* accum_bits, float* dx, uint32_t* dx_absmax, uint32_t flags,
+                                             void* stream) {
+  EVK_REQUIRE(wsplit_t && dy_absmax && w_absmax && accum && accum_bits, EVK_E_INVALID, "conv2d_dgrad_f16x2_masked: null pointer");
+  EVK_REQUIRE((flags & ~EVK_CONV_DY_PACKED) == 0, EVK_E_INVALID, "conv2d_dgrad_f16x2_masked: unknown flag 0x%x", flags);
+  EVK_REQUIRE(d && d->stride_h == 1 && d->stride_w == 1 && d->Cin % 4 == 0 && accum != dx, EVK_E_UNSUPPORTED,
+              "conv2d_dgrad_f16x2_masked: stride-1 convolutions with Cin %% 4 == 0, accum distinct from dx");
+  return conv_dgrad_any(d, reinterpret_cast<const float*>(dy), nullptr, reinterpret_cast<const uint16_t*>(wsplit_t), accum, dx,
+                        stream, 2, dy_absmax, w_absmax, dx_absmax, (flags & EVK_CONV_DY_PACKED) ? 1 : 0, accum_bits);
 }
 
 extern "C" int evk_conv2d_dgrad_x3(const evk_conv_desc* d, const float* dy, const void* wsplit_t, const float* accum,

@@ -39,6 +39,10 @@ struct IGemmArgs {
   int bn_parts;             // host side, out: row-parts written (0 = this launch produced no statistics)
   float* bn_buf;            // host side: the caller's partial buffer (bn_part is set from it when the kernel supports it)
   int bn_cap;               // host side: capacity of bn_buf in parts
+  // ReLU bits of `accum` (common.hpp: relu_bits_*): accum is the UNMASKED gradient that arrived at a residual block's
+  // BatchNorm + add + ReLU, the identity branch's gradient is accum where the block's output was positive — masked here, in
+  // the epilogue that adds it, instead of being written and re-read as a tensor of its own (evk_bn_bwd: EVK_BN_LAZY_RES)
+  const uint32_t* accum_bits;
 };
 
 // f16x2 arithmetic: the accumulators hold (x / s_a) * (w / s_w) sums; multiply by s_a * s_w before the epilogue
@@ -92,7 +96,11 @@ __device__ __forceinline__ void igemm_store_rows(const IGemmArgs& p, f32x16 (&ac
           const int col = n0 + wn * WN + b * 32 + 8 * r4 + 4 * lh;
           f32x4 t = {0.f, 0.f, 0.f, 0.f};
           if (has_b) t = *reinterpret_cast<const f32x4*>(p.bias + col);
-          if (has_a) t += *reinterpret_cast<const f32x4*>(p.accum + roff + col);
+          if (has_a) {
+            f32x4 av = *reinterpret_cast<const f32x4*>(p.accum + roff + col);
+            if (p.accum_bits) av = relu_bits_mask(av, p.accum_bits, (roff + col) >> 2);
+            t += av;
+          }
           add[b][r4] = t;
         }
     }
@@ -117,7 +125,11 @@ __device__ __forceinline__ void igemm_store_rows(const IGemmArgs& p, f32x16 (&ac
       f32x4 v = {accrow[b][4 * r4], accrow[b][4 * r4 + 1], accrow[b][4 * r4 + 2], accrow[b][4 * r4 + 3]};
       if (col + 3 < p.Cd && (p.Cd & 3) == 0) {
         if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
-        if (p.accum) v += *reinterpret_cast<const f32x4*>(p.accum + roff + col);
+        if (p.accum) {
+          f32x4 av = *reinterpret_cast<const f32x4*>(p.accum + roff + col);
+          if (p.accum_bits) av = relu_bits_mask(av, p.accum_bits, (roff + col) >> 2);
+          v += av;
+        }
         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         *reinterpret_cast<f32x4*>(p.dst + roff + col) = v;
         amax_quad(am, v);

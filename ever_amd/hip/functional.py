@@ -231,6 +231,34 @@ def _is_packed(t):
     return hit is not None and hit[0] == t._version and hit[1] == t.data_ptr()
 
 
+# ReLU bits (include/ever_hip.h: evk_bn_fwd_train_parts_bits): the BatchNorm + add + ReLU that ends a residual block keeps one
+# bit per output element and its backward reads those instead of the output tensor; with `lazy_res` the identity branch's
+# gradient is not written either — the unmasked incoming gradient travels on with the bits (`_evk_relu_bits` on a view of
+# it) and is masked by its consumer: the block input's data-gradient launch while it adds, or the shortcut's BatchNorm.
+_RELU_BITS = os.environ.get('EVK_RELU_BITS', '1') != '0'
+_LAZY_RES = os.environ.get('EVK_LAZY_RES', '1') != '0'
+relu_bits_stats = {'forward': 0, 'lazy': 0, 'masked_dgrad': 0, 'masked_bn': 0, 'materialized': 0}   # tests / tools
+
+
+def _lazy_bits(t):
+    """The ReLU bits an unmasked gradient travels with, or None."""
+    hit = getattr(t, '_evk_relu_bits', None)
+    if hit is not None and hit[0] == t._version and hit[1] == t.data_ptr():
+        return hit[2]
+    return None
+
+
+def materialize_lazy(t):
+    """`t` itself unless it is an unmasked gradient travelling with ReLU bits: then the masked tensor (one pass)."""
+    bits = _lazy_bits(t) if t is not None else None
+    if bits is None:
+        return t
+    out = torch.empty_like(t)
+    _C.call('evk_relu_bits_apply', t.data_ptr(), bits.data_ptr(), out.data_ptr(), t.numel(), _stream())
+    relu_bits_stats['materialized'] += 1
+    return _inherit_amax(out, t)
+
+
 _top_saved_hooks = getattr(torch._C._autograd, '_top_saved_tensors_default_hooks', None)
 
 
@@ -494,7 +522,7 @@ def _sparse_dgrad(cs):
             and cs.cin == d.Cin)
 
 
-def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False):
+def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False, accum_bits=None):
     """(dx, dw, db) of one convolution.  `accum` (a tensor of x's shape or None) is added to dx inside
     the data-gradient epilogue: dx = conv_transpose(dy, w) + accum; with `inplace` (plane kernels only) dx IS accum."""
     d, xk, w_ohwi = cs.desc, cs.xk, cs.w_ohwi
@@ -502,6 +530,10 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False)
     st = _stream()
     n, cin_p, cout, kh, kw = d.N, d.Cin, d.Cout, d.kh, d.kw
     cin = cs.cin
+    dy = materialize_lazy(dy)       # (an unmasked gradient with ReLU bits is only understood as `accum`)
+    if accum_bits is not None and not (need_dx and _f16x2() and d.stride_h == 1 and d.stride_w == 1 and not inplace
+                                       and cin_p == cin and cin % 8 == 0 and cout % 8 == 0):
+        accum, accum_bits = materialize_lazy(accum), None
     dy = as_nhwc(dy, 'conv2d.backward')
     dy_pk = _is_packed(dy)      # written packed by the BatchNorm backward that follows this convolution
     if dy_pk and (cs.relu or need_db or not _f16x2() or d.Cout % 8 or cs.cin != d.Cin):
@@ -544,8 +576,13 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False)
             # in place: the slots the main branch's launch raised stay (an upper bound is all a scale needs)
             hit = getattr(dx, '_evk_amax', None) if inplace else None
             dxbits = hit[2] if hit is not None else _amax_zeroed(dev)
-            _C.call('evk_conv2d_dgrad_f16x2_ex', ctypes.byref(dk), dy_ptr, dybits.data_ptr(), pl_ptr, wabs_ptr, acc_ptr,
-                    dx.data_ptr(), _ptr(dxbits), 4 if dy_pk else 0, st)
+            if accum_bits is not None and acc_ptr is not None:
+                relu_bits_stats['masked_dgrad'] += 1
+                _C.call('evk_conv2d_dgrad_f16x2_masked', ctypes.byref(dk), dy_ptr, dybits.data_ptr(), pl_ptr, wabs_ptr,
+                        acc_ptr, accum_bits.data_ptr(), dx.data_ptr(), _ptr(dxbits), 4 if dy_pk else 0, st)
+            else:
+                _C.call('evk_conv2d_dgrad_f16x2_ex', ctypes.byref(dk), dy_ptr, dybits.data_ptr(), pl_ptr, wabs_ptr, acc_ptr,
+                        dx.data_ptr(), _ptr(dxbits), 4 if dy_pk else 0, st)
             if dxbits is not None:
                 _note_amax(dx, dxbits)
         else:
@@ -781,8 +818,10 @@ class _ConvForkFn(Function):
             slot_g, ctx.slot.grad = ctx.slot.grad, None
             if not need_dx:
                 slot_g = None
+        acc_bits = None
         if ctx.cs_short is None:
-            acc = dshort  # gradient of the identity shortcut
+            acc = dshort  # gradient of the identity shortcut (possibly unmasked, with the block's ReLU bits)
+            acc_bits = _lazy_bits(acc) if acc is not None else None
         elif dshort is not None and dy is not None and need_dx and _sparse_dgrad(ctx.cs_short):
             # strided 1x1 shortcut: the main branch's (dense) data gradient first, the shortcut's one-pixel-in-four
             # contribution accumulated into it in place — no zero fill / copy of the whole tensor for the other three
@@ -796,12 +835,12 @@ class _ConvForkFn(Function):
                                            ctx.cs_short.has_bias and ctx.needs_input_grad[4], accum=slot_g)
             slot_g = None
         if slot_g is not None:     # the shortcut convolution did not run: plain sum
-            acc = slot_g if acc is None else add(acc, slot_g)
+            acc, acc_bits = (slot_g if acc is None else add(materialize_lazy(acc), slot_g)), None
         if dy is None:   # only the second branch reached the loss
-            return acc, None, dws, None, dbs, None, None, None, None
+            return materialize_lazy(acc), None, dws, None, dbs, None, None, None, None
         dx, dw, db = _conv_backward(ctx.cs_main, dy, need_dx, ctx.needs_input_grad[1],
                                     ctx.cs_main.has_bias and ctx.needs_input_grad[3],
-                                    accum=acc if need_dx else None)
+                                    accum=acc if need_dx else None, accum_bits=acc_bits if need_dx else None)
         return dx, dw, dws, db, dbs, None, None, None, None
 
 
@@ -1035,7 +1074,7 @@ class _BatchNormActFn(Function):
 
     @staticmethod
     def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu, parts=None,
-                pack_out=False):
+                pack_out=False, lazy_res=False):
         n, c, h, w = x.shape
         rows = n * h * w
         dev = x.device
@@ -1057,7 +1096,16 @@ class _BatchNormActFn(Function):
             flags |= 4
         # algorithmic bytes (fp32): statistics read + apply read/write (+ residual read)
         nb = 4.0 * x.numel() * ((3 if training else 2) + (1 if residual is not None else 0))
-        if training and parts is not None:
+        rbits = None
+        if training and parts is not None and residual is not None and relu and _RELU_BITS:
+            # the end of a residual block: the ReLU bits go out beside y and the backward reads them instead of y
+            rbits = torch.empty((lib.evk_relu_bits_bytes(x.numel()) // 4,), device=dev, dtype=torch.int32)
+            relu_bits_stats['forward'] += 1
+            _timed_call('bn', nb - 4.0 * x.numel(), 'evk_bn_fwd_train_parts_bits', x.data_ptr(), _ptr(residual), _ptr(weight),
+                        _ptr(bias), _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), y.data_ptr(),
+                        save_mean.data_ptr(), save_invstd.data_ptr(), rows, c, flags, parts[0].data_ptr(), parts[1],
+                        ws.data_ptr(), ws_bytes, _ptr(abits), rbits.data_ptr(), st)
+        elif training and parts is not None:
             # statistics came with x from the convolution's epilogue: merge the records, apply (2|x| of traffic)
             _timed_call('bn', nb - 4.0 * x.numel(), 'evk_bn_fwd_train_parts', x.data_ptr(), _ptr(residual), _ptr(weight),
                         _ptr(bias), _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), y.data_ptr(),
@@ -1077,40 +1125,55 @@ class _BatchNormActFn(Function):
         ctx.pack_dx = bool(parts is not None and len(parts) > 2 and parts[2])
         ctx.relu = relu
         ctx.has_res = residual is not None
-        # the ReLU mask is recomputed from x in backward unless a residual was added (then y is needed)
-        ctx.save_for_backward(x, y if (relu and residual is not None) else None, weight, bias, save_mean, save_invstd)
+        # the ReLU mask is recomputed from x in backward unless a residual was added (then y — or its bits — is needed)
+        ctx.lazy_res = bool(lazy_res and rbits is not None and _LAZY_RES and not observers_active())
+        ctx.save_for_backward(x, y if (relu and residual is not None and rbits is None) else None, weight, bias, save_mean,
+                              save_invstd, rbits)
         ctx.mark_non_differentiable(*[t for t in (running_mean, running_var) if t is not None])
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x, y, weight, bias, save_mean, save_invstd = ctx.saved_tensors
+        x, y, weight, bias, save_mean, save_invstd, rbits = ctx.saved_tensors
         n, c, h, w = x.shape
         rows = n * h * w
         dev = x.device
         st = _stream()
+        in_bits = _lazy_bits(dy)
+        if in_bits is not None and (ctx.relu or rbits is not None):
+            dy, in_bits = materialize_lazy(dy), None     # an own mask AND an incoming one: apply the incoming one first
         dy = as_nhwc(dy, 'batch_norm.backward')
         lib = _C.load()
         ws_bytes = lib.evk_bn_workspace_bytes(rows, c)
         ws = workspace(dev, ws_bytes)
         dx = torch.empty_like(x)
         need_res = ctx.has_res and ctx.needs_input_grad[1]
-        dres = torch.empty_like(x) if need_res else None
+        lazy = need_res and ctx.lazy_res and rbits is not None and in_bits is None
+        dres = torch.empty_like(x) if (need_res and not lazy) else None
         has_affine = weight is not None
         dgamma = torch.empty((c,), device=dev, dtype=torch.float32) if has_affine else None
         dbeta = torch.empty((c,), device=dev, dtype=torch.float32) if has_affine else None
         # reduce pass reads dy, x (+y mask); apply pass reads g, x and writes dx (+ the residual gradient write)
-        nb = 4.0 * x.numel() * (5 + (1 if y is not None else 0) + (1 if need_res else 0))
+        nb = 4.0 * x.numel() * (5 + (1 if y is not None else 0) + (1 if dres is not None else 0))
         # dx is the producing convolution's dy (data and weight gradient operand) — and, when that convolution said so
         # in forward, nothing else: written packed under a scale bounded before the apply pass (EVK_BN_PACK_DX)
         pack = ctx.pack_dx and _f16x2()
         abits = _amax_zeroed(dev) if pack else _amax_out(dev)
         pack = pack and abits is not None
-        _timed_call('bn', nb, 'evk_bn_bwd', dy.data_ptr(), x.data_ptr(), _ptr(y), _ptr(weight), _ptr(bias), save_mean.data_ptr(),
-                save_invstd.data_ptr(), dx.data_ptr(), _ptr(dres), _ptr(dgamma), _ptr(dbeta), rows, c,
-                (1 if ctx.relu else 0) | (2 if pack else 0) | (8 if _collectives_in_flight() else 0),
-                1 if ctx.training else 0, ws.data_ptr(), ws_bytes, _ptr(abits), st)
+        mask_bits = rbits if rbits is not None else in_bits
+        if in_bits is not None:
+            relu_bits_stats['masked_bn'] += 1
+        _timed_call('bn', nb, 'evk_bn_bwd_bits', dy.data_ptr(), x.data_ptr(), _ptr(y), _ptr(weight), _ptr(bias),
+                    save_mean.data_ptr(), save_invstd.data_ptr(), dx.data_ptr(), _ptr(dres), _ptr(dgamma), _ptr(dbeta), rows, c,
+                    (1 if ctx.relu else 0) | (2 if pack else 0) | (8 if _collectives_in_flight() else 0),
+                    1 if ctx.training else 0, ws.data_ptr(), ws_bytes, _ptr(abits), _ptr(mask_bits), st)
+        if lazy:
+            # the identity branch's gradient = dy where the block's output was positive: handed on unmasked with the bits
+            relu_bits_stats['lazy'] += 1
+            dres = dy.view_as(dy)
+            dres._evk_relu_bits = (dres._version, dres.data_ptr(), rbits)
+            _inherit_amax(dres, dy)
         if pack:
             _mark_packed(dx, abits)
         elif abits is not None:
@@ -1118,12 +1181,15 @@ class _BatchNormActFn(Function):
         if ctx.has_res and not need_res:
             dres = None
         return (dx, dres, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None,
-                None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None)
 
 
 def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentum, eps, residual=None, relu=False,
-                   pack_out=False):
-    """pack_out: the caller guarantees that ONE convolution of this package (forward + weight gradient) is the only
+                   pack_out=False, lazy_res=False):
+    """lazy_res: the caller guarantees that the gradient of `residual` reaches only readers of this package that take an
+    unmasked gradient with ReLU bits (a `conv2d_fork` identity output, or the BatchNorm of a shortcut convolution): the
+    backward then hands the incoming gradient on as it is instead of writing a masked copy (EVK_LAZY_RES).
+    pack_out: the caller guarantees that ONE convolution of this package (forward + weight gradient) is the only
     reader of the result; under the f16x2 arithmetic it is then stored packed (include/ever_hip.h: EVK_BN_PACK_Y)."""
     _require_cuda(x, 'batch_norm')
     x = as_nhwc(x, 'batch_norm')
@@ -1140,7 +1206,7 @@ def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentu
     if use_batch_stats and running_mean is not None:
         weight_planes.note_running_stats_changed()
     y = _BatchNormActFn.apply(x, residual, weight, bias, running_mean, running_var, bool(use_batch_stats),
-                              0.0 if momentum is None else momentum, eps, bool(relu), parts, bool(pack_out))
+                              0.0 if momentum is None else momentum, eps, bool(relu), parts, bool(pack_out), bool(lazy_res))
     if _AMAX_HANDOFF is not None:       # the pass left max|y| (or its bound) there: y is the next convolution's operand
         abits, packed = _AMAX_HANDOFF
         if packed:

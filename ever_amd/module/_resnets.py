@@ -46,6 +46,12 @@ def _fork(block, x):
     return h, block.downsample[1](s)
 
 
+def _lazy_ok(bn):
+    """the block's last BatchNorm is this package's own (layers.BatchNorm2d: the only one that takes lazy_res)"""
+    from .layers import BatchNorm2d
+    return type(bn) is BatchNorm2d
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -72,7 +78,8 @@ class BasicBlock(nn.Module):
             return conv_bn(self.conv2, self.bn2, out, residual=shortcut, relu=True)
         h, shortcut = _fork(self, x)
         out = self.bn1(h, relu=True, conv_only=True)       # read by conv2 alone
-        return conv_bn(self.conv2, self.bn2, out, residual=shortcut, relu=True)
+        # (the shortcut's gradient reaches only the fork node or the down-sampling BatchNorm: lazy_res)
+        return conv_bn(self.conv2, self.bn2, out, residual=shortcut, relu=True, lazy_res=_lazy_ok(self.bn2))
 
 
 class Bottleneck(nn.Module):
@@ -102,7 +109,7 @@ class Bottleneck(nn.Module):
         h, shortcut = _fork(self, x)
         out = self.bn1(h, relu=True, conv_only=True)       # read by conv2 alone
         out = conv_bn(self.conv2, self.bn2, out, relu=True, conv_only=True)   # ... and this by conv3 alone
-        return conv_bn(self.conv3, self.bn3, out, residual=shortcut, relu=True)
+        return conv_bn(self.conv3, self.bn3, out, residual=shortcut, relu=True, lazy_res=_lazy_ok(self.bn3))
 
 
 class ResNet(nn.Module):

@@ -117,11 +117,13 @@ def _takes_epilogue_stats(bn):
     return type(bn) is BatchNorm2d and (bn.training or bn.running_mean is None)
 
 
-def conv_bn(conv, bn, x, residual=None, relu=False, conv_only=False):
+def conv_bn(conv, bn, x, residual=None, relu=False, conv_only=False, lazy_res=False):
     """bn(conv(x)) (+ residual) (ReLU): one folded convolution at inference, conv + fused BatchNorm pass otherwise.
-    conv_only: see layers.BatchNorm2d.forward."""
+    conv_only, lazy_res: see layers.BatchNorm2d.forward."""
     if _use_folded(conv, bn):
         return folded_conv2d(x, conv, residual=residual, relu=relu)
+    if lazy_res:
+        return bn(conv(x, bn_stats=_takes_epilogue_stats(bn)), residual=residual, relu=relu, conv_only=conv_only, lazy_res=True)
     return bn(conv(x, bn_stats=_takes_epilogue_stats(bn)), residual=residual, relu=relu, conv_only=conv_only)
 
 

@@ -64,8 +64,9 @@ def _check_conv(m):
 class BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d with optional fused residual add and ReLU (one apply pass over HBM)."""
 
-    def forward(self, x, residual=None, relu=False, conv_only=False):
-        """conv_only: the result is read by ONE convolution of this package (and that convolution's weight gradient) and
+    def forward(self, x, residual=None, relu=False, conv_only=False, lazy_res=False):
+        """lazy_res: see hip/functional.py:batch_norm_act (residual blocks of this package only).
+        conv_only: the result is read by ONE convolution of this package (and that convolution's weight gradient) and
         by nothing else — under the f16x2 arithmetic the pass may then store it already split ("packed",
         hip/functional.py:batch_norm_act); any other reader would see raw words."""
         if self.momentum is None:
@@ -80,7 +81,8 @@ class BatchNorm2d(nn.BatchNorm2d):
         # a forward hook on this module would be handed the packed words: store fp32 then
         conv_only = conv_only and not self._forward_hooks
         return HF.batch_norm_act(x, self.weight, self.bias, rm, rv, training, self.momentum, self.eps,
-                                 residual=residual, relu=relu, pack_out=conv_only)
+                                 residual=residual, relu=relu, pack_out=conv_only,
+                                 lazy_res=lazy_res and not self._forward_hooks)
 
 
     def forward_relu_pool(self, x):

@@ -112,7 +112,7 @@ class SyncBatchNorm(nn.SyncBatchNorm):
 
     _stats_hook = None  # tests inject a stand-in for the collectives
 
-    def forward(self, x, residual=None, relu=False, conv_only=False):   # (conv_only: layers.BatchNorm2d; fp32 here)
+    def forward(self, x, residual=None, relu=False, conv_only=False, lazy_res=False):   # (conv_only / lazy_res: layers.BatchNorm2d; not used here)
         _require_cuda(x, 'SyncBatchNorm')
         x = as_nhwc(x, 'SyncBatchNorm')
         if x.shape[1] % 4 != 0:

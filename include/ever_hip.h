@@ -189,6 +189,13 @@ int evk_unpack_planar_f16x2(const void* planar, int64_t n, const uint32_t* x_abs
 int evk_conv2d_dgrad_f16x2_ex(const evk_conv_desc* d, const void* dy, const uint32_t* dy_absmax, const void* wsplit_t,
                               const uint32_t* w_absmax, const float* accum, float* dx, uint32_t* dx_absmax,
                               uint32_t flags, void* stream);
+/* dx = dgrad(dy) + (accum where its ReLU bit is set): the identity branch of a residual block hands its gradient over
+ * UNMASKED together with the bits of the block's output (evk_bn_fwd_train_parts_bits / evk_bn_bwd_bits), and the mask is
+ * applied here, in the epilogue that adds it.  Replaces the `out += identity; relu` backward of reference
+ * ever/module/_resnets.py:95-112 as autograd would run it (a masked tensor written by the ReLU backward, read by the add). */
+int evk_conv2d_dgrad_f16x2_masked(const evk_conv_desc* d, const void* dy, const uint32_t* dy_absmax, const void* wsplit_t,
+                                  const uint32_t* w_absmax, const float* accum, const uint32_t* accum_bits, float* dx,
+                                  uint32_t* dx_absmax, uint32_t flags, void* stream);
 int evk_conv2d_wgrad_f16x2_ex(const evk_conv_desc* d, const void* x, const uint32_t* x_absmax, const void* dy,
                               const uint32_t* dy_absmax, float* dw, float* dbias, void* workspace,
                               size_t workspace_bytes, uint32_t flags, void* stream);
@@ -299,6 +306,17 @@ int evk_bn_fwd_train_parts(const float* x, const float* residual, const float* g
                            float* save_mean, float* save_invstd, int64_t rows, int32_t C, uint32_t flags,
                            const float* parts, int32_t nparts, void* workspace, size_t workspace_bytes,
                            uint32_t* y_absmax, void* stream);
+/* ... and with the ReLU bits of the output written beside it (relu_bits: evk_relu_bits_bytes(rows * C) bytes, one bit per
+ * element, "y > 0"; layout in csrc/common.hpp).  For the BatchNorm + add + ReLU that ends a residual block (reference
+ * _resnets.py:95-112): its backward (evk_bn_bwd_bits) then reads the bits instead of the whole output tensor. */
+int evk_bn_fwd_train_parts_bits(const float* x, const float* residual, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps, float* y,
+                                float* save_mean, float* save_invstd, int64_t rows, int32_t C, uint32_t flags,
+                                const float* parts, int32_t nparts, void* workspace, size_t workspace_bytes,
+                                uint32_t* y_absmax, uint32_t* relu_bits, void* stream);
+size_t evk_relu_bits_bytes(int64_t n);
+/* out = g where the bit is set, else 0 (n % 4 == 0): materialises a gradient that travels unmasked with its bits */
+int evk_relu_bits_apply(const float* g, const uint32_t* bits, float* out, int64_t n, void* stream);
 /* The stem: BatchNorm (batch statistics from the convolution epilogue's records, as evk_bn_fwd_train_parts) + ReLU +
  * MaxPool2d(3, 2, 1) in one pass each way — reference _resnets.py:150-153 (bn1, relu, maxpool).  x [N,H,W,C] ->
  * y [N,Ho,Wo,C] and code [N,Ho,Wo,C] uint8 (winning tap ky*3+kx of each window, first maximum in scan order, as
@@ -326,6 +344,17 @@ int evk_bn_bwd(const float* dy, const float* x, const float* y, const float* gam
                const float* save_mean, const float* save_invstd, float* dx, float* d_residual,
                float* dgamma, float* dbeta, int64_t rows, int32_t C, uint32_t flags, int32_t train,
                void* workspace, size_t workspace_bytes, uint32_t* dx_absmax, void* stream);
+/* evk_bn_bwd with the mask of the incoming gradient given as bits (relu_bits != NULL; y is then not read):
+ *  - with EVK_BN_RELU: the forward's own ReLU bits (evk_bn_fwd_train_parts_bits) — a residual block's last BatchNorm reads
+ *    dy, x and 1/32 of a tensor instead of dy, x and y in both passes; with d_residual == NULL the masked gradient of the
+ *    identity branch is not written either: the caller hands (dy, bits) on, and the consumer masks while it adds
+ *    (evk_conv2d_dgrad_f16x2_masked), or another BatchNorm takes them as below — 5 tensor transfers instead of 7;
+ *  - without EVK_BN_RELU: dy is such an unmasked gradient and relu_bits its mask (the down-sampling branch's BatchNorm
+ *    behind a residual block's add). */
+int evk_bn_bwd_bits(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
+                    const float* save_mean, const float* save_invstd, float* dx, float* d_residual,
+                    float* dgamma, float* dbeta, int64_t rows, int32_t C, uint32_t flags, int32_t train,
+                    void* workspace, size_t workspace_bytes, uint32_t* dx_absmax, const uint32_t* relu_bits, void* stream);
 
 /* ------------------------------------------------------------------ pointwise / resampling - */
 /* nn.ReLU (fs_relation.py:25) and its backward; elementwise add (fpn.py:105). */
