@@ -496,6 +496,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // Statistics that arrive as per-row-part records (count, mean, M2) from the producing convolution's epilogue
 // (igemm_common.hpp: igemm_store_rows_stats): Chan's pairwise merge in fp64, 32 lanes per channel over a fixed strided
 // subset each, then the 32 lanes folded in index order — the same outputs as bn_stats_final_kernel, no pass over x.
+// FC channels x FL record lanes per workgroup (FC * FL = 256): 8 x 32 for the small maps; 2 x 128 where a channel has
+// hundreds of records (the 128^2 maps: 2048 per channel — at 32 lanes each lane walked 64 strided records: 9-47 us a launch)
+template <int FC, int FL>
 __global__ __launch_bounds__(256) void bn_parts_final_kernel(const float* __restrict__ parts, int nparts, int C,
                                                              double rows, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
@@ -514,20 +517,20 @@ __global__ __launch_bounds__(256) void bn_parts_final_kernel(const float* __rest
   // With a common pivot p (the first record's mean) the merge of all records is three plain sums,
   //   N = sum n_i,  A = sum n_i (mean_i - p),  B = sum [M2_i + n_i (mean_i - p)^2]:  mean = p + A/N,  M2 = B - A^2/N
   // (Chan's pairwise formula telescoped; no division inside the loop, no order dependence beyond the fixed one below).
-  __shared__ double red[3][kFinLanes][kFinCh];
-  const int tc = threadIdx.x % kFinCh, tl = threadIdx.x / kFinCh;
-  const int c = blockIdx.x * kFinCh + tc;
+  __shared__ double red[3][FL][FC];
+  const int tc = threadIdx.x % FC, tl = threadIdx.x / FC;
+  const int c = blockIdx.x * FC + tc;
   double N = 0.0, A = 0.0, B = 0.0, piv = 0.0;
   if (c < C) {
     const size_t st = (size_t)3 * C;
     piv = (double)parts[C + c];
     const float* r = parts + c;
     int b = tl;
-    for (; b + 3 * kFinLanes < nparts; b += 4 * kFinLanes) {   // four independent records in flight per lane
+    for (; b + 3 * FL < nparts; b += 4 * FL) {   // four independent records in flight per lane
       const float* r0 = r + (size_t)b * st;
-      const float* r1 = r0 + (size_t)kFinLanes * st;
-      const float* r2 = r1 + (size_t)kFinLanes * st;
-      const float* r3 = r2 + (size_t)kFinLanes * st;
+      const float* r1 = r0 + (size_t)FL * st;
+      const float* r2 = r1 + (size_t)FL * st;
+      const float* r3 = r2 + (size_t)FL * st;
       const float n0 = r0[0], m0 = r0[C], q0 = r0[2 * C], n1 = r1[0], m1 = r1[C], q1 = r1[2 * C];
       const float n2 = r2[0], m2 = r2[C], q2 = r2[2 * C], n3 = r3[0], m3 = r3[C], q3 = r3[2 * C];
       const double d0 = (double)m0 - piv, d1 = (double)m1 - piv, d2 = (double)m2 - piv, d3 = (double)m3 - piv;
@@ -541,7 +544,7 @@ __global__ __launch_bounds__(256) void bn_parts_final_kernel(const float* __rest
         E = fmaxf(E, fmaxf(fmaxf(e0, e1), fmaxf(e2, e3)));
       }
     }
-    for (; b < nparts; b += kFinLanes) {
+    for (; b < nparts; b += FL) {
       const float* r0 = r + (size_t)b * st;
       const double n0 = (double)r0[0], d0 = (double)r0[C] - piv;
       N += n0;
@@ -550,14 +553,14 @@ __global__ __launch_bounds__(256) void bn_parts_final_kernel(const float* __rest
       if (pack && n0 > 0.0) E = fmaxf(E, sqrtf(r0[2 * C]) + fabsf((float)d0));
     }
   }
-  __shared__ float ered[kFinLanes][kFinCh];
+  __shared__ float ered[FL][FC];
   if (pack) ered[tl][tc] = E;
   red[0][tl][tc] = N;
   red[1][tl][tc] = A;
   red[2][tl][tc] = B;
   __syncthreads();
   if (tl != 0 || c >= C) return;
-  for (int k = 1; k < kFinLanes; ++k) {
+  for (int k = 1; k < FL; ++k) {
     N += red[0][k][tc];
     A += red[1][k][tc];
     B += red[2][k][tc];
@@ -577,7 +580,7 @@ __global__ __launch_bounds__(256) void bn_parts_final_kernel(const float* __rest
   scale_shift[c] = sc;
   scale_shift[C + c] = bb - meanf * sc;
   if (pack) {
-    for (int k = 1; k < kFinLanes; ++k) E = fmaxf(E, ered[k][tc]);
+    for (int k = 1; k < FL; ++k) E = fmaxf(E, ered[k][tc]);
     const float bound = fabsf(sc) * (E * 1.001f + fabsf((float)(piv - mean))) + fabsf(bb);
     uint32_t bits = __builtin_bit_cast(uint32_t, bound);
     if (bound != bound) bits = 0x7fc00000u;
@@ -1121,6 +1124,17 @@ __global__ __launch_bounds__(kFusedThreads) void bn_bwd_fused_kernel(
 
 static unsigned oneshot_grid(size_t n4) { return (unsigned)((n4 + 255) / 256); }
 
+static void launch_parts_final(hipStream_t st, const float* parts, int nparts, int C, double rows, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                               float* save_mean, float* save_invstd, float* scale_shift, uint32_t* amax, int pack) {
+  if (nparts >= 512)
+    hipLaunchKernelGGL((bn_parts_final_kernel<2, 128>), dim3((C + 1) / 2), dim3(256), 0, st, parts, nparts, C, rows, gamma, beta,
+                       running_mean, running_var, momentum, eps, save_mean, save_invstd, scale_shift, amax, pack);
+  else
+    hipLaunchKernelGGL((bn_parts_final_kernel<8, 32>), dim3((C + 7) / 8), dim3(256), 0, st, parts, nparts, C, rows, gamma, beta,
+                       running_mean, running_var, momentum, eps, save_mean, save_invstd, scale_shift, amax, pack);
+}
+
 }  // namespace evk
 
 using namespace evk;
@@ -1176,9 +1190,8 @@ extern "C" int evk_bn_fwd_train_parts_bits(const float* x, const float* residual
               "bn_fwd_train_parts: EVK_BN_PACK_Y needs y_absmax (slots zero on entry) and no residual");
   hipStream_t st = (hipStream_t)stream;
   float* scale_shift = (float*)workspace + (size_t)kMaxStatBlocks * 2 * C;
-  hipLaunchKernelGGL(bn_parts_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, parts, nparts, C,
-                     (double)rows, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
-                     scale_shift, y_absmax, pack ? 1 : 0);
+  launch_parts_final(st, parts, nparts, C, (double)rows, gamma, beta, running_mean, running_var, momentum, eps, save_mean,
+                     save_invstd, scale_shift, y_absmax, pack ? 1 : 0);
   int rc = check_launch("bn_parts_final");
   if (rc) return rc;
   const size_t n4 = (size_t)rows * C / 4;
@@ -1215,9 +1228,8 @@ extern "C" int evk_bn_relu_pool_fwd_train_parts(const float* x, const float* gam
               "bn_relu_pool_fwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   float* scale_shift = (float*)workspace + (size_t)kMaxStatBlocks * 2 * C;
-  hipLaunchKernelGGL(bn_parts_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, parts, nparts, C,
-                     (double)rows, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
-                     scale_shift, y_absmax, 0);
+  launch_parts_final(st, parts, nparts, C, (double)rows, gamma, beta, running_mean, running_var, momentum, eps, save_mean,
+                     save_invstd, scale_shift, y_absmax, 0);
   int rc = check_launch("bn_parts_final");
   if (rc) return rc;
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;

@@ -4,15 +4,17 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ever_amd as er
 from ever_amd.hip import timing
+import bench
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
-m = er.module.FarSeg(dict()).to(dev).train()
-x = torch.randn(16, 3, 512, 512, device=dev)
-y = (torch.rand(16, 512, 512, device=dev) > 0.5).long()
+cfg = sys.argv[1] if len(sys.argv) > 1 else 'c2'      # BASELINE.json configs[1..4] as bench.py --config builds them
+m, inputs = bench.make_workload(er, cfg, dev, bench.BATCH, 0)[:2]
+m = m.to(dev).train()
+print(f'config {cfg}')
 for it in range(3):
     t = timing.KernelTimer() if it == 2 else None
     if t: t.__enter__()
-    loss = sum(m(x, y).values()); loss.backward()
+    loss = sum(v for k, v in m(*inputs).items() if k.endswith('loss')); loss.backward()
     if t: t.__exit__()
     m.zero_grad(set_to_none=True)
 torch.cuda.synchronize()
