@@ -9,6 +9,8 @@
 #include <mutex>
 #include <unordered_map>
 
+static uint32_t* fused_counter(hipStream_t st);   // (defined with the one-launch backward, below)
+
 namespace evk {
 
 constexpr int kMaxStatBlocks = 2048;
@@ -1127,6 +1129,9 @@ static unsigned oneshot_grid(size_t n4) { return (unsigned)((n4 + 255) / 256); }
 static void launch_parts_final(hipStream_t st, const float* parts, int nparts, int C, double rows, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                float* save_mean, float* save_invstd, float* scale_shift, uint32_t* amax, int pack) {
+  // the one-launch backward belongs to ONE stream per device (fused_counter): claimed here, by the stream of the first
+  // training-mode forward (the encoder's), not by whichever stream happens to run the first backward node
+  (void)fused_counter(st);
   if (nparts >= 512)
     hipLaunchKernelGGL((bn_parts_final_kernel<2, 128>), dim3((C + 1) / 2), dim3(256), 0, st, parts, nparts, C, rows, gamma, beta,
                        running_mean, running_var, momentum, eps, save_mean, save_invstd, scale_shift, amax, pack);

@@ -101,9 +101,10 @@ def _amax_zeroed(dev):
     if not _AMAX_WORDS[0]:
         _AMAX_WORDS[0] = int(_C.load().evk_absmax_words())
     nw = _AMAX_WORDS[0]
-    pool = _ZERO_POOL.get(dev)
+    key = (dev, _stream())          # the fill launch and the kernels that raise the slots must share a stream's order
+    pool = _ZERO_POOL.get(key)
     if pool is None or pool[1] >= pool[0].shape[0]:
-        pool = _ZERO_POOL[dev] = [torch.zeros((256, nw), device=dev, dtype=torch.int32), 0]
+        pool = _ZERO_POOL[key] = [torch.zeros((256, nw), device=dev, dtype=torch.int32), 0]
     buf = pool[0][pool[1]]
     pool[1] += 1
     return buf
