@@ -113,6 +113,17 @@ def make_batch(dev, batch, rank):
     return x, y
 
 
+def pmc_kernel_launches_per_step(family):
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')), reverse=True):
+        try:
+            with open(path) as f:
+                return json.load(f)[family]['kernel_launches_per_step']
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
 def pmc_traffic(family):
     """(HBM bytes per launch, file) of a kernel family from the newest committed rocprofv3 PMC passes (FETCH_SIZE x2 +
     WRITE_SIZE, MI355X_MICROARCH.md §HBM; profiles/rNN_traffic.json states the method); (None, None) if absent."""
@@ -121,6 +132,19 @@ def pmc_traffic(family):
         try:
             with open(path) as f:
                 return json.load(f)[family]['hbm_bytes_per_launch'], os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+def pmc_busy(family):
+    """matrix-pipe occupancy of a kernel family from the newest committed PMC summary (profiles/rNN_pmc_conv_kernels.json,
+    tools/pmc_bench.sh), or None"""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_conv_kernels.json')), reverse=True):
+        try:
+            with open(path) as f:
+                return json.load(f)[family]['mfma_busy'], os.path.relpath(path, ROOT)
         except (OSError, KeyError, ValueError):
             continue
     return None, None
@@ -243,6 +267,8 @@ def main():
     host_unblocked_ms = sorted(unblocked)[1] * 1e3
     # HIP-event timing of the conv launches costs ~2 % of the step (two event records per launch), so
     # it samples every 4th step of the timed region rather than all of them.
+    if use_ddp and hasattr(ddp, 'measure_exposed'):
+        ddp.measure_exposed = True
     timer = None if args.no_kernel_timer else timing.KernelTimer()
     sampled = 0
     t0 = time.perf_counter()
@@ -261,10 +287,18 @@ def main():
         print('host ms per step:', [round((b - a) * 1e3, 1) for a, b in zip(marks, marks[1:])], file=sys.stderr)
     fence()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if use_ddp:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+        # per-rank host cost and exposed all-reduce time: what a rank's Python thread needs to enqueue a
+        # step (timed loop / empty queue) and how long its compute stream waited for the last gradient bucket
+        mine = torch.tensor([enqueued / args.steps * 1e3, host_unblocked_ms,
+                             ddp.exposed_ms() if hasattr(ddp, 'exposed_ms') else 0.0], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        per_rank = [[round(float(v), 3) for v in r.tolist()] for r in allr]
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -292,6 +326,10 @@ def main():
         }
         if gf_per_unit is not None:
             line['config']['whole_model_tflops'] = round(tiles_s * gf_per_unit / 1e3 / world, 2)
+        if per_rank is not None:
+            line['per_rank'] = {'host_enqueue_ms_per_step': [r[0] for r in per_rank],
+                                'host_unblocked_ms_per_step': [r[1] for r in per_rank],
+                                'exposed_allreduce_ms_per_step': [r[2] for r in per_rank]}
         if use_ddp:
             line['config']['gradient_exchange'] = ('FlatGradDDP: 64 MB buckets, one pack launch + one RCCL all-reduce per bucket'
                                                    if args.ddp == 'flat' else 'torch DistributedDataParallel') + \
@@ -338,6 +376,10 @@ def main():
                     'launches_per_step': ig['launches'] // max(1, sampled), 'sampled_steps': sampled,
                     'avg_launch_us': round(ig['seconds'] / ig['launches'] * 1e6, 2),
                     'algorithmic_gflop_per_launch': round(ig['flops'] / ig['launches'] / 1e9, 3)}
+                if conv_math == 'f16x2' and args.config == 'c2':
+                    busy, busy_file = pmc_busy('conv_igemm')
+                    line['roofline']['mfma_busy'] = busy
+                    line['roofline']['mfma_busy_note'] = f'matrix-pipe occupancy, time-weighted over the family (PMC, {busy_file})'
             wg = fam.get('conv_wgrad' if x3 else 'conv_wgrad_f32')
             if wg:
                 ach = wg['flops'] / wg['seconds'] / 1e12
@@ -351,6 +393,8 @@ def main():
                                           'launches_per_step': wg['launches'] // max(1, sampled),
                                           'avg_launch_us': round(wg['seconds'] / wg['launches'] * 1e6, 2),
                                           'algorithmic_gflop_per_launch': round(wg['flops'] / wg['launches'] / 1e9, 3)}
+                if conv_math == 'f16x2' and args.config == 'c2':
+                    line['roofline_wgrad']['mfma_busy'] = pmc_busy('conv_wgrad')[0]
             # the ResNet-50 encoder's convolutions alone (BASELINE.json north_star: >= 0.6 x MFMA roofline on this
             # stack): forward + data gradient + weight gradient of every `en.*` convolution, the 7x7 stem on the
             # exact-fp32 kernel included, all priced against the default arithmetic's peak
@@ -379,8 +423,12 @@ def main():
                     gbs = hb['bytes'] / hb['seconds'] / 1e9
                     line['roofline_hbm_' + fam_name] = {
                         'bound': 'hbm', 'kernel': label, 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                        'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': None,
+                        'frac': round(gbs / PEAK_HBM_GBS, 4),
+                        # PMC bytes are per KERNEL launch (a call is 2-3 kernels): compare with algorithmic_bytes_per_kernel
+                        'traffic': (pmc_traffic('bn')[0] if (fam_name == 'bn' and conv_math == 'f16x2' and args.config == 'c2') else None),
                         'algorithmic_bytes_per_call': round(hb['bytes'] / hb['launches']),
+                        'algorithmic_bytes_per_kernel': (round(hb['bytes'] / max(1, sampled) / pmc_kernel_launches_per_step('bn'))
+                                                         if (fam_name == 'bn' and pmc_kernel_launches_per_step('bn')) else None),
                         'avg_call_us': round(hb['seconds'] / hb['launches'] * 1e6, 2)}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()

@@ -57,6 +57,10 @@ class FlatGradDDP(nn.Module):
         self._next = 0              # buckets are reduced in order on every rank
         self._callback_queued = False
         self._comm_stream = torch.cuda.Stream(device=self.device) if self._cuda else None
+        # bench.py --gpus N: HIP events around the point where the compute stream waits for the communication stream, i.e.
+        # how long the last bucket's all-reduce runs past the end of backward ("exposed" time); off by default
+        self.measure_exposed = False
+        self._exposed = []
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
         self._sync_initial_state()
 
@@ -183,9 +187,23 @@ class FlatGradDDP(nn.Module):
             if self._cuda:
                 b._keep = None
         if self._cuda and self.world > 1:
-            torch.cuda.current_stream().wait_stream(self._comm_stream)
+            if self.measure_exposed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                torch.cuda.current_stream().wait_stream(self._comm_stream)
+                e1.record()
+                self._exposed.append((e0, e1))
+            else:
+                torch.cuda.current_stream().wait_stream(self._comm_stream)
         self._next = 0
         self._callback_queued = False
+
+    def exposed_ms(self):
+        """mean time per step the compute stream spent waiting for the gradient all-reduce after backward had finished
+        (call after torch.cuda.synchronize(); measure_exposed must have been on)"""
+        ms = [a.elapsed_time(b) for a, b in self._exposed]
+        self._exposed = []
+        return sum(ms) / len(ms) if ms else 0.0
 
     # DDP API surface the trainer / launcher use
     def state_dict(self, *args, **kwargs):

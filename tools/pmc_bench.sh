@@ -11,5 +11,5 @@ i=$((i+1))
 timeout 400 rocprofv3 --kernel-trace --pmc $set -d $O/p$i -o r -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer > $O/p$i.log 2>&1 < /dev/null
 done
 cd $R
-python tools/pmc_bench_summary.py $O/p1/*.db $O/p2/*.db $O/p3/*.db $O/p4/*.db > gpurun_out/pmc_bench_$tag.txt 2>&1
+python tools/pmc_bench_summary.py $O/p1/*.db $O/p2/*.db $O/p3/*.db $O/p4/*.db gpurun_out/pmc_bench_$tag.json > gpurun_out/pmc_bench_$tag.txt 2>&1
 rm -rf $O/p1 $O/p2 $O/p3 $O/p4

@@ -35,8 +35,34 @@ def load(paths):
 
 def main():
     paths = [a for a in sys.argv[1:] if a.endswith('.db')]
+    jpath = [a for a in sys.argv[1:] if a.endswith('.json')]
     top = 14
     k = load(paths)
+    if jpath:
+        # machine-readable: per kernel family the time-weighted matrix-pipe occupancy (bench.py puts it into `roofline`)
+        import json
+        fams = {'conv_igemm': ('conv_igemm', 'conv3x3_halo'), 'conv_wgrad': ('conv_wgrad',), 'bn': ('bn_',)}
+        out = {}
+        for fam, pats in fams.items():
+            num = den = 0.0
+            per = {}
+            for n, r in k.items():
+                if not any(p in n for p in pats):
+                    continue
+                c = r['c']
+                if 'SQ_BUSY_CYCLES' not in c or 'SQ_VALU_MFMA_BUSY_CYCLES' not in c:
+                    continue
+                busy = c['SQ_VALU_MFMA_BUSY_CYCLES'] / (32.0 * c['SQ_BUSY_CYCLES'])
+                w = r['total_us']
+                num, den = num + busy * w, den + w
+                per[n[:100]] = dict(mfma_busy=round(busy, 4), avg_us=round(r['dur_us'], 1), dispatches_per_pass=r['n'] // max(1, len(paths)))
+            if den > 0:
+                out[fam] = dict(mfma_busy=round(num / den, 4), kernels=per)
+        out['method'] = ('rocprofv3 --kernel-trace --pmc <4 counters per pass> on `python bench.py --steps 2 --warmup 1 '
+                         '--no-cpu-baseline --no-kernel-timer` (tools/pmc_bench.sh); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / '
+                         '(32 x SQ_BUSY_CYCLES) per dispatch, averaged per kernel, weighted by kernel time over the family')
+        with open(jpath[0], 'w') as f:
+            json.dump(out, f, indent=1)
     names = sorted(k, key=lambda n: -k[n]['total_us'])[:top]
     print(__doc__.split('usage')[0])
     for n in names:

@@ -23,7 +23,8 @@ def per_dispatch(db_path, counter):
     return acc, name_of
 
 
-def main(fetch_db, write_db, out):
+def main(fetch_db, write_db, out, steps=7):
+    steps = int(steps)   # steps the profiled command ran: 1 warm-up + 3 unblocked-host probes + 3 timed (tools/profile_round.sh)
     res = {}
     f_acc, f_name = per_dispatch(fetch_db, 'FETCH_SIZE')
     w_acc, w_name = per_dispatch(write_db, 'WRITE_SIZE')
@@ -34,7 +35,8 @@ def main(fetch_db, write_db, out):
             continue
         fb = 2.0 * 1024.0 * sum(fsel) / len(fsel)
         wb = 1024.0 * sum(wsel) / len(wsel)
-        res[fam] = {'launches': len(fsel), 'fetch_bytes_per_launch': round(fb), 'write_bytes_per_launch': round(wb),
+        res[fam] = {'launches': len(fsel), 'kernel_launches_per_step': round(len(fsel) / steps, 1),
+                    'fetch_bytes_per_launch': round(fb), 'write_bytes_per_launch': round(wb),
                     'hbm_bytes_per_launch': round(fb + wb)}
     res['method'] = __doc__.split('\n\n')[0] if False else (
         'rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE on `python bench.py --steps 3 '
@@ -47,4 +49,4 @@ def main(fetch_db, write_db, out):
 
 
 if __name__ == '__main__':
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
