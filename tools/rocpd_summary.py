@@ -9,7 +9,8 @@ import sqlite3
 import sys
 
 
-def main(db_path, out, steps=25):
+def main(db_path, out, steps=28):
+    steps = int(steps)   # bench.py --steps 20 --warmup 5 runs 28 steps since round 3 (+ 3 empty-queue host probes)
     db = sqlite3.connect(db_path)
     rows = db.execute('select name, count(*), sum(duration), avg(duration), min(duration), max(duration) '
                       'from kernels group by name order by sum(duration) desc').fetchall()
@@ -23,8 +24,8 @@ def main(db_path, out, steps=25):
                         round(100.0 * s / total, 2)])
     fams = [('conv_igemm (forward + data gradient: conv3x3_halo_x3 / conv_igemm_x3ws / conv_igemm_x3 / conv_igemm kernels)', ('conv_igemm', 'conv3x3_halo')),
             ('conv_wgrad (conv_wgrad_x3ws / conv_wgrad_x3 / conv_wgrad kernels)', ('conv_wgrad',)),
-            ('conv_wgrad as bench.py brackets it (one span per C-ABI call: + splitk_reduce, colsum_*, pack_f16x2 kernels; '
-             '"launches" = weight-gradient kernels)', ('conv_wgrad', 'splitk_reduce', 'colsum_', 'pack_f16x2')),
+            ('conv_wgrad as bench.py brackets it (one span per C-ABI call: + splitk_reduce, colsum_*, pack_f16x2 / pack_planar kernels; '
+             '"launches" = weight-gradient kernels)', ('conv_wgrad', 'splitk_reduce', 'colsum_', 'pack_f16x2', 'pack_planar')),
             ('BatchNorm (bn_* kernels; bench.py times C-ABI calls of 2-3 kernels each)', ('bn_',))]
     fam_rows = []
     for label, pats in fams:
@@ -49,4 +50,4 @@ def main(db_path, out, steps=25):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 25)
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 28)
