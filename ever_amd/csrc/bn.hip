@@ -94,9 +94,25 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
 // workgroups instead of C/32 spreads it over more CUs), then fold the 32 lanes through LDS in a fixed
 // order.  Returns true on the lane that holds the totals.
 constexpr int kFinCh = 8, kFinLanes = 32;
+// Fold one value per thread over the FL lanes of a channel (thread = lane * FC + channel, FC * FL = 256): xor-shuffles
+// inside a wave (a channel's lanes sit FC apart), then the four waves' results through LDS — a fixed tree, so the result
+// is reproducible, and 4 + log2 steps where a serial fold by one thread took FL dependent LDS round trips (32 / 128 of
+// them: 4 / 16 us of the 6 / 16 us these finalisation launches took).  Every thread gets the total of its channel.
+template <int FC, typename T, typename Op>
+__device__ __forceinline__ T fold_channel_lanes(T v, T (*lds)[FC], Op op) {
+#pragma unroll
+  for (int o = FC; o < 64; o <<= 1) v = op(v, __shfl_xor(v, o, 64));
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane < FC) lds[w][lane] = v;
+  __syncthreads();
+  const int tc = threadIdx.x % FC;
+  const T r = op(op(lds[0][tc], lds[1][tc]), op(lds[2][tc], lds[3][tc]));
+  __syncthreads();
+  return r;
+}
 __device__ __forceinline__ bool reduce_partials(const float* __restrict__ partial, int nblk, int C, int& c, double& s,
                                                 double& q) {
-  __shared__ double red[2][kFinLanes][kFinCh];
+  __shared__ double red[4][kFinCh];
   const int tc = threadIdx.x % kFinCh, tl = threadIdx.x / kFinCh;
   c = blockIdx.x * kFinCh + tc;
   s = 0.0;
@@ -118,15 +134,10 @@ __device__ __forceinline__ bool reduce_partials(const float* __restrict__ partia
       q += (double)ps[b * st + C];
     }
   }
-  red[0][tl][tc] = s;
-  red[1][tl][tc] = q;
-  __syncthreads();
-  if (tl != 0 || c >= C) return false;
-  for (int k = 1; k < kFinLanes; ++k) {
-    s += red[0][k][tc];
-    q += red[1][k][tc];
-  }
-  return true;
+  auto add = [](double a, double b) { return a + b; };
+  s = fold_channel_lanes<kFinCh>(s, red, add);
+  q = fold_channel_lanes<kFinCh>(q, red, add);
+  return tl == 0 && c < C;
 }
 
 // mean / biased var -> save_mean, save_invstd, scale/shift for the apply pass; running stats update
@@ -391,7 +402,7 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
   if (!pmax) zero_amax(amax);
   float gmax = 0.f, xmax = 0.f;
   if (pmax) {
-    __shared__ float mred[2][kFinLanes][kFinCh];
+    __shared__ float mred[4][kFinCh];
     const int tc = threadIdx.x % kFinCh, tl = threadIdx.x / kFinCh;
     const int cc = blockIdx.x * kFinCh + tc;
     if (cc < C) {
@@ -411,14 +422,9 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
         xmax = fmaxf(xmax, pm[b * st + C]);
       }
     }
-    mred[0][tl][tc] = gmax;
-    mred[1][tl][tc] = xmax;
-    __syncthreads();
-    if (tl == 0)
-      for (int k = 1; k < kFinLanes; ++k) {
-        gmax = fmaxf(gmax, mred[0][k][tc]);
-        xmax = fmaxf(xmax, mred[1][k][tc]);
-      }
+    auto mx = [](float a, float b) { return fmaxf(a, b); };
+    gmax = fold_channel_lanes<kFinCh>(gmax, mred, mx);
+    xmax = fold_channel_lanes<kFinCh>(xmax, mred, mx);
   }
   int c;
   double s, q;
@@ -519,7 +525,7 @@ __global__ __launch_bounds__(256) void bn_parts_final_kernel(const float* __rest
   // With a common pivot p (the first record's mean) the merge of all records is three plain sums,
   //   N = sum n_i,  A = sum n_i (mean_i - p),  B = sum [M2_i + n_i (mean_i - p)^2]:  mean = p + A/N,  M2 = B - A^2/N
   // (Chan's pairwise formula telescoped; no division inside the loop, no order dependence beyond the fixed one below).
-  __shared__ double red[3][FL][FC];
+  __shared__ double red[4][FC];
   const int tc = threadIdx.x % FC, tl = threadIdx.x / FC;
   const int c = blockIdx.x * FC + tc;
   double N = 0.0, A = 0.0, B = 0.0, piv = 0.0;
@@ -555,18 +561,13 @@ __global__ __launch_bounds__(256) void bn_parts_final_kernel(const float* __rest
       if (pack && n0 > 0.0) E = fmaxf(E, sqrtf(r0[2 * C]) + fabsf((float)d0));
     }
   }
-  __shared__ float ered[FL][FC];
-  if (pack) ered[tl][tc] = E;
-  red[0][tl][tc] = N;
-  red[1][tl][tc] = A;
-  red[2][tl][tc] = B;
-  __syncthreads();
+  __shared__ float ered[4][FC];
+  auto add = [](double a, double b) { return a + b; };
+  N = fold_channel_lanes<FC>(N, red, add);
+  A = fold_channel_lanes<FC>(A, red, add);
+  B = fold_channel_lanes<FC>(B, red, add);
+  if (pack) E = fold_channel_lanes<FC>(E, ered, [](float a, float b) { return fmaxf(a, b); });
   if (tl != 0 || c >= C) return;
-  for (int k = 1; k < FL; ++k) {
-    N += red[0][k][tc];
-    A += red[1][k][tc];
-    B += red[2][k][tc];
-  }
   const double mean = N > 0.0 ? piv + A / N : 0.0;
   double var = N > 0.0 ? (B - A * A / N) / N : 0.0;
   if (var < 0.0) var = 0.0;
@@ -582,7 +583,6 @@ __global__ __launch_bounds__(256) void bn_parts_final_kernel(const float* __rest
   scale_shift[c] = sc;
   scale_shift[C + c] = bb - meanf * sc;
   if (pack) {
-    for (int k = 1; k < FL; ++k) E = fmaxf(E, ered[k][tc]);
     const float bound = fabsf(sc) * (E * 1.001f + fabsf((float)(piv - mean))) + fabsf(bb);
     uint32_t bits = __builtin_bit_cast(uint32_t, bound);
     if (bound != bound) bits = 0x7fc00000u;
