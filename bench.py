@@ -56,6 +56,9 @@ def parse():
                         'MFMA products, fp32 grade; bf16x3 = 3-term bf16 split, 6 products, fp32 grade; f32 = exact fp32 '
                         'MFMA; bf16 = plain bf16 operands, the --mixed_precision bf16 mode: NOT the headline configuration)')
     p.add_argument('--no-kernel-timer', action='store_true')
+    p.add_argument('--graph', action='store_true',
+                   help='run the step as one captured hipGraph (ever_amd/core/graph.py; N = 1, no per-kernel event timer): '
+                        'what the host costs then is in host_*_ms_per_step')
     p.add_argument('--config', choices=['c2', 'c3', 'c4', 'c5'], default='c2',
                    help='BASELINE.json configs[1..4] at N = 1 (per-GPU size): c2 = the headline (default, the only one the '
                         'driver times); c3 = FarSeg++ R50 4-band 1024x1024 batch 8; c4 = ChangeStar (FarSeg-R50 + ChangeMixin) '
@@ -240,11 +243,25 @@ def main():
                                                             bucket_cap_mb=64, gradient_as_bucket_view=True)
     opt = er.opt.FusedSGD(model.parameters(), lr=0.007, momentum=0.9, weight_decay=1e-4)
 
-    def step():
-        out = ddp(*inputs)
+    def eager_step(*data):
+        out = ddp(*data)
         sum(v for k, v in out.items() if k.endswith('loss')).backward()
         opt.step()
         opt.zero_grad(set_to_none=True)
+        return out
+
+    if args.graph:
+        if use_ddp:
+            raise SystemExit('--graph: single-process only (no collective inside the captured step)')
+        from ever_amd.core.graph import GraphedTrainStep
+        graphed = GraphedTrainStep(eager_step, opt, modules=(model,))
+        args.no_kernel_timer = True
+
+        def step():
+            graphed(*inputs)
+    else:
+        def step():
+            eager_step(*inputs)
 
     def fence():
         torch.cuda.synchronize()
@@ -309,6 +326,7 @@ def main():
             'host_enqueue_ms_per_step': round(enqueued / args.steps * 1e3, 3),
             'host_unblocked_ms_per_step': round(host_unblocked_ms, 3),
             'host_cores': host_cores(), 'host_affinity': len(os.sched_getaffinity(0)),
+            'hip_graph': bool(args.graph),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if conv_math == 'bf16' else 'f32', 'data': 'synthetic',
             'config': {'workload': workload,

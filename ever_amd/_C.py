@@ -101,6 +101,7 @@ SIGNATURES = {
                                                  P, c_size_t, P, P]),
     'evk_bn_relu_pool_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, P, c_size_t, P, P]),
     'evk_bn_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_i64, c_i32, c_u32, c_i32, P, c_size_t, P, P]),
+    'evk_bn_fused_stream_claim': (c_int, [P]),
     'evk_bn_bwd_bits': (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_i64, c_i32, c_u32, c_i32, P, c_size_t, P, P, P]),
     'evk_relu_fwd': (c_int, [P, P, c_i64, P]),
     'evk_relu_bwd': (c_int, [P, P, P, c_i64, P]),
@@ -136,6 +137,7 @@ SIGNATURES = {
     'evk_opt_blocks_per_tensor': (c_i32, []),
     'evk_sqnorm_multi': (c_int, [P, P, c_i32, P, c_f32, P, P, P]),
     'evk_sgd_multi': (c_int, [P, P, P, P, c_i32, c_f32, c_f32, c_f32, c_f32, c_i32, c_i32, P, P]),
+    'evk_sgd_multi_lr': (c_int, [P, P, P, P, c_i32, c_f32, P, c_f32, c_f32, c_f32, c_i32, c_i32, P, P]),
     'evk_adam_multi': (c_int, [P, P, P, P, P, c_i32, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_f32, P, P]),
     'evk_prob_stats_doubles': (c_i64, [c_i32]),
     'evk_prob_stats': (c_int, [P, P, c_i64, c_i32, c_i64, P, P]),

@@ -238,6 +238,28 @@ class Launcher:
         else:
             raise NotImplementedError()
 
+    def _graphed_step(self, n_micro, distributed):
+        """EVK_GRAPH=1: the step as one captured hipGraph (core/graph.py) — single process, one micro-batch, fp32-grade or
+        bf16 arithmetic without a GradScaler, FusedSGD on a CUDA model; None = the eager path."""
+        import os
+        if os.environ.get('EVK_GRAPH', '0') != '1':
+            return None
+        if getattr(self, '_graph_step', None) is None:
+            from ..opt.optimizer import FusedSGD
+            from .graph import GraphedTrainStep
+            ok = (n_micro == 1 and not distributed and get_world_size() == 1 and self.scaler is None
+                  and isinstance(self._optimizer, FusedSGD) and next(self._model.parameters()).is_cuda)
+            if not ok:
+                self._graph_step = False
+                return None
+
+            def step_fn(*sub):
+                msg = self.compute_loss_gradient(sub, 1)
+                msg |= self.unwrapped_model.apply_gradients(self.optimizer, self._amp, scaler=self.scaler)
+                return {k: v for k, v in msg.items() if isinstance(v, torch.Tensor)}
+            self._graph_step = GraphedTrainStep(step_fn, self._optimizer, modules=(self._model,))
+        return self._graph_step or None
+
     # ------------------------------------------------------------------ the loop
     def train_iters(self, train_data_loader, test_data_loader=None, **kwargs):
         num_iters = kwargs.get('num_iters', -1)
@@ -277,9 +299,14 @@ class Launcher:
 
             with torch.autograd.profiler.record_function('forward_backward'):
                 n_micro = len(data)
-                for sub in data:
-                    msg_dict = self.compute_loss_gradient(sub, n_micro)
-                grad_info = self.unwrapped_model.apply_gradients(self.optimizer, self._amp, scaler=self.scaler)
+                graphed = self._graphed_step(n_micro, distributed)
+                if graphed is not None:
+                    msg_dict = dict(graphed(*data[0]))      # one hipGraph replay (core/graph.py): forward .. SGD update
+                    grad_info = {}
+                else:
+                    for sub in data:
+                        msg_dict = self.compute_loss_gradient(sub, n_micro)
+                    grad_info = self.unwrapped_model.apply_gradients(self.optimizer, self._amp, scaler=self.scaler)
             msg_dict |= grad_info
             pending = self._start_log(msg_dict)
 

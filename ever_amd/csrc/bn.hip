@@ -9,7 +9,7 @@
 #include <mutex>
 #include <unordered_map>
 
-static uint32_t* fused_counter(hipStream_t st);   // (defined with the one-launch backward, below)
+static uint32_t* fused_counter(hipStream_t st, bool take_over = false);   // (defined with the one-launch backward, below)
 
 namespace evk {
 
@@ -1346,7 +1346,7 @@ static FusedPlan fused_plan(int64_t rows, int C) {
 // The barrier words of a device (device memory owned by the library, zeroed once; the barrier resets itself).  The
 // kernel's grid must be resident as a whole, so two such grids must never run concurrently: the one-launch form is given
 // to ONE stream per device (the first that asks); any other stream gets nullptr = the three-launch form.
-static uint32_t* fused_counter(hipStream_t st) {
+static uint32_t* fused_counter(hipStream_t st, bool take_over) {
   struct Entry { hipStream_t stream; uint32_t* words; };
   static std::mutex mu;
   static std::unordered_map<int, Entry> by_dev;
@@ -1360,7 +1360,16 @@ static uint32_t* fused_counter(hipStream_t st) {
     if (hipMalloc((void**)&w, bytes) != hipSuccess || hipMemset(w, 0, bytes) != hipSuccess) return nullptr;
     it = by_dev.emplace(dev, Entry{st, w}).first;
   }
+  if (take_over) it->second.stream = st;
   return it->second.stream == st ? it->second.words : nullptr;
+}
+
+// Hand the one-launch backward of the current device to `stream` (hipGraph capture runs on a stream of its own:
+// ever_amd/core/graph.py claims it for the capture and gives it back afterwards).  The CALLER guarantees that the previous
+// owner has no such kernel in flight or queued — synchronise the device first.
+extern "C" int evk_bn_fused_stream_claim(void* stream) {
+  EVK_REQUIRE(fused_counter((hipStream_t)stream, true) != nullptr, EVK_E_LAUNCH, "bn_fused_stream_claim: no barrier words");
+  return EVK_OK;
 }
 
 extern "C" int evk_bn_bwd_bits(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,

@@ -48,7 +48,9 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(float* const* __restrict
                                                         float* const* __restrict__ bufs,
                                                         const int64_t* __restrict__ sizes, float lr, float momentum,
                                                         float dampening, float wd, int nesterov, int first_step,
-                                                        const float* __restrict__ clip_coef) {
+                                                        const float* __restrict__ clip_coef,
+                                                        const float* __restrict__ lr_dev) {
+  if (lr_dev) lr = *lr_dev;   // a captured launch (hipGraph replay) must not bake the schedule's value in
   const int t = blockIdx.y;
   float* p = params[t];
   const float* g = grads[t];
@@ -152,16 +154,23 @@ extern "C" int evk_sqnorm_multi(const float* const* grads, const int64_t* sizes,
   return check_launch("sqnorm_multi");
 }
 
-extern "C" int evk_sgd_multi(float* const* params, const float* const* grads, float* const* momentum_bufs,
-                             const int64_t* sizes, int32_t ntensors, float lr, float momentum, float dampening,
-                             float weight_decay, int32_t nesterov, int32_t first_step, const float* clip_coef,
-                             void* stream) {
+extern "C" int evk_sgd_multi_lr(float* const* params, const float* const* grads, float* const* momentum_bufs,
+                                const int64_t* sizes, int32_t ntensors, float lr, const float* lr_dev, float momentum,
+                                float dampening, float weight_decay, int32_t nesterov, int32_t first_step,
+                                const float* clip_coef, void* stream) {
   EVK_REQUIRE(params && grads && sizes && ntensors > 0, EVK_E_INVALID, "sgd_multi: bad argument");
   EVK_REQUIRE(momentum == 0.f || momentum_bufs, EVK_E_INVALID, "sgd_multi: momentum needs buffers");
   hipLaunchKernelGGL(sgd_multi_kernel, dim3(kOptBlocksPerTensor, ntensors), dim3(256), 0, (hipStream_t)stream, params,
                      grads, momentum_bufs, sizes, lr, momentum, dampening, weight_decay, nesterov, first_step,
-                     clip_coef);
+                     clip_coef, lr_dev);
   return check_launch("sgd_multi");
+}
+extern "C" int evk_sgd_multi(float* const* params, const float* const* grads, float* const* momentum_bufs,
+                             const int64_t* sizes, int32_t ntensors, float lr, float momentum, float dampening,
+                             float weight_decay, int32_t nesterov, int32_t first_step, const float* clip_coef,
+                             void* stream) {
+  return evk_sgd_multi_lr(params, grads, momentum_bufs, sizes, ntensors, lr, nullptr, momentum, dampening, weight_decay,
+                          nesterov, first_step, clip_coef, stream);
 }
 
 // dst[offsets[t] + i] = srcs[t][i] * scale  (srcs[t] == NULL: zeros) — one launch packs every gradient of a

@@ -22,6 +22,21 @@ class FusedSGD(SGD):
         self._clip = None          # (max_norm,) set by fused_clip for the next step
         self._tabs = {}
         self.last_grad_norm = None
+        self._lr_dev = None        # per-group device words holding the learning rate (hipGraph capture: core/graph.py)
+
+    def use_device_lr(self, device):
+        """From now on the update kernel reads each group's learning rate from a device word, so that a launch captured
+        into a hipGraph follows the schedule on replay; `sync_device_lr()` refreshes the words from `param_groups`."""
+        self._lr_host = torch.empty((len(self.param_groups),), dtype=torch.float32).pin_memory()
+        self._lr_dev = torch.empty((len(self.param_groups),), dtype=torch.float32, device=device)
+        self.sync_device_lr()
+
+    def sync_device_lr(self):
+        if self._lr_dev is None:
+            return
+        for i, g in enumerate(self.param_groups):
+            self._lr_host[i] = float(g['lr'])
+        self._lr_dev.copy_(self._lr_host, non_blocking=True)
 
     # ERModule.clip_grad calls this instead of torch's clip_grad_norm_ (reference module.py:96-108)
     def fused_clip(self, max_norm=35, norm_type=2):
@@ -99,8 +114,10 @@ class FusedSGD(SGD):
                     buf = st['momentum_buffer'] = torch.empty_like(p).copy_(buf)
                 bufs.append(buf)
             bt = self._table((slot, 'b'), bufs, dev)
-        _C.call('evk_sgd_multi', pt.data_ptr(), gt.data_ptr(), None if bt is None else bt.data_ptr(),
-                sizes.data_ptr(), len(params), float(group['lr']), float(mom), float(group['dampening']),
+        gi = slot[0]
+        lr_ptr = None if self._lr_dev is None else self._lr_dev.data_ptr() + 4 * gi
+        _C.call('evk_sgd_multi_lr', pt.data_ptr(), gt.data_ptr(), None if bt is None else bt.data_ptr(),
+                sizes.data_ptr(), len(params), float(group['lr']), lr_ptr, float(mom), float(group['dampening']),
                 float(group['weight_decay']), 1 if group['nesterov'] else 0, 1 if first else 0,
                 None if self._clip is None else self._clip.data_ptr(), torch.cuda.current_stream().cuda_stream)
         # the kernel wrote the parameters through raw pointers: autograd's version counters did not move

@@ -356,6 +356,14 @@ int evk_bn_bwd_bits(const float* dy, const float* x, const float* y, const float
                     float* dgamma, float* dbeta, int64_t rows, int32_t C, uint32_t flags, int32_t train,
                     void* workspace, size_t workspace_bytes, uint32_t* dx_absmax, const uint32_t* relu_bits, void* stream);
 
+/* The one-launch form of evk_bn_bwd* synchronises its workgroups through a device-wide barrier, so only ONE stream per
+ * device may use it (the stream of the first training-mode forward); other streams get the three-launch form, whose
+ * partial sums fold in another order (last-bit differences).  A training step captured into a hipGraph runs on a stream of
+ * its own (ever_amd/core/graph.py): it claims the one-launch form for the capture and hands it back afterwards.  The
+ * caller guarantees the previous owner has no BatchNorm backward in flight (synchronise the device first).
+ * No reference counterpart (torch's batch_norm backward has no stream affinity). */
+int evk_bn_fused_stream_claim(void* stream);
+
 /* ------------------------------------------------------------------ pointwise / resampling - */
 /* nn.ReLU (fs_relation.py:25) and its backward; elementwise add (fpn.py:105). */
 int evk_relu_fwd(const float* x, float* y, int64_t n, void* stream);
@@ -476,6 +484,12 @@ int evk_sgd_multi(float* const* params, const float* const* grads, float* const*
                   const int64_t* sizes, int32_t ntensors, float lr, float momentum, float dampening,
                   float weight_decay, int32_t nesterov, int32_t first_step,
                   const float* clip_coef /* device scalar or NULL */, void* stream);
+/* ... with the learning rate read from a device word when lr_dev != NULL (lr is then ignored): a launch captured into a
+ * hipGraph (ever_amd/core/graph.py) must follow the schedule on replay. */
+int evk_sgd_multi_lr(float* const* params, const float* const* grads, float* const* momentum_bufs,
+                     const int64_t* sizes, int32_t ntensors, float lr, const float* lr_dev, float momentum,
+                     float dampening, float weight_decay, int32_t nesterov, int32_t first_step,
+                     const float* clip_coef, void* stream);
 /* torch.optim.Adam (decoupled = 0) / AdamW (decoupled = 1) step, no amsgrad — opt/optimizer.py:8-9 registers both.
  * bias_correction1 = 1 - beta1^step, sqrt_bias_correction2 = sqrt(1 - beta2^step) for the step being taken. */
 int evk_adam_multi(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
