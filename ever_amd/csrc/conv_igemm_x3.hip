@@ -290,18 +290,21 @@ int launch_igemm_x3(IGemmArgs& a, hipStream_t stream) {
       if (!strcmp(f, "w256")) return launch_igemm_x3ws_forced(a, 256, stream);
       if (!strcmp(f, "w128")) return launch_igemm_x3ws_forced(a, 128, stream);
       if (!strcmp(f, "w64")) return launch_igemm_x3ws_forced(a, 64, stream);
+      if (!strcmp(f, "d256") && conv1x1_dma_applicable(a)) return launch_conv1x1_dma_forced(a, 256, stream);
+      if (!strcmp(f, "d128") && conv1x1_dma_applicable(a)) return launch_conv1x1_dma_forced(a, 128, stream);
+      if (!strcmp(f, "d64") && conv1x1_dma_applicable(a)) return launch_conv1x1_dma_forced(a, 64, stream);
+      if (!strcmp(f, "e128") && conv1x1_dma_applicable(a)) return launch_conv1x1_dma_forced(a, 2128, stream);
+      if (!strcmp(f, "e64") && conv1x1_dma_applicable(a)) return launch_conv1x1_dma_forced(a, 2064, stream);
       if (!strcmp(f, "c128x128")) return launch_cfg3<128, 128, 2, 2, 1>(a, stream);
       if (!strcmp(f, "c64x128")) return launch_cfg3<64, 128, 2, 2, 1>(a, stream);
       if (!strcmp(f, "c128x64")) return launch_cfg3<128, 64, 2, 2, 1>(a, stream);
       if (!strcmp(f, "c64x64")) return launch_cfg3<64, 64, 2, 2, 1>(a, stream);
     }
   }
-#ifdef EVK_WITH_X3DMA   // experimental/conv_igemm_x3dma.hip, `make EXPERIMENTAL=1` only
   {
-    const int rc = launch_igemm_x3dma(a, stream);  // LDS-DMA form for the one-tap (1x1) convolutions
+    const int rc = launch_conv1x1_dma(a, stream);  // both operands by LDS-DMA: the one-tap layers of the f16x2 arithmetic
     if (rc != 1) return rc;
   }
-#endif
   {
     const int rc = launch_igemm_x3ws(a, stream);  // wave-specialised form for the large layers
     if (rc != 1) return rc;

@@ -243,11 +243,11 @@ __device__ __forceinline__ void igemm_store_rows_stats(const IGemmArgs& p, f32x1
 // merge the RPI lanes that share a channel group, then the row waves of the tile (through `xch`, an LDS area of
 // WAVES_N x 3 x WN floats outside every wave's scratch; ONE workgroup barrier — waves that have already ended are not
 // waited for), and write ONE record per tile: bn_part[tile][3][Cd]
-template <int WN, int WAVES_M>
+template <int WN, int WAVES_M, int WAVES_N = 2>
 __device__ __forceinline__ void bn_part_write(const IGemmArgs& p, const BnLaneStat& st, int tile, int n0, int wm, int wn,
                                               int lane, float* xch) {
   constexpr int LPR = WN / 4;
-  static_assert(WAVES_M == 1 || WAVES_M == 2, "row waves per tile");
+  static_assert(WAVES_M == 1 || WAVES_M == 2 || WAVES_M == 4, "row waves per tile");
   float n = st.n;
   const float inv = n > 0.f ? 1.f / n : 0.f;
   f32x4 mean = st.piv + st.s * inv;
@@ -282,6 +282,23 @@ __device__ __forceinline__ void bn_part_write(const IGemmArgs& p, const BnLaneSt
     if (wm == 1) return;
     if (lane < LPR) merge(x[0], *reinterpret_cast<const f32x4*>(x + WN), *reinterpret_cast<const f32x4*>(x + 2 * WN));
   }
+  if (WAVES_M == 4) {   // (xch: 3 x WAVES_N x 3 x WN floats) row waves 1..3 park their record, row wave 0 merges them in order
+    float* x = xch + ((wm > 0 ? wm - 1 : 0) * WAVES_N + wn) * 3 * WN + lane * 4;
+    if (wm >= 1 && lane < LPR) {
+      *reinterpret_cast<f32x4*>(x) = f32x4{n, n, n, n};
+      *reinterpret_cast<f32x4*>(x + WN) = mean;
+      *reinterpret_cast<f32x4*>(x + 2 * WN) = m2;
+    }
+    __syncthreads();
+    if (wm >= 1) return;
+    if (lane < LPR) {
+#pragma unroll
+      for (int o = 0; o < 3; ++o) {
+        const float* y = xch + (o * WAVES_N + wn) * 3 * WN + lane * 4;
+        merge(y[0], *reinterpret_cast<const f32x4*>(y + WN), *reinterpret_cast<const f32x4*>(y + 2 * WN));
+      }
+    }
+  }
   if (lane < LPR) {
     const int col = n0 + wn * WN + lane * 4;
     float* rec = p.bn_part + (size_t)tile * 3 * p.Cd + col;
@@ -305,7 +322,7 @@ __device__ __forceinline__ void igemm_epilogue_stats(const IGemmArgs& p, f32x16 
     const size_t roff = row < p.M ? (size_t)row * p.Cd : ~(size_t)0;
     igemm_store_rows_stats<NB, WN>(p, acc[a], roff, n0, wn, li, lh, scratch, st);
   }
-  bn_part_write<WN, WAVES_M>(p, st, m0 / (WM * WAVES_M), n0, wm, wn, lh * 32 + li,
+  bn_part_write<WN, WAVES_M, WAVES_N>(p, st, m0 / (WM * WAVES_M), n0, wm, wn, lh * 32 + li,
                              scratch_base + WAVES_M * WAVES_N * 32 * (WN + 4));
 }
 
@@ -325,7 +342,9 @@ int launch_igemm(IGemmArgs& a, hipStream_t stream);
 int launch_igemm_x3(IGemmArgs& a, hipStream_t stream);
 int launch_igemm_x3ws(IGemmArgs& a, hipStream_t stream);  // 1 = not applicable
 int launch_igemm_x3ws_forced(IGemmArgs& a, int bn, hipStream_t stream);
-int launch_igemm_x3dma(IGemmArgs& a, hipStream_t stream);  // 1 = not applicable
+int launch_conv1x1_dma(IGemmArgs& a, hipStream_t stream);  // 1 = not applicable (conv1x1_dma.hip)
+int launch_conv1x1_dma_forced(IGemmArgs& a, int bn, hipStream_t stream);
+bool conv1x1_dma_applicable(const IGemmArgs& a);
 int launch_conv3x3_halo(IGemmArgs& a, hipStream_t stream);  // 1 = not applicable
 bool conv_desc_uses_halo(const evk_conv_desc* d, int for_dgrad);
 int launch_split_weight_halo(const float* w, uint16_t* out, int Cout, int Cin, int for_dgrad, hipStream_t st,
