@@ -7,6 +7,7 @@ Module names / Sequential indices equal the reference's, so state-dict keys are 
 (`fpn_inner1.0.weight`, `blocks.3.2.0.weight`, `classifier.0.bias`, ...).
 """
 import math
+import os
 
 import torch.nn as nn
 
@@ -121,10 +122,65 @@ class AssymetricDecoder(nn.Module):
         return _Scale.apply(out, 1.0 / len(inner))
 
     def forward(self, feat_list):
+        if self.cls_cfg and self._classifier_commutes():
+            return self._forward_commuted(feat_list)
         out = self.features(feat_list)
         if self.cls_cfg:
             out = self.classifier(self.dropout(out))
         return out
+
+    # ---- classifier before the last upsampling -------------------------------------------------------------------
+    # Reference fpn.py:186-193: out = mean_i(branch_i(feat_i)); logits = up4(conv1x1(out) + b).  Every branch ends in
+    # `ReLU -> bilinear x2` (or in the ReLU, at the output stride), the mean is linear, and a 1x1 convolution (per pixel,
+    # across channels) commutes with a bilinear interpolation (per channel, across pixels; its weights sum to one, so the
+    # bias passes through as well):
+    #     conv1x1(mean_i up(r_i)) + b  =  mean_i up(conv1x1(r_i) + b)
+    # The right-hand side upsamples num_classes channels instead of out_channels, never forms the full-width mean, and
+    # its backward hands each branch a gradient at the branch's own resolution: at FarSeg-R50 512^2 x 16 this takes three
+    # 268 MB upsampled tensors, the 1.34 GB mean pass, the classifier's read of the mean and their backward counterparts
+    # off the step.  Same function, same parameters and gradients up to fp32 rounding (tests/test_decoder_commute_gpu.py);
+    # taken only when nothing could observe the tensors that no longer exist (hooks), EVK_DECODER_COMMUTE=0 disables it.
+    def _classifier_commutes(self):
+        if os.environ.get('EVK_DECODER_COMMUTE', '1') == '0':
+            return False
+        conv = self.classifier[0]
+        if tuple(conv.kernel_size) != (1, 1) or tuple(conv.stride) != (1, 1) or conv.groups != 1:
+            return False
+        if conv.out_channels >= conv.in_channels:
+            return False
+        if self.training and not isinstance(self.dropout, nn.Identity):
+            return False
+        if HF.observers_active():
+            return False
+        watched = [self.classifier, conv, self.dropout]
+        for block in self.blocks:
+            last = list(block)[-1]
+            watched += [block, last, list(last)[-1], getattr(list(last)[-1], '_inner_module', None)]
+        return not any(m is not None and (m._forward_hooks or m._forward_pre_hooks) for m in watched)
+
+    def _forward_commuted(self, feat_list):
+        from .layers import run_sequence
+        conv = self.classifier[0]
+        zs = []
+        for i, block in enumerate(self.blocks):
+            subs = list(block)
+            x = feat_list[i]
+            for sub in subs[:-1]:
+                x = sub(x)
+            last = list(subs[-1])
+            up = last[-1]
+            has_up = not isinstance(up, nn.Identity)
+            x = run_sequence(last[:-1] if has_up else last, x)
+            z = conv(x)
+            zs.append(up(z) if has_up else z)
+        if len(zs) == 4:
+            out = HF.mean4(*zs)
+        else:
+            out = zs[0]
+            for t in zs[1:]:
+                out = HF.add(out, t)
+            out = _Scale.apply(out, 1.0 / len(zs))
+        return run_sequence(list(self.classifier)[1:], out)
 
 
 class _Scale:
