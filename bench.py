@@ -11,7 +11,7 @@ BASELINE.json configs[1]: FarSeg ResNet-50 FPN, 3-band 512x512, batch 16 per GPU
 
 Rank 0 prints ONE JSON line: the contract fields plus
   roofline     — achieved MFMA rate of the dominant kernel family (conv forward + data gradient:
-                 conv3x3_halo_x3 / conv_igemm_x3ws / conv_igemm_x3 kernels) = algorithmic FLOPs / HIP-event
+                 conv3x3_halo_x3 / conv1x1_dma / conv_igemm_x3ws / conv_igemm_x3 kernels) = algorithmic FLOPs / HIP-event
                  time of its launches over the timed region, against the peak of the instruction the
                  arithmetic issues: dense 16-bit MFMA 2500 TF / partial products per fp32 product — 3 for the default
                  f16x2 arithmetic (2-term scaled fp16 split) = 833.3 TF, 6 under --conv-math bf16x3 = 416.7 TF
@@ -385,7 +385,7 @@ def main():
                 traffic, traffic_file = pmc_traffic('conv_igemm') if (conv_math == 'f16x2' and args.config == 'c2') else (None, None)
                 line['roofline'] = {
                     'bound': 'mfma',
-                    'kernel': ('evk::conv3x3_halo_x3_kernel / conv_igemm_x3ws_kernel / conv_igemm_x3_kernel' if x3
+                    'kernel': ('evk::conv3x3_halo_x3_kernel / conv1x1_dma_kernel / conv_igemm_x3ws_kernel / conv_igemm_x3_kernel' if x3
                                else 'evk::conv_igemm_kernel') + ' (conv forward + data-gradient launches)',
                     'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'peak_note': peak_note,
                     'frac': round(ach / peak, 4), 'traffic': traffic,

@@ -16,6 +16,7 @@
 // 32-byte row are swapped on odd 8-row groups (conflict-free b128 reads for any tap shift).
 #include "igemm_common.hpp"
 #include "split_weight.hpp"
+#include "lds_dma.hpp"
 #include <stdlib.h>
 #include <string.h>
 
@@ -39,8 +40,8 @@ constexpr int kRB = kCh * 2;                   // bytes per row and plane
 
 __device__ __forceinline__ int half_off(int row, int c16) { return row * kRB + ((c16 ^ ((row >> 3) & 1)) << 4); }
 
-template <int BN, int PH, int NPX>
-__global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p, int tiles_y, int tiles_x) {
+template <int BN, int PH, int NPX, bool WDMA>
+__global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p, int tiles_y, int tiles_x, int dbg) {
   constexpr int NP = X3Mode<NPX>::NP;
   constexpr bool PK = X3Mode<NPX>::PK;   // the activation operand arrives packed (x3_common.hpp)
   constexpr int PL = NP == 2 ? 2 : 3;
@@ -51,9 +52,12 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
   constexpr int WMR = PH * kPW / 2;                   // rows per matrix wave (2 waves along M)
   constexpr int WN = BN / 2, NB = WN / 32, MB = WMR / 32;
   constexpr int AI = (kHaloPix * 4 + 255) / 256;      // halo items per staging thread
+  // f16x2: the weight tiles go global -> LDS by DMA (they are pre-split planes in this kernel's own order: nothing to
+  // convert), three stages deep; the other arithmetics stage them through registers, two stages
+  constexpr bool BDMA = WDMA && NP == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
   unsigned char* const Abase = smem3;                 // [2][kAStage]
-  unsigned char* const Bbase = smem3 + 2 * kAStage;   // [2][kBStage]
+  unsigned char* const Bbase = smem3 + 2 * kAStage;   // [BDMA ? 3 : 2][kBStage]
 
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = bid % p.tiles_n;
@@ -142,6 +146,69 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
         if (b_has[i]) *reinterpret_cast<u32x4*>(B + b_lds[i]) = rbv[i];
     };
 
+    if (dbg & 1) {   // ablation (EVK_TUNE + EVK_HALO_DBG=1, tools/ab_halo.py): the staging waves only keep the barriers
+      __syncthreads();
+      for (int it = 0; it < niter; ++it) __syncthreads();
+      return;
+    }
+    if constexpr (BDMA) {
+      // ---- weights by DMA.  A (tap, plane) tile is BN rows x 32 B, contiguous in HBM; one instruction moves 32 rows, the
+      // 16-byte halves of a row swapped on the source side where half_off() swaps them in LDS.  Iteration it + 2 is issued
+      // during iteration it (ring of three), so a tile has two iterations to land; completion is counted by hand and the
+      // barriers are raw (a __syncthreads would drain the DMA: lds_dma.hpp).
+      constexpr int NQ = BN / 32, NBI = 3 * PL * NQ, PERB = NBI / 4;
+      static_assert(NBI % 4 == 0, "weight DMA instructions split over four staging waves");
+      const int swave = __builtin_amdgcn_readfirstlane(ptid >> 6), lane = ptid & 63;
+      const uint32_t tap_bytes = (uint32_t)tap_stride * 2u, plane_bytes = 9u * tap_bytes;
+      const i32x4 rs_b = make_rsrc(p.wgt3, (uint32_t)PL * plane_bytes);
+      const uint32_t ldsB = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)Bbase;
+      uint32_t bd_voff[PERB], bd_lds[PERB];
+#pragma unroll
+      for (int i = 0; i < PERB; ++i) {
+        const int id = swave * PERB + i;
+        const int jx = id / (PL * NQ), pt = (id / NQ) % PL, q = id % NQ;
+        const int row = 32 * q + (lane >> 1), half = (lane & 1) ^ ((row >> 3) & 1);
+        const int co = n0 + row;
+        bd_voff[i] = co < p.Cd ? (uint32_t)pt * plane_bytes + (uint32_t)jx * tap_bytes + (uint32_t)co * kRB + (uint32_t)half * 16u
+                               : kDmaOOB;
+        bd_lds[i] = (uint32_t)((jx * PL + pt) * BN * kRB + q * 1024);
+      }
+      auto issue_b = [&](int it, int stage) {
+        const int c = it / 3, jy = it - 3 * c;
+        const uint32_t soff = (uint32_t)(jy * 3) * tap_bytes + (uint32_t)c * (uint32_t)p.Cd * kRB;
+        const uint32_t S = ldsB + stage * kBStage;
+#pragma unroll
+        for (int i = 0; i < PERB; ++i) {
+          uint32_t keep;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"(bd_voff[i]), "s"(S + bd_lds[i]), "s"(rs_b), "s"(soff) : "memory");
+        }
+      };
+      issue_b(0, 0);
+      if (niter > 1) issue_b(1, 1);
+      load_a(0);
+      store_a(0);
+      if (nchunk > 1) load_a(1);
+      wait_vmcnt<0>();
+      ring_barrier();
+      int st2 = 2;   // stage of iteration it + 2
+      for (int it = 0; it < niter; ++it) {
+        const int c = it / 3, jy = it - 3 * c;
+        // (halo first: its loads were issued an iteration or more ago; the wait the compiler puts in front of their use
+        // then finds the previous iteration's DMA landed too, not one issued a moment ago)
+        if (jy == 0 && c + 1 < nchunk) store_a((c + 1) & 1);   // the other halo stage was last read in chunk c-1
+        if (jy == 1 && c + 2 < nchunk) load_a(c + 2);
+        if (it + 2 < niter) {
+          issue_b(it + 2, st2);   // last read in iteration it - 1
+          wait_vmcnt<PERB>();     // everything older than these PERB instructions: iteration it + 1's tiles, the halo loads
+        } else {
+          wait_vmcnt<0>();
+        }
+        st2 = st2 == 2 ? 0 : st2 + 1;
+        ring_barrier();
+      }
+      return;
+    }
     load_a(0);
     load_b(0);
     store_a(0);
@@ -187,10 +254,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
   for (int b = 0; b < NB; ++b) fb[b] = half_off(wn * WN + b * 32 + li, lh);
 
   __syncthreads();
+  if (dbg & 2) {   // ablation (EVK_HALO_DBG=2): the matrix waves only keep the barriers
+    for (int it = 0; it < niter; ++it) __syncthreads();
+    return;
+  }
   for (int it = 0; it < niter; ++it) {
     const int c = it / 3, jy = it - 3 * c;
     const unsigned char* A = Abase + (c & 1) * kAStage;
-    const unsigned char* B = Bbase + (it & 1) * kBStage;
+    const unsigned char* B = Bbase + (BDMA ? it % 3 : (it & 1)) * kBStage;
     const int dy = p.oy0 + jy * p.oys;
 #pragma unroll
     for (int jx = 0; jx < 3; ++jx) {
@@ -279,7 +350,13 @@ bool conv_desc_uses_halo(const evk_conv_desc* d, int for_dgrad) {
   return conv3x3_halo_applies(a);
 }
 
-template <int BN, int PH, int NPX>
+// ablation switches, read on every launch under EVK_TUNE only: 1 = no staging work, 2 = no matrix work
+static int tune_dbg() {
+  static const bool tune = getenv("EVK_TUNE") != nullptr;
+  return tune && getenv("EVK_HALO_DBG") ? atoi(getenv("EVK_HALO_DBG")) : 0;
+}
+
+template <int BN, int PH, int NPX, bool WDMA = false>
 static int launch_halo_np(IGemmArgs& a, hipStream_t stream) {
   constexpr int NP = X3Mode<NPX>::NP;
   a.tiles_n = ceil_div(a.Cd, BN);
@@ -287,22 +364,28 @@ static int launch_halo_np(IGemmArgs& a, hipStream_t stream) {
   a.tiles_m = a.N * tiles_y * tiles_x;
   bn_stats_setup(a, PH * kPW, BN, 2, a.tiles_m);   // two row waves per patch; the ring (>= 100 KB) is the scratch
   constexpr int PL = NP == 2 ? 2 : 3;
-  const size_t lds = (size_t)2 * (PL * HaloGeom<PH, PL>::kHSlots * kRB) + (size_t)2 * (3 * PL * BN * kRB);
+  const size_t lds = (size_t)2 * (PL * HaloGeom<PH, PL>::kHSlots * kRB) + (size_t)(WDMA ? 3 : 2) * (3 * PL * BN * kRB);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_x3_kernel<BN, PH, NPX>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_x3_kernel<BN, PH, NPX, WDMA>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const long long nwg = (long long)a.tiles_m * a.tiles_n;
-  hipLaunchKernelGGL((conv3x3_halo_x3_kernel<BN, PH, NPX>), dim3((unsigned)nwg), dim3(512), lds, stream, a, tiles_y, tiles_x);
+  hipLaunchKernelGGL((conv3x3_halo_x3_kernel<BN, PH, NPX, WDMA>), dim3((unsigned)nwg), dim3(512), lds, stream, a, tiles_y, tiles_x,
+                     tune_dbg());
   return check_launch("conv3x3_halo_x3");
 }
 
 template <int BN, int PH>
 static int launch_halo(IGemmArgs& a, hipStream_t stream) {
   if (a.planes == 1) return launch_halo_np<BN, PH, 1>(a, stream);
-  if (a.planes == 2) return a.a_packed ? launch_halo_np<BN, PH, 4>(a, stream) : launch_halo_np<BN, PH, 2>(a, stream);
+  if (a.planes == 2) {
+    // EVK_HALO_WDMA=0: the weight tiles through registers as in the other arithmetics (A/B switch)
+    static const bool wdma = !(getenv("EVK_HALO_WDMA") && atoi(getenv("EVK_HALO_WDMA")) == 0);
+    if (wdma) return a.a_packed ? launch_halo_np<BN, PH, 4, true>(a, stream) : launch_halo_np<BN, PH, 2, true>(a, stream);
+    return a.a_packed ? launch_halo_np<BN, PH, 4>(a, stream) : launch_halo_np<BN, PH, 2>(a, stream);
+  }
   return launch_halo_np<BN, PH, 3>(a, stream);
 }
 

@@ -40,7 +40,7 @@ for (h, c, packed) in [(128, 256, 0), (128, 256, 1), (64, 256, 0), (64, 256, 1),
     fn = lambda: _C.call('evk_conv2d_fwd_f16x2', ctypes.byref(d), src.data_ptr(), bits[0].data_ptr(), planes.data_ptr(),
                          bits[1].data_ptr(), None, None, out.data_ptr(), flags, None, 0, ctypes.byref(z), None, st)
     row = []
-    for force in ('', 'm128x16', 'm128x8'):
+    for force in ('', 'h128x8'):
         os.environ['EVK_X3_HALO_FORCE'] = force
         for dbg in (0, 1, 2):
             os.environ['EVK_HALO_DBG'] = str(dbg)

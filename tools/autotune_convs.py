@@ -33,7 +33,7 @@ def record_problems():
     orig = _C.call
 
     def spy(name, *args):
-        if name in ('evk_conv2d_fwd_f16x2', 'evk_conv2d_dgrad_f16x2'):
+        if name in ('evk_conv2d_fwd_f16x2', 'evk_conv2d_dgrad_f16x2', 'evk_conv2d_dgrad_f16x2_ex', 'evk_conv2d_dgrad_f16x2_masked'):
             d = args[0]._obj
             key = tuple(getattr(d, f) for f in FIELDS)
             if name == 'evk_conv2d_fwd_f16x2':

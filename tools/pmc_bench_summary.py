@@ -41,7 +41,7 @@ def main():
     if jpath:
         # machine-readable: per kernel family the time-weighted matrix-pipe occupancy (bench.py puts it into `roofline`)
         import json
-        fams = {'conv_igemm': ('conv_igemm', 'conv3x3_halo'), 'conv_wgrad': ('conv_wgrad',), 'bn': ('bn_',)}
+        fams = {'conv_igemm': ('conv_igemm', 'conv3x3_halo', 'conv1x1_dma'), 'conv_wgrad': ('conv_wgrad',), 'bn': ('bn_',)}
         out = {}
         for fam, pats in fams.items():
             num = den = 0.0

@@ -22,7 +22,7 @@ def main(db_path, out, steps=28):
         for n, c, s, a, mn, mx in rows:
             w.writerow([n, c, round(s / 1e3, 1), round(a / 1e3, 2), round(mn / 1e3, 2), round(mx / 1e3, 2),
                         round(100.0 * s / total, 2)])
-    fams = [('conv_igemm (forward + data gradient: conv3x3_halo_x3 / conv_igemm_x3ws / conv_igemm_x3 / conv_igemm kernels)', ('conv_igemm', 'conv3x3_halo')),
+    fams = [('conv_igemm (forward + data gradient: conv3x3_halo_x3 / conv1x1_dma / conv_igemm_x3ws / conv_igemm_x3 / conv_igemm kernels)', ('conv_igemm', 'conv3x3_halo', 'conv1x1_dma')),
             ('conv_wgrad (conv_wgrad_x3ws / conv_wgrad_x3 / conv_wgrad kernels)', ('conv_wgrad',)),
             ('conv_wgrad as bench.py brackets it (one span per C-ABI call: + splitk_reduce, colsum_*, pack_f16x2 / pack_planar kernels; '
              '"launches" = weight-gradient kernels)', ('conv_wgrad', 'splitk_reduce', 'colsum_', 'pack_f16x2', 'pack_planar')),

@@ -9,7 +9,7 @@ import sqlite3
 import sys
 from collections import defaultdict
 
-FAMILIES = {'conv_igemm': ('conv_igemm', 'conv3x3_halo'), 'conv_wgrad': ('conv_wgrad',), 'bn': ('bn_',)}
+FAMILIES = {'conv_igemm': ('conv_igemm', 'conv3x3_halo', 'conv1x1_dma'), 'conv_wgrad': ('conv_wgrad',), 'bn': ('bn_',)}
 
 
 def per_dispatch(db_path, counter):
@@ -41,7 +41,7 @@ def main(fetch_db, write_db, out, steps=7):
     res['method'] = __doc__.split('\n\n')[0] if False else (
         'rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE on `python bench.py --steps 3 '
         '--warmup 1 --no-cpu-baseline --no-kernel-timer`; counters are KB summed over the 8 XCDs per dispatch; FETCH_SIZE '
-        'doubled (gfx950 reports half of a wide coalesced stream, guide §HBM); families: every conv_igemm* / conv3x3_halo* kernel '
+        'doubled (gfx950 reports half of a wide coalesced stream, guide §HBM); families: every conv_igemm* / conv3x3_halo* / conv1x1_dma* kernel '
         '(fp32, x3, x3ws, halo; forward + data gradient), every conv_wgrad* kernel, every bn_* kernel; tools/traffic_from_pmc.py')
     with open(out, 'w') as f:
         json.dump(res, f, indent=1)
