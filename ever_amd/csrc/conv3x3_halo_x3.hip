@@ -40,8 +40,9 @@ constexpr int kRB = kCh * 2;                   // bytes per row and plane
 
 __device__ __forceinline__ int half_off(int row, int c16) { return row * kRB + ((c16 ^ ((row >> 3) & 1)) << 4); }
 
-template <int BN, int PH, int NPX, bool WDMA>
-__global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p, int tiles_y, int tiles_x, int dbg) {
+// MW = matrix waves: 4 (2 x 2, one per SIMD) or 8 (4 x 2, two per SIMD: one's fragment reads under the other's MFMAs)
+template <int BN, int PH, int NPX, bool WDMA, int MW>
+__global__ __launch_bounds__(256 + 64 * MW) void conv3x3_halo_x3_kernel(const IGemmArgs p, int tiles_y, int tiles_x, int dbg) {
   constexpr int NP = X3Mode<NPX>::NP;
   constexpr bool PK = X3Mode<NPX>::PK;   // the activation operand arrives packed (x3_common.hpp)
   constexpr int PL = NP == 2 ? 2 : 3;
@@ -49,7 +50,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
   constexpr int kPH = PH, kHP = Geo::kHP, kHSlots = Geo::kHSlots, kHaloPix = Geo::kHaloPix;
   constexpr int kAStage = PL * kHSlots * kRB;         // three planes: 30720 B (PH 8) / 31104 B (PH 16); two: 20480 / 36864
   constexpr int kBStage = 3 * PL * BN * kRB;          // 36864 B at BN = 128 (24576 with two planes)
-  constexpr int WMR = PH * kPW / 2;                   // rows per matrix wave (2 waves along M)
+  constexpr int MWM = MW / 2;                         // matrix waves along M
+  constexpr int WMR = PH * kPW / MWM;                 // rows per matrix wave
   constexpr int WN = BN / 2, NB = WN / 32, MB = WMR / 32;
   constexpr int AI = (kHaloPix * 4 + 255) / 256;      // halo items per staging thread
   // f16x2: the weight tiles go global -> LDS by DMA (they are pre-split planes in this kernel's own order: nothing to
@@ -71,9 +73,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
   const int niter = nchunk * 3;
   const int tid = threadIdx.x;
 
-  if (tid >= 256) {
+  if (tid >= 64 * MW) {
     // ------------------------------------------------------------------ staging waves
-    const int ptid = tid - 256;
+    const int ptid = tid - 64 * MW;
     // halo items: (pixel 0..179, float4 q 0..3); three per thread, the last pass partially filled
     int a_src[AI], a_lds[AI];
     bool a_ok[AI], a_has[AI];
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
     BnLaneStat st;
     bn_stat_init(st);
     float* scratch = reinterpret_cast<float*>(smem3) + (wm * 2 + wn) * 32 * (WN + 4);
-    float* xch = reinterpret_cast<float*>(smem3) + 4 * 32 * (WN + 4);
+    float* xch = reinterpret_cast<float*>(smem3) + MW * 32 * (WN + 4);
 #pragma unroll
     for (int a = 0; a < MB; ++a) {
       const int m = wm * WMR + a * 32 + li;
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_x3_kernel(const IGemmArgs p,
       const size_t roff = (((size_t)n * p.Hd + (size_t)(gy * p.dsh + p.doy)) * p.Wd + (size_t)(gx * p.dsw + p.dox)) * p.Cd;
       igemm_store_rows_stats<NB, WN>(p, acc[a], roff, n0, wn, li, lh, scratch, st);
     }
-    bn_part_write<WN, 2>(p, st, (n * tiles_y + ty) * tiles_x + tx, n0, wm, wn, lh * 32 + li, xch);
+    bn_part_write<WN, MWM, 2>(p, st, (n * tiles_y + ty) * tiles_x + tx, n0, wm, wn, lh * 32 + li, xch);
     return;
   }
   AmaxAcc amax_l{0u, p.out_amax != nullptr};
@@ -356,7 +358,7 @@ static int tune_dbg() {
   return tune && getenv("EVK_HALO_DBG") ? atoi(getenv("EVK_HALO_DBG")) : 0;
 }
 
-template <int BN, int PH, int NPX, bool WDMA = false>
+template <int BN, int PH, int NPX, bool WDMA = false, int MW = 4>
 static int launch_halo_np(IGemmArgs& a, hipStream_t stream) {
   constexpr int NP = X3Mode<NPX>::NP;
   a.tiles_n = ceil_div(a.Cd, BN);
@@ -367,18 +369,22 @@ static int launch_halo_np(IGemmArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)2 * (PL * HaloGeom<PH, PL>::kHSlots * kRB) + (size_t)(WDMA ? 3 : 2) * (3 * PL * BN * kRB);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_x3_kernel<BN, PH, NPX, WDMA>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_x3_kernel<BN, PH, NPX, WDMA, MW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const long long nwg = (long long)a.tiles_m * a.tiles_n;
-  hipLaunchKernelGGL((conv3x3_halo_x3_kernel<BN, PH, NPX, WDMA>), dim3((unsigned)nwg), dim3(512), lds, stream, a, tiles_y, tiles_x,
+  hipLaunchKernelGGL((conv3x3_halo_x3_kernel<BN, PH, NPX, WDMA, MW>), dim3((unsigned)nwg), dim3(256 + 64 * MW), lds, stream, a, tiles_y, tiles_x,
                      tune_dbg());
   return check_launch("conv3x3_halo_x3");
 }
 
-template <int BN, int PH>
+template <int BN, int PH, int MW = 4>
 static int launch_halo(IGemmArgs& a, hipStream_t stream) {
+  if constexpr (MW == 8) {   // (the eight-matrix-wave form exists for the f16x2 arithmetic with DMA-fed weights)
+    if (a.planes == 2)
+      return a.a_packed ? launch_halo_np<BN, PH, 4, true, 8>(a, stream) : launch_halo_np<BN, PH, 2, true, 8>(a, stream);
+  }
   if (a.planes == 1) return launch_halo_np<BN, PH, 1>(a, stream);
   if (a.planes == 2) {
     // EVK_HALO_WDMA=0: the weight tiles through registers as in the other arithmetics (A/B switch)
@@ -398,16 +404,23 @@ int launch_conv3x3_halo(IGemmArgs& a, hipStream_t stream) {
       if (!strcmp(f, "h64x8")) return launch_halo<64, 8>(a, stream);
       if (!strcmp(f, "h128x8") && a.Cd > 64) return launch_halo<128, 8>(a, stream);
       if (!strcmp(f, "h128x16") && a.Cd > 64 && (a.Hm % 16) == 0) return launch_halo<128, 16>(a, stream);
+      if (!strcmp(f, "m128x8") && a.Cd > 64) return launch_halo<128, 8, 8>(a, stream);
+      if (!strcmp(f, "m128x16") && a.Cd > 64 && (a.Hm % 16) == 0) return launch_halo<128, 16, 8>(a, stream);
     }
   }
   if (a.Cd <= 64 || (long long)a.N * (a.Hm / 8) * (a.Wm / kPW) * ceil_div(a.Cd, 128) < 256)
     return launch_halo<64, 8>(a, stream);   // small maps (16^2 .. 32^2): 64-wide tiles keep every CU busy
   // 16 x 16 patches (256 GEMM rows) halve the weight bytes per MFMA, the larger share of the staging traffic now;
-  // taken when they still fill the chip
+  // taken when they still fill the chip.  With the weights fed by DMA (f16x2) the staging waves no longer hold the matrix
+  // waves back, and eight matrix waves (two per SIMD) are 1-7 % ahead of four on every 128-wide shape
+  // (tools/autotune_convs.py: 777 -> 763 us on 3x3x256 @128^2, 61 -> 57 on 3x3x128 @64^2, 59-62 -> 58 on 3x3x256 @32^2).
   static const int tall = getenv("EVK_X3_HALO_TALL") ? atoi(getenv("EVK_X3_HALO_TALL")) : 1;
+  static const bool m8 = !(getenv("EVK_HALO_WDMA") && atoi(getenv("EVK_HALO_WDMA")) == 0) &&
+                         !(getenv("EVK_HALO_M8") && atoi(getenv("EVK_HALO_M8")) == 0);
+  const bool wide8 = m8 && a.planes == 2;
   if (tall && (a.Hm % 16) == 0 && (long long)a.N * (a.Hm / 16) * (a.Wm / kPW) * ceil_div(a.Cd, 128) >= 256)
-    return launch_halo<128, 16>(a, stream);
-  return launch_halo<128, 8>(a, stream);
+    return wide8 ? launch_halo<128, 16, 8>(a, stream) : launch_halo<128, 16>(a, stream);
+  return wide8 ? launch_halo<128, 8, 8>(a, stream) : launch_halo<128, 8>(a, stream);
 }
 
 // planes for the halo kernel: out[pt][tap][chunk][row][16] bf16; tap = jy*3 + jx in the kernel's (affine) tap
