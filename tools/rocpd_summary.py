@@ -22,16 +22,17 @@ def main(db_path, out, steps=28):
         for n, c, s, a, mn, mx in rows:
             w.writerow([n, c, round(s / 1e3, 1), round(a / 1e3, 2), round(mn / 1e3, 2), round(mx / 1e3, 2),
                         round(100.0 * s / total, 2)])
-    fams = [('conv_igemm (forward + data gradient: conv3x3_halo_x3 / conv1x1_dma / conv_igemm_x3ws / conv_igemm_x3 / conv_igemm kernels)', ('conv_igemm', 'conv3x3_halo', 'conv1x1_dma')),
-            ('conv_wgrad (conv_wgrad_x3ws / conv_wgrad_x3 / conv_wgrad kernels)', ('conv_wgrad',)),
+    fams = [('conv_igemm (forward + data gradient: conv3x3_halo_x3 / conv1x1_dma / conv_igemm_x3ws / conv_igemm_x3 / conv_igemm kernels)', ('conv_igemm', 'conv3x3_halo', 'conv1x1_dma'), None),
+            ('conv_wgrad (conv_wgrad_x3ws / conv_wgrad_x3 / conv_wgrad_tr / conv_wgrad kernels)', ('conv_wgrad',), None),
             ('conv_wgrad as bench.py brackets it (one span per C-ABI call: + splitk_reduce, colsum_*, pack_f16x2 / pack_planar kernels; '
-             '"launches" = weight-gradient kernels)', ('conv_wgrad', 'splitk_reduce', 'colsum_', 'pack_f16x2', 'pack_planar')),
-            ('BatchNorm (bn_* kernels; bench.py times C-ABI calls of 2-3 kernels each)', ('bn_',))]
+             '"launches" = weight-gradient kernels)', ('conv_wgrad', 'splitk_reduce', 'colsum_', 'pack_f16x2', 'pack_planar'), ('conv_wgrad',)),
+            ('BatchNorm (bn_* kernels; bench.py times C-ABI calls of 2-3 kernels each)', ('bn_',), None)]
     fam_rows = []
-    for label, pats in fams:
+    for label, pats, count_pats in fams:
         sel = [r for r in rows if any(p in r[0] for p in pats)]
         if sel:
-            calls, tot = sum(r[1] for r in sel if pats[0] in r[0] or len(pats) < 3), sum(r[2] for r in sel)
+            calls = sum(r[1] for r in sel if any(p in r[0] for p in (count_pats or pats)))
+            tot = sum(r[2] for r in sel)
             fam_rows.append((label, calls, tot, tot / calls))
     with open(out + '.md', 'w') as f:
         f.write(f'# rocprofv3 --kernel-trace --stats summary\n\nsource: `{db_path}`; {sum(r[1] for r in rows)} '
