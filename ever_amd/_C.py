@@ -107,6 +107,8 @@ SIGNATURES = {
     'evk_relu_bwd': (c_int, [P, P, P, c_i64, P]),
     'evk_add': (c_int, [P, P, P, c_i64, P]),
     'evk_scale': (c_int, [P, c_f32, P, c_i64, P]),
+    'evk_group_weight_expand': (c_int, [P, P, c_i32, c_i32, c_i32, c_i32, P]),
+    'evk_group_weight_gather': (c_int, [P, P, c_i32, c_i32, c_i32, c_i32, P]),
     'evk_mul_scale': (c_int, [P, P, c_f32, P, c_i64, P]),
     'evk_gelu_fwd': (c_int, [P, P, c_i64, P]),
     'evk_gelu_bwd': (c_int, [P, P, P, c_i64, P]),

@@ -625,6 +625,46 @@ extern "C" int evk_add(const float* a, const float* b, float* out, int64_t n, vo
 extern "C" int evk_scale(const float* a, float alpha, float* out, int64_t n, void* stream) {
   EW_LAUNCH(3, a, (const float*)nullptr, out, n, alpha, "scale");
 }
+// Grouped convolution as a dense one (reference _resnets.py:21-24 `groups=groups`, the ResNeXt bodies :291-324): the
+// weight [Cout][taps][Cin / groups] becomes the block-diagonal dense [Cout][taps][Cin], zeros outside an output channel's
+// group — exact (the zeros contribute exact zeros in every arithmetic), and at 32 groups x 4..8 channels the dense form is
+// what fills an MFMA tile anyway.  The adjoint gathers the diagonal blocks of the dense weight gradient.
+__global__ __launch_bounds__(256) void group_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout,
+                                                           int taps, int Cin, int groups, int gather) {
+  const int cpg = Cin / groups, opg = Cout / groups;
+  const size_t n = (size_t)Cout * taps * (gather ? cpg : Cin);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    if (gather) {   // dst = grouped [Cout][taps][cpg], src = dense
+      const int c = (int)(i % cpg);
+      const size_t r = i / cpg;           // co * taps + tap
+      const int co = (int)(r / taps);
+      dst[i] = src[r * Cin + (size_t)(co / opg) * cpg + c];
+    } else {        // dst = dense [Cout][taps][Cin], src = grouped
+      const int ci = (int)(i % Cin);
+      const size_t r = i / Cin;
+      const int co = (int)(r / taps), g = co / opg;
+      const int c = ci - g * cpg;
+      dst[i] = (c >= 0 && c < cpg) ? src[r * cpg + c] : 0.f;
+    }
+  }
+}
+static int group_weight(const float* src, float* dst, int Cout, int taps, int Cin, int groups, int gather, void* stream) {
+  EVK_REQUIRE(src && dst, EVK_E_INVALID, "group_weight: null pointer");
+  EVK_REQUIRE(Cout > 0 && taps > 0 && Cin > 0 && groups > 0 && Cin % groups == 0 && Cout % groups == 0, EVK_E_INVALID,
+              "group_weight: Cout=%d Cin=%d groups=%d", Cout, Cin, groups);
+  const size_t n = (size_t)Cout * taps * (gather ? Cin / groups : Cin);
+  const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(group_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, Cout, taps, Cin, groups, gather);
+  return check_launch("group_weight");
+}
+extern "C" int evk_group_weight_expand(const float* w, float* dense, int32_t Cout, int32_t taps, int32_t Cin, int32_t groups,
+                                       void* stream) {
+  return group_weight(w, dense, Cout, taps, Cin, groups, 0, stream);
+}
+extern "C" int evk_group_weight_gather(const float* ddense, float* dw, int32_t Cout, int32_t taps, int32_t Cin, int32_t groups,
+                                       void* stream) {
+  return group_weight(ddense, dw, Cout, taps, Cin, groups, 1, stream);
+}
 extern "C" int evk_mul_scale(const float* a, const float* b, float alpha, float* out, int64_t n, void* stream) {
   EVK_REQUIRE(b, EVK_E_INVALID, "mul_scale: null b");
   EW_LAUNCH(4, a, b, out, n, alpha, "mul_scale");

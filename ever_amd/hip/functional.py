@@ -716,6 +716,38 @@ def _attach_parts(y, parts):
     return y
 
 
+class _GroupDenseFn(Function):
+    """grouped weight [Cout, Cin/g, kh, kw] -> block-diagonal dense [Cout, Cin, kh, kw] (include/ever_hip.h:
+    evk_group_weight_expand); backward gathers the diagonal blocks of the dense gradient"""
+
+    @staticmethod
+    def forward(ctx, weight, groups):
+        w = _weight_ohwi(weight.detach())
+        cout, cpg, kh, kw = weight.shape
+        dense = empty_nhwc(cout, cpg * groups, kh, kw, weight.device)
+        _C.call('evk_group_weight_expand', w.data_ptr(), dense.data_ptr(), cout, kh * kw, cpg * groups, groups, _stream())
+        ctx.groups, ctx.shape = groups, tuple(weight.shape)
+        return dense
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g = _weight_ohwi(g)
+        cout, cpg, kh, kw = ctx.shape
+        dw = empty_nhwc(cout, cpg, kh, kw, g.device)
+        _C.call('evk_group_weight_gather', g.data_ptr(), dw.data_ptr(), cout, kh * kw, cpg * ctx.groups, ctx.groups, _stream())
+        return dw, None
+
+
+def grouped_dense_weight(weight, groups):
+    """The dense weight a grouped convolution (reference _resnets.py:21-24, ResNeXt) runs with: exact zeros outside the
+    groups, so every dense kernel computes the grouped convolution; differentiable w.r.t. `weight`."""
+    if groups == 1:
+        return weight
+    _require_cuda(weight, 'grouped convolution weight')
+    return _GroupDenseFn.apply(weight, int(groups))
+
+
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, bn_stats=False):
     """bn_stats=True: the caller applies a training-mode BatchNorm to the result next; where the kernel can, the
     epilogue leaves that BatchNorm's partial statistics on the returned tensor (`_evk_bn_parts`) and

@@ -12,7 +12,7 @@ from .fold import _takes_epilogue_stats, _use_folded, conv_bn
 from .layers import AdaptiveAvgPool2d, BatchNorm2d, Conv2d, HipSequential, MaxPool2d, ReLU
 
 __all__ = ['ResNet', 'BasicBlock', 'Bottleneck', 'resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152',
-           'resnet50_v1c', 'resnet101_v1c']
+           'resnext50_32x4d', 'resnext101_32x4d', 'resnext101_32x8d', 'resnet50_v1c', 'resnet101_v1c']
 
 
 def conv3x3(cin, cout, stride=1, groups=1, dilation=1):
@@ -206,6 +206,9 @@ _URLS = {
     'resnet50': 'https://download.pytorch.org/models/resnet50-19c8e357.pth',
     'resnet101': 'https://download.pytorch.org/models/resnet101-5d3b4d8f.pth',
     'resnet152': 'https://download.pytorch.org/models/resnet152-b121ed2d.pth',
+    'resnext50_32x4d': 'https://download.pytorch.org/models/resnext50_32x4d-7cdf4587.pth',
+    'resnext101_32x8d': 'https://download.pytorch.org/models/resnext101_32x8d-8ba56ff5.pth',
+    'resnext101_32x4d': 'https://s3.ap-northeast-2.amazonaws.com/open-mmlab/pretrain/third_party/resnext101_32x4d-a5af3160.pth',
     'resnet50_v1c': 'https://download.openmmlab.com/pretrain/third_party/resnet50_v1c-2cccc1ad.pth',
     'resnet101_v1c': 'https://download.openmmlab.com/pretrain/third_party/resnet101_v1c-e67eebb6.pth',
 }
@@ -239,6 +242,20 @@ def resnet101(pretrained=False, progress=True, **kw):
 
 def resnet152(pretrained=False, progress=True, **kw):
     return _build('resnet152', Bottleneck, [3, 8, 36, 3], pretrained, progress, **kw)
+
+
+# ResNeXt (reference _resnets.py:291-324): the grouped 3x3 convolution runs dense with a block-diagonal weight
+# (layers.Conv2d), everything else is the bottleneck above at another width
+def resnext50_32x4d(pretrained=False, progress=True, **kw):
+    return _build('resnext50_32x4d', Bottleneck, [3, 4, 6, 3], pretrained, progress, **dict(kw, groups=32, width_per_group=4))
+
+
+def resnext101_32x4d(pretrained=False, progress=True, **kw):
+    return _build('resnext101_32x4d', Bottleneck, [3, 4, 23, 3], pretrained, progress, **dict(kw, groups=32, width_per_group=4))
+
+
+def resnext101_32x8d(pretrained=False, progress=True, **kw):
+    return _build('resnext101_32x8d', Bottleneck, [3, 4, 23, 3], pretrained, progress, **dict(kw, groups=32, width_per_group=8))
 
 
 def resnet50_v1c(pretrained=False, progress=True, **kw):

@@ -33,6 +33,8 @@ def _stamp(conv, bn):
 def _fold_pair(conv, bn):
     if not isinstance(bn, torch.nn.BatchNorm2d) or bn.running_mean is None:
         return None
+    if conv.groups != 1:      # grouped convolutions (ResNeXt) keep the conv + BatchNorm pair at inference
+        return None
     with torch.no_grad():
         dev = conv.weight.device
         s = (bn.weight if bn.affine else torch.ones_like(bn.running_mean)) * torch.rsqrt(bn.running_var + bn.eps)

@@ -19,7 +19,9 @@ Identity = nn.Identity
 
 
 class Conv2d(nn.Conv2d):
-    """nn.Conv2d (groups=1, zero padding) on the MFMA implicit-GEMM kernels; weight kept OHWI in memory."""
+    """nn.Conv2d (zero padding) on the MFMA implicit-GEMM kernels; weight kept OHWI in memory.  groups > 1 (the ResNeXt
+    bodies of reference _resnets.py:291-324) runs as a dense convolution with the block-diagonal weight
+    (HF.grouped_dense_weight: exact zeros outside the groups)."""
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
@@ -28,8 +30,8 @@ class Conv2d(nn.Conv2d):
 
     def forward(self, x, relu=False, bn_stats=False):
         """bn_stats: a training-mode BatchNorm consumes the result next (hip/functional.py:conv2d)"""
-        y = HF.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, relu=relu,
-                      bn_stats=bn_stats)
+        w = self.weight if self.groups == 1 else HF.grouped_dense_weight(self.weight, self.groups)
+        y = HF.conv2d(x, w, self.bias, self.stride, self.padding, self.dilation, relu=relu, bn_stats=bn_stats)
         if self._forward_hooks and getattr(y, '_evk_bn_parts', None) is not None and len(y._evk_bn_parts) > 2:
             # a forward hook may hang a tensor hook on y: its gradient (the BatchNorm's dx) must then stay fp32
             y._evk_bn_parts = y._evk_bn_parts[:2] + (False,)
@@ -54,9 +56,8 @@ class ConvTranspose2d(nn.ConvTranspose2d):
 
 
 def _check_conv(m):
-    if m.groups != 1:
-        raise NotImplementedError('ever_amd Conv2d: groups != 1 is not on the FarSeg hot path (SURVEY §8) and has '
-                                  'no HIP kernel')
+    if m.groups != 1 and isinstance(m, nn.ConvTranspose2d):
+        raise NotImplementedError('ever_amd ConvTranspose2d: groups != 1 has no HIP kernel')
     if m.padding_mode != 'zeros' or isinstance(m.padding, str):
         raise NotImplementedError('ever_amd Conv2d: only explicit zero padding is implemented')
 

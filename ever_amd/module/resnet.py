@@ -21,7 +21,8 @@ from .layers import Conv2d
 _logger = logger.get_logger()
 __all__ = ['ResNetEncoder']
 
-for _name in ('resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152', 'resnet50_v1c', 'resnet101_v1c'):
+for _name in ('resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152', 'resnext50_32x4d', 'resnext101_32x4d',
+              'resnext101_32x8d', 'resnet50_v1c', 'resnet101_v1c'):
     registry.MODEL.register(_name, getattr(_resnets, _name), verbose=False)
 
 

@@ -370,6 +370,13 @@ int evk_relu_fwd(const float* x, float* y, int64_t n, void* stream);
 int evk_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
 int evk_add(const float* a, const float* b, float* out, int64_t n, void* stream);
 int evk_scale(const float* a, float alpha, float* out, int64_t n, void* stream);
+/* Grouped convolution (reference _resnets.py:21-24 `groups=groups`; the ResNeXt bodies :291-324) runs as a DENSE one: the
+ * weight w [Cout][taps][Cin / groups] (OHWI memory) is expanded to the block-diagonal dense [Cout][taps][Cin] with exact zeros
+ * outside an output channel's group, the dense kernels above take it, and the adjoint gathers the diagonal blocks of the
+ * dense weight gradient.  Exact in every arithmetic; at 32 groups of 4..8 channels the dense form is what fills an MFMA
+ * tile anyway. */
+int evk_group_weight_expand(const float* w, float* dense, int32_t Cout, int32_t taps, int32_t Cin, int32_t groups, void* stream);
+int evk_group_weight_gather(const float* ddense, float* dw, int32_t Cout, int32_t taps, int32_t Cin, int32_t groups, void* stream);
 /* out = a * b * alpha — nn.Dropout(p) with a 0/1 keep mask (fpn.py:183,190 `self.dropout(out_feat)`), alpha = 1/(1-p) */
 int evk_mul_scale(const float* a, const float* b, float alpha, float* out, int64_t n, void* stream);
 /* nn.GELU() (exact, erf form) and its derivative: the decoder's activation when norm_fn is not BatchNorm2d — fpn.py:167 */

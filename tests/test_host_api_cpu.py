@@ -164,8 +164,12 @@ def test_to_hip_retargets_a_stock_model():
     er.module.to_hip(net)
     assert isinstance(net, er.module.HipSequential) and isinstance(net[0], er.module.Conv2d)
     assert isinstance(net[1], er.module.BatchNorm2d) and list(net.state_dict()) == keys
+    grouped = er.module.to_hip(torch.nn.Sequential(torch.nn.Conv2d(4, 4, 3, groups=2)))   # runs dense (ResNeXt)
+    assert isinstance(grouped[0], er.module.Conv2d) and grouped[0].weight.shape == (4, 2, 3, 3)
     with pytest.raises(NotImplementedError):
-        er.module.to_hip(torch.nn.Sequential(torch.nn.Conv2d(4, 4, 3, groups=2)))
+        er.module.to_hip(torch.nn.Sequential(torch.nn.Conv2d(4, 4, 3, padding=1, padding_mode='reflect')))
+    with pytest.raises(NotImplementedError):
+        er.module.to_hip(torch.nn.Sequential(torch.nn.ConvTranspose2d(4, 4, 2, 2, groups=2)))
 
 
 # ------------------------------------------------------------------ the C-ABI
@@ -186,7 +190,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, f'declared in include/ever_hip.h but not exported: {missing}'
     assert sorted(_C.SIGNATURES) == declared, 'ctypes signature table out of sync with the header'
     lib = _C.load()
-    assert lib.evk_abi_version() == 15 and lib.evk_build_arch() == b'gfx950'
+    assert lib.evk_abi_version() == 16 and lib.evk_build_arch() == b'gfx950'
     # argument validation happens before any launch: safe without a GPU
     d = _C.ConvDesc(1, 8, 8, 3, 8, 8, 4, 1, 1, 1, 1, 0, 0, 1, 1)
     rc = lib.evk_conv2d_fwd(ctypes.byref(d), 1, 1, None, 1, 0, None)
