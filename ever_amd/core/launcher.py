@@ -12,7 +12,8 @@ Differences, all outside the numerics:
     iteration (reference launcher.py:211 calls .item() per loss per step);
   * `mixed_precision` defaults to 'fp32' so `Trainer.build_launcher` works (reference defect,
     SURVEY §0.5); for models built from the HIP layers 'bf16' selects the plain-bf16 convolution arithmetic
-    (hip/functional.py: conv math 'bf16') and 'fp16' raises; stock torch models keep the reference's autocast.
+    (hip/functional.py: conv math 'bf16'), 'fp16' keeps the default fp16-MFMA arithmetic and adds the GradScaler protocol;
+    stock torch models keep the reference's autocast.
 """
 import os
 import time
@@ -93,14 +94,18 @@ class Launcher:
             # autocast is its plain-bf16 convolution arithmetic (operands rounded to bf16, one MFMA product, fp32
             # accumulate; BatchNorm statistics, resampling and losses stay fp32, as the reference keeps them: ops.py:152-166,
             # fpn.py:96-102); tensors stay fp32, so no torch.autocast region and no GradScaler are involved.
-            # fp16 has no kernel set: refused rather than silently run in another arithmetic.
-            if mixed_precision != 'bf16':
-                raise NotImplementedError(
-                    f"mixed_precision='{mixed_precision}' is not implemented on the HIP path; use fp32 (default: fp32-grade "
-                    f"products on the bf16 matrix pipe) or bf16 (plain bf16 operands)")
+            # fp16 (reference launcher.py:46-80, interface/module.py:63-94: fp16 autocast + GradScaler): the DEFAULT arithmetic of
+            # the HIP path already runs on the fp16 matrix pipe — operands scaled per tensor by a power of two and split into two
+            # fp16 terms, so neither overflow nor the 11-bit significand of plain fp16 shows (csrc/x3_common.hpp).  'fp16' therefore
+            # keeps those kernels and only adds the reference's GradScaler protocol (scale -> backward -> unscale_ -> clip ->
+            # step -> update) on the fp32 gradients, where scaling by a power of two is exact.
             from ..hip import functional as HF
-            HF.set_conv_math('bf16')
-            self._amp = False
+            if mixed_precision == 'bf16':
+                HF.set_conv_math('bf16')
+                self._amp = False
+            else:
+                HF.set_conv_math('f16x2')
+                self._hip_fp16 = True
         self._model_dir = model_dir
         self._model = model
         self._optimizer = optimizer
@@ -116,6 +121,8 @@ class Launcher:
         self._buffer = dict()
         self._callbacks = []
         if self._amp and mixed_precision == 'fp16':
+            if getattr(self, '_hip_fp16', False):
+                self._amp = 'scaler'      # truthy for the scaler branches; `autocast(enabled=...)` below tests `is True`
             self.scaler = ({k: GradScaler() for k in optimizer} if isinstance(optimizer, dict) else GradScaler())
         else:
             self.scaler = None
@@ -180,7 +187,7 @@ class Launcher:
     def compute_loss_gradient(self, data, forward_times):
         """forward under autocast; entries whose key ends in 'loss' are scaled by 1/forward_times and
         differentiated by the model's own `backward` (reference launcher.py:193-200)."""
-        with autocast(device_type='cuda', enabled=self._amp, dtype=self._mixed_precision):
+        with autocast(device_type='cuda', enabled=self._amp is True, dtype=self._mixed_precision):
             msg_dict = self._model(*data)
             losses = {k: v / forward_times for k, v in msg_dict.items() if k.endswith('loss')}
         self.unwrapped_model.backward(loss_dict=losses, amp=self._amp, scaler=self.scaler)

@@ -260,17 +260,21 @@ def test_pending_log_total_is_the_sum_of_the_losses_only():
 
 
 def test_launcher_amp_flags_for_hip_models(tmp_path):
-    """a9: `--mixed_precision` must not silently train in another arithmetic on the HIP path: bf16 selects the
-    plain-bf16 convolution kernels, fp16 (no kernel set) raises."""
+    """a9: `--mixed_precision` on the HIP path: bf16 selects the plain-bf16 convolution kernels (no autocast, no scaler);
+    fp16 keeps the default arithmetic — already fp16 MFMAs on scaled, split operands — and adds the reference's GradScaler
+    protocol (launcher.py:46-80)."""
     import torch
     import pytest
     import ever_amd as er
     from ever_amd.core.launcher import Launcher
     from ever_amd.hip import functional as HF
     hip = torch.nn.Sequential(er.module.Conv2d(8, 8, 1))
-    with pytest.raises(NotImplementedError, match='mixed_precision'):
-        Launcher(str(tmp_path), hip, None, None, mixed_precision='fp16')
     prev = HF.get_conv_math()
+    try:
+        lz = Launcher(str(tmp_path), hip, torch.optim.SGD(hip.parameters(), lr=0.1), None, mixed_precision='fp16')
+        assert HF.get_conv_math() == 'f16x2' and lz._amp and lz._amp is not True and lz.scaler is not None
+    finally:
+        HF.set_conv_math(prev)
     try:   # bf16 = the plain-bf16 convolution arithmetic, no autocast region, no GradScaler
         lz = Launcher(str(tmp_path), hip, torch.optim.SGD(hip.parameters(), lr=0.1), None, mixed_precision='bf16')
         assert HF.get_conv_math() == 'bf16' and lz._amp is False and lz.scaler is None

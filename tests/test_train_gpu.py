@@ -277,3 +277,39 @@ def test_no_activation_outlives_the_step(cuda):
         gc.enable()
     assert not cyclic, [tuple(t.shape) for t in cyclic]
     assert after <= before + (1 << 20), (before, after)
+
+
+def test_launcher_fp16_mode_runs_the_gradscaler_protocol(cuda, tmp_path):
+    """`mixed_precision='fp16'` (reference launcher.py:46-80, interface/module.py:63-94) on a HIP model: same kernels as the
+    default (fp16 MFMAs on scaled, split operands), plus GradScaler scale / unscale_ / step / update.  The scale is a power of
+    two and every backward kernel is linear in the incoming gradient, so the logged losses equal the fp32 launcher's."""
+    import ever_amd as er
+    from tests import plumbing_common as pc
+    widths = (64, 128, 256, 512)
+    loader = torch.utils.data.DataLoader(pc.ToyTiles(n=8), batch_size=2, shuffle=False)
+    recs = {}
+    for name in ('fp32', 'fp16'):
+        torch.manual_seed(7)
+        m = er.module.FarSeg(dict(encoder=dict(resnet_type='resnet18', in_channels=4),
+                                  head=dict(fpn=dict(in_channels_list=widths, out_channels=256),
+                                            fs_relation=dict(scene_embedding_channels=512)))).to(cuda)
+        sched = er.builder.make_learningrate(dict(type='poly', params=dict(base_lr=0.01, power=0.9, max_iters=4)))
+        opt = er.builder.make_optimizer(er.AttrDict.from_dict(dict(type='sgd', params=dict(momentum=0.9, weight_decay=1e-4, lr=0.01),
+                                                                   grad_clip=dict(max_norm=35, norm_type=2))),
+                                        params=m.custom_param_groups())
+        tl = er.Launcher(str(tmp_path / name), m, opt, sched, mixed_precision=name)
+        rec = []
+        orig = tl._logger.train_log
+
+        def spy(_rec=rec, _orig=orig, **kw):
+            _rec.append({k: float(v) for k, v in kw['loss_dict'].items()})
+            return _orig(**kw)
+        tl._logger.train_log = spy
+        tl.train_by_config(loader, config=er.AttrDict.from_dict(dict(num_iters=4, save_ckpt_interval_epoch=1000)))
+        recs[name] = rec
+        if name == 'fp16':
+            assert tl.scaler is not None and tl.scaler.get_scale() > 1.0
+    assert len(recs['fp16']) == 4
+    for a, b in zip(recs['fp32'], recs['fp16']):
+        for k in ('bce_loss', 'dice_loss'):
+            assert a[k] == pytest.approx(b[k], rel=1e-5), (k, a, b)
