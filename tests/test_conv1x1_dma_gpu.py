@@ -14,9 +14,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('env', [dict(EVK_C1_DMA='2'), dict(EVK_TUNE='1', EVK_X3_FORCE='d256'),
-                                 dict(EVK_TUNE='1', EVK_X3_FORCE='d128'), dict(EVK_TUNE='1', EVK_X3_FORCE='d64'),
-                                 dict(EVK_TUNE='1', EVK_X3_FORCE='e64'), dict(EVK_C1_DMA='0')],
+@pytest.mark.parametrize('env', [dict(EVK_C1_DMA='2'),                              # two-stage ring, 128-wide tiles (production form)
+                                 dict(EVK_TUNE='1', EVK_X3_FORCE='e64'),            # ... 64-wide tiles
+                                 dict(EVK_TUNE='1', EVK_X3_FORCE='d256'),           # three-stage ring, 256-wide tiles
+                                 dict(EVK_C1_DMA='0')],                             # the register-staged kernels, same checks
                          ids=lambda e: '-'.join(e.values()))
 def test_dma_one_tap_convolution_matches_torch(cuda, env):
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_dma.py')], env=dict(os.environ, **env),
