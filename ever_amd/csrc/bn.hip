@@ -1447,6 +1447,52 @@ extern "C" int evk_bn_bwd(const float* dy, const float* x, const float* y, const
                          workspace, workspace_bytes, dx_absmax, nullptr, stream);
 }
 
+// ---- BatchNorm around a fused consumer (FS-Relation, pointwise.hip: relation_bn_*): the statistics records of the
+// producing convolution are merged into (mean, invstd, scale, shift) WITHOUT an apply pass — the consumer applies scale /
+// shift / ReLU while it reads z — and the backward takes per-workgroup partial sums that the consumer's backward formed
+// while it had g and z in registers, instead of a reduce pass of its own.
+extern "C" int evk_bn_finalize_parts(const float* parts, int32_t nparts, int32_t C, int64_t rows, const float* gamma,
+                                     const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                     float* save_mean, float* save_invstd, float* scale_shift, void* stream) {
+  EVK_REQUIRE(parts && nparts > 0 && save_mean && save_invstd && scale_shift, EVK_E_INVALID, "bn_finalize_parts: null pointer");
+  EVK_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 2048, EVK_E_UNSUPPORTED, "bn_finalize_parts: rows=%lld C=%d",
+              (long long)rows, C);
+  launch_parts_final((hipStream_t)stream, parts, nparts, C, (double)rows, gamma, beta, running_mean, running_var, momentum, eps,
+                     save_mean, save_invstd, scale_shift, nullptr, 0);
+  return check_launch("bn_parts_final");
+}
+// dx from g (already masked), x and `nparts` partial records: partial [nparts][2][C] = (sum g, sum g * xhat) and, with
+// EVK_BN_PACK_DX, maxima [nparts][2][C] = (max|g|, max|xhat|).  workspace: 16 C floats.
+extern "C" int evk_bn_bwd_from_partials(const float* g, const float* x, const float* gamma, const float* save_mean,
+                                        const float* save_invstd, const float* partial, const float* maxima, int32_t nparts,
+                                        float* dx, float* dgamma, float* dbeta, int64_t rows, int32_t C, uint32_t flags,
+                                        int32_t train, void* workspace, size_t workspace_bytes, uint32_t* dx_absmax,
+                                        void* stream) {
+  EVK_REQUIRE(g && x && save_mean && save_invstd && partial && dx && nparts > 0, EVK_E_INVALID, "bn_bwd_from_partials: null pointer");
+  EVK_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 2048, EVK_E_UNSUPPORTED, "bn_bwd_from_partials: rows=%lld C=%d",
+              (long long)rows, C);
+  EVK_REQUIRE(workspace && workspace_bytes >= (size_t)16 * C * sizeof(float), EVK_E_WORKSPACE,
+              "bn_bwd_from_partials: workspace too small");
+  const bool pack = (flags & EVK_BN_PACK_DX) != 0;
+  EVK_REQUIRE(!pack || (dx_absmax && maxima), EVK_E_INVALID,
+              "bn_bwd_from_partials: EVK_BN_PACK_DX needs dx_absmax (slots zero on entry) and the maxima");
+  hipStream_t st = (hipStream_t)stream;
+  float* coef = (float*)workspace;
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, partial, nparts, C,
+                     1.0 / (double)rows, gamma, save_invstd, dgamma, dbeta, coef, train ? 1 : 0, dx_absmax,
+                     pack ? maxima : (const float*)nullptr);
+  int rc = check_launch("bn_bwd_final");
+  if (rc) return rc;
+  const size_t n4 = (size_t)rows * C / 4;
+  if (pack)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(oneshot_grid(n4)), dim3(256), 0, st, g, x, (const float*)nullptr, save_mean,
+                       save_invstd, coef, gamma, (const float*)nullptr, dx, n4, C, 0, dx_absmax, (const uint32_t*)nullptr);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(oneshot_grid(n4)), dim3(256), 0, st, g, x, (const float*)nullptr, save_mean,
+                       save_invstd, coef, gamma, (const float*)nullptr, dx, n4, C, 0, dx_absmax, (const uint32_t*)nullptr);
+  return check_launch("bn_bwd_apply");
+}
+
 // ---- ReLU bits (common.hpp: relu_bits_*)
 namespace evk {
 __global__ __launch_bounds__(256) void relu_bits_apply_kernel(const float* __restrict__ g, const uint32_t* __restrict__ bits,

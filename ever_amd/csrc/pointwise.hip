@@ -593,6 +593,140 @@ __global__ __launch_bounds__(256) void relation_dscene_final_kernel(const float*
   }
 }
 
+// ---- FS-Relation with the two BatchNorm + ReLU passes inside (reference fs_relation.py:39-53,61-71: content / re-encoding =
+// ReLU(BN(conv1x1(p))), out = sigmoid(<scene, content>) * re-encoded).  The separate passes wrote the two normalised
+// 256-channel maps only for this kernel to read them back, and their backward re-read both pairs (g, z) just to form the
+// per-channel sums: here the forward reads the convolution outputs z and applies scale / shift / ReLU on the fly, the
+// backward rebuilds both activations from z, writes the MASKED gradients g and leaves the BatchNorm partial sums
+// (sum g, sum g * xhat, max|g|, max|xhat| per workgroup and channel) for evk_bn_bwd_from_partials.
+__device__ __forceinline__ f32x4 bn_relu4(const f32x4 z, const f32x4 sc, const f32x4 sh) {
+  f32x4 y = z * sc + sh;
+  y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
+  return y;
+}
+__global__ __launch_bounds__(256) void relation_bn_fwd_kernel(const float* __restrict__ scene, const float* __restrict__ zc,
+                                                              const float* __restrict__ ssc, const float* __restrict__ zf,
+                                                              const float* __restrict__ ssf, float* __restrict__ out,
+                                                              float* __restrict__ r, int N, int HW, int C,
+                                                              uint32_t* __restrict__ amax) {
+  const int c4 = C >> 2;
+  const int lane = threadIdx.x & 63;
+  const size_t npix = (size_t)N * HW;
+  const size_t wstride = (size_t)gridDim.x * 4;
+  uint32_t m = 0;
+  for (size_t pix = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); pix < npix; pix += wstride) {
+    const size_t n = pix / HW;
+    const float* sc = scene + n * C;
+    const float* ct = zc + pix * C;
+    float dot = 0.f;
+    for (int cb = lane; cb < c4; cb += 64) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(sc + cb * 4);
+      const f32x4 b = bn_relu4(*reinterpret_cast<const f32x4*>(ct + cb * 4), *reinterpret_cast<const f32x4*>(ssc + cb * 4),
+                               *reinterpret_cast<const f32x4*>(ssc + C + cb * 4));
+      dot += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+    dot = wave_sum(dot);
+    const float rv = 1.f / (1.f + expf(-dot));
+    if (lane == 0) r[pix] = rv;
+    const float* ft = zf + pix * C;
+    float* o = out + pix * C;
+    for (int cb = lane; cb < c4; cb += 64) {
+      const f32x4 v = bn_relu4(*reinterpret_cast<const f32x4*>(ft + cb * 4), *reinterpret_cast<const f32x4*>(ssf + cb * 4),
+                               *reinterpret_cast<const f32x4*>(ssf + C + cb * 4)) * rv;
+      *reinterpret_cast<f32x4*>(o + cb * 4) = v;
+      m = abs4_bits(m, v);
+    }
+  }
+  if (amax) commit_absmax(amax, m);
+}
+// LDS: [4 waves][9][C] floats: dscene, then per BatchNorm (content, re-encoding): sum g, sum g*xhat, max|g|, max|xhat|
+__global__ __launch_bounds__(256) void relation_bn_bwd_kernel(
+    const float* __restrict__ dout, const float* __restrict__ scene, const float* __restrict__ zc,
+    const float* __restrict__ ssc, const float* __restrict__ mic, const float* __restrict__ zf, const float* __restrict__ ssf,
+    const float* __restrict__ mif, const float* __restrict__ r, float* __restrict__ gc, float* __restrict__ gf,
+    float* __restrict__ partial, float* __restrict__ bnp_c, float* __restrict__ bnm_c, float* __restrict__ bnp_f,
+    float* __restrict__ bnm_f, int HW, int C, int pix_per_blk, int nblk) {
+  extern __shared__ __attribute__((aligned(16))) float sacc[];
+  const int c4 = C >> 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.y;
+  const int p0 = blockIdx.x * pix_per_blk, p1 = min(HW, p0 + pix_per_blk);
+  const float* sc = scene + (size_t)n * C;
+  float* my = sacc + (size_t)wave * 9 * C;
+  for (int c = lane; c < 9 * C; c += 64) my[c] = 0.f;
+  for (int p = p0 + wave; p < p1; p += 4) {
+    const size_t pix = (size_t)n * HW + p;
+    const float rv = r[pix];
+    const float* d_o = dout + pix * C;
+    float dot = 0.f;
+    for (int cb = lane; cb < c4; cb += 64) {   // re-encoding branch: g_f = dout * r where the activation is positive
+      const f32x4 a = *reinterpret_cast<const f32x4*>(d_o + cb * 4);
+      const f32x4 z = *reinterpret_cast<const f32x4*>(zf + pix * C + cb * 4);
+      const f32x4 y = bn_relu4(z, *reinterpret_cast<const f32x4*>(ssf + cb * 4), *reinterpret_cast<const f32x4*>(ssf + C + cb * 4));
+      dot += a.x * y.x + a.y * y.y + a.z * y.z + a.w * y.w;
+      f32x4 g = a * rv;
+      g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f; g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
+      *reinterpret_cast<f32x4*>(gf + pix * C + cb * 4) = g;
+      const f32x4 xh = (z - *reinterpret_cast<const f32x4*>(mif + cb * 4)) * *reinterpret_cast<const f32x4*>(mif + C + cb * 4);
+      f32x4* s0 = reinterpret_cast<f32x4*>(my + 5 * C + cb * 4);
+      f32x4* s1 = reinterpret_cast<f32x4*>(my + 6 * C + cb * 4);
+      f32x4* m0 = reinterpret_cast<f32x4*>(my + 7 * C + cb * 4);
+      f32x4* m1 = reinterpret_cast<f32x4*>(my + 8 * C + cb * 4);
+      *s0 = *s0 + g;
+      *s1 = *s1 + g * xh;
+      f32x4 t = *m0;
+      t.x = fmaxf(t.x, fabsf(g.x)); t.y = fmaxf(t.y, fabsf(g.y)); t.z = fmaxf(t.z, fabsf(g.z)); t.w = fmaxf(t.w, fabsf(g.w));
+      *m0 = t;
+      t = *m1;
+      t.x = fmaxf(t.x, fabsf(xh.x)); t.y = fmaxf(t.y, fabsf(xh.y)); t.z = fmaxf(t.z, fabsf(xh.z)); t.w = fmaxf(t.w, fabsf(xh.w));
+      *m1 = t;
+    }
+    dot = wave_sum(dot);
+    const float dz = dot * rv * (1.f - rv);
+    for (int cb = lane; cb < c4; cb += 64) {   // content branch: g_c = dz * scene where the activation is positive
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(sc + cb * 4);
+      const f32x4 z = *reinterpret_cast<const f32x4*>(zc + pix * C + cb * 4);
+      const f32x4 y = bn_relu4(z, *reinterpret_cast<const f32x4*>(ssc + cb * 4), *reinterpret_cast<const f32x4*>(ssc + C + cb * 4));
+      f32x4 g = s4 * dz;
+      g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f; g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
+      *reinterpret_cast<f32x4*>(gc + pix * C + cb * 4) = g;
+      f32x4* a = reinterpret_cast<f32x4*>(my + cb * 4);
+      *a = *a + y * dz;
+      const f32x4 xh = (z - *reinterpret_cast<const f32x4*>(mic + cb * 4)) * *reinterpret_cast<const f32x4*>(mic + C + cb * 4);
+      f32x4* s0 = reinterpret_cast<f32x4*>(my + 1 * C + cb * 4);
+      f32x4* s1 = reinterpret_cast<f32x4*>(my + 2 * C + cb * 4);
+      f32x4* m0 = reinterpret_cast<f32x4*>(my + 3 * C + cb * 4);
+      f32x4* m1 = reinterpret_cast<f32x4*>(my + 4 * C + cb * 4);
+      *s0 = *s0 + g;
+      *s1 = *s1 + g * xh;
+      f32x4 t = *m0;
+      t.x = fmaxf(t.x, fabsf(g.x)); t.y = fmaxf(t.y, fabsf(g.y)); t.z = fmaxf(t.z, fabsf(g.z)); t.w = fmaxf(t.w, fabsf(g.w));
+      *m0 = t;
+      t = *m1;
+      t.x = fmaxf(t.x, fabsf(xh.x)); t.y = fmaxf(t.y, fabsf(xh.y)); t.z = fmaxf(t.z, fabsf(xh.z)); t.w = fmaxf(t.w, fabsf(xh.w));
+      *m1 = t;
+    }
+  }
+  __syncthreads();
+  const size_t blk = (size_t)n * nblk + blockIdx.x;
+  const size_t W9 = (size_t)9 * C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    auto fold = [&](int k) { return (sacc[k * C + c] + sacc[W9 + k * C + c]) + (sacc[2 * W9 + k * C + c] + sacc[3 * W9 + k * C + c]); };
+    auto fmx = [&](int k) {
+      return fmaxf(fmaxf(sacc[k * C + c], sacc[W9 + k * C + c]), fmaxf(sacc[2 * W9 + k * C + c], sacc[3 * W9 + k * C + c]));
+    };
+    partial[blk * C + c] = fold(0);
+    bnp_c[blk * 2 * C + c] = fold(1);
+    bnp_c[blk * 2 * C + C + c] = fold(2);
+    bnm_c[blk * 2 * C + c] = fmx(3);
+    bnm_c[blk * 2 * C + C + c] = fmx(4);
+    bnp_f[blk * 2 * C + c] = fold(5);
+    bnp_f[blk * 2 * C + C + c] = fold(6);
+    bnm_f[blk * 2 * C + c] = fmx(7);
+    bnm_f[blk * 2 * C + C + c] = fmx(8);
+  }
+}
+
 static int relation_blocks(int HW) {
   int b = (HW + 63) / 64;
   return b > 256 ? 256 : (b < 1 ? 1 : b);
@@ -828,6 +962,59 @@ extern "C" int evk_relation_fwd(const float* scene, const float* content, const 
   hipLaunchKernelGGL(relation_fwd_kernel, dim3(grid_for((size_t)N * HW, 4, 8192)), dim3(256), 0, (hipStream_t)stream,
                      scene, content, feat, out, r, N, HW, C);
   return check_launch("relation_fwd");
+}
+extern "C" int evk_relation_bn_fwd(const float* scene, const float* zc, const float* scale_shift_c, const float* zf,
+                                   const float* scale_shift_f, float* out, float* r, int32_t N, int32_t HW, int32_t C,
+                                   uint32_t* out_absmax, void* stream) {
+  EVK_REQUIRE(scene && zc && scale_shift_c && zf && scale_shift_f && out && r && N > 0 && HW > 0 && C > 0 && C % 4 == 0,
+              EVK_E_INVALID, "relation_bn_fwd: bad argument");
+  hipLaunchKernelGGL(relation_bn_fwd_kernel, dim3(grid_for((size_t)N * HW, 4, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     scene, zc, scale_shift_c, zf, scale_shift_f, out, r, N, HW, C, out_absmax);
+  return check_launch("relation_bn_fwd");
+}
+// partial records per BatchNorm: evk_relation_bn_parts(N, HW); workspace: evk_relation_bn_workspace_bytes
+extern "C" int32_t evk_relation_bn_parts(int32_t N, int32_t HW) { return N > 0 && HW > 0 ? N * relation_blocks(HW) : 0; }
+extern "C" size_t evk_relation_bn_workspace_bytes(int32_t N, int32_t HW, int32_t C) {
+  if (N <= 0 || HW <= 0 || C <= 0) return 0;
+  return (size_t)N * relation_blocks(HW) * C * 9 * sizeof(float);   // dscene partials + 2 x (sums [2][C] + maxima [2][C])
+}
+extern "C" int evk_relation_bn_bwd(const float* dout, const float* scene, const float* zc, const float* scale_shift_c,
+                                   const float* mean_invstd_c, const float* zf, const float* scale_shift_f,
+                                   const float* mean_invstd_f, const float* r, float* dscene, float* gc, float* gf,
+                                   int32_t N, int32_t HW, int32_t C, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+  EVK_REQUIRE(dout && scene && zc && scale_shift_c && mean_invstd_c && zf && scale_shift_f && mean_invstd_f && r && dscene &&
+                  gc && gf,
+              EVK_E_INVALID, "relation_bn_bwd: null pointer");
+  EVK_REQUIRE(N > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 1024, EVK_E_UNSUPPORTED, "relation_bn_bwd: C=%d", C);
+  EVK_REQUIRE(workspace && workspace_bytes >= evk_relation_bn_workspace_bytes(N, HW, C), EVK_E_WORKSPACE,
+              "relation_bn_bwd: workspace too small");
+  const int nblk = relation_blocks(HW);
+  const int ppb = (HW + nblk - 1) / nblk;
+  const size_t nb = (size_t)N * nblk;
+  // workspace, in floats (nb = evk_relation_bn_parts records): [nb C] scene-gradient partials | content BatchNorm sums
+  // [nb][2][C] | its maxima [nb][2][C] | re-encoding BatchNorm sums | its maxima  (evk_bn_bwd_from_partials takes the pairs)
+  float* w = (float*)workspace;
+  float* partial = w;
+  float* bnp_c = w + nb * C;
+  float* bnm_c = w + nb * 3 * C;
+  float* bnp_f = w + nb * 5 * C;
+  float* bnm_f = w + nb * 7 * C;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)4 * 9 * C * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&relation_bn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              4 * 9 * 1024 * (int)sizeof(float));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(relation_bn_bwd_kernel, dim3(nblk, N), dim3(256), lds, st, dout, scene, zc, scale_shift_c, mean_invstd_c,
+                     zf, scale_shift_f, mean_invstd_f, r, gc, gf, partial, bnp_c, bnm_c, bnp_f, bnm_f, HW, C, ppb, nblk);
+  int rc = check_launch("relation_bn_bwd");
+  if (rc) return rc;
+  hipLaunchKernelGGL(relation_dscene_final_kernel, dim3((C + 7) / 8, N), dim3(256), 0, st, (const float*)partial, dscene, nblk,
+                     C);
+  return check_launch("relation_dscene_final");
 }
 extern "C" size_t evk_relation_workspace_bytes(int32_t N, int32_t HW, int32_t C) {
   if (N <= 0 || HW <= 0 || C <= 0) return 0;

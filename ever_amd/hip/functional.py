@@ -1544,6 +1544,102 @@ def fs_relation(scene, content, feat):
     return _inherit_amax(_RelationFn.apply(scene, content, feat), feat)   # sigmoid(.) * feat
 
 
+class _RelationBnFn(Function):
+    """FS-Relation on the two convolution outputs directly: BatchNorm (batch statistics from the convolutions' epilogue
+    records) + ReLU of both branches happen inside the relation kernels (include/ever_hip.h: evk_relation_bn_*), their
+    backward sums come out of the relation backward.  Replaces content_encoder[1:], feature_reencoder[1:] and the relation
+    of reference fs_relation.py:39-53,61-71 as one node."""
+
+    @staticmethod
+    def forward(ctx, scene, zc, zf, wc, bc, wf, bf, rmc, rvc, rmf, rvf, cfg):
+        (parts_c, parts_f, mom_c, eps_c, mom_f, eps_f) = cfg
+        n, c, h, w = zc.shape
+        rows, dev, st = n * h * w, zc.device, _stream()
+        stats = torch.empty((2, 4, c), device=dev, dtype=torch.float32)   # per BatchNorm: mean, invstd, scale, shift
+        for k, (parts, g, b, rm, rv, mom, eps) in enumerate(((parts_c, wc, bc, rmc, rvc, mom_c, eps_c),
+                                                               (parts_f, wf, bf, rmf, rvf, mom_f, eps_f))):
+            _C.call('evk_bn_finalize_parts', parts[0].data_ptr(), parts[1], c, rows, _ptr(g), _ptr(b), _ptr(rm), _ptr(rv),
+                    float(mom), float(eps), stats[k, 0].data_ptr(), stats[k, 1].data_ptr(), stats[k, 2].data_ptr(), st)
+        out = empty_nhwc(n, c, h, w, dev)
+        r = torch.empty((n, h * w), device=dev, dtype=torch.float32)
+        abits = _amax_zeroed(dev)
+        _C.call('evk_relation_bn_fwd', scene.data_ptr(), zc.data_ptr(), stats[0, 2].data_ptr(), zf.data_ptr(),
+                stats[1, 2].data_ptr(), out.data_ptr(), r.data_ptr(), n, h * w, c, _ptr(abits), st)
+        global _AMAX_HANDOFF
+        _AMAX_HANDOFF = (abits, False)
+        ctx.pack = (bool(len(parts_c) > 2 and parts_c[2]), bool(len(parts_f) > 2 and parts_f[2]))
+        ctx.save_for_backward(scene, zc, zf, wc, wf, stats, r)
+        ctx.mark_non_differentiable(*[t for t in (rmc, rvc, rmf, rvf) if t is not None])
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        scene, zc, zf, wc, wf, stats, r = ctx.saved_tensors
+        n, c, h, w = zc.shape
+        rows, dev, st = n * h * w, zc.device, _stream()
+        dout = as_nhwc(dout, 'fs_relation.backward')
+        lib = _C.load()
+        nb = int(lib.evk_relation_bn_parts(n, h * w))
+        ws_bytes = lib.evk_relation_bn_workspace_bytes(n, h * w, c)
+        # (own buffer, not the shared workspace: the BatchNorm backward launches below read it while they use that one)
+        ws = torch.empty((ws_bytes // 4,), device=dev, dtype=torch.float32)
+        dscene = empty_nhwc(n, c, 1, 1, dev)
+        gc, gf = torch.empty_like(zc), torch.empty_like(zf)
+        _C.call('evk_relation_bn_bwd', dout.data_ptr(), scene.data_ptr(), zc.data_ptr(), stats[0, 2].data_ptr(),
+                stats[0, 0].data_ptr(), zf.data_ptr(), stats[1, 2].data_ptr(), stats[1, 0].data_ptr(), r.data_ptr(),
+                dscene.data_ptr(), gc.data_ptr(), gf.data_ptr(), n, h * w, c, ws.data_ptr(), ws_bytes, st)
+        coef = workspace(dev, 16 * c * 4)
+        grads = []
+        for k, (g, z, gamma) in enumerate(((gc, zc, wc), (gf, zf, wf))):
+            sums = ws[nb * c * (1 + 4 * k):]
+            maxima = ws[nb * c * (3 + 4 * k):]
+            pack = ctx.pack[k] and _f16x2()
+            abits = _amax_zeroed(dev) if pack else _amax_out(dev)
+            pack = pack and abits is not None
+            dz = torch.empty_like(z)
+            dgamma = torch.empty((c,), device=dev, dtype=torch.float32) if gamma is not None else None
+            dbeta = torch.empty((c,), device=dev, dtype=torch.float32) if gamma is not None else None
+            # algorithmic bytes: read g, z, write dz
+            _timed_call('bn', 12.0 * z.numel(), 'evk_bn_bwd_from_partials', g.data_ptr(), z.data_ptr(), _ptr(gamma),
+                        stats[k, 0].data_ptr(), stats[k, 1].data_ptr(), sums.data_ptr(), maxima.data_ptr(), nb, dz.data_ptr(),
+                        _ptr(dgamma), _ptr(dbeta), rows, c, 2 if pack else 0, 1, coef.data_ptr(), 16 * c * 4, _ptr(abits), st)
+            if pack:
+                _mark_packed(dz, abits)
+            elif abits is not None:
+                _note_amax(dz, abits)
+            grads.append((dz, dgamma, dbeta))
+        (dzc, dgc, dbc), (dzf, dgf, dbf) = grads
+        return dscene, dzc, dzf, dgc, dbc, dgf, dbf, None, None, None, None, None
+
+
+def fs_relation_bn(scene, zc, zf, bn_c, bn_f):
+    """`sigmoid(<scene, relu(bn_c(zc))>) * relu(bn_f(zf))` with both training-mode BatchNorms inside the relation kernels
+    (see _RelationBnFn); zc, zf carry their convolutions' statistics records (`_evk_bn_parts`), or None is returned and the
+    caller runs the layers one by one."""
+    pc, pf = getattr(zc, '_evk_bn_parts', None), getattr(zf, '_evk_bn_parts', None)
+    if pc is None or pf is None or pc[1] <= 0 or pf[1] <= 0 or zc.shape != zf.shape or zc.shape[1] % 4 or zc.shape[1] > 1024:
+        return None
+    del zc._evk_bn_parts, zf._evk_bn_parts
+    n, c, h, w = zc.shape
+    scene = as_nhwc(scene.reshape(n, c, 1, 1), 'fs_relation.scene')
+    weight_planes.note_running_stats_changed()
+    global _AMAX_HANDOFF
+    _AMAX_HANDOFF = None
+
+    def stat(bn, name):
+        return getattr(bn, name) if bn.track_running_stats else None
+    out = _RelationBnFn.apply(scene, zc, zf, bn_c.weight, bn_c.bias, bn_f.weight, bn_f.bias, stat(bn_c, 'running_mean'),
+                              stat(bn_c, 'running_var'), stat(bn_f, 'running_mean'), stat(bn_f, 'running_var'),
+                              (pc, pf, bn_c.momentum, bn_c.eps, bn_f.momentum, bn_f.eps))
+    if _AMAX_HANDOFF is not None:
+        abits, _ = _AMAX_HANDOFF
+        if abits is not None:
+            _note_amax(out, abits)
+        _AMAX_HANDOFF = None
+    return out
+
+
 class _Mean4Fn(Function):
     @staticmethod
     def forward(ctx, a, b, c, d):

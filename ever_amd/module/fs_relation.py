@@ -23,6 +23,49 @@ def _conv_bn_relu(cin, cout):
     return HipSequential(Conv2d(cin, cout, 1), BatchNorm2d(cout), ReLU(True))
 
 
+def _fusable_bn(seq):
+    """Conv2d -> BatchNorm2d (training, batch statistics from the convolution's epilogue) -> ReLU, nothing watching"""
+    from .fold import _takes_epilogue_stats
+    if not (isinstance(seq, nn.Sequential) and len(seq) == 3 and isinstance(seq[0], Conv2d) and isinstance(seq[2], nn.ReLU)):
+        return False
+    bn = seq[1]
+    if not (_takes_epilogue_stats(bn) and bn.training and bn.momentum is not None):
+        return False
+    return not any(m._forward_hooks or m._forward_pre_hooks for m in (seq, seq[0], bn, seq[2]))
+
+
+def _relation_levels(content_encoders, feature_reencoders, scenes, features):
+    """[relation(scene_i, content_i(f_i), reencode_i(f_i))].  Training, plain BatchNorm: the two 1x1 convolutions of a level
+    run as one fork node and BatchNorm + ReLU of both branches run INSIDE the relation kernels (HF.fs_relation_bn:
+    the normalised maps are never written, the BatchNorm backward sums come out of the relation backward);
+    EVK_RELATION_BN=0, hooks, SyncBatchNorm, eval mode or foreign layer stacks take the layers one by one."""
+    import os
+    import torch
+    fuse = (os.environ.get('EVK_RELATION_BN', '1') != '0' and torch.is_grad_enabled() and not HF.observers_active())
+    outs = []
+    rest_c, rest_f, rest_s, rest_x, idx = [], [], [], [], []
+    for i, (ce, fr, s, f) in enumerate(zip(content_encoders, feature_reencoders, scenes, features)):
+        out = None
+        if fuse and f.requires_grad and _fusable_bn(ce) and _fusable_bn(fr):
+            zc, zf = HF.conv2d_fork(f, ce[0], fr[0], bn_stats=(True, True))
+            out = HF.fs_relation_bn(s, zc, zf, ce[1], fr[1])
+            if out is None:     # the convolutions left no statistics records: finish the level layer by layer
+                from .layers import run_sequence
+                out = HF.fs_relation(s, run_sequence(list(ce)[1:], zc), run_sequence(list(fr)[1:], zf))
+            else:
+                for bn in (ce[1], fr[1]):
+                    if bn.track_running_stats and bn.num_batches_tracked is not None:
+                        bn._nbt_pending = getattr(bn, '_nbt_pending', 0) + 1
+        outs.append(out)
+        if out is None:
+            rest_c.append(ce); rest_f.append(fr); rest_s.append(s); rest_x.append(f); idx.append(i)
+    if idx:
+        contents, feats = _content_and_reencoded(rest_c, rest_f, rest_x)
+        for i, s, c, p in zip(idx, rest_s, contents, feats):
+            outs[i] = HF.fs_relation(s, c, p)
+    return outs
+
+
 def _content_and_reencoded(content_encoders, feature_reencoders, features):
     """[content_i(f_i)], [reencode_i(f_i)].  Each pyramid level feeds both 1x1 convolutions: under autograd the pair
     runs as one node whose backward sums the two input gradients in the second data-gradient's epilogue (no add
@@ -61,12 +104,11 @@ class FSRelation(nn.Module):
         self.normalizer = nn.Sigmoid()  # parameter-free; the sigmoid runs inside the relation kernel
 
     def forward(self, scene_feature, features):
-        contents, feats = _content_and_reencoded(self.content_encoders, self.feature_reencoders, features)
         if self.scale_aware_proj:
             scenes = [enc(scene_feature) for enc in self.scene_encoder]
         else:
-            scenes = [self.scene_encoder(scene_feature)] * len(contents)
-        return [HF.fs_relation(s, c, p) for s, c, p in zip(scenes, contents, feats)]
+            scenes = [self.scene_encoder(scene_feature)] * len(features)
+        return _relation_levels(self.content_encoders, self.feature_reencoders, scenes, features)
 
 
 class FSRelationV2(nn.Module):
@@ -99,12 +141,12 @@ class FSRelationV2(nn.Module):
 
     def forward(self, scene_feature, features):
         from ..hip import functional_next as HN
-        contents, feats = _content_and_reencoded(self.content_encoders, self.feature_reencoders, features)
         if self.scale_aware_proj:
             scenes = [enc(scene_feature) for enc in self.scene_encoder]
         else:
-            scenes = [self.scene_encoder(scene_feature)] * len(contents)
-        refined = [HN.concat_channels(HF.fs_relation(s, c, p), o) for s, c, p, o in zip(scenes, contents, feats, features)]
+            scenes = [self.scene_encoder(scene_feature)] * len(features)
+        related = _relation_levels(self.content_encoders, self.feature_reencoders, scenes, features)
+        refined = [HN.concat_channels(rel, o) for rel, o in zip(related, features)]
         if self.scale_aware_proj:
             return [op(x) for op, x in zip(self.project, refined)]
         return [self.project(x) for x in refined]

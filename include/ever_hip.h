@@ -556,6 +556,38 @@ int evk_split_channels(const float* src, float* a, float* b, int64_t rows, int32
 int evk_channel_scale(const float* x, const float* scale, float* y, int32_t N, int64_t HW, int32_t C,
                       void* stream);
 
+/* FS-Relation with its two BatchNorm + ReLU passes inside (reference fs_relation.py:39-53: content / re-encoding =
+ * ReLU(BN(conv1x1(p))); :61-71: out = sigmoid(<scene, content>) * re-encoded).  The stand-alone passes wrote both normalised
+ * maps only for the relation kernel to read them back, and their backward read (g, z) of both once more just for the
+ * per-channel sums.  Here:
+ *  - evk_bn_finalize_parts merges the producing convolution's statistics records (evk_conv2d_fwd_f16x2: bn_parts) into
+ *    save_mean / save_invstd / scale_shift [2][C] and updates the running statistics — no apply pass;
+ *  - evk_relation_bn_fwd reads the convolution outputs zc, zf and applies scale / shift / ReLU on the fly; it raises the
+ *    64 slots of out_absmax (zero on entry; may be NULL) with max|out|;
+ *  - evk_relation_bn_bwd rebuilds both activations from z, writes the MASKED gradients gc, gf (w.r.t. the BatchNorm
+ *    outputs, zero where the ReLU was off) and leaves, per workgroup, (sum g, sum g * xhat) and (max|g|, max|xhat|) of both
+ *    BatchNorms in the workspace: floats [nb C] scene partials | content sums [nb][2][C] | content maxima [nb][2][C] |
+ *    re-encoding sums | re-encoding maxima, nb = evk_relation_bn_parts(N, HW); mean_invstd = save_mean, save_invstd
+ *    contiguous [2][C];
+ *  - evk_bn_bwd_from_partials turns such records into dgamma, dbeta and dx = BatchNorm backward of the masked g (with
+ *    EVK_BN_PACK_DX: packed, dx_absmax zero on entry); workspace 16 C floats. */
+int evk_bn_finalize_parts(const float* parts, int32_t nparts, int32_t C, int64_t rows, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
+                          float* save_invstd, float* scale_shift, void* stream);
+int evk_relation_bn_fwd(const float* scene, const float* zc, const float* scale_shift_c, const float* zf,
+                        const float* scale_shift_f, float* out, float* r, int32_t N, int32_t HW, int32_t C,
+                        uint32_t* out_absmax, void* stream);
+int32_t evk_relation_bn_parts(int32_t N, int32_t HW);
+size_t evk_relation_bn_workspace_bytes(int32_t N, int32_t HW, int32_t C);
+int evk_relation_bn_bwd(const float* dout, const float* scene, const float* zc, const float* scale_shift_c,
+                        const float* mean_invstd_c, const float* zf, const float* scale_shift_f, const float* mean_invstd_f,
+                        const float* r, float* dscene, float* gc, float* gf, int32_t N, int32_t HW, int32_t C, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int evk_bn_bwd_from_partials(const float* g, const float* x, const float* gamma, const float* save_mean,
+                             const float* save_invstd, const float* partial, const float* maxima, int32_t nparts, float* dx,
+                             float* dgamma, float* dbeta, int64_t rows, int32_t C, uint32_t flags, int32_t train,
+                             void* workspace, size_t workspace_bytes, uint32_t* dx_absmax, void* stream);
+
 /* Synchronized BatchNorm in stages (torch.nn.SyncBatchNorm under the trainer's `sync_bn`, reference
  * ever/trainer/th_ddp_trainer.py + SURVEY §8 C5): the exchange between the stages is the caller's
  * (torch.distributed over RCCL): forward all-gather of `stats` (local mean, local sum of squared deviations,
