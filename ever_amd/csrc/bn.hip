@@ -1493,6 +1493,341 @@ extern "C" int evk_bn_bwd_from_partials(const float* g, const float* x, const fl
   return check_launch("bn_bwd_apply");
 }
 
+// ---- BatchNorm + ReLU + a narrow 1x1 convolution as one consumer (the decoder's classifier applied per branch,
+// module/fpn.py:_forward_commuted; reference fpn.py:163-170,179-193): out[pix][k] = sum_c relu(bn(z))[pix][c] * w[k][c] + b[k]
+// for K <= 16 classes.  The normalised map is never written: the forward reads z once; the backward reads z twice (sums,
+// then dz) and the K-channel gradient dl, rebuilding g[pix][c] = (y > 0) * sum_k dl[pix][k] w[k][c] in registers — against
+// apply (r z, w y), convolution (r y), its data gradient (w g), its weight gradient (r y), BatchNorm reduce (r g, r z) and
+// apply (r g, r z, w dz) of the layer-by-layer form: 4 tensor passes instead of 10.
+namespace evk {
+constexpr int kDotMaxK = 16;
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ f32x4 bn_relu_4(const f32x4 z, const f32x4 sc, const f32x4 sh) {
+  f32x4 y = z * sc + sh;
+  y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
+  return y;
+}
+// one wave per pixel; a lane owns NCH 16-byte channel chunks whose scale / shift / classifier weights stay in registers
+// (re-loading them per pixel — L1 hits, but a vector-memory round trip in front of every row — held the first form to
+// 2.3 TB/s); a workgroup walks a contiguous pixel range, two rows of z in flight per wave
+template <int NCH, int KT>
+__global__ __launch_bounds__(256) void bn_relu_dot_fwd_kernel(const float* __restrict__ z, const float* __restrict__ ss,
+                                                              const float* __restrict__ w, const float* __restrict__ bias,
+                                                              float* __restrict__ out, size_t npix, int C, int K,
+                                                              size_t pix_per_blk) {
+  const int c4 = C >> 2, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 sc[NCH], sh[NCH], wk[NCH][KT];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int cb = lane + 64 * j;
+    const bool ok = cb < c4;
+    sc[j] = ok ? *reinterpret_cast<const f32x4*>(ss + cb * 4) : zero4;
+    sh[j] = ok ? *reinterpret_cast<const f32x4*>(ss + C + cb * 4) : zero4;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) wk[j][k] = (ok && k < K) ? *reinterpret_cast<const f32x4*>(w + (size_t)k * C + cb * 4) : zero4;
+  }
+  float bk[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) bk[k] = (bias && k < K) ? bias[k] : 0.f;
+  const size_t p0 = (size_t)blockIdx.x * pix_per_blk, p1 = p0 + pix_per_blk < npix ? p0 + pix_per_blk : npix;
+  for (size_t pix = p0 + wave; pix < p1; pix += 8) {
+    f32x4 za[NCH], zb[NCH];
+    const bool inb = pix + 4 < p1;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int cb = lane + 64 * j;
+      za[j] = cb < c4 ? *reinterpret_cast<const f32x4*>(z + pix * C + cb * 4) : zero4;
+      zb[j] = (inb && cb < c4) ? *reinterpret_cast<const f32x4*>(z + (pix + 4) * C + cb * 4) : zero4;
+    }
+    float da[KT], db[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) da[k] = db[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const f32x4 ya = bn_relu_4(za[j], sc[j], sh[j]), yb = bn_relu_4(zb[j], sc[j], sh[j]);
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        da[k] += ya.x * wk[j][k].x + ya.y * wk[j][k].y + ya.z * wk[j][k].z + ya.w * wk[j][k].w;
+        db[k] += yb.x * wk[j][k].x + yb.y * wk[j][k].y + yb.z * wk[j][k].z + yb.w * wk[j][k].w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+      if (k < K) {
+        const float a = wave_sum_f(da[k]), b = wave_sum_f(db[k]);
+        if (lane == 0) {
+          out[pix * K + k] = a + bk[k];
+          if (inb) out[(pix + 4) * K + k] = b + bk[k];
+        }
+      }
+  }
+}
+// Per-lane REGISTER accumulators over a workgroup's pixels (a lane owns NCH 16-byte channel chunks: C <= 256 NCH): sum g,
+// sum g*xhat, max|g|, max|xhat|, dW[k] = sum_pix y * dl[k]; the four waves are folded through LDS once, at the end
+// ([4 waves][4 + KT][C] floats).  (A first form accumulated in LDS per pixel: five dependent read-modify-writes per pixel
+// held it to 0.9 TB/s.)  Two pixels per iteration keep two rows of z in flight per wave.
+template <int NCH, int KT>
+__global__ __launch_bounds__(256) void bn_relu_dot_bwd_partial_kernel(
+    const float* __restrict__ dl, const float* __restrict__ z, const float* __restrict__ ss, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ w, float* __restrict__ bnp, float* __restrict__ bnm,
+    float* __restrict__ dwp, float* __restrict__ dbp, size_t npix, int C, int K, size_t pix_per_blk) {
+  extern __shared__ __attribute__((aligned(16))) float sdot[];
+  const int c4 = C >> 2, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int R = 4 + K;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 sg[NCH], sq[NCH], mg[NCH], mx[NCH], dwa[NCH][KT];
+  f32x4 sc[NCH], sh[NCH], mu[NCH], is[NCH], wk[NCH][KT];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int cb = lane + 64 * j;
+    const bool ok = cb < c4;
+    sg[j] = sq[j] = mg[j] = mx[j] = zero4;
+    sc[j] = ok ? *reinterpret_cast<const f32x4*>(ss + cb * 4) : zero4;
+    sh[j] = ok ? *reinterpret_cast<const f32x4*>(ss + C + cb * 4) : zero4;
+    mu[j] = ok ? *reinterpret_cast<const f32x4*>(mean + cb * 4) : zero4;
+    is[j] = ok ? *reinterpret_cast<const f32x4*>(invstd + cb * 4) : zero4;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      dwa[j][k] = zero4;
+      wk[j][k] = (ok && k < K) ? *reinterpret_cast<const f32x4*>(w + (size_t)k * C + cb * 4) : zero4;
+    }
+  }
+  const size_t p0 = (size_t)blockIdx.x * pix_per_blk, p1 = p0 + pix_per_blk < npix ? p0 + pix_per_blk : npix;
+  float db[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) db[k] = 0.f;
+  auto one = [&](const f32x4 (&zz)[NCH], const float (&d)[KT]) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const f32x4 y = bn_relu_4(zz[j], sc[j], sh[j]);
+      f32x4 g = zero4;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        g += wk[j][k] * d[k];
+        dwa[j][k] += y * d[k];
+      }
+      g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f; g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
+      const f32x4 xh = (zz[j] - mu[j]) * is[j];
+      sg[j] += g;
+      sq[j] += g * xh;
+      mg[j].x = fmaxf(mg[j].x, fabsf(g.x)); mg[j].y = fmaxf(mg[j].y, fabsf(g.y));
+      mg[j].z = fmaxf(mg[j].z, fabsf(g.z)); mg[j].w = fmaxf(mg[j].w, fabsf(g.w));
+      mx[j].x = fmaxf(mx[j].x, fabsf(xh.x)); mx[j].y = fmaxf(mx[j].y, fabsf(xh.y));
+      mx[j].z = fmaxf(mx[j].z, fabsf(xh.z)); mx[j].w = fmaxf(mx[j].w, fabsf(xh.w));
+    }
+  };
+  auto fetch = [&](size_t pix, f32x4 (&zz)[NCH], float (&d)[KT]) {
+    const bool in = pix < p1;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      d[k] = (in && k < K) ? dl[pix * K + k] : 0.f;
+      db[k] += d[k];
+    }
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int cb = lane + 64 * j;
+      // out of range: z = mean gives xhat = 0, d = 0 gives g = 0 and no dW contribution
+      zz[j] = (in && cb < c4) ? *reinterpret_cast<const f32x4*>(z + pix * C + cb * 4) : mu[j];
+    }
+  };
+  for (size_t pix = p0 + wave; pix < p1; pix += 8) {
+    f32x4 za[NCH], zb[NCH];
+    float da[KT], dbb[KT];
+    fetch(pix, za, da);
+    fetch(pix + 4, zb, dbb);
+    one(za, da);
+    one(zb, dbb);
+  }
+  float* my = sdot + (size_t)wave * R * C;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int cb = lane + 64 * j;
+    if (cb < c4) {
+      *reinterpret_cast<f32x4*>(my + cb * 4) = sg[j];
+      *reinterpret_cast<f32x4*>(my + C + cb * 4) = sq[j];
+      *reinterpret_cast<f32x4*>(my + 2 * C + cb * 4) = mg[j];
+      *reinterpret_cast<f32x4*>(my + 3 * C + cb * 4) = mx[j];
+#pragma unroll
+      for (int k = 0; k < KT; ++k)
+        if (k < K) *reinterpret_cast<f32x4*>(my + (size_t)(4 + k) * C + cb * 4) = dwa[j][k];
+    }
+  }
+  __shared__ float sdb[4][kDotMaxK];
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < KT; ++k) sdb[wave][k] = db[k];   // (every lane of a wave accumulated the same dl values)
+  __syncthreads();
+  const size_t W = (size_t)R * C, blk = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    auto fold = [&](int k) { return (sdot[(size_t)k * C + c] + sdot[W + (size_t)k * C + c]) + (sdot[2 * W + (size_t)k * C + c] + sdot[3 * W + (size_t)k * C + c]); };
+    auto fmx = [&](int k) {
+      return fmaxf(fmaxf(sdot[(size_t)k * C + c], sdot[W + (size_t)k * C + c]), fmaxf(sdot[2 * W + (size_t)k * C + c], sdot[3 * W + (size_t)k * C + c]));
+    };
+    bnp[blk * 2 * C + c] = fold(0);
+    bnp[blk * 2 * C + C + c] = fold(1);
+    bnm[blk * 2 * C + c] = fmx(2);
+    bnm[blk * 2 * C + C + c] = fmx(3);
+    for (int k = 0; k < K; ++k) dwp[(blk * K + k) * C + c] = fold(4 + k);
+  }
+  if (threadIdx.x < K) dbp[blk * K + threadIdx.x] = (sdb[0][threadIdx.x] + sdb[1][threadIdx.x]) + (sdb[2][threadIdx.x] + sdb[3][threadIdx.x]);
+}
+// dW[k][c] = sum_blk dwp[blk][k][c], dbias[k] = sum_blk dbp[blk][k] (fp64, fixed order): 8 outputs x 32 partial-lanes per
+// workgroup, as the other finalisations (a serial walk over up to 2048 partials per thread is latency)
+__global__ __launch_bounds__(256) void bn_relu_dot_bwd_wfinal_kernel(const float* __restrict__ dwp, const float* __restrict__ dbp,
+                                                                     float* __restrict__ dw, float* __restrict__ dbias, int nblk,
+                                                                     int C, int K) {
+  __shared__ double red[32][8];
+  const int to = threadIdx.x & 7, tl = threadIdx.x >> 3;
+  const int i = blockIdx.x * 8 + to;           // output index: [0, K*C) weights, [K*C, K*C + K) biases
+  const int nw = K * C;
+  double s = 0.0;
+  if (i < nw) {
+    for (int b = tl; b < nblk; b += 32) s += (double)dwp[(size_t)b * nw + i];
+  } else if (i < nw + K) {
+    for (int b = tl; b < nblk; b += 32) s += (double)dbp[(size_t)b * K + (i - nw)];
+  }
+  red[tl][to] = s;
+  __syncthreads();
+  if (tl == 0) {
+    for (int k = 1; k < 32; ++k) s += red[k][to];
+    if (i < nw) dw[i] = (float)s;
+    else if (i < nw + K && dbias) dbias[i - nw] = (float)s;
+  }
+}
+// dz = k0 (g - k1 - xhat k2) with g rebuilt from dl and w; one 16-byte element per thread
+template <bool PK>
+__global__ __launch_bounds__(256) void bn_relu_dot_bwd_apply_kernel(const float* __restrict__ dl, const float* __restrict__ z,
+                                                                    const float* __restrict__ ss, const float* __restrict__ mean,
+                                                                    const float* __restrict__ invstd,
+                                                                    const float* __restrict__ coef, const float* __restrict__ w,
+                                                                    float* __restrict__ dz, size_t n4, int C, int K,
+                                                                    uint32_t* __restrict__ amax) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const bool valid = i < n4;
+  f32x4 out = {0.f, 0.f, 0.f, 0.f};
+  float pk_inv = 1.f;
+  if constexpr (PK) pk_inv = op_scale(amax[0]).inv;
+  if (valid) {
+    const int c4 = C >> 2;
+    const size_t pix = i / c4;
+    const int c = (int)(i - pix * c4);
+    const f32x4 zz = reinterpret_cast<const f32x4*>(z)[i];
+    const f32x4 y = zz * reinterpret_cast<const f32x4*>(ss)[c] + reinterpret_cast<const f32x4*>(ss + C)[c];
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K; ++k) g += reinterpret_cast<const f32x4*>(w + (size_t)k * C)[c] * dl[pix * K + k];
+    g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f; g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
+    const f32x4 xh = (zz - reinterpret_cast<const f32x4*>(mean)[c]) * reinterpret_cast<const f32x4*>(invstd)[c];
+    out = reinterpret_cast<const f32x4*>(coef)[c] * (g - reinterpret_cast<const f32x4*>(coef + C)[c] - xh * reinterpret_cast<const f32x4*>(coef + 2 * C)[c]);
+    if constexpr (PK) {
+      reinterpret_cast<u32x4*>(dz)[i] = pack_hl4(out, pk_inv);
+    } else {
+      reinterpret_cast<f32x4*>(dz)[i] = out;
+    }
+  }
+  if constexpr (!PK) {
+    if (amax) block_absmax(out, valid, amax);
+  }
+}
+static int dot_blocks(size_t npix) {
+  size_t b = (npix + 63) / 64;      // (16 pixels per wave at least: the 64^2 maps get 1024 workgroups, four per CU)
+  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+}  // namespace evk
+
+extern "C" int evk_bn_relu_dot_fwd(const float* z, const float* scale_shift, const float* w, const float* bias, float* out,
+                                   int64_t rows, int32_t C, int32_t K, void* stream) {
+  EVK_REQUIRE(z && scale_shift && w && out, EVK_E_INVALID, "bn_relu_dot_fwd: null pointer");
+  EVK_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && K > 0 && K <= kDotMaxK, EVK_E_UNSUPPORTED, "bn_relu_dot_fwd: C=%d K=%d", C, K);
+  int nch = (C / 4 + 63) / 64;
+  if (nch == 3) nch = 4;
+  const int kt = K <= 1 ? 1 : (K <= 4 ? 4 : 16);
+  EVK_REQUIRE((nch == 1) || (nch == 2 && kt <= 4) || (nch == 4 && kt <= 4), EVK_E_UNSUPPORTED,
+              "bn_relu_dot_fwd: C=%d K=%d has no instantiation", C, K);
+  const int nb = dot_blocks((size_t)rows);
+  const size_t ppb = ((size_t)rows + nb - 1) / nb;
+  hipStream_t st = (hipStream_t)stream;
+#define EVK_DOT_FWD(NCH, KT)                                                                                              \
+  hipLaunchKernelGGL((bn_relu_dot_fwd_kernel<NCH, KT>), dim3(nb), dim3(256), 0, st, z, scale_shift, w, bias, out, (size_t)rows, \
+                     C, K, ppb)
+  if (nch == 1 && kt == 1) EVK_DOT_FWD(1, 1);
+  else if (nch == 1 && kt == 4) EVK_DOT_FWD(1, 4);
+  else if (nch == 1) EVK_DOT_FWD(1, 16);
+  else if (nch == 2 && kt == 1) EVK_DOT_FWD(2, 1);
+  else if (nch == 2) EVK_DOT_FWD(2, 4);
+  else if (kt == 1) EVK_DOT_FWD(4, 1);
+  else EVK_DOT_FWD(4, 4);
+#undef EVK_DOT_FWD
+  return check_launch("bn_relu_dot_fwd");
+}
+extern "C" size_t evk_bn_relu_dot_workspace_bytes(int64_t rows, int32_t C, int32_t K) {
+  if (rows <= 0 || C <= 0 || K <= 0) return 0;
+  const size_t nb = (size_t)dot_blocks((size_t)rows);
+  return (nb * (size_t)(4 + K) * C + nb * K + (size_t)16 * C) * sizeof(float);
+}
+// dz (the BatchNorm input's gradient; EVK_BN_PACK_DX: packed, dx_absmax zero on entry), dgamma, dbeta, dw [K][C], dbias [K]
+extern "C" int evk_bn_relu_dot_bwd(const float* dl, const float* z, const float* scale_shift, const float* gamma,
+                                   const float* save_mean, const float* save_invstd, const float* w, float* dz, float* dgamma,
+                                   float* dbeta, float* dw, float* dbias, int64_t rows, int32_t C, int32_t K, uint32_t flags,
+                                   void* workspace, size_t workspace_bytes, uint32_t* dx_absmax, void* stream) {
+  EVK_REQUIRE(dl && z && scale_shift && save_mean && save_invstd && w && dz && dw, EVK_E_INVALID, "bn_relu_dot_bwd: null pointer");
+  EVK_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 1024 && K > 0 && K <= kDotMaxK, EVK_E_UNSUPPORTED,
+              "bn_relu_dot_bwd: C=%d K=%d", C, K);
+  EVK_REQUIRE(workspace && workspace_bytes >= evk_bn_relu_dot_workspace_bytes(rows, C, K), EVK_E_WORKSPACE,
+              "bn_relu_dot_bwd: workspace too small");
+  const bool pack = (flags & EVK_BN_PACK_DX) != 0;
+  EVK_REQUIRE(!pack || dx_absmax, EVK_E_INVALID, "bn_relu_dot_bwd: EVK_BN_PACK_DX needs dx_absmax (slots zero on entry)");
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = dot_blocks((size_t)rows);
+  const size_t ppb = ((size_t)rows + nb - 1) / nb;
+  float* bnp = (float*)workspace;
+  float* bnm = bnp + (size_t)nb * 2 * C;
+  float* dwp = bnm + (size_t)nb * 2 * C;
+  float* dbp = dwp + (size_t)nb * K * C;
+  float* coef = dbp + (size_t)nb * K;
+  const size_t lds = (size_t)4 * (4 + K) * C * sizeof(float);
+  EVK_REQUIRE(lds <= 64 * 1024, EVK_E_UNSUPPORTED, "bn_relu_dot_bwd: C=%d K=%d do not fit the LDS", C, K);
+  int nch = (C / 4 + 63) / 64;
+  if (nch == 3) nch = 4;
+  const int kt = K <= 1 ? 1 : (K <= 4 ? 4 : 16);
+  EVK_REQUIRE((nch == 1) || (nch == 2 && kt <= 4) || (nch == 4 && kt <= 4), EVK_E_UNSUPPORTED,
+              "bn_relu_dot_bwd: C=%d K=%d has no instantiation", C, K);
+#define EVK_DOT_PARTIAL(NCH, KT)                                                                                          \
+  hipLaunchKernelGGL((bn_relu_dot_bwd_partial_kernel<NCH, KT>), dim3(nb), dim3(256), lds, st, dl, z, scale_shift, save_mean, \
+                     save_invstd, w, bnp, bnm, dwp, dbp, (size_t)rows, C, K, ppb)
+  if (nch == 1 && kt == 1) EVK_DOT_PARTIAL(1, 1);
+  else if (nch == 1 && kt == 4) EVK_DOT_PARTIAL(1, 4);
+  else if (nch == 1) EVK_DOT_PARTIAL(1, 16);
+  else if (nch == 2 && kt == 1) EVK_DOT_PARTIAL(2, 1);
+  else if (nch == 2) EVK_DOT_PARTIAL(2, 4);
+  else if (kt == 1) EVK_DOT_PARTIAL(4, 1);
+  else EVK_DOT_PARTIAL(4, 4);
+#undef EVK_DOT_PARTIAL
+  int rc = check_launch("bn_relu_dot_bwd_partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, (const float*)bnp, nb, C,
+                     1.0 / (double)rows, gamma, save_invstd, dgamma, dbeta, coef, 1, dx_absmax,
+                     pack ? (const float*)bnm : (const float*)nullptr);
+  rc = check_launch("bn_bwd_final");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_relu_dot_bwd_wfinal_kernel, dim3((K * C + K + 7) / 8), dim3(256), 0, st, (const float*)dwp,
+                     (const float*)dbp, dw, dbias, nb, C, K);
+  rc = check_launch("bn_relu_dot_bwd_wfinal");
+  if (rc) return rc;
+  const size_t n4 = (size_t)rows * C / 4;
+  if (pack)
+    hipLaunchKernelGGL(bn_relu_dot_bwd_apply_kernel<true>, dim3(oneshot_grid(n4)), dim3(256), 0, st, dl, z, scale_shift, save_mean,
+                       save_invstd, (const float*)coef, w, dz, n4, C, K, dx_absmax);
+  else
+    hipLaunchKernelGGL(bn_relu_dot_bwd_apply_kernel<false>, dim3(oneshot_grid(n4)), dim3(256), 0, st, dl, z, scale_shift, save_mean,
+                       save_invstd, (const float*)coef, w, dz, n4, C, K, dx_absmax);
+  return check_launch("bn_relu_dot_bwd_apply");
+}
+
 // ---- ReLU bits (common.hpp: relu_bits_*)
 namespace evk {
 __global__ __launch_bounds__(256) void relu_bits_apply_kernel(const float* __restrict__ g, const uint32_t* __restrict__ bits,

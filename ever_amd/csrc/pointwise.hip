@@ -639,7 +639,11 @@ __global__ __launch_bounds__(256) void relation_bn_fwd_kernel(const float* __res
   }
   if (amax) commit_absmax(amax, m);
 }
-// LDS: [4 waves][9][C] floats: dscene, then per BatchNorm (content, re-encoding): sum g, sum g*xhat, max|g|, max|xhat|
+// Per-lane REGISTER accumulators over a workgroup's pixels (a lane owns NCH 16-byte channel chunks): the scene gradient,
+// then per BatchNorm (content, re-encoding) sum g, sum g*xhat, max|g|, max|xhat|; the four waves are folded through LDS once,
+// at the end ([4 waves][9][C] floats).  (Accumulating in LDS per pixel — nine dependent read-modify-writes — made this
+// kernel slower than the plain relation backward it replaces.)
+template <int NCH>
 __global__ __launch_bounds__(256) void relation_bn_bwd_kernel(
     const float* __restrict__ dout, const float* __restrict__ scene, const float* __restrict__ zc,
     const float* __restrict__ ssc, const float* __restrict__ mic, const float* __restrict__ zf, const float* __restrict__ ssf,
@@ -652,60 +656,79 @@ __global__ __launch_bounds__(256) void relation_bn_bwd_kernel(
   const int n = blockIdx.y;
   const int p0 = blockIdx.x * pix_per_blk, p1 = min(HW, p0 + pix_per_blk);
   const float* sc = scene + (size_t)n * C;
-  float* my = sacc + (size_t)wave * 9 * C;
-  for (int c = lane; c < 9 * C; c += 64) my[c] = 0.f;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[NCH][9];
+  f32x4 s4[NCH], scc[NCH], shc[NCH], muc[NCH], isc[NCH], scf[NCH], shf[NCH], muf[NCH], isf[NCH];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int cb = lane + 64 * j;
+    const bool ok = cb < c4;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[j][k] = zero4;
+    s4[j] = ok ? *reinterpret_cast<const f32x4*>(sc + cb * 4) : zero4;
+    scc[j] = ok ? *reinterpret_cast<const f32x4*>(ssc + cb * 4) : zero4;
+    shc[j] = ok ? *reinterpret_cast<const f32x4*>(ssc + C + cb * 4) : zero4;
+    muc[j] = ok ? *reinterpret_cast<const f32x4*>(mic + cb * 4) : zero4;
+    isc[j] = ok ? *reinterpret_cast<const f32x4*>(mic + C + cb * 4) : zero4;
+    scf[j] = ok ? *reinterpret_cast<const f32x4*>(ssf + cb * 4) : zero4;
+    shf[j] = ok ? *reinterpret_cast<const f32x4*>(ssf + C + cb * 4) : zero4;
+    muf[j] = ok ? *reinterpret_cast<const f32x4*>(mif + cb * 4) : zero4;
+    isf[j] = ok ? *reinterpret_cast<const f32x4*>(mif + C + cb * 4) : zero4;
+  }
+  auto amax4 = [](f32x4& m, const f32x4 v) {
+    m.x = fmaxf(m.x, fabsf(v.x)); m.y = fmaxf(m.y, fabsf(v.y)); m.z = fmaxf(m.z, fabsf(v.z)); m.w = fmaxf(m.w, fabsf(v.w));
+  };
   for (int p = p0 + wave; p < p1; p += 4) {
     const size_t pix = (size_t)n * HW + p;
     const float rv = r[pix];
-    const float* d_o = dout + pix * C;
+    f32x4 a[NCH], zfv[NCH], zcv[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {     // all three rows of the pixel in flight before the first use
+      const int cb = lane + 64 * j;
+      const bool ok = cb < c4;
+      a[j] = ok ? *reinterpret_cast<const f32x4*>(dout + pix * C + cb * 4) : zero4;
+      zfv[j] = ok ? *reinterpret_cast<const f32x4*>(zf + pix * C + cb * 4) : zero4;
+      zcv[j] = ok ? *reinterpret_cast<const f32x4*>(zc + pix * C + cb * 4) : zero4;
+    }
     float dot = 0.f;
-    for (int cb = lane; cb < c4; cb += 64) {   // re-encoding branch: g_f = dout * r where the activation is positive
-      const f32x4 a = *reinterpret_cast<const f32x4*>(d_o + cb * 4);
-      const f32x4 z = *reinterpret_cast<const f32x4*>(zf + pix * C + cb * 4);
-      const f32x4 y = bn_relu4(z, *reinterpret_cast<const f32x4*>(ssf + cb * 4), *reinterpret_cast<const f32x4*>(ssf + C + cb * 4));
-      dot += a.x * y.x + a.y * y.y + a.z * y.z + a.w * y.w;
-      f32x4 g = a * rv;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {     // re-encoding branch: g_f = dout * r where the activation is positive
+      const int cb = lane + 64 * j;
+      const f32x4 y = bn_relu4(zfv[j], scf[j], shf[j]);
+      dot += a[j].x * y.x + a[j].y * y.y + a[j].z * y.z + a[j].w * y.w;
+      f32x4 g = a[j] * rv;
       g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f; g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
-      *reinterpret_cast<f32x4*>(gf + pix * C + cb * 4) = g;
-      const f32x4 xh = (z - *reinterpret_cast<const f32x4*>(mif + cb * 4)) * *reinterpret_cast<const f32x4*>(mif + C + cb * 4);
-      f32x4* s0 = reinterpret_cast<f32x4*>(my + 5 * C + cb * 4);
-      f32x4* s1 = reinterpret_cast<f32x4*>(my + 6 * C + cb * 4);
-      f32x4* m0 = reinterpret_cast<f32x4*>(my + 7 * C + cb * 4);
-      f32x4* m1 = reinterpret_cast<f32x4*>(my + 8 * C + cb * 4);
-      *s0 = *s0 + g;
-      *s1 = *s1 + g * xh;
-      f32x4 t = *m0;
-      t.x = fmaxf(t.x, fabsf(g.x)); t.y = fmaxf(t.y, fabsf(g.y)); t.z = fmaxf(t.z, fabsf(g.z)); t.w = fmaxf(t.w, fabsf(g.w));
-      *m0 = t;
-      t = *m1;
-      t.x = fmaxf(t.x, fabsf(xh.x)); t.y = fmaxf(t.y, fabsf(xh.y)); t.z = fmaxf(t.z, fabsf(xh.z)); t.w = fmaxf(t.w, fabsf(xh.w));
-      *m1 = t;
+      if (cb < c4) *reinterpret_cast<f32x4*>(gf + pix * C + cb * 4) = g;
+      const f32x4 xh = (zfv[j] - muf[j]) * isf[j];
+      acc[j][5] += g;
+      acc[j][6] += g * xh;
+      amax4(acc[j][7], g);
+      amax4(acc[j][8], xh);
     }
     dot = wave_sum(dot);
     const float dz = dot * rv * (1.f - rv);
-    for (int cb = lane; cb < c4; cb += 64) {   // content branch: g_c = dz * scene where the activation is positive
-      const f32x4 s4 = *reinterpret_cast<const f32x4*>(sc + cb * 4);
-      const f32x4 z = *reinterpret_cast<const f32x4*>(zc + pix * C + cb * 4);
-      const f32x4 y = bn_relu4(z, *reinterpret_cast<const f32x4*>(ssc + cb * 4), *reinterpret_cast<const f32x4*>(ssc + C + cb * 4));
-      f32x4 g = s4 * dz;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {     // content branch: g_c = dz * scene where the activation is positive
+      const int cb = lane + 64 * j;
+      const f32x4 y = bn_relu4(zcv[j], scc[j], shc[j]);
+      f32x4 g = s4[j] * dz;
       g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f; g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
-      *reinterpret_cast<f32x4*>(gc + pix * C + cb * 4) = g;
-      f32x4* a = reinterpret_cast<f32x4*>(my + cb * 4);
-      *a = *a + y * dz;
-      const f32x4 xh = (z - *reinterpret_cast<const f32x4*>(mic + cb * 4)) * *reinterpret_cast<const f32x4*>(mic + C + cb * 4);
-      f32x4* s0 = reinterpret_cast<f32x4*>(my + 1 * C + cb * 4);
-      f32x4* s1 = reinterpret_cast<f32x4*>(my + 2 * C + cb * 4);
-      f32x4* m0 = reinterpret_cast<f32x4*>(my + 3 * C + cb * 4);
-      f32x4* m1 = reinterpret_cast<f32x4*>(my + 4 * C + cb * 4);
-      *s0 = *s0 + g;
-      *s1 = *s1 + g * xh;
-      f32x4 t = *m0;
-      t.x = fmaxf(t.x, fabsf(g.x)); t.y = fmaxf(t.y, fabsf(g.y)); t.z = fmaxf(t.z, fabsf(g.z)); t.w = fmaxf(t.w, fabsf(g.w));
-      *m0 = t;
-      t = *m1;
-      t.x = fmaxf(t.x, fabsf(xh.x)); t.y = fmaxf(t.y, fabsf(xh.y)); t.z = fmaxf(t.z, fabsf(xh.z)); t.w = fmaxf(t.w, fabsf(xh.w));
-      *m1 = t;
+      if (cb < c4) *reinterpret_cast<f32x4*>(gc + pix * C + cb * 4) = g;
+      acc[j][0] += y * dz;
+      const f32x4 xh = (zcv[j] - muc[j]) * isc[j];
+      acc[j][1] += g;
+      acc[j][2] += g * xh;
+      amax4(acc[j][3], g);
+      amax4(acc[j][4], xh);
     }
+  }
+  float* my = sacc + (size_t)wave * 9 * C;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int cb = lane + 64 * j;
+    if (cb < c4)
+#pragma unroll
+      for (int k = 0; k < 9; ++k) *reinterpret_cast<f32x4*>(my + (size_t)k * C + cb * 4) = acc[j][k];
   }
   __syncthreads();
   const size_t blk = (size_t)n * nblk + blockIdx.x;
@@ -986,7 +1009,7 @@ extern "C" int evk_relation_bn_bwd(const float* dout, const float* scene, const 
   EVK_REQUIRE(dout && scene && zc && scale_shift_c && mean_invstd_c && zf && scale_shift_f && mean_invstd_f && r && dscene &&
                   gc && gf,
               EVK_E_INVALID, "relation_bn_bwd: null pointer");
-  EVK_REQUIRE(N > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 1024, EVK_E_UNSUPPORTED, "relation_bn_bwd: C=%d", C);
+  EVK_REQUIRE(N > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 448, EVK_E_UNSUPPORTED, "relation_bn_bwd: C=%d", C);
   EVK_REQUIRE(workspace && workspace_bytes >= evk_relation_bn_workspace_bytes(N, HW, C), EVK_E_WORKSPACE,
               "relation_bn_bwd: workspace too small");
   const int nblk = relation_blocks(HW);
@@ -1002,14 +1025,16 @@ extern "C" int evk_relation_bn_bwd(const float* dout, const float* scene, const 
   float* bnm_f = w + nb * 7 * C;
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = (size_t)4 * 9 * C * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&relation_bn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              4 * 9 * 1024 * (int)sizeof(float));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(relation_bn_bwd_kernel, dim3(nblk, N), dim3(256), lds, st, dout, scene, zc, scale_shift_c, mean_invstd_c,
-                     zf, scale_shift_f, mean_invstd_f, r, gc, gf, partial, bnp_c, bnm_c, bnp_f, bnm_f, HW, C, ppb, nblk);
+  EVK_REQUIRE(lds <= 64 * 1024, EVK_E_UNSUPPORTED, "relation_bn_bwd: C=%d does not fit the LDS", C);
+  const int nch = (C / 4 + 63) / 64;
+#define EVK_REL_BWD(NCH)                                                                                                   \
+  hipLaunchKernelGGL(relation_bn_bwd_kernel<NCH>, dim3(nblk, N), dim3(256), lds, st, dout, scene, zc, scale_shift_c,        \
+                     mean_invstd_c, zf, scale_shift_f, mean_invstd_f, r, gc, gf, partial, bnp_c, bnm_c, bnp_f, bnm_f, HW, C, \
+                     ppb, nblk)
+  if (nch == 1) EVK_REL_BWD(1);
+  else if (nch == 2) EVK_REL_BWD(2);
+  else EVK_REL_BWD(4);
+#undef EVK_REL_BWD
   int rc = check_launch("relation_bn_bwd");
   if (rc) return rc;
   hipLaunchKernelGGL(relation_dscene_final_kernel, dim3((C + 7) / 8, N), dim3(256), 0, st, (const float*)partial, dscene, nblk,

@@ -13,5 +13,5 @@ void set_error(const char* fmt, ...) {
 }  // namespace evk
 
 extern "C" const char* evk_last_error(void) { return evk::g_err; }
-extern "C" int evk_abi_version(void) { return 17; }
+extern "C" int evk_abi_version(void) { return 18; }
 extern "C" const char* evk_build_arch(void) { return "gfx950"; }

@@ -1618,7 +1618,7 @@ def fs_relation_bn(scene, zc, zf, bn_c, bn_f):
     (see _RelationBnFn); zc, zf carry their convolutions' statistics records (`_evk_bn_parts`), or None is returned and the
     caller runs the layers one by one."""
     pc, pf = getattr(zc, '_evk_bn_parts', None), getattr(zf, '_evk_bn_parts', None)
-    if pc is None or pf is None or pc[1] <= 0 or pf[1] <= 0 or zc.shape != zf.shape or zc.shape[1] % 4 or zc.shape[1] > 1024:
+    if pc is None or pf is None or pc[1] <= 0 or pf[1] <= 0 or zc.shape != zf.shape or zc.shape[1] % 4 or zc.shape[1] > 448:
         return None
     del zc._evk_bn_parts, zf._evk_bn_parts
     n, c, h, w = zc.shape
@@ -1638,6 +1638,78 @@ def fs_relation_bn(scene, zc, zf, bn_c, bn_f):
             _note_amax(out, abits)
         _AMAX_HANDOFF = None
     return out
+
+
+class _BnReluDotFn(Function):
+    """out = conv1x1(relu(bn(z))) for a narrow classifier (K <= 16), BatchNorm with batch statistics from the producing
+    convolution's epilogue records, as one consumer of z (include/ever_hip.h: evk_bn_relu_dot_*): the normalised map is
+    never written, its K-fold outer-product gradient never formed.  Replaces blocks[i][-1][1:3] + classifier[0] of reference
+    fpn.py:163-170,179-193 in the commuted decoder (module/fpn.py)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, w, bias, rm, rv, cfg):
+        parts, mom, eps = cfg
+        n, c, h, wd = z.shape
+        k = w.shape[0]
+        rows, dev, st = n * h * wd, z.device, _stream()
+        stats = torch.empty((4, c), device=dev, dtype=torch.float32)      # mean, invstd, scale, shift
+        _C.call('evk_bn_finalize_parts', parts[0].data_ptr(), parts[1], c, rows, _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv),
+                float(mom), float(eps), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), st)
+        w2 = _weight_ohwi(w.detach()).reshape(k, c)
+        out = empty_nhwc(n, k, h, wd, dev)
+        # algorithmic bytes: read z (the K-channel result is noise beside it)
+        _timed_call('bn', 4.0 * z.numel(), 'evk_bn_relu_dot_fwd', z.data_ptr(), stats[2].data_ptr(), w2.data_ptr(), _ptr(bias),
+                    out.data_ptr(), rows, c, k, st)
+        ctx.pack = bool(len(parts) > 2 and parts[2])
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(z, gamma, w, stats)
+        ctx.mark_non_differentiable(*[t for t in (rm, rv) if t is not None])
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dl):
+        z, gamma, w, stats = ctx.saved_tensors
+        n, c, h, wd = z.shape
+        k = w.shape[0]
+        rows, dev, st = n * h * wd, z.device, _stream()
+        dl = as_nhwc(dl, 'bn_relu_dot.backward')
+        lib = _C.load()
+        ws_bytes = lib.evk_bn_relu_dot_workspace_bytes(rows, c, k)
+        ws = workspace(dev, ws_bytes)
+        pack = ctx.pack and _f16x2()
+        abits = _amax_zeroed(dev) if pack else _amax_out(dev)
+        pack = pack and abits is not None
+        dz = torch.empty_like(z)
+        dgamma = torch.empty((c,), device=dev, dtype=torch.float32) if gamma is not None else None
+        dbeta = torch.empty((c,), device=dev, dtype=torch.float32) if gamma is not None else None
+        dw = torch.empty_like(w, memory_format=torch.channels_last)
+        dbias = torch.empty((k,), device=dev, dtype=torch.float32) if ctx.has_bias else None
+        w2 = _weight_ohwi(w.detach()).reshape(k, c)
+        # algorithmic bytes: read z twice, write dz
+        _timed_call('bn', 12.0 * z.numel(), 'evk_bn_relu_dot_bwd', dl.data_ptr(), z.data_ptr(), stats[2].data_ptr(), _ptr(gamma),
+                    stats[0].data_ptr(), stats[1].data_ptr(), w2.data_ptr(), dz.data_ptr(), _ptr(dgamma), _ptr(dbeta),
+                    dw.data_ptr(), _ptr(dbias), rows, c, k, 2 if pack else 0, ws.data_ptr(), ws_bytes, _ptr(abits), st)
+        if pack:
+            _mark_packed(dz, abits)
+        elif abits is not None:
+            _note_amax(dz, abits)
+        return dz, dgamma, dbeta, dw, dbias, None, None, None
+
+
+def bn_relu_dot(z, bn, conv):
+    """`conv(relu(bn(z)))` for a training-mode BatchNorm2d whose statistics records ride on z (`_evk_bn_parts`) and a 1x1
+    convolution with at most 16 outputs, as one pass each way (see _BnReluDotFn); None when that form does not apply."""
+    parts = getattr(z, '_evk_bn_parts', None)
+    k, c = conv.weight.shape[0], z.shape[1]
+    if (parts is None or parts[1] <= 0 or k > 16 or c % 4 or c > 1024 or tuple(conv.weight.shape[2:]) != (1, 1)
+            or conv.weight.shape[1] != c or (c > 256 and k > 4) or 16 * (4 + k) * c > 65536):
+        return None      # (the kernel's register / LDS budget: csrc/bn.hip evk_bn_relu_dot_bwd)
+    del z._evk_bn_parts
+    weight_planes.note_running_stats_changed()
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return _BnReluDotFn.apply(z, bn.weight, bn.bias, conv.weight, conv.bias, rm, rv, (parts, bn.momentum, bn.eps))
 
 
 class _Mean4Fn(Function):

@@ -158,6 +158,31 @@ class AssymetricDecoder(nn.Module):
             watched += [block, last, list(last)[-1], getattr(list(last)[-1], '_inner_module', None)]
         return not any(m is not None and (m._forward_hooks or m._forward_pre_hooks) for m in watched)
 
+    def _bn_relu_classifier(self, last, x, conv):
+        """`classifier(relu(bn(conv3x3(x))))` of a branch's last block with BatchNorm + ReLU + the 1x1 classifier as ONE
+        consumer of the 3x3 convolution's output (HF.bn_relu_dot: the normalised 256-channel map is never written and the
+        classifier's rank-K gradient never formed); None = run the layers one by one (eval / folded BatchNorm,
+        GroupNorm or no norm, hooks, EVK_BN_DOT=0)."""
+        from .fold import _takes_epilogue_stats
+        import torch
+        if os.environ.get('EVK_BN_DOT', '1') == '0' or not torch.is_grad_enabled():
+            return None
+        if not (len(last) == 4 and isinstance(last[0], Conv2d) and isinstance(last[2], nn.ReLU)):
+            return None
+        bn = last[1]
+        if not (_takes_epilogue_stats(bn) and bn.training and bn.momentum is not None):
+            return None
+        if any(m._forward_hooks or m._forward_pre_hooks for m in (last[0], bn, last[2])):
+            return None
+        z = last[0](x, bn_stats=True)
+        out = HF.bn_relu_dot(z, bn, conv)
+        if out is None:      # no statistics records on z: finish the block layer by layer
+            from .layers import run_sequence
+            return conv(run_sequence(last[1:3], z))
+        if bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn._nbt_pending = getattr(bn, '_nbt_pending', 0) + 1
+        return out
+
     def _forward_commuted(self, feat_list):
         from .layers import run_sequence
         conv = self.classifier[0]
@@ -170,8 +195,10 @@ class AssymetricDecoder(nn.Module):
             last = list(subs[-1])
             up = last[-1]
             has_up = not isinstance(up, nn.Identity)
-            x = run_sequence(last[:-1] if has_up else last, x)
-            z = conv(x)
+            z = self._bn_relu_classifier(last, x, conv)
+            if z is None:
+                x = run_sequence(last[:-1] if has_up else last, x)
+                z = conv(x)
             zs.append(up(z) if has_up else z)
         if len(zs) == 4:
             out = HF.mean4(*zs)

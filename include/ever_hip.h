@@ -588,6 +588,20 @@ int evk_bn_bwd_from_partials(const float* g, const float* x, const float* gamma,
                              float* dgamma, float* dbeta, int64_t rows, int32_t C, uint32_t flags, int32_t train,
                              void* workspace, size_t workspace_bytes, uint32_t* dx_absmax, void* stream);
 
+/* BatchNorm + ReLU + a narrow 1x1 convolution as ONE consumer of a convolution output z (the decoder's classifier applied
+ * per branch: reference fpn.py:163-170 `conv3x3 -> BN -> ReLU`, :179-193 the 1x1 classifier; ever_amd/module/fpn.py runs the
+ * classifier before the last upsampling): out[pix][k] = sum_c relu(bn(z))[pix][c] * w[k][c] + bias[k], K <= 16.  The
+ * normalised map is never written.  scale_shift / save_mean / save_invstd from evk_bn_finalize_parts.  Backward: dl
+ * [rows][K] -> dz (gradient of z; EVK_BN_PACK_DX: packed, dx_absmax zero on entry), dgamma, dbeta, dw [K][C], dbias [K];
+ * it reads z twice and never forms the C-channel gradient of the normalised map. */
+int evk_bn_relu_dot_fwd(const float* z, const float* scale_shift, const float* w, const float* bias, float* out, int64_t rows,
+                        int32_t C, int32_t K, void* stream);
+size_t evk_bn_relu_dot_workspace_bytes(int64_t rows, int32_t C, int32_t K);
+int evk_bn_relu_dot_bwd(const float* dl, const float* z, const float* scale_shift, const float* gamma, const float* save_mean,
+                        const float* save_invstd, const float* w, float* dz, float* dgamma, float* dbeta, float* dw,
+                        float* dbias, int64_t rows, int32_t C, int32_t K, uint32_t flags, void* workspace,
+                        size_t workspace_bytes, uint32_t* dx_absmax, void* stream);
+
 /* Synchronized BatchNorm in stages (torch.nn.SyncBatchNorm under the trainer's `sync_bn`, reference
  * ever/trainer/th_ddp_trainer.py + SURVEY §8 C5): the exchange between the stages is the caller's
  * (torch.distributed over RCCL): forward all-gather of `stats` (local mean, local sum of squared deviations,
