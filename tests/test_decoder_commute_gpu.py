@@ -66,3 +66,41 @@ def test_reference_order_is_kept_where_the_difference_could_be_seen(cuda):
     assert not drop._classifier_commutes()         # training-mode dropout acts on the mean
     assert drop.eval()._classifier_commutes()
     assert not _decoder(cuda, num_classes=64)._classifier_commutes()     # nothing to gain: as many classes as channels
+
+
+@pytest.mark.parametrize('c,k,hw', [(64, 1, (17, 23)), (128, 3, (32, 20)), (192, 2, (9, 11)), (256, 5, (16, 16)), (320, 4, (8, 24))])
+def test_bn_relu_classifier_pass_on_ragged_shapes(cuda, c, k, hw):
+    """HF.bn_relu_dot (BatchNorm + ReLU + narrow 1x1 convolution as one consumer of a convolution output) against the three
+    layers one by one, on channel counts that leave lanes idle, several chunks per lane, odd pixel counts, 1..5 classes"""
+    import ever_amd as er
+    from ever_amd.hip import functional as HF
+    from ever_amd.module.layers import BatchNorm2d, Conv2d
+    torch.manual_seed(c + k)
+    conv = Conv2d(32, c, 3, 1, 1, bias=False).to(cuda)
+    bn = BatchNorm2d(c).to(cuda).train()
+    cls = Conv2d(c, k, 1).to(cuda)
+    torch.nn.init.uniform_(bn.weight, 0.5, 1.5)
+    torch.nn.init.uniform_(bn.bias, -0.3, 0.3)
+    x = torch.randn(3, 32, *hw, device=cuda).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(3, k, *hw, device=cuda)
+    res = []
+    for fused in (True, False):
+        for m in (conv, bn, cls):
+            m.zero_grad(set_to_none=True)
+        bn.reset_running_stats()
+        xi = x.clone().requires_grad_()
+        z = conv(xi, bn_stats=True)
+        out = HF.bn_relu_dot(z, bn, cls) if fused else None
+        if out is None:
+            assert not fused, 'the fused form should take this shape'
+            out = cls(bn(z, relu=True))
+        (out * g).sum().backward()
+        torch.cuda.synchronize()
+        res.append((out.detach(), xi.grad, conv.weight.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(),
+                    cls.weight.grad.clone(), cls.bias.grad.clone(), bn.running_mean.clone(), bn.running_var.clone()))
+
+    def rel(a, b):
+        return float((a.double() - b.double()).abs().max() / b.double().abs().max())
+    names = ('out', 'dx', 'dconv', 'dgamma', 'dbeta', 'dcls_w', 'dcls_b', 'running_mean', 'running_var')
+    for name, a, b in zip(names, res[0], res[1]):
+        assert rel(a, b) < 5e-5, (name, rel(a, b))

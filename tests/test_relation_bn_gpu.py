@@ -96,3 +96,25 @@ def test_layerwise_path_is_kept_where_the_tensors_could_be_seen(cuda, monkeypatc
     sum(o.sum() for o in outs).backward()
     hk.remove()
     assert seen == [(2, 64, 4, 4)] and all(f.grad is not None for f in feats)
+
+
+@pytest.mark.parametrize('c,hw', [(64, (13, 9)), (128, (20, 12)), (192, (7, 31)), (320, (8, 8))])
+def test_fused_relation_on_ragged_shapes(cuda, monkeypatch, c, hw):
+    """channel counts that leave lanes idle or need two chunks per lane, odd pixel counts per image"""
+    import ever_amd as er
+    torch.manual_seed(c)
+    m = er.module.fs_relation.FSRelation(96, (c,), c).to(cuda).train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            torch.nn.init.uniform_(mod.weight, 0.5, 1.5)
+            torch.nn.init.uniform_(mod.bias, -0.3, 0.3)
+    scene = (torch.randn(3, 96, 1, 1) * 0.1).to(cuda)
+    feats = [(torch.randn(3, c, *hw) + 0.2).to(cuda).contiguous(memory_format=torch.channels_last)]
+    ws = [torch.randn(3, c, *hw).to(cuda)]
+    o1, s1, f1, p1, st1 = _run(m, scene, feats, ws, monkeypatch, True)
+    o0, s0, f0, p0, st0 = _run(m, scene, feats, ws, monkeypatch, False)
+    assert _rel(o1[0], o0[0]) < 1e-5 and _rel(s1, s0) < 5e-5 and _rel(f1[0], f0[0]) < 1e-4
+    for k in p0:
+        if k.endswith('.0.bias') and ('content_encoders' in k or 'feature_reencoders' in k):
+            continue
+        assert _rel(p1[k], p0[k]) < 2e-4 or float(p0[k].abs().max()) < 1e-6, (k, _rel(p1[k], p0[k]))
