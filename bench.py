@@ -49,6 +49,9 @@ def parse():
     p.add_argument('--warmup', type=int, default=5)
     p.add_argument('--batch', type=int, default=BATCH, help='tiles per GPU (default: the BASELINE config)')
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-graph-line', action='store_true',
+                   help='skip the `hip_graph_replay` object (the same step captured as one hipGraph and replayed, measured in a '
+                        'child process after the timed region; never the headline value)')
     p.add_argument('--ddp', choices=['flat', 'torch'], default='flat',
                    help='gradient exchange under --gpus N>1: ever_amd FlatGradDDP (default) or torch DistributedDataParallel')
     p.add_argument('--conv-math', choices=['f16x2', 'bf16x3', 'f32', 'bf16'], default=None,
@@ -164,6 +167,26 @@ def host_cores():
     except (OSError, ValueError):
         pass
     return n
+
+
+def graph_replay_line(args):
+    """The same workload with the step captured once as a hipGraph and replayed (`bench.py --graph`, ever_amd/core/graph.py;
+    bit-identical to the eager step: tests/test_graph_gpu.py), measured in a CHILD process after the timed region — a capture
+    problem can then not take the headline line with it.  Reported beside `value`, never instead of it: a replay exposes no
+    per-launch HIP events, so it carries no roofline."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--graph', '--steps', str(args.steps), '--warmup', str(max(args.warmup, 4)),
+           '--config', args.config, '--no-cpu-baseline', '--no-graph-line']
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        rows = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+        d = json.loads(rows[-1])
+        return {'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'],
+                'host_enqueue_ms_per_step': d['host_enqueue_ms_per_step'],
+                'how': 'python bench.py --graph (child process, same box, right after the timed region): forward + losses + '
+                       'backward + fused SGD captured once by torch.cuda.graph and replayed; EVK_GRAPH=1 in the Launcher'}
+    except Exception as e:   # never at the expense of the headline line
+        return {'value': None, 'error': f'{type(e).__name__}: {str(e)[:160]}'}
 
 
 def cpu_baseline(seconds_budget=20.0):
@@ -448,6 +471,8 @@ def main():
                         'algorithmic_bytes_per_kernel': (round(hb['bytes'] / max(1, sampled) / pmc_kernel_launches_per_step('bn'))
                                                          if (fam_name == 'bn' and pmc_kernel_launches_per_step('bn')) else None),
                         'avg_call_us': round(hb['seconds'] / hb['launches'] * 1e6, 2)}
+        if world == 1 and not use_ddp and not args.graph and not args.no_graph_line and conv_math == 'f16x2':
+            line['hip_graph_replay'] = graph_replay_line(args)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         out_line = json.dumps(line)
