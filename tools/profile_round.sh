@@ -1,9 +1,9 @@
 # Round profile on the GPU box: kernel-trace stats + the two PMC traffic passes of bench.py; outputs under gpurun_out/prof_round.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_round; mkdir -p $O
-rocprofv3 --kernel-trace --stats -d $O/stats -o farseg -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o r -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timer > $O/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o r -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timer > $O/write.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/stats -o farseg -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph-line > $O/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o r -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph-line --no-kernel-timer > $O/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o r -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph-line --no-kernel-timer > $O/write.log 2>&1
 cd $R
 python bench.py > $O/bench.log 2>&1
 tail -1 $O/bench.log > $O/bench.json

@@ -36,7 +36,7 @@ def main(db_path, out, steps=28):
             fam_rows.append((label, calls, tot, tot / calls))
     with open(out + '.md', 'w') as f:
         f.write('# rocprofv3 --kernel-trace --stats summary\n\nsource: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 '
-                f'--no-cpu-baseline` (tools/profile_round.sh; rocpd db summarised by tools/rocpd_summary.py; {steps} steps: 5 warm-up + 3 '
+                f'--no-cpu-baseline --no-graph-line` (tools/profile_round.sh; rocpd db summarised by tools/rocpd_summary.py; {steps} steps: 5 warm-up + 3 '
                 f'empty-queue host probes + 20 timed); {sum(r[1] for r in rows)} '
                 f'dispatches, {total / 1e6:.1f} ms of kernel time over a {(span[1] - span[0]) / 1e6:.1f} ms window\n\n')
         f.write('Kernel families as bench.py times them with HIP events.  Its `avg_launch_us` is per C-ABI CALL (a strided data '
