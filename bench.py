@@ -327,6 +327,20 @@ def main():
         print('host ms per step:', [round((b - a) * 1e3, 1) for a, b in zip(marks, marks[1:])], file=sys.stderr)
     fence()
     elapsed = time.perf_counter() - t0
+    # With the weight gradients on their own stream the per-launch durations above are measured UNDER the
+    # overlap: the families share the chip.  Two more steps, after the timed region, with the side stream off give the same
+    # kernels alone for the *_alone fields of the roofline objects.
+    alone = None
+    if timer is not None and HF.wgrad_stream_enabled() and not args.graph:
+        HF.set_wgrad_stream(False)
+        timer_alone = timing.KernelTimer()
+        step(); fence()
+        for _ in range(2):
+            with timer_alone:
+                step()
+        fence()
+        HF.set_wgrad_stream(True)
+        alone = timer_alone.summary()
     per_rank = None
     if use_ddp:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -457,6 +471,18 @@ def main():
                     'frac': round(fl / sec / 1e12 / peak, 4),
                     'gflop_per_step': round(fl / max(1, sampled) / 1e9, 1),
                     'ms_per_step': round(sec / max(1, sampled) * 1e3, 3), 'families': parts}
+            if alone is not None:
+                note = ('weight gradients run on a second stream beside the main stream\'s kernels (DESIGN 2.8): achieved / frac / '
+                        'avg_launch_us are measured under that overlap, inside the timed region; *_alone = the same launches in 2 '
+                        'extra steps after it with the side stream off')
+                for key, fname in (('roofline', 'conv_igemm' if x3 else 'conv_igemm_f32'),
+                                   ('roofline_wgrad', 'conv_wgrad' if x3 else 'conv_wgrad_f32')):
+                    a = alone.get(fname)
+                    if a and key in line:
+                        ach = a['flops'] / a['seconds'] / 1e12
+                        line[key].update({'overlap': True, 'achieved_alone': round(ach, 2), 'frac_alone': round(ach / peak, 4),
+                                          'avg_launch_us_alone': round(a['seconds'] / a['launches'] * 1e6, 2)})
+                line['roofline']['overlap_note'] = note
             for fam_name, label in (('bn', 'evk::bn_* (BatchNorm+residual+ReLU forward/backward passes)'),
                                     ('resample_loss', 'evk::bilinear_fwd/bwd + bce/dice kernels (upsample x2/x4, pixel losses)')):
                 hb = fam.get(fam_name)
@@ -471,6 +497,11 @@ def main():
                         'algorithmic_bytes_per_kernel': (round(hb['bytes'] / max(1, sampled) / pmc_kernel_launches_per_step('bn'))
                                                          if (fam_name == 'bn' and pmc_kernel_launches_per_step('bn')) else None),
                         'avg_call_us': round(hb['seconds'] / hb['launches'] * 1e6, 2)}
+                    a = alone.get(fam_name) if alone is not None else None
+                    if a and a['seconds'] > 0:
+                        g1 = a['bytes'] / a['seconds'] / 1e9
+                        line['roofline_hbm_' + fam_name].update({'overlap': True, 'achieved_alone': round(g1, 1),
+                                                                 'frac_alone': round(g1 / PEAK_HBM_GBS, 4)})
         if world == 1 and not use_ddp and not args.graph and not args.no_graph_line and conv_math == 'f16x2':
             line['hip_graph_replay'] = graph_replay_line(args)
         if world == 1 and not args.no_cpu_baseline:

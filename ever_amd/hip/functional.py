@@ -177,11 +177,148 @@ _BN_EPILOGUE = os.environ.get('EVK_BN_EPILOGUE', '1') != '0'
 _PACKED = os.environ.get('EVK_PACKED', '1') != '0'
 
 
+# Weight gradients on a second stream.  Nothing downstream in a backward pass depends on dw, and a weight gradient is
+# MFMA-bound where the chain it would otherwise interrupt (BatchNorm backward, one-tap data gradients, pointwise passes) is
+# HBM-bound: launched beside that chain it fills the matrix pipe while the chain fills the memory system (+14 % on the
+# FarSeg-R50 step).  Rules that keep it invisible:
+#  * only for LEAF weight (and bias) whose .grad is None and that nobody else hooks (AccumulateGrad then only stores the
+#    tensor; an in-place accumulation or a foreign hook would read dw on the main stream) — FlatGradDDP opts its parameters
+#    in and packs the bucket on this stream (trainer/grad_reducer.py); an arrival hook on each such parameter makes the main
+#    stream wait before a SECOND gradient of the same pass is added to it, whatever produced either of them;
+#  * only for parameters used ONCE in the forward of this pass (_note_param_use): the engine sums the gradients of a
+#    multiply used leaf in its own input buffer, on the main stream, before any hook runs;
+#  * operands are kept from reuse until the launch has run (record_stream), the weight gradient's own temporaries belong
+#    to the side stream;
+#  * the main stream waits for the side stream at the END of the backward pass (autograd final callback), so everything
+#    after backward() — optimiser, clipping, .grad readers — is ordered as before;
+#  * the one-launch BatchNorm backward (a grid that must be resident as a whole) is not used while weight gradients are
+#    pending (EVK_BN_NO_FUSE, as under RCCL);
+#  * under a hipGraph capture the side stream forks from the capturing stream by the same event and joins it again in the
+#    end-of-backward callback, so a replay has the same overlap (and the same BatchNorm form) as the eager step.
+_WGRAD_STREAM = [os.environ.get('EVK_WGRAD_STREAM', '1') != '0']
+_WGRAD_SIDE = {}
+_WGRAD_PASS = {'pending': False, 'queued': False, 'id': 0}
+
+
+def set_wgrad_stream(on):
+    """runtime switch of the weight-gradient side stream (bench.py measures the kernels alone with it off)"""
+    prev, _WGRAD_STREAM[0] = _WGRAD_STREAM[0], bool(on)
+    return prev
+
+
+_USED_PARAMS = []
+
+
+def _note_param_use(*params):
+    """Forward bookkeeping of the side-stream rule "one use per pass": every entry point of this package that consumes a
+    parameter as a convolution weight / bias counts it.  A leaf that feeds SEVERAL nodes gets its gradients summed in the
+    autograd engine's input buffer as they arrive — an add on the main stream that no hook sees — so only single-use
+    parameters may take their gradient from the side stream.  (Not visible here: a use of the same parameter by a torch op
+    outside this package, e.g. an explicit L2 term in the loss; set EVK_WGRAD_STREAM=0 for such models.)"""
+    if not _WGRAD_STREAM[0]:
+        return
+    for p in params:
+        if p is not None and p.requires_grad and p.is_leaf:
+            n = p.__dict__.get('_evk_uses', 0)
+            if n == 0:
+                _USED_PARAMS.append(p)
+            p._evk_uses = n + 1
+
+
+def wgrad_stream_enabled():
+    return bool(_WGRAD_STREAM[0])
+
+
+def _leaf_ok(t):
+    """a leaf whose gradient arrives for the first time in this accumulation and that nobody but this module hooks"""
+    if not t.is_leaf or t.grad is not None or t.__dict__.get('_evk_uses', 0) != 1:
+        return False
+    own = 1 if getattr(t, '_evk_wgrad_hook', None) is not None else 0
+    if len(t._backward_hooks or ()) > own:
+        return False
+    return not getattr(t, '_post_accumulate_grad_hooks', None) or getattr(t, '_evk_flat_ddp', False)
+
+
+def _arrival_hook(t):
+    """Tensor hook on a parameter whose gradient may come from the side stream: the engine calls it for EVERY gradient that
+    arrives for t, before it is accumulated.  The first arrival of a pass is only stored; from the second on the engine adds
+    on the main stream — whoever produced the earlier one (a shared weight, a second use through another op of this
+    package, a regulariser built from torch ops), the main stream first waits for the side stream."""
+    def hook(grad):
+        if t.__dict__.get('_evk_pass') == _WGRAD_PASS['id']:
+            wait_wgrad_stream()
+        else:
+            t._evk_pass = _WGRAD_PASS['id']
+        return None
+    return hook
+
+
+def _wgrad_side_stream(dev, weight, bias=None):
+    """the side stream for this weight gradient, or None (see the rules above)"""
+    if not _WGRAD_STREAM[0] or dev.type != 'cuda' or weight is None:
+        return None
+    leaves = (weight,) if bias is None else (weight, bias)
+    flat_ddp = all(getattr(t, '_evk_flat_ddp', False) for t in leaves)
+    if not _WGRAD_PASS['queued']:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_wgrad_pass_done)
+            _WGRAD_PASS['queued'] = True
+        except RuntimeError:         # not inside a backward pass (a direct call): stay on the main stream
+            return None
+    if not all(_leaf_ok(t) for t in leaves) or (_dist_initialized() and not flat_ddp):
+        # a second use of a shared weight in this pass, an accumulation onto an existing .grad, somebody's hook — or another
+        # reducer (torch DDP hooks the gradient ACCUMULATORS, invisible on the tensor, and copies gradients into its buckets
+        # on the main stream as they arrive): this one runs on the main stream, behind whatever is pending
+        wait_wgrad_stream()
+        return None
+    s = _WGRAD_SIDE.get(dev)
+    if s is None:
+        s = _WGRAD_SIDE[dev] = torch.cuda.Stream(dev)
+    for t in leaves:
+        if getattr(t, '_evk_wgrad_hook', None) is None:
+            t._evk_wgrad_hook = t.register_hook(_arrival_hook(t))
+    _WGRAD_PASS['pending'] = True
+    return s
+
+
+def _wgrad_pass_done():
+    _WGRAD_PASS['queued'] = False
+    _WGRAD_PASS['id'] += 1
+    for p in _USED_PARAMS:
+        p._evk_uses = 0
+    del _USED_PARAMS[:]
+    wait_wgrad_stream()
+
+
+def wait_wgrad_stream():
+    """the current stream waits for every weight gradient launched on the side stream"""
+    if _WGRAD_PASS['pending']:
+        for s in _WGRAD_SIDE.values():
+            torch.cuda.current_stream(s.device).wait_stream(s)
+        _WGRAD_PASS['pending'] = False
+
+
+def wgrad_side_stream_of(dev):
+    """FlatGradDDP: the stream its bucket pack has to follow (None when no weight gradient is pending there)"""
+    return _WGRAD_SIDE.get(dev) if _WGRAD_PASS['pending'] else None
+
+
+def _dist_initialized():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
+def _collectives_world():
+    import torch.distributed as dist
+    return dist.get_world_size() if _dist_initialized() else 1
+
+
 def _collectives_in_flight():
     """RCCL kernels may share the device with the backward (gradient buckets reduced while it runs): the one-launch
     BatchNorm backward, whose grid has to be resident as a whole, is not used then (EVK_BN_NO_FUSE)."""
-    import torch.distributed as dist
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if _WGRAD_PASS['pending']:
+        return True      # a weight gradient may hold CUs while this backward runs: same rule
+    return _collectives_world() > 1
 
 
 def _mark_packed(t, bits):
@@ -405,7 +542,7 @@ class _ConvState:
     its own node forms no reference cycle, in-place writes to a saved tensor are caught by the version check, and
     saved-tensor hooks (activation checkpointing, offloading) see them."""
     __slots__ = ('desc', 'relu', 'cin', 'has_bias', 'flops', 'abytes', 'w_stride', 'xk', 'w_ohwi', 'y', 'weight',
-                 'w_alias', 'scope', 'bn_parts')
+                 'w_alias', 'scope', 'bn_parts', 'bias_leaf')
 
 
 def _stash(states):
@@ -430,7 +567,7 @@ def _drop(states):
     every other state's xk / y — allocated until the cyclic collector runs: 2.8 GB per step on FarSeg-R50, and a
     caching allocator that has to grow (hipMalloc inside the step) whenever the collector is late."""
     for cs in states:
-        cs.xk = cs.y = cs.weight = cs.w_ohwi = None
+        cs.xk = cs.y = cs.weight = cs.w_ohwi = cs.bias_leaf = None
 
 
 def _conv_forward(x, weight, bias, stride, padding, dilation, relu, want_stats=False):
@@ -508,6 +645,7 @@ def _conv_forward(x, weight, bias, stride, padding, dilation, relu, want_stats=F
     if sp is not None:
         sp.stop()
     cs.desc, cs.relu, cs.cin, cs.has_bias = d, relu, cin, bias is not None
+    cs.bias_leaf = bias      # (the parameter itself, not saved for backward: the weight-gradient side stream's rules look at it)
     cs.w_stride = tuple(weight.stride())
     # xk (channel-padded copy when Cin % 4 != 0) is what wgrad reads
     cs.xk, cs.w_ohwi, cs.y, cs.weight = xk, w_ohwi, (y if relu else None), weight
@@ -622,13 +760,28 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False,
         lib = _C.load()
         ws_bytes = (lib.evk_conv2d_wgrad_x3_workspace_bytes if x3 else lib.evk_conv2d_wgrad_workspace_bytes)(
             ctypes.byref(dk))
-        ws = workspace(dev, ws_bytes)
         dwk = torch.empty((cout_p, taps, cin_p), device=dev, dtype=torch.float32)
         dbk = torch.empty((cout_p,), device=dev, dtype=torch.float32) if need_db else None
+        side = _wgrad_side_stream(dev, cs.weight, cs.bias_leaf if need_db else None)
+        if side is not None:
+            # the weight gradient beside the rest of the backward (see _WGRAD_STREAM above)
+            ev = torch.cuda.Event()
+            ev.record()
+            for t in (xk, dyk, dwk, dbk):
+                if t is not None:
+                    t.record_stream(side)
+            side.wait_event(ev)
+            _ctx = torch.cuda.stream(side)
+            _ctx.__enter__()
+            st = _stream()
+        ws = workspace(dev, ws_bytes)
         h2 = x3 and _f16x2()
         sp = timing.span('conv_wgrad' if x3 else 'conv_wgrad_f32', cs.flops, cs.abytes, cs.scope)
         if h2:
             xbits, dybits = absmax_bits(xk, st), absmax_bits(dyk, st)
+            if side is not None:     # (slices of a pooled buffer of the main stream: keep the pool block until this has run)
+                xbits.record_stream(side)
+                dybits.record_stream(side)
             x_pk = _is_packed(xk)
             xw_ptr, dyw_ptr, _tmp = xk.data_ptr(), dy_ptr, None
             planar = 0
@@ -674,6 +827,8 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False,
                 dw = dw.as_strided(dw.shape, wstr)
         if need_db:
             db = dbk[:cout]
+        if side is not None:
+            _ctx.__exit__(None, None, None)
     return dx, dw, db
 
 
@@ -687,6 +842,8 @@ class _Conv2dFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation, relu, want_stats=False):
         y, cs = _conv_forward(x, weight, bias, stride, padding, dilation, relu, want_stats)
+        if any(ctx.needs_input_grad):
+            _note_param_use(weight, bias)
         ctx.cs = cs
         ctx.save_for_backward(*_stash([cs]))
         _BN_HANDOFF[0] = cs.bn_parts      # picked up by conv2d() right after apply (same thread, no autograd in between)
@@ -815,6 +972,8 @@ class _ConvForkFn(Function):
     @staticmethod
     def forward(ctx, x, w_main, w_short, b_main, b_short, cfg_main, cfg_short, slot=None, want_stats=(False, False)):
         y, cs = _conv_forward(x, w_main, b_main, *cfg_main, False, want_stats[0])
+        if any(ctx.needs_input_grad):
+            _note_param_use(w_main, b_main, w_short, b_short)
         ctx.cs_main = cs
         ctx.slot = slot
         _BN_HANDOFF[0], _BN_HANDOFF[1] = cs.bn_parts, None
@@ -1707,6 +1866,8 @@ def bn_relu_dot(z, bn, conv):
         return None      # (the kernel's register / LDS budget: csrc/bn.hip evk_bn_relu_dot_bwd)
     del z._evk_bn_parts
     weight_planes.note_running_stats_changed()
+    if torch.is_grad_enabled():
+        _note_param_use(conv.weight, conv.bias)
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
     return _BnReluDotFn.apply(z, bn.weight, bn.bias, conv.weight, conv.bias, rm, rv, (parts, bn.momentum, bn.eps))

@@ -42,6 +42,8 @@ class FusedSGD(SGD):
     def fused_clip(self, max_norm=35, norm_type=2):
         if norm_type != 2:
             raise NotImplementedError('FusedSGD: only the L2 norm is implemented')
+        from ..hip import functional as HF
+        HF.wait_wgrad_stream()
         params = [p for g in self.param_groups for p in g['params'] if p.grad is not None]
         if not params or not params[0].is_cuda:
             self.last_grad_norm = torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm, norm_type=2)
@@ -136,6 +138,8 @@ class FusedSGD(SGD):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        from ..hip import functional as HF
+        HF.wait_wgrad_stream()       # (EVK_WGRAD_STREAM experiment: weight gradients launched beside the backward)
         for gi, group in enumerate(self.param_groups):
             params = [p for p in group['params'] if p.grad is not None]
             if not params:

@@ -62,6 +62,9 @@ class FlatGradDDP(nn.Module):
         self.measure_exposed = False
         self._exposed = []
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
+        if self._cuda:
+            for p in params:      # hip/functional.py: these hooks read the gradients through _flush below, which follows
+                p._evk_flat_ddp = True   # the weight-gradient side stream — the convolutions may use it
         self._sync_initial_state()
 
     # ------------------------------------------------------------------ construction
@@ -139,6 +142,9 @@ class FlatGradDDP(nn.Module):
     def _dense_like_param(self, g, p):
         if g.shape == p.shape and g.stride() == p.stride():
             return g
+        if g.is_cuda:
+            from ..hip import functional as HF
+            HF.wait_wgrad_stream()       # (this copy runs on the main stream; the gradient may come from the side stream)
         out = torch.empty_strided(p.shape, p.stride(), dtype=g.dtype, device=g.device)
         out.copy_(g)
         return out
@@ -153,8 +159,21 @@ class FlatGradDDP(nn.Module):
                 from ..hip.ptr_table import PtrTable
                 b.ptr_table = PtrTable(len(grads), self.device)
             ptrs = b.ptr_table.upload([0 if g is None else g.data_ptr() for g in grads])
-            _C.call('evk_pack_multi', ptrs.data_ptr(), b.sizes_dev.data_ptr(), b.offsets_dev.data_ptr(), len(grads),
-                    scale, b.flat.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            from ..hip import functional as HF
+            side = HF.wgrad_side_stream_of(self.device)
+            main = torch.cuda.current_stream()
+            if side is not None:
+                # weight gradients of this bucket may still be running on the side stream (hip/functional.py): the pack
+                # follows them THERE — after everything the main stream has produced so far (BatchNorm / bias gradients,
+                # the pointer table) — instead of making the main stream wait
+                side.wait_stream(main)
+                for g in grads:
+                    if g is not None:
+                        g.record_stream(side)
+                b.flat.record_stream(side)
+            with torch.cuda.stream(side if side is not None else main):
+                _C.call('evk_pack_multi', ptrs.data_ptr(), b.sizes_dev.data_ptr(), b.offsets_dev.data_ptr(), len(grads),
+                        scale, b.flat.data_ptr(), torch.cuda.current_stream().cuda_stream)
             b._keep = grads  # alive until the pack has run
         else:
             for g, v in zip(grads, b.views):
@@ -164,7 +183,7 @@ class FlatGradDDP(nn.Module):
                     v.copy_(g).mul_(scale)
         if self.world > 1:
             if self._cuda:
-                self._comm_stream.wait_stream(torch.cuda.current_stream())
+                self._comm_stream.wait_stream(side if side is not None else torch.cuda.current_stream())
                 with torch.cuda.stream(self._comm_stream):
                     b.work = dist.all_reduce(b.flat, group=self.process_group, async_op=True)
             else:

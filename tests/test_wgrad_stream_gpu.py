@@ -1,0 +1,119 @@
+"""Weight gradients on a second stream (hip/functional.py: _WGRAD_STREAM, default on): nothing in a backward pass depends
+on dw, so the MFMA-bound weight-gradient launches run beside the HBM-bound rest of the backward.  It must be invisible:
+gradients and trained weights equal to the one-stream run, shared weights / hooks / accumulated gradients / direct
+autograd.grad calls handled, the FlatGradDDP pack ordered behind the side stream."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model(cuda):
+    import ever_amd as er
+    torch.manual_seed(13)
+    widths = (64, 128, 256, 512)
+    return er.module.FarSeg(dict(encoder=dict(resnet_type='resnet18', in_channels=4),
+                                 head=dict(fpn=dict(in_channels_list=widths, out_channels=256),
+                                           fs_relation=dict(scene_embedding_channels=512)))).to(cuda).train()
+
+
+def _train(cuda, on, steps=4):
+    import ever_amd as er
+    from ever_amd.hip import functional as HF
+    prev = HF.set_wgrad_stream(on)
+    try:
+        m = _model(cuda)
+        opt = er.opt.FusedSGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+        g = torch.Generator().manual_seed(2)
+        grads = None
+        for i in range(steps):
+            x = torch.randn(2, 4, 128, 128, generator=g).to(cuda)
+            y = (torch.rand(2, 128, 128, generator=g) < 0.3).long().to(cuda)
+            out = m(x, y)
+            sum(out.values()).backward()
+            if i == 0:
+                torch.cuda.synchronize()
+                grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+            opt.fused_clip(max_norm=35)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        return grads, {k: v.detach().clone() for k, v in m.state_dict().items()}
+    finally:
+        HF.set_wgrad_stream(prev)
+
+
+def test_training_is_the_same_with_and_without_the_side_stream(cuda):
+    """first-step gradients and the weights after four clipped SGD steps; the only arithmetic difference allowed is the
+    BatchNorm backward's summation order (the one-launch form is not used while weight gradients are pending)"""
+    g1, s1 = _train(cuda, True)
+    g0, s0 = _train(cuda, False)
+
+    def rel(a, b):
+        return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+    # (biases of convolutions in front of a BatchNorm have a true gradient of zero: rounding noise on both sides)
+    skip = lambda k: k.endswith('.0.bias') and ('content_encoders' in k or 'feature_reencoders' in k)
+    bad = [(k, rel(g1[k], g0[k])) for k in g0 if not skip(k) and rel(g1[k], g0[k]) > 2e-4]
+    assert not bad, bad[:5]
+    # (four steps amplify the last-bit differences of the two BatchNorm backward forms; the bitwise test below pins them)
+    bad = [(k, rel(s1[k], s0[k])) for k in s0 if s0[k].dtype.is_floating_point and rel(s1[k], s0[k]) > 5e-3]
+    assert not bad, bad[:5]
+
+
+def test_bitwise_equal_when_the_batchnorm_form_is_pinned(cuda):
+    """with the one-launch BatchNorm backward off in both runs (EVK_BN_FUSED=0, read once per process) nothing differs"""
+    code = (
+        "import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+        "from test_wgrad_stream_gpu import _train\n"
+        "dev = torch.device('cuda:0')\n"
+        "g1, s1 = _train(dev, True); g0, s0 = _train(dev, False)\n"
+        "bad = [k for k in g0 if not torch.equal(g1[k], g0[k])] + [k for k in s0 if not torch.equal(s1[k], s0[k])]\n"
+        "print('BITWISE', len(bad), bad[:4])\n" % (ROOT, ROOT))
+    out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, EVK_BN_FUSED='0'), capture_output=True, text=True,
+                         timeout=900)
+    assert 'BITWISE 0 ' in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+
+
+def test_shared_hooked_and_accumulated_weights_stay_correct(cuda):
+    import ever_amd as er
+    from ever_amd.hip import functional as HF
+    torch.manual_seed(5)
+    conv = er.module.layers.Conv2d(32, 32, 3, 1, 1, bias=True).to(cuda)
+    x = torch.randn(2, 32, 24, 24, device=cuda).contiguous(memory_format=torch.channels_last)
+    ref = torch.nn.Conv2d(32, 32, 3, 1, 1).to(cuda).double()
+    ref.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+
+    def check(run, tol=3e-6):
+        conv.zero_grad(set_to_none=True)
+        ref.zero_grad(set_to_none=True)
+        run(conv, x).backward()
+        run(ref, x.double()).backward()
+        torch.cuda.synchronize()
+        for a, b in ((conv.weight.grad, ref.weight.grad), (conv.bias.grad, ref.bias.grad)):
+            assert float((a.double() - b).abs().max() / b.abs().max()) < tol
+    check(lambda m, t: m(m(t)).square().sum())                     # the same weight twice in one pass
+    seen = []
+    h = conv.weight.register_hook(lambda g: seen.append(float(g.abs().max())))
+    check(lambda m, t: m(t).square().sum())                        # a tensor hook reads dw on the main stream
+    h.remove()
+    assert len(seen) == 1 and seen[0] > 0
+    # gradient accumulation over two micro-batches (.grad is not None at the second backward)
+    conv.zero_grad(set_to_none=True)
+    ref.zero_grad(set_to_none=True)
+    for part in (x[:1], x[1:]):
+        conv(part).square().sum().backward()
+        ref(part.double()).square().sum().backward()
+    torch.cuda.synchronize()
+    assert float((conv.weight.grad.double() - ref.weight.grad).abs().max() / ref.weight.grad.abs().max()) < 3e-6
+    # torch.autograd.grad (no AccumulateGrad): the result is ordered behind the side stream when the call returns
+    y = conv(x).square().sum()
+    (gw,) = torch.autograd.grad(y, conv.weight)
+    yr = ref(x.double()).square().sum()
+    (gr,) = torch.autograd.grad(yr, ref.weight)
+    assert float((gw.double() - gr).abs().max() / gr.abs().max()) < 3e-6     # (an ATen op on the main stream reads gw)
+    assert HF._WGRAD_STREAM[0]
