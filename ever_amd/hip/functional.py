@@ -179,7 +179,7 @@ _PACKED = os.environ.get('EVK_PACKED', '1') != '0'
 
 # Weight gradients on a second stream.  Nothing downstream in a backward pass depends on dw, and a weight gradient is
 # MFMA-bound where the chain it would otherwise interrupt (BatchNorm backward, one-tap data gradients, pointwise passes) is
-# HBM-bound: launched beside that chain it fills the matrix pipe while the chain fills the memory system (+14 % on the
+# HBM-bound: launched beside that chain it fills the matrix pipe while the chain fills the memory system (+4.7 % on the
 # FarSeg-R50 step).  Rules that keep it invisible:
 #  * only for LEAF weight (and bias) whose .grad is None and that nobody else hooks (AccumulateGrad then only stores the
 #    tensor; an in-place accumulation or a foreign hook would read dw on the main stream) — FlatGradDDP opts its parameters
@@ -187,8 +187,10 @@ _PACKED = os.environ.get('EVK_PACKED', '1') != '0'
 #    stream wait before a SECOND gradient of the same pass is added to it, whatever produced either of them;
 #  * only for parameters used ONCE in the forward of this pass (_note_param_use): the engine sums the gradients of a
 #    multiply used leaf in its own input buffer, on the main stream, before any hook runs;
-#  * operands are kept from reuse until the launch has run (record_stream), the weight gradient's own temporaries belong
-#    to the side stream;
+#  * operands and results (allocated on the main stream) are kept alive in _WGRAD_HOLD until the join — cheaper on the
+#    host than record_stream (an event per block when it is freed: 5 ms per step) at the price of saved activations and
+#    output gradients living to the end of the backward pass (bounded by EVK_WGRAD_HOLD_GB: a join in mid-pass beyond it);
+#    the weight gradient's own temporaries belong to the side stream;
 #  * the main stream waits for the side stream at the END of the backward pass (autograd final callback), so everything
 #    after backward() — optimiser, clipping, .grad readers — is ordered as before;
 #  * the one-launch BatchNorm backward (a grid that must be resident as a whole) is not used while weight gradients are
@@ -197,7 +199,21 @@ _PACKED = os.environ.get('EVK_PACKED', '1') != '0'
 #    end-of-backward callback, so a replay has the same overlap (and the same BatchNorm form) as the eager step.
 _WGRAD_STREAM = [os.environ.get('EVK_WGRAD_STREAM', '1') != '0']
 _WGRAD_SIDE = {}
-_WGRAD_PASS = {'pending': False, 'queued': False, 'id': 0}
+_WGRAD_PASS = {'pending': False, 'queued': False}
+_WGRAD_HOLD = []                 # tensors of the main stream's pool that a pending weight gradient reads or writes
+_WGRAD_HOLD_BYTES = [0]
+_WGRAD_HOLD_CAP = int(float(os.environ.get('EVK_WGRAD_HOLD_GB', '64')) * 2 ** 30)
+_WGRAD_MAIN = {}                 # device -> the stream the pending weight gradients forked from (joins go there)
+_cuda_get_stream = getattr(torch._C, '_cuda_getCurrentStream', None)
+_cuda_set_stream = getattr(torch._C, '_cuda_setStream', None)
+
+
+def _wgrad_hold(*tensors):
+    for t in tensors:
+        if t is not None:
+            _WGRAD_HOLD.append(t)
+            _WGRAD_HOLD_BYTES[0] += t.numel() * t.element_size()
+wgrad_stream_stats = {'side': 0, 'main': 0}     # weight gradients launched on the side stream / kept on the main stream
 
 
 def set_wgrad_stream(on):
@@ -245,10 +261,11 @@ def _arrival_hook(t):
     on the main stream — whoever produced the earlier one (a shared weight, a second use through another op of this
     package, a regulariser built from torch ops), the main stream first waits for the side stream."""
     def hook(grad):
-        if t.__dict__.get('_evk_pass') == _WGRAD_PASS['id']:
+        gid = torch._C._current_graph_task_id()       # (one id per backward() call, whoever started it)
+        if t.__dict__.get('_evk_pass') == gid:
             wait_wgrad_stream()
         else:
-            t._evk_pass = _WGRAD_PASS['id']
+            t._evk_pass = gid
         return None
     return hook
 
@@ -270,10 +287,20 @@ def _wgrad_side_stream(dev, weight, bias=None):
         # reducer (torch DDP hooks the gradient ACCUMULATORS, invisible on the tensor, and copies gradients into its buckets
         # on the main stream as they arrive): this one runs on the main stream, behind whatever is pending
         wait_wgrad_stream()
+        wgrad_stream_stats['main'] += 1
         return None
+    wgrad_stream_stats['side'] += 1
+    if _WGRAD_HOLD_BYTES[0] > _WGRAD_HOLD_CAP:
+        wait_wgrad_stream()
     s = _WGRAD_SIDE.get(dev)
     if s is None:
-        s = _WGRAD_SIDE[dev] = torch.cuda.Stream(dev)
+        s = _pick_side_stream(dev)
+        if s is not None:
+            _WGRAD_SIDE[dev] = s
+    if not s:                   # no stream of this process overlaps with the backward's stream: stay on it
+        wgrad_stream_stats['side'] -= 1
+        wgrad_stream_stats['main'] += 1
+        return None
     for t in leaves:
         if getattr(t, '_evk_wgrad_hook', None) is None:
             t._evk_wgrad_hook = t.register_hook(_arrival_hook(t))
@@ -281,9 +308,37 @@ def _wgrad_side_stream(dev, weight, bias=None):
     return s
 
 
+_SIDE_CANDIDATES = []
+
+
+def _pick_side_stream(dev):
+    """A stream whose kernels really run beside those of the current stream.  HIP multiplexes streams onto a few hardware
+    queues, and which stream objects share one depends on how many streams the process made before (RCCL, a communication
+    stream, torch's pools): with FlatGradDDP in the process the first stream made here sat on the backward's own queue —
+    every weight gradient serialised behind it, the step SLOWER than without a side stream.  So candidates are measured
+    (evk_streams_overlap: two 150 us spin kernels, forked and joined by events, take 150 us or 300) and the first that
+    overlaps is kept; the rejected ones stay allocated so that the next candidate lands on another queue.  False when none
+    of eight overlaps; None under a stream capture, where nothing can be measured (the caller asks again later)."""
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    main = _stream()
+    took = ctypes.c_float(0.0)
+    for _ in range(8):
+        cand = torch.cuda.Stream(dev)
+        rc = _C.load().evk_streams_overlap(main, cand.cuda_stream, 150, ctypes.byref(took))
+        if rc < 0:
+            _C.check(rc, 'evk_streams_overlap')
+        if rc == 1:
+            return cand
+        _SIDE_CANDIDATES.append(cand)
+    import warnings
+    warnings.warn('ever_amd: no HIP stream of this process runs beside the backward stream (all share its hardware queue); '
+                  'weight gradients stay on the backward stream')
+    return False
+
+
 def _wgrad_pass_done():
     _WGRAD_PASS['queued'] = False
-    _WGRAD_PASS['id'] += 1
     for p in _USED_PARAMS:
         p._evk_uses = 0
     del _USED_PARAMS[:]
@@ -291,16 +346,25 @@ def _wgrad_pass_done():
 
 
 def wait_wgrad_stream():
-    """the current stream waits for every weight gradient launched on the side stream"""
+    """the current stream — and the stream the weight gradients forked from, whose pool the held tensors go back to —
+    waits for every weight gradient launched on the side stream"""
     if _WGRAD_PASS['pending']:
-        for s in _WGRAD_SIDE.values():
-            torch.cuda.current_stream(s.device).wait_stream(s)
+        for dev, s in _WGRAD_SIDE.items():
+            if s is False:
+                continue
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_stream(s)
+            main = _WGRAD_MAIN.get(dev)
+            if main is not None and main != cur:
+                main.wait_stream(s)
         _WGRAD_PASS['pending'] = False
+        del _WGRAD_HOLD[:]
+        _WGRAD_HOLD_BYTES[0] = 0
 
 
 def wgrad_side_stream_of(dev):
     """FlatGradDDP: the stream its bucket pack has to follow (None when no weight gradient is pending there)"""
-    return _WGRAD_SIDE.get(dev) if _WGRAD_PASS['pending'] else None
+    return (_WGRAD_SIDE.get(dev) or None) if _WGRAD_PASS['pending'] else None
 
 
 def _dist_initialized():
@@ -764,71 +828,72 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False,
         dbk = torch.empty((cout_p,), device=dev, dtype=torch.float32) if need_db else None
         side = _wgrad_side_stream(dev, cs.weight, cs.bias_leaf if need_db else None)
         if side is not None:
-            # the weight gradient beside the rest of the backward (see _WGRAD_STREAM above)
-            ev = torch.cuda.Event()
-            ev.record()
-            for t in (xk, dyk, dwk, dbk):
-                if t is not None:
-                    t.record_stream(side)
-            side.wait_event(ev)
-            _ctx = torch.cuda.stream(side)
-            _ctx.__enter__()
-            st = _stream()
-        ws = workspace(dev, ws_bytes)
-        h2 = x3 and _f16x2()
-        sp = timing.span('conv_wgrad' if x3 else 'conv_wgrad_f32', cs.flops, cs.abytes, cs.scope)
-        if h2:
-            xbits, dybits = absmax_bits(xk, st), absmax_bits(dyk, st)
-            if side is not None:     # (slices of a pooled buffer of the main stream: keep the pool block until this has run)
-                xbits.record_stream(side)
-                dybits.record_stream(side)
-            x_pk = _is_packed(xk)
-            xw_ptr, dyw_ptr, _tmp = xk.data_ptr(), dy_ptr, None
-            planar = 0
-            if cout_p == cout and cin_p == cin and not x_pk and not dy_pk and _wgrad_planar_pays(dk, need_db):
-                xq, dq = torch.empty_like(xk), torch.empty_like(dyk)
-                _C.call('evk_pack_planar_f16x2', xk.data_ptr(), xk.numel(), xbits.data_ptr(), xq.data_ptr(), st)
-                _C.call('evk_pack_planar_f16x2', dy_ptr, dyk.numel(), dybits.data_ptr(), dq.data_ptr(), st)
-                xw_ptr, dyw_ptr, _tmp, planar = xq.data_ptr(), dq.data_ptr(), [xq, dq], 8 | 16
-            elif _PACKED and not need_db and cout_p == cout and _wgrad_pack_pays(cs.flops, 0 if x_pk else xk.numel(),
-                                                                             0 if dy_pk else dyk.numel()):
-                # the kernel's bound is the split of its operands while staging (each element is staged by many
-                # workgroups): where the matrix work per byte is high, one streaming pass that stores them split first
-                _tmp = []
-                if not x_pk:
-                    xp = torch.empty_like(xk)
-                    _C.call('evk_pack_f16x2', xk.data_ptr(), xk.numel(), xbits.data_ptr(), xp.data_ptr(), st)
-                    xw_ptr, x_pk = xp.data_ptr(), True
-                    _tmp.append(xp)
-                if not dy_pk:
-                    dp = torch.empty_like(dyk)
-                    _C.call('evk_pack_f16x2', dy_ptr, dyk.numel(), dybits.data_ptr(), dp.data_ptr(), st)
-                    dyw_ptr, dy_pk = dp.data_ptr(), True
-                    _tmp.append(dp)
-            _C.call('evk_conv2d_wgrad_f16x2_ex', ctypes.byref(dk), xw_ptr, xbits.data_ptr(), dyw_ptr, dybits.data_ptr(),
-                    dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes,
-                    planar if planar else ((2 if x_pk else 0) | (4 if dy_pk else 0)), st)
-        else:
-            _C.call(_entry('evk_conv2d_wgrad_x3') if x3 else 'evk_conv2d_wgrad', ctypes.byref(dk), xk.data_ptr(), dy_ptr,
-                    dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes, st)
-        if sp is not None:
-            sp.stop()
-        if need_dw:
-            if cin_p != cin:
-                dw2 = torch.empty((cout_p * taps, cin), device=dev, dtype=torch.float32)
-                _C.call('evk_unpad_channels', dwk.data_ptr(), dw2.data_ptr(), cout_p * taps, cin_p, cin, st)
-                dwk = dw2.reshape(cout_p, taps, cin)
-            # logical OIHW view over OHWI memory (matches a channels_last parameter)
-            dw = dwk[:cout].reshape(cout, kh, kw, cin).permute(0, 3, 1, 2)
-            wstr = cs.w_stride
-            if kh * kw == 1 and dw.stride() != wstr and wstr[0] == cin and wstr[1] == 1:
-                # 1x1 kernels: the size-1 dims make the stride tuple ambiguous; present exactly the
-                # parameter's strides so AccumulateGrad / DDP bucket views alias instead of copying
-                dw = dw.as_strided(dw.shape, wstr)
-        if need_db:
-            db = dbk[:cout]
-        if side is not None:
-            _ctx.__exit__(None, None, None)
+            # the weight gradient beside the rest of the backward (see _WGRAD_STREAM above): fork by a pooled event, switch
+            # torch's current stream by the raw setter (the Python context manager costs 20 us per layer)
+            main_id = _cuda_get_stream(dev.index)
+            main = _WGRAD_MAIN.get(dev)
+            if main is None or main.stream_id != main_id[0]:
+                main = _WGRAD_MAIN[dev] = torch.cuda.current_stream(dev)
+            _C.call('evk_stream_fork', st, side.cuda_stream)
+            _wgrad_hold(xk, dyk, dwk, dbk)
+            _cuda_set_stream(stream_id=side.stream_id, device_index=side.device_index, device_type=side.device_type)
+            st = side.cuda_stream
+        try:
+            ws = workspace(dev, ws_bytes)
+            h2 = x3 and _f16x2()
+            sp = timing.span('conv_wgrad' if x3 else 'conv_wgrad_f32', cs.flops, cs.abytes, cs.scope)
+            if h2:
+                xbits, dybits = absmax_bits(xk, st), absmax_bits(dyk, st)
+                if side is not None:     # (slices of a pooled buffer of the main stream: keep the pool block until this has run)
+                    _wgrad_hold(xbits, dybits)
+                x_pk = _is_packed(xk)
+                xw_ptr, dyw_ptr, _tmp = xk.data_ptr(), dy_ptr, None
+                planar = 0
+                if cout_p == cout and cin_p == cin and not x_pk and not dy_pk and _wgrad_planar_pays(dk, need_db):
+                    xq, dq = torch.empty_like(xk), torch.empty_like(dyk)
+                    _C.call('evk_pack_planar_f16x2', xk.data_ptr(), xk.numel(), xbits.data_ptr(), xq.data_ptr(), st)
+                    _C.call('evk_pack_planar_f16x2', dy_ptr, dyk.numel(), dybits.data_ptr(), dq.data_ptr(), st)
+                    xw_ptr, dyw_ptr, _tmp, planar = xq.data_ptr(), dq.data_ptr(), [xq, dq], 8 | 16
+                elif _PACKED and not need_db and cout_p == cout and _wgrad_pack_pays(cs.flops, 0 if x_pk else xk.numel(),
+                                                                                 0 if dy_pk else dyk.numel()):
+                    # the kernel's bound is the split of its operands while staging (each element is staged by many
+                    # workgroups): where the matrix work per byte is high, one streaming pass that stores them split first
+                    _tmp = []
+                    if not x_pk:
+                        xp = torch.empty_like(xk)
+                        _C.call('evk_pack_f16x2', xk.data_ptr(), xk.numel(), xbits.data_ptr(), xp.data_ptr(), st)
+                        xw_ptr, x_pk = xp.data_ptr(), True
+                        _tmp.append(xp)
+                    if not dy_pk:
+                        dp = torch.empty_like(dyk)
+                        _C.call('evk_pack_f16x2', dy_ptr, dyk.numel(), dybits.data_ptr(), dp.data_ptr(), st)
+                        dyw_ptr, dy_pk = dp.data_ptr(), True
+                        _tmp.append(dp)
+                _C.call('evk_conv2d_wgrad_f16x2_ex', ctypes.byref(dk), xw_ptr, xbits.data_ptr(), dyw_ptr, dybits.data_ptr(),
+                        dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes,
+                        planar if planar else ((2 if x_pk else 0) | (4 if dy_pk else 0)), st)
+            else:
+                _C.call(_entry('evk_conv2d_wgrad_x3') if x3 else 'evk_conv2d_wgrad', ctypes.byref(dk), xk.data_ptr(), dy_ptr,
+                        dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes, st)
+            if sp is not None:
+                sp.stop()
+            if need_dw:
+                if cin_p != cin:
+                    dw2 = torch.empty((cout_p * taps, cin), device=dev, dtype=torch.float32)
+                    _C.call('evk_unpad_channels', dwk.data_ptr(), dw2.data_ptr(), cout_p * taps, cin_p, cin, st)
+                    dwk = dw2.reshape(cout_p, taps, cin)
+                # logical OIHW view over OHWI memory (matches a channels_last parameter)
+                dw = dwk[:cout].reshape(cout, kh, kw, cin).permute(0, 3, 1, 2)
+                wstr = cs.w_stride
+                if kh * kw == 1 and dw.stride() != wstr and wstr[0] == cin and wstr[1] == 1:
+                    # 1x1 kernels: the size-1 dims make the stride tuple ambiguous; present exactly the
+                    # parameter's strides so AccumulateGrad / DDP bucket views alias instead of copying
+                    dw = dw.as_strided(dw.shape, wstr)
+            if need_db:
+                db = dbk[:cout]
+        finally:
+            if side is not None:
+                _cuda_set_stream(stream_id=main_id[0], device_index=main_id[1], device_type=main_id[2])
     return dx, dw, db
 
 

@@ -10,6 +10,8 @@ is what the fused optimizer reads.
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): ring collectives are per-link bound, so buckets are large
 (64 MB default => 3 all-reduces of the 129 MB of FarSeg-R50 gradients) rather than DDP's 25 MB default.
 On CPU (gloo, tests) the pack is a torch copy; the product path is the HIP kernel."""
+import contextlib
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -142,36 +144,33 @@ class FlatGradDDP(nn.Module):
     def _dense_like_param(self, g, p):
         if g.shape == p.shape and g.stride() == p.stride():
             return g
-        if g.is_cuda:
-            from ..hip import functional as HF
-            HF.wait_wgrad_stream()       # (this copy runs on the main stream; the gradient may come from the side stream)
         out = torch.empty_strided(p.shape, p.stride(), dtype=g.dtype, device=g.device)
-        out.copy_(g)
+        out.copy_(g)       # (on the stream _flush has made current: the side stream while weight gradients are pending)
         return out
 
     def _flush(self, b):
         scale = 1.0 / self.world
-        grads = [None if p.grad is None else self._dense_like_param(p.grad, p) for p in b.params]
+        side = None
+        if self._cuda:
+            from ..hip import functional as HF
+            side = HF.wgrad_side_stream_of(self.device)
+            main = torch.cuda.current_stream()
+            if side is not None:
+                # weight gradients of this bucket may still be running on the side stream (hip/functional.py): the layout
+                # copies and the pack follow them THERE — after everything the main stream has produced so far (BatchNorm
+                # / bias gradients, the pointer table) — instead of making the main stream wait.  The gradients stay
+                # alive in b._keep until _finalize, which runs after the join.
+                side.wait_stream(main)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            grads = [None if p.grad is None else self._dense_like_param(p.grad, p) for p in b.params]
         if self._cuda:
             # addresses go up from a persistent pinned table, and only when one changed (the caching allocator hands
             # the same blocks back step after step): no pageable H2D copy per bucket on the backward's critical path
             if b.ptr_table is None:
                 from ..hip.ptr_table import PtrTable
                 b.ptr_table = PtrTable(len(grads), self.device)
-            ptrs = b.ptr_table.upload([0 if g is None else g.data_ptr() for g in grads])
-            from ..hip import functional as HF
-            side = HF.wgrad_side_stream_of(self.device)
-            main = torch.cuda.current_stream()
-            if side is not None:
-                # weight gradients of this bucket may still be running on the side stream (hip/functional.py): the pack
-                # follows them THERE — after everything the main stream has produced so far (BatchNorm / bias gradients,
-                # the pointer table) — instead of making the main stream wait
-                side.wait_stream(main)
-                for g in grads:
-                    if g is not None:
-                        g.record_stream(side)
-                b.flat.record_stream(side)
-            with torch.cuda.stream(side if side is not None else main):
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                ptrs = b.ptr_table.upload([0 if g is None else g.data_ptr() for g in grads])
                 _C.call('evk_pack_multi', ptrs.data_ptr(), b.sizes_dev.data_ptr(), b.offsets_dev.data_ptr(), len(grads),
                         scale, b.flat.data_ptr(), torch.cuda.current_stream().cuda_stream)
             b._keep = grads  # alive until the pack has run
@@ -193,6 +192,9 @@ class FlatGradDDP(nn.Module):
         b.flushed = True
 
     def _finalize(self):
+        if self._cuda:
+            from ..hip import functional as HF
+            HF.wait_wgrad_stream()   # (a no-op after the end-of-backward join; b._keep below must not go before it)
         # parameters that received no gradient this step: their buckets are completed with zeros
         while self._next < len(self.buckets):
             self._flush(self.buckets[self._next])

@@ -364,6 +364,19 @@ int evk_bn_bwd_bits(const float* dy, const float* x, const float* y, const float
  * No reference counterpart (torch's batch_norm backward has no stream affinity). */
 int evk_bn_fused_stream_claim(void* stream);
 
+/* `to` waits for everything enqueued on `from` so far (an event of a per-device ring recorded on `from`, waited for on
+ * `to`): the fork of the weight-gradient side stream from the backward's stream, once per convolution layer
+ * (ever_amd/hip/functional.py).  Not thread-safe per device (the backward of one device runs on one thread).
+ * No reference counterpart (the reference runs its backward on one stream). */
+int evk_stream_fork(void* from, void* to);
+
+/* 1 when kernels of streams `a` and `b` run at the same time, 0 when the runtime serialises them (HIP multiplexes streams
+ * onto a few hardware queues; two streams on one queue never overlap), -1 on error.  Measured: a single-workgroup kernel
+ * spinning `us` microseconds on each stream, forked and joined by events; *elapsed_us (optional) receives what the pair
+ * took.  Synchronises stream `a`; not to be called under a stream capture.  Used once per device to choose the
+ * weight-gradient side stream (ever_amd/hip/functional.py).  No reference counterpart. */
+int evk_streams_overlap(void* a, void* b, int32_t us, float* elapsed_us);
+
 /* ------------------------------------------------------------------ pointwise / resampling - */
 /* nn.ReLU (fs_relation.py:25) and its backward; elementwise add (fpn.py:105). */
 int evk_relu_fwd(const float* x, float* y, int64_t n, void* stream);

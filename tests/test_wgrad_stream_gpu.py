@@ -117,3 +117,33 @@ def test_shared_hooked_and_accumulated_weights_stay_correct(cuda):
     (gr,) = torch.autograd.grad(yr, ref.weight)
     assert float((gw.double() - gr).abs().max() / gr.abs().max()) < 3e-6     # (an ATen op on the main stream reads gw)
     assert HF._WGRAD_STREAM[0]
+
+
+@pytest.mark.gpu
+def test_streams_overlap_probe_and_side_stream_choice():
+    """evk_streams_overlap: a stream against itself is serial by construction (2 x the spin time); the stream the product
+    picks for the weight gradients overlaps with the current stream (HIP multiplexes streams onto a few hardware queues:
+    a side stream on the backward's own queue would serialise every weight gradient behind it)."""
+    import ctypes
+    from ever_amd import _C
+    from ever_amd.hip import functional as HF
+    dev = torch.device('cuda:0')
+    lib = _C.load()
+    main = torch.cuda.current_stream(dev).cuda_stream
+    took = ctypes.c_float(0.0)
+    assert lib.evk_streams_overlap(main, main, 200, ctypes.byref(took)) == 0
+    assert 380.0 < took.value < 700.0, took.value
+    side = HF._pick_side_stream(dev)
+    assert side, 'no stream of this process overlaps with the default stream'
+    assert lib.evk_streams_overlap(main, side.cuda_stream, 200, ctypes.byref(took)) == 1
+    assert 190.0 < took.value < 320.0, took.value
+    # fork: `side` waits for what was enqueued on main (a spin) before its own work
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    assert lib.evk_streams_overlap(main, main, 100, None) == 0          # ~200 us of spinning on main
+    _C.call('evk_stream_fork', main, side.cuda_stream)
+    with torch.cuda.stream(side):
+        e.record()
+    e.synchronize()
+    assert s.elapsed_time(e) * 1e3 > 150.0
