@@ -21,8 +21,8 @@ Rank 0 prints ONE JSON line: the contract fields plus
                  the stack BASELINE.json's 0.6 target is stated on);
   roofline_hbm_* — achieved algorithmic GB/s of the BatchNorm and resample/loss families vs 8 TB/s;
                  (weight gradients run on a second stream, DESIGN 2.8: the sampled steps of the timed region alternate —
-                 steps 0, 8, 16 single-stream = each kernel alone = the achieved / frac fields; steps 4, 12 as every
-                 other step = the *_overlapped fields)
+                 two single-stream = each kernel alone = the achieved / frac fields; two as every other step =
+                 the *_overlapped fields)
   cpu_baseline — the CPU oracle (stock PyTorch port of the reference path) timed on this box's host
                  cores on a bounded sample of the same workload (N=1 only).
 """
@@ -48,7 +48,7 @@ TILE, BANDS, BATCH = 512, 3, 16
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=20)
+    p.add_argument('--steps', type=int, default=40)
     p.add_argument('--warmup', type=int, default=5)
     p.add_argument('--batch', type=int, default=BATCH, help='tiles per GPU (default: the BASELINE config)')
     p.add_argument('--no-cpu-baseline', action='store_true')
@@ -308,28 +308,31 @@ def main():
         unblocked.append(time.perf_counter() - t_h)
         fence()
     host_unblocked_ms = sorted(unblocked)[1] * 1e3
-    # HIP-event timing of the conv launches costs ~2 % of the step (two event records per launch), so
-    # it samples every 4th step of the timed region rather than all of them.
+    # HIP-event timing of the launches costs 2-3 ms per step (an event pair around each of ~250 C-ABI calls), so it
+    # samples four steps of the timed region rather than all of them.
     if use_ddp and hasattr(ddp, 'measure_exposed'):
         ddp.measure_exposed = True
     timer = None if args.no_kernel_timer else timing.KernelTimer()
     # With the weight gradients on their own stream a launch bracketed by events shares the chip with the other
     # stream's kernels and its duration says how the two split it, not how good the kernel is.  So the sampled steps of the
-    # timed region alternate: steps 0, 8, 16 run single-stream (the figures the roofline objects quote: each kernel alone),
-    # steps 4, 12 as every other step runs (the *_overlapped fields).  `value` includes all of them.
+    # timed region alternate: two run single-stream (the figures the roofline objects quote: each kernel alone), two as every
+    # other step runs (the *_overlapped fields).  `value` includes all of them: an event pair around every launch costs
+    # 2-3 ms of pipeline bubbles per sampled step, a single-stream step another 1.4 ms, so four sampled steps whatever K is.
     two_streams = timer is not None and HF.wgrad_stream_enabled() and not args.graph
     timer_ov = timing.KernelTimer() if two_streams else None
+    q = max(1, args.steps // 4)
+    alone_at = {0, 2 * q} if args.steps >= 4 else {0}
+    ov_at = {q, 3 * q} if (two_streams and args.steps >= 4) else set()
     sampled = sampled_ov = 0
     t0 = time.perf_counter()
     marks = []
     for i in range(args.steps):
         marks.append(time.perf_counter())
-        if timer is not None and i % 4 == 0:
-            if two_streams and i % 8 == 4:
-                with timer_ov:
-                    step()
-                sampled_ov += 1
-                continue
+        if timer is not None and i in ov_at:
+            with timer_ov:
+                step()
+            sampled_ov += 1
+        elif timer is not None and i in alone_at:
             if two_streams:
                 HF.set_wgrad_stream(False)
             with timer:
