@@ -9,7 +9,7 @@ import sqlite3
 import sys
 
 
-def main(db_path, out, steps=28):
+def main(db_path, out, steps=28, mode='two'):
     steps = int(steps)   # bench.py --steps 20 --warmup 5 runs 28 steps since round 3 (+ 3 empty-queue host probes)
     db = sqlite3.connect(db_path)
     rows = db.execute('select name, count(*), sum(duration), avg(duration), min(duration), max(duration) '
@@ -35,7 +35,15 @@ def main(db_path, out, steps=28):
             tot = sum(r[2] for r in sel)
             fam_rows.append((label, calls, tot, tot / calls))
     with open(out + '.md', 'w') as f:
-        f.write('# rocprofv3 --kernel-trace --stats summary\n\nsource: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 '
+        f.write('# rocprofv3 --kernel-trace --stats summary\n\n' + (
+                '**Single-stream run (`EVK_WGRAD_STREAM=0`): every kernel alone on the chip — the durations behind the `achieved` / '
+                '`frac` / `avg_launch_us` fields of the bench line\'s roofline objects (its two single-stream sampled steps).**\n\n'
+                if mode == 'single' else
+                '**Default run: weight gradients on a second stream (DESIGN 2.8).  Durations of kernels that ran beside a kernel of '
+                'the other stream are longer than alone, and the families below add up to MORE than the step — compare with the '
+                '`*_overlapped` fields of the bench line; the kernels alone are in `*_kernel_stats_single_stream.md`.**\n\n') +
+                'source: `' + ('EVK_WGRAD_STREAM=0 ' if mode == 'single' else '') +
+                'rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 '
                 f'--no-cpu-baseline --no-graph-line` (tools/profile_round.sh; rocpd db summarised by tools/rocpd_summary.py; {steps} steps: 5 warm-up + 3 '
                 f'empty-queue host probes + 20 timed); {sum(r[1] for r in rows)} '
                 f'dispatches, {total / 1e6:.1f} ms of kernel time over a {(span[1] - span[0]) / 1e6:.1f} ms window\n\n')
@@ -53,4 +61,4 @@ def main(db_path, out, steps=28):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 28)
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 28, sys.argv[4] if len(sys.argv) > 4 else 'two')
