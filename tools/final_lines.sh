@@ -10,6 +10,7 @@ python bench.py --conv-math bf16x3 --no-cpu-baseline --no-graph-line 2>/dev/null
 python bench.py --conv-math bf16 --no-cpu-baseline --no-graph-line 2>/dev/null | last > $O/bench_conv_math_bf16.json
 EVK_BENCH_FORCE_DDP=1 python bench.py --ddp flat --no-cpu-baseline --no-graph-line 2>/dev/null | last > $O/bench_ddp_flat_world1.json
 python bench.py --no-cpu-baseline --no-graph-line 2>/dev/null | last > $O/bench_host_full.json
+EVK_WGRAD_STREAM=0 python bench.py --no-cpu-baseline --no-graph-line 2>/dev/null | last > $O/bench_single_stream.json
 taskset -c 0-1 python bench.py --no-cpu-baseline --no-graph-line 2>/dev/null | last > $O/bench_host_2cores.json
 taskset -c 0 python bench.py --no-cpu-baseline --no-graph-line 2>/dev/null | last > $O/bench_host_1core.json
 python bench.py --no-cpu-baseline --no-graph-line 2>/dev/null | last > $O/g_eager.json

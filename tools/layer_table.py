@@ -4,7 +4,9 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ever_amd as er
 from ever_amd.hip import timing
+from ever_amd.hip import functional as _HF0
 import bench
+_HF0.set_wgrad_stream(False)     # every launch alone on the chip (durations under overlap say how two streams share it)
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
 cfg = sys.argv[1] if len(sys.argv) > 1 else 'c2'      # BASELINE.json configs[1..4] as bench.py --config builds them
