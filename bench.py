@@ -317,12 +317,14 @@ def main():
     # stream's kernels and its duration says how the two split it, not how good the kernel is.  So the sampled steps of the
     # timed region alternate: two run single-stream (the figures the roofline objects quote: each kernel alone), two as every
     # other step runs (the *_overlapped fields).  `value` includes all of them: an event pair around every launch costs
-    # 2-3 ms of pipeline bubbles per sampled step, a single-stream step another 1.4 ms, so four sampled steps whatever K is.
+    # 2-3 ms of pipeline bubbles per sampled step, a single-stream step another 1.4 ms, so four sampled steps from K = 40 on, two below.
     two_streams = timer is not None and HF.wgrad_stream_enabled() and not args.graph
     timer_ov = timing.KernelTimer() if two_streams else None
     q = max(1, args.steps // 4)
-    alone_at = {0, 2 * q} if args.steps >= 4 else {0}
-    ov_at = {q, 3 * q} if (two_streams and args.steps >= 4) else set()
+    if args.steps >= 40:
+        alone_at, ov_at = {0, 2 * q}, ({q, 3 * q} if two_streams else set())
+    else:       # a short run: one step of each kind (a sampled step costs 2-4 ms)
+        alone_at, ov_at = {0}, ({2 * q} if (two_streams and args.steps >= 2) else set())
     sampled = sampled_ov = 0
     t0 = time.perf_counter()
     marks = []

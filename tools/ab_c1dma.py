@@ -54,16 +54,16 @@ SHAPES = [(128, 64, 256), (128, 256, 64), (128, 256, 256), (128, 256, 128), (64,
 def main():
     ablate = len(sys.argv) > 1 and sys.argv[1] == 'ablate'
     if ablate:
-        for (h, ci, co) in [(128, 256, 256), (128, 64, 256), (64, 128, 512)]:
-            for packed in (0, 1):
+        for (h, ci, co) in [(128, 256, 256), (64, 128, 512), (32, 1024, 256), (32, 256, 1024), (16, 2048, 512), (16, 512, 2048)]:
+            for packed, force in ((0, 'd128'), (1, 'd128'), (1, 'e128'), (1, 'e64')):
                 fn, out, keep = problem(h, ci, co, packed, 0)
-                os.environ['EVK_X3_FORCE'] = 'd256'
+                os.environ['EVK_X3_FORCE'] = force
                 row = []
                 for dbg in (0, 1, 2, 3, 4, 8, 12, 7, 11):
                     os.environ['EVK_C1_DMA_DBG'] = str(dbg)
                     row.append(f'dbg{dbg}={timeit(fn):.0f}')
                 os.environ['EVK_C1_DMA_DBG'] = '0'
-                print(f'{ci:4d}->{co:4d} @{h:3d}^2 packed={packed}: ' + ' '.join(row), flush=True)
+                print(f'{ci:4d}->{co:4d} @{h:3d}^2 packed={packed} {force}: ' + ' '.join(row), flush=True)
         return
     tot = {}
     for (h, ci, co) in SHAPES:
