@@ -199,7 +199,7 @@ _PACKED = os.environ.get('EVK_PACKED', '1') != '0'
 #    end-of-backward callback, so a replay has the same overlap (and the same BatchNorm form) as the eager step.
 _WGRAD_STREAM = [os.environ.get('EVK_WGRAD_STREAM', '1') != '0']
 _WGRAD_SIDE = {}
-_WGRAD_PASS = {'pending': False, 'queued': False}
+_WGRAD_PASS = {'pending': False, 'gid': None}     # gid: the backward pass (graph task) whose end-of-pass join is queued
 _WGRAD_HOLD = []                 # tensors of the main stream's pool that a pending weight gradient reads or writes
 _WGRAD_HOLD_BYTES = [0]
 _WGRAD_HOLD_CAP = int(float(os.environ.get('EVK_WGRAD_HOLD_GB', '64')) * 2 ** 30)
@@ -276,12 +276,18 @@ def _wgrad_side_stream(dev, weight, bias=None):
         return None
     leaves = (weight,) if bias is None else (weight, bias)
     flat_ddp = all(getattr(t, '_evk_flat_ddp', False) for t in leaves)
-    if not _WGRAD_PASS['queued']:
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(_wgrad_pass_done)
-            _WGRAD_PASS['queued'] = True
-        except RuntimeError:         # not inside a backward pass (a direct call): stay on the main stream
-            return None
+    gid = torch._C._current_graph_task_id()
+    if gid < 0:                      # not inside a backward pass (a direct call): stay on the main stream
+        return None
+    if _WGRAD_PASS['gid'] != gid:
+        # first weight gradient of this backward pass
+        if _WGRAD_PASS['gid'] is not None:
+            # the previous pass died with an exception before its callback ran: join what it left pending.  (Its forward's
+            # use counts are still there, so this pass's weights read "used twice" and stay on the main stream; the callback
+            # below clears them.)
+            wait_wgrad_stream()
+        torch.autograd.Variable._execution_engine.queue_callback(_wgrad_pass_done)
+        _WGRAD_PASS['gid'] = gid
     if not all(_leaf_ok(t) for t in leaves) or (_dist_initialized() and not flat_ddp):
         # a second use of a shared weight in this pass, an accumulation onto an existing .grad, somebody's hook — or another
         # reducer (torch DDP hooks the gradient ACCUMULATORS, invisible on the tensor, and copies gradients into its buckets
@@ -338,7 +344,7 @@ def _pick_side_stream(dev):
 
 
 def _wgrad_pass_done():
-    _WGRAD_PASS['queued'] = False
+    _WGRAD_PASS['gid'] = None
     for p in _USED_PARAMS:
         p._evk_uses = 0
     del _USED_PARAMS[:]

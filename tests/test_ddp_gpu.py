@@ -157,7 +157,8 @@ def test_flat_grad_ddp_world1_matches_plain_training(cuda, side_stream):
             # 1e-7 apart; the strict child-process run below pins the form and compares bit for bit)
             return float((a.double() - b.double()).abs().max()) <= 1e-3 * float(b.double().abs().max()) + 2e-6
         for (k, p), (_, q) in zip(ref.named_parameters(), wrapped.named_parameters()):
-            assert same(p, q), k
+            assert same(p, q), (k, side_stream, float((p.double() - q.double()).abs().max()), float(q.double().abs().max()),
+                                dict(HF.wgrad_stream_stats))
         sa, sb = ref.state_dict(), wrapped.state_dict()
         for k in sa:
             assert same(sa[k], sb[k]), k       # running statistics live in the flat buffer tensor now

@@ -147,3 +147,42 @@ def test_streams_overlap_probe_and_side_stream_choice():
         e.record()
     e.synchronize()
     assert s.elapsed_time(e) * 1e3 > 150.0
+
+
+@pytest.mark.gpu
+def test_a_backward_pass_that_raises_does_not_lose_the_join(cuda):
+    """An exception inside a backward pass skips the engine's final callbacks; the next pass must still join the side
+    stream (and the one after runs on it again)."""
+    import ever_amd as er
+    from ever_amd.hip import functional as HF
+    torch.manual_seed(5)
+    conv = er.module.layers.Conv2d(64, 64, 3, padding=1).to(cuda)
+    ref = torch.nn.Conv2d(64, 64, 3, padding=1).to(cuda).double()
+    ref.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    x = torch.randn(8, 64, 64, 64, device=cuda)
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError('boom')
+
+    before = dict(HF.wgrad_stream_stats)
+    y = conv(Boom.apply(x.clone().requires_grad_()))      # the convolution's backward runs (weight gradient on the side
+    with pytest.raises(RuntimeError, match='boom'):       # stream), then the pass dies in the node below it
+        y.square().sum().backward()
+    assert HF.wgrad_stream_stats['side'] == before['side'] + 1
+    for step in range(2):
+        conv.zero_grad(set_to_none=True)
+        ref.zero_grad(set_to_none=True)
+        before = dict(HF.wgrad_stream_stats)
+        conv(x).square().sum().backward()
+        ref(x.double()).square().sum().backward()
+        torch.cuda.synchronize()
+        err = float((conv.weight.grad.double() - ref.weight.grad).abs().max() / ref.weight.grad.abs().max())
+        assert err < 3e-6, (step, err)
+        if step == 1:                             # the counts of the dead pass were cleared by the first good one
+            assert HF.wgrad_stream_stats['side'] == before['side'] + 1
