@@ -186,3 +186,35 @@ def test_a_backward_pass_that_raises_does_not_lose_the_join(cuda):
         assert err < 3e-6, (step, err)
         if step == 1:                             # the counts of the dead pass were cleared by the first good one
             assert HF.wgrad_stream_stats['side'] == before['side'] + 1
+
+
+def test_join_in_mid_pass_beyond_the_hold_cap_and_no_overlapping_stream(cuda):
+    """Two fall-backs of the side stream: (a) operands held for pending weight gradients exceed EVK_WGRAD_HOLD_GB — the
+    backward joins the side stream in mid-pass and goes on; (b) no stream of the process overlaps with the backward's
+    (_pick_side_stream said False) — every weight gradient stays on the backward's stream.  Same first-step gradients as
+    the one-stream run either way."""
+    from ever_amd.hip import functional as HF
+    g0, _ = _train(cuda, False, steps=1)
+
+    def rel(a, b):
+        return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+    skip = lambda k: k.endswith('.0.bias') and ('content_encoders' in k or 'feature_reencoders' in k)
+    cap = HF._WGRAD_HOLD_CAP
+    HF._WGRAD_HOLD_CAP = 1 << 20            # 1 MB: exceeded after the first layer or two
+    try:
+        g1, _ = _train(cuda, True, steps=1)
+    finally:
+        HF._WGRAD_HOLD_CAP = cap
+    bad = [(k, rel(g1[k], g0[k])) for k in g0 if not skip(k) and rel(g1[k], g0[k]) > 2e-4]
+    assert not bad, bad[:5]
+    saved = dict(HF._WGRAD_SIDE)
+    before = dict(HF.wgrad_stream_stats)
+    HF._WGRAD_SIDE[cuda] = False
+    try:
+        g2, _ = _train(cuda, True, steps=1)
+    finally:
+        HF._WGRAD_SIDE.clear()
+        HF._WGRAD_SIDE.update(saved)
+    assert HF.wgrad_stream_stats['side'] == before['side'] and HF.wgrad_stream_stats['main'] > before['main']
+    bad = [(k, rel(g2[k], g0[k])) for k in g0 if not skip(k) and rel(g2[k], g0[k]) > 2e-4]
+    assert not bad, bad[:5]
