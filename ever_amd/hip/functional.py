@@ -181,12 +181,14 @@ _PACKED = os.environ.get('EVK_PACKED', '1') != '0'
 # MFMA-bound where the chain it would otherwise interrupt (BatchNorm backward, one-tap data gradients, pointwise passes) is
 # HBM-bound: launched beside that chain it fills the matrix pipe while the chain fills the memory system (+4.7 % on the
 # FarSeg-R50 step).  Rules that keep it invisible:
-#  * only for LEAF weight (and bias) whose .grad is None and that nobody else hooks (AccumulateGrad then only stores the
-#    tensor; an in-place accumulation or a foreign hook would read dw on the main stream) — FlatGradDDP opts its parameters
-#    in and packs the bucket on this stream (trainer/grad_reducer.py); an arrival hook on each such parameter makes the main
-#    stream wait before a SECOND gradient of the same pass is added to it, whatever produced either of them;
+#  * only for LEAF weight (and bias) whose .grad is None, that nobody hooks, and whose memory order is the one the gradient
+#    comes in (AccumulateGrad then only STORES the tensor; an in-place accumulation, a hook, or the deep copy it makes of a
+#    gradient that breaks the layout contract would read dw on the main stream) — FlatGradDDP opts its parameters in and
+#    packs the bucket on this stream (trainer/grad_reducer.py);
 #  * only for parameters used ONCE in the forward of this pass (_note_param_use): the engine sums the gradients of a
-#    multiply used leaf in its own input buffer, on the main stream, before any hook runs;
+#    multiply used leaf in its own input buffer, on the main stream, before any hook runs.  A second consumer OUTSIDE this
+#    package (an L2 term built from the weights in the loss) is invisible to that count; the end-of-pass check
+#    (_wgrad_pass_done) sees that .grad is not the tensor the weight gradient was written to and raises;
 #  * operands and results (allocated on the main stream) are kept alive in _WGRAD_HOLD until the join — cheaper on the
 #    host than record_stream (an event per block when it is freed: 5 ms per step) at the price of saved activations and
 #    output gradients living to the end of the backward pass (bounded by EVK_WGRAD_HOLD_GB: a join in mid-pass beyond it);
@@ -201,6 +203,7 @@ _WGRAD_STREAM = [os.environ.get('EVK_WGRAD_STREAM', '1') != '0']
 _WGRAD_SIDE = {}
 _WGRAD_PASS = {'pending': False, 'gid': None}     # gid: the backward pass (graph task) whose end-of-pass join is queued
 _WGRAD_HOLD = []                 # tensors of the main stream's pool that a pending weight gradient reads or writes
+_WGRAD_OWNED = []                # (leaf, storage address of the gradient the side stream wrote) of this pass
 _WGRAD_HOLD_BYTES = [0]
 _WGRAD_HOLD_CAP = int(float(os.environ.get('EVK_WGRAD_HOLD_GB', '64')) * 2 ** 30)
 _WGRAD_MAIN = {}                 # device -> the stream the pending weight gradients forked from (joins go there)
@@ -247,27 +250,11 @@ def wgrad_stream_enabled():
 
 def _leaf_ok(t):
     """a leaf whose gradient arrives for the first time in this accumulation and that nobody but this module hooks"""
-    if not t.is_leaf or t.grad is not None or t.__dict__.get('_evk_uses', 0) != 1:
-        return False
-    own = 1 if getattr(t, '_evk_wgrad_hook', None) is not None else 0
-    if len(t._backward_hooks or ()) > own:
+    if not t.is_leaf or t.grad is not None or t.__dict__.get('_evk_uses', 0) != 1 or torch.is_grad_enabled():
+        return False         # (grad mode inside a backward pass = create_graph: AccumulateGrad copies instead of storing)
+    if t._backward_hooks:
         return False
     return not getattr(t, '_post_accumulate_grad_hooks', None) or getattr(t, '_evk_flat_ddp', False)
-
-
-def _arrival_hook(t):
-    """Tensor hook on a parameter whose gradient may come from the side stream: the engine calls it for EVERY gradient that
-    arrives for t, before it is accumulated.  The first arrival of a pass is only stored; from the second on the engine adds
-    on the main stream — whoever produced the earlier one (a shared weight, a second use through another op of this
-    package, a regulariser built from torch ops), the main stream first waits for the side stream."""
-    def hook(grad):
-        gid = torch._C._current_graph_task_id()       # (one id per backward() call, whoever started it)
-        if t.__dict__.get('_evk_pass') == gid:
-            wait_wgrad_stream()
-        else:
-            t._evk_pass = gid
-        return None
-    return hook
 
 
 def _wgrad_side_stream(dev, weight, bias=None):
@@ -286,6 +273,7 @@ def _wgrad_side_stream(dev, weight, bias=None):
             # use counts are still there, so this pass's weights read "used twice" and stay on the main stream; the callback
             # below clears them.)
             wait_wgrad_stream()
+        del _WGRAD_OWNED[:]          # (records of a pass that died: nothing stored its gradients)
         torch.autograd.Variable._execution_engine.queue_callback(_wgrad_pass_done)
         _WGRAD_PASS['gid'] = gid
     if not all(_leaf_ok(t) for t in leaves) or (_dist_initialized() and not flat_ddp):
@@ -307,9 +295,6 @@ def _wgrad_side_stream(dev, weight, bias=None):
         wgrad_stream_stats['side'] -= 1
         wgrad_stream_stats['main'] += 1
         return None
-    for t in leaves:
-        if getattr(t, '_evk_wgrad_hook', None) is None:
-            t._evk_wgrad_hook = t.register_hook(_arrival_hook(t))
     _WGRAD_PASS['pending'] = True
     return s
 
@@ -349,6 +334,23 @@ def _wgrad_pass_done():
         p._evk_uses = 0
     del _USED_PARAMS[:]
     wait_wgrad_stream()
+    # AccumulateGrad must have STORED each side-stream gradient as it was.  If .grad lives elsewhere the engine summed it with
+    # a gradient from a consumer this package did not see (or copied it) — on the main stream, possibly before the weight
+    # gradient had run: loud instead of wrong.  (FlatGradDDP has replaced .grad by its bucket views by now; a parameter
+    # without .grad was differentiated by torch.autograd.grad, whose result nothing here can check.)
+    owned, bad = list(_WGRAD_OWNED), None
+    del _WGRAD_OWNED[:]
+    for leaf, addr in owned:
+        g = leaf.grad
+        if g is not None and not getattr(leaf, '_evk_flat_ddp', False) and g.untyped_storage().data_ptr() != addr:
+            bad = leaf
+            break
+    if bad is not None:
+        raise RuntimeError(
+            'ever_amd: a convolution parameter of shape %s received a second gradient in this backward pass from outside the '
+            'HIP convolutions (e.g. a regulariser built from the weights) while its weight gradient ran on the side stream; '
+            'the sum may have read it too early.  Set EVK_WGRAD_STREAM=0 (or functional.set_wgrad_stream(False)) for this '
+            'model.' % (tuple(bad.shape),))
 
 
 def wait_wgrad_stream():
@@ -832,7 +834,11 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False,
             ctypes.byref(dk))
         dwk = torch.empty((cout_p, taps, cin_p), device=dev, dtype=torch.float32)
         dbk = torch.empty((cout_p,), device=dev, dtype=torch.float32) if need_db else None
-        side = _wgrad_side_stream(dev, cs.weight, cs.bias_leaf if need_db else None)
+        # (the gradient comes in OHWI memory order: a parameter laid out otherwise gets a deep copy from AccumulateGrad —
+        # a read of dw on the backward's stream — so its weight gradient stays there)
+        wstr = cs.w_stride
+        contract = tuple(wstr) == (taps * cin, 1, kw * cin, cin) or (taps == 1 and wstr[0] == cin and wstr[1] == 1)
+        side = _wgrad_side_stream(dev, cs.weight, cs.bias_leaf if need_db else None) if contract else None
         if side is not None:
             # the weight gradient beside the rest of the backward (see _WGRAD_STREAM above): fork by a pooled event, switch
             # torch's current stream by the raw setter (the Python context manager costs 20 us per layer)
@@ -897,6 +903,11 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False,
                     dw = dw.as_strided(dw.shape, wstr)
             if need_db:
                 db = dbk[:cout]
+            if side is not None:     # what AccumulateGrad has to store as it is (checked at the end of the pass)
+                if need_dw:
+                    _WGRAD_OWNED.append((cs.weight, dw.untyped_storage().data_ptr()))
+                if need_db:
+                    _WGRAD_OWNED.append((cs.bias_leaf, db.untyped_storage().data_ptr()))
         finally:
             if side is not None:
                 _cuda_set_stream(stream_id=main_id[0], device_index=main_id[1], device_type=main_id[2])

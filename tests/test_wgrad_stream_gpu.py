@@ -218,3 +218,43 @@ def test_join_in_mid_pass_beyond_the_hold_cap_and_no_overlapping_stream(cuda):
     assert HF.wgrad_stream_stats['side'] == before['side'] and HF.wgrad_stream_stats['main'] > before['main']
     bad = [(k, rel(g2[k], g0[k])) for k in g0 if not skip(k) and rel(g2[k], g0[k]) > 2e-4]
     assert not bad, bad[:5]
+
+
+def test_foreign_consumer_of_a_weight_is_loud_and_other_layouts_stay_on_the_main_stream(cuda):
+    """(a) A regulariser built from a convolution weight with torch ops is a second consumer this package cannot count: the
+    engine sums its gradient with the side stream's on the main stream.  The end-of-pass check sees that .grad is not the
+    tensor the weight gradient was written to and raises (with the side stream off the same loss is fine).
+    (b) A weight that is not in OHWI memory order would get a deep copy from AccumulateGrad: its gradient is computed on
+    the main stream, and is right."""
+    import ever_amd as er
+    from ever_amd.hip import functional as HF
+    torch.manual_seed(7)
+    conv = er.module.layers.Conv2d(32, 32, 3, padding=1).to(cuda)
+    x = torch.randn(4, 32, 32, 32, device=cuda)
+    assert HF.wgrad_stream_enabled()
+    with pytest.raises(RuntimeError, match='EVK_WGRAD_STREAM=0'):
+        (conv(x).square().sum() + 1e-3 * conv.weight.pow(2).sum()).backward()
+    torch.cuda.synchronize()
+    conv.zero_grad(set_to_none=True)
+    prev = HF.set_wgrad_stream(False)
+    try:
+        (conv(x).square().sum() + 1e-3 * conv.weight.pow(2).sum()).backward()
+    finally:
+        HF.set_wgrad_stream(prev)
+    ref = torch.nn.Conv2d(32, 32, 3, padding=1).to(cuda).double()
+    ref.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    (ref(x.double()).square().sum() + 1e-3 * ref.weight.pow(2).sum()).backward()
+    torch.cuda.synchronize()
+    assert float((conv.weight.grad.double() - ref.weight.grad).abs().max() / ref.weight.grad.abs().max()) < 3e-6
+    # (b) the same layer with its weight re-laid out as plain NCHW-contiguous memory
+    conv.zero_grad(set_to_none=True)
+    ref.zero_grad(set_to_none=True)
+    with torch.no_grad():
+        conv.weight.data = conv.weight.data.contiguous(memory_format=torch.contiguous_format)
+    assert not conv.weight.is_contiguous(memory_format=torch.channels_last)
+    before = dict(HF.wgrad_stream_stats)
+    conv(x).square().sum().backward()
+    ref(x.double()).square().sum().backward()
+    torch.cuda.synchronize()
+    assert HF.wgrad_stream_stats['side'] == before['side']
+    assert float((conv.weight.grad.double() - ref.weight.grad).abs().max() / ref.weight.grad.abs().max()) < 3e-6
