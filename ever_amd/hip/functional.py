@@ -203,7 +203,7 @@ _WGRAD_STREAM = [os.environ.get('EVK_WGRAD_STREAM', '1') != '0']
 _WGRAD_SIDE = {}
 _WGRAD_PASS = {'pending': False, 'gid': None}     # gid: the backward pass (graph task) whose end-of-pass join is queued
 _WGRAD_HOLD = []                 # tensors of the main stream's pool that a pending weight gradient reads or writes
-_WGRAD_OWNED = []                # (leaf, storage address of the gradient the side stream wrote) of this pass
+_WGRAD_OWNED = {}                # id(leaf) -> (leaf, storage address of the gradient the side stream wrote), this pass
 _WGRAD_HOLD_BYTES = [0]
 _WGRAD_HOLD_CAP = int(float(os.environ.get('EVK_WGRAD_HOLD_GB', '64')) * 2 ** 30)
 _WGRAD_MAIN = {}                 # device -> the stream the pending weight gradients forked from (joins go there)
@@ -273,7 +273,7 @@ def _wgrad_side_stream(dev, weight, bias=None):
             # use counts are still there, so this pass's weights read "used twice" and stay on the main stream; the callback
             # below clears them.)
             wait_wgrad_stream()
-        del _WGRAD_OWNED[:]          # (records of a pass that died: nothing stored its gradients)
+        _WGRAD_OWNED.clear()         # (records of a pass that died: nothing stored its gradients)
         torch.autograd.Variable._execution_engine.queue_callback(_wgrad_pass_done)
         _WGRAD_PASS['gid'] = gid
     if not all(_leaf_ok(t) for t in leaves) or (_dist_initialized() and not flat_ddp):
@@ -328,6 +328,20 @@ def _pick_side_stream(dev):
     return False
 
 
+def check_side_stream_gradient(leaf):
+    """FlatGradDDP, before it replaces .grad by its bucket view: the gradient AccumulateGrad stored for `leaf` must be the
+    tensor the side stream wrote (see _wgrad_pass_done, which cannot look any more once the view is in place)"""
+    rec = _WGRAD_OWNED.get(id(leaf))
+    g = leaf.grad
+    if rec is None or g is None:
+        return
+    if rec[0] is leaf and rec[1] != g.untyped_storage().data_ptr():
+        raise RuntimeError(
+            'ever_amd: a convolution parameter of shape %s received a second gradient in this backward pass from outside '
+            'the HIP convolutions while its weight gradient ran on the side stream; set EVK_WGRAD_STREAM=0 for this model'
+            % (tuple(leaf.shape),))
+
+
 def _wgrad_pass_done():
     _WGRAD_PASS['gid'] = None
     for p in _USED_PARAMS:
@@ -338,8 +352,8 @@ def _wgrad_pass_done():
     # a gradient from a consumer this package did not see (or copied it) — on the main stream, possibly before the weight
     # gradient had run: loud instead of wrong.  (FlatGradDDP has replaced .grad by its bucket views by now; a parameter
     # without .grad was differentiated by torch.autograd.grad, whose result nothing here can check.)
-    owned, bad = list(_WGRAD_OWNED), None
-    del _WGRAD_OWNED[:]
+    owned, bad = list(_WGRAD_OWNED.values()), None
+    _WGRAD_OWNED.clear()
     for leaf, addr in owned:
         g = leaf.grad
         if g is not None and not getattr(leaf, '_evk_flat_ddp', False) and g.untyped_storage().data_ptr() != addr:
@@ -905,9 +919,9 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False,
                 db = dbk[:cout]
             if side is not None:     # what AccumulateGrad has to store as it is (checked at the end of the pass)
                 if need_dw:
-                    _WGRAD_OWNED.append((cs.weight, dw.untyped_storage().data_ptr()))
+                    _WGRAD_OWNED[id(cs.weight)] = (cs.weight, dw.untyped_storage().data_ptr())
                 if need_db:
-                    _WGRAD_OWNED.append((cs.bias_leaf, db.untyped_storage().data_ptr()))
+                    _WGRAD_OWNED[id(cs.bias_leaf)] = (cs.bias_leaf, db.untyped_storage().data_ptr())
         finally:
             if side is not None:
                 _cuda_set_stream(stream_id=main_id[0], device_index=main_id[1], device_type=main_id[2])

@@ -161,6 +161,9 @@ class FlatGradDDP(nn.Module):
                 # / bias gradients, the pointer table) — instead of making the main stream wait.  The gradients stay
                 # alive in b._keep until _finalize, which runs after the join.
                 side.wait_stream(main)
+        if side is not None:
+            for p in b.params:
+                HF.check_side_stream_gradient(p)
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             grads = [None if p.grad is None else self._dense_like_param(p.grad, p) for p in b.params]
         if self._cuda:
