@@ -21,7 +21,7 @@ Rank 0 prints ONE JSON line: the contract fields plus
                  the stack BASELINE.json's 0.6 target is stated on);
   roofline_hbm_* — achieved algorithmic GB/s of the BatchNorm and resample/loss families vs 8 TB/s;
                  (weight gradients run on a second stream, DESIGN 2.8: the sampled steps of the timed region alternate —
-                 two single-stream = each kernel alone = the achieved / frac fields; two as every other step =
+                 step 0 single-stream = each kernel alone = the achieved / frac fields; step K/2 as every other step =
                  the *_overlapped fields)
   cpu_baseline — the CPU oracle (stock PyTorch port of the reference path) timed on this box's host
                  cores on a bounded sample of the same workload (N=1 only).
@@ -309,22 +309,20 @@ def main():
         fence()
     host_unblocked_ms = sorted(unblocked)[1] * 1e3
     # HIP-event timing of the launches costs 2-3 ms per step (an event pair around each of ~250 C-ABI calls), so it
-    # samples four steps of the timed region rather than all of them.
+    # samples two steps of the timed region rather than all of them.
     if use_ddp and hasattr(ddp, 'measure_exposed'):
         ddp.measure_exposed = True
     timer = None if args.no_kernel_timer else timing.KernelTimer()
     # With the weight gradients on their own stream a launch bracketed by events shares the chip with the other
     # stream's kernels and its duration says how the two split it, not how good the kernel is.  So the sampled steps of the
-    # timed region alternate: two run single-stream (the figures the roofline objects quote: each kernel alone), two as every
-    # other step runs (the *_overlapped fields).  `value` includes all of them: an event pair around every launch costs
-    # 2-3 ms of pipeline bubbles per sampled step, a single-stream step another 1.4 ms, so four sampled steps from K = 40 on, two below.
+    # timed region are two: step 0 runs single-stream (the figures the roofline objects quote: each kernel alone), step K/2 as
+    # every other step runs (the *_overlapped fields).  `value` includes all of them: an event pair around every launch costs
+    # 2-3 ms of pipeline bubbles per sampled step, a single-stream step another 1.4 ms, so two sampled steps whatever K is.
     two_streams = timer is not None and HF.wgrad_stream_enabled() and not args.graph
     timer_ov = timing.KernelTimer() if two_streams else None
-    q = max(1, args.steps // 4)
-    if args.steps >= 40:
-        alone_at, ov_at = {0, 2 * q}, ({q, 3 * q} if two_streams else set())
-    else:       # a short run: one step of each kind (a sampled step costs 2-4 ms)
-        alone_at, ov_at = {0}, ({2 * q} if (two_streams and args.steps >= 2) else set())
+    # one step of each kind: every launch of a step is in it (159 + 84 convolution calls, ~110 BatchNorm calls), and a
+    # sampled step costs 2-4 ms
+    alone_at, ov_at = {0}, ({args.steps // 2} if (two_streams and args.steps >= 2) else set())
     sampled = sampled_ov = 0
     t0 = time.perf_counter()
     marks = []
