@@ -32,7 +32,9 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')   # (ever_amd/__init__.py; here before torch can touch the HIP runtime)
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
