@@ -49,7 +49,12 @@ TILE, BANDS, BATCH = 512, 3, 16
 
 def parse():
     p = argparse.ArgumentParser()
-    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--gpus', type=int, default=1,
+                   help='ranks = GPUs of this node.  Under torchrun (WORLD_SIZE set) it must equal the world size; without it '
+                        'and N > 1 this script starts the N ranks itself (torch.distributed.run, rendezvous on 127.0.0.1)')
+    p.add_argument('--dry-launch', action='store_true',
+                   help='launch check without a GPU: start the ranks exactly as a real run would, join a gloo group, have rank 0 '
+                        'print what every rank saw (tests/test_bench_launch_cpu.py), and exit')
     p.add_argument('--steps', type=int, default=40)
     p.add_argument('--warmup', type=int, default=5)
     p.add_argument('--batch', type=int, default=BATCH, help='tiles per GPU (default: the BASELINE config)')
@@ -227,13 +232,64 @@ def cpu_baseline(seconds_budget=20.0):
                        f'torch {torch.__version__} CPU, {cores} threads')
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no torchrun around it: become the launcher.  The reference's contract is an `env://`
+    rendezvous prepared by torchrun (`ever/trainer/th_ddp_trainer.py:13-17`, README "torchrun --nproc_per_node"); the same
+    ranks, environment and argv are produced here, so a rank cannot tell the two ways of starting apart."""
+    import subprocess
+    if args.gpus < 1:
+        raise SystemExit(f'bench.py: --gpus {args.gpus}: need at least one rank')
+    if not args.dry_launch:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f'bench.py: --gpus {args.gpus} asked for, but this node shows {have} GPU(s) '
+                             f'(torch.cuda.device_count()); refusing to report an n_gpus={args.gpus} line from fewer devices')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('OMP_NUM_THREADS', '1' if args.dry_launch else str(max(1, host_cores() // args.gpus)))
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def dry_launch(args, world, rank, local_rank):
+    """Every rank joins a gloo group over the rendezvous it was handed and reports; rank 0 prints one JSON line."""
+    import torch.distributed as dist
+    dist.init_process_group(backend='gloo', init_method='env://', rank=rank, world_size=world)
+    mine = torch.tensor([rank, local_rank, int(os.environ.get('WORLD_SIZE', -1)), os.getpid()], dtype=torch.int64)
+    seen = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(seen, mine)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({'dry_launch': True, 'n_gpus': world, 'gpus_arg': args.gpus,
+                          'ranks': [{'rank': int(t[0]), 'local_rank': int(t[1]), 'world_size_env': int(t[2]), 'pid': int(t[3])}
+                                    for t in seen]}), flush=True)
+
+
 def main():
     args = parse()
+    if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or args.dry_launch):
+        self_launch(args)    # does not return
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree '
+                         '(n_gpus in the JSON line is the number of ranks that actually ran)')
+    if args.dry_launch:
+        return dry_launch(args, world, rank, local_rank)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (the HIP path has no CPU fallback)')
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f'bench.py: rank {rank} (local rank {local_rank}) has no GPU of its own: this node shows '
+                         f'{torch.cuda.device_count()} device(s) for {world} ranks')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     use_ddp = world > 1 or os.environ.get('EVK_BENCH_FORCE_DDP') == '1'   # the env knob runs the DDP path on 1 GPU (tests)
