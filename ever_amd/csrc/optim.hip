@@ -180,7 +180,7 @@ namespace evk {
 __global__ __launch_bounds__(256) void pack_multi_kernel(const float* const* __restrict__ srcs,
                                                          const int64_t* __restrict__ sizes,
                                                          const int64_t* __restrict__ offsets, float scale,
-                                                         float* __restrict__ dst) {
+                                                         float* dst) {   // (no __restrict__: a source may BE its slot)
   const int t = blockIdx.y;
   const float* s = srcs[t];
   float* d = dst + offsets[t];

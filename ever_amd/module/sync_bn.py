@@ -51,8 +51,10 @@ class _SyncBNFn(Function):
             gathered = stats_hook(local)
         elif world > 1:
             import torch.distributed as dist
-            gathered = torch.empty((world, 2 * c + 1), device=dev, dtype=torch.float64)
-            dist.all_gather_into_tensor(gathered, local, group=group)
+            # flat output: RCCL accepts [world, n] as well, gloo (two ranks on one device in the tests) only world * n
+            flat = torch.empty((world * (2 * c + 1),), device=dev, dtype=torch.float64)
+            dist.all_gather_into_tensor(flat, local, group=group)
+            gathered = flat.view(world, 2 * c + 1)
         else:
             gathered = local[None]
         mean64, var64, total = merge_local_stats(gathered[:, :2 * c], gathered[:, 2 * c])

@@ -637,7 +637,10 @@ int evk_bn_bwd_apply_sums(const float* dy, const float* x, const float* y, const
 /* dst[offsets[t] + i] = srcs[t][i] * scale for t < ntensors (a NULL source packs zeros): one launch gathers the
  * gradients of a bucket into the flat RCCL all-reduce buffer, pre-divided by the world size — the gradient
  * exchange of the DDP trainer (reference ever/trainer/th_ddp_trainer.py: DistributedDataParallel's reducer).
- * srcs / sizes / offsets are device arrays. */
+ * srcs / sizes / offsets are device arrays.  A source may be EXACTLY its own destination slot (srcs[t] == dst +
+ * offsets[t]: gradient accumulation over several backward passes without no_sync, reference core/launcher.py:196,317-321 —
+ * the second pass accumulates into the bucket view and the pack scales it in place); partially overlapping ranges are not
+ * allowed.  tests/world2_gpu_worker.py:case_forward_times_2 holds the in-place case at world size 2. */
 int evk_pack_multi(const float* const* srcs, const int64_t* sizes, const int64_t* offsets,
                    int32_t ntensors, float scale, float* dst, void* stream);
 
