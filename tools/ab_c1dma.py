@@ -54,12 +54,12 @@ SHAPES = [(128, 64, 256), (128, 256, 64), (128, 256, 256), (128, 256, 128), (64,
 def main():
     ablate = len(sys.argv) > 1 and sys.argv[1] == 'ablate'
     if ablate:
-        for (h, ci, co) in [(128, 256, 256), (64, 128, 512), (32, 1024, 256), (32, 256, 1024), (16, 2048, 512), (16, 512, 2048)]:
-            for packed, force in ((0, 'd128'), (1, 'd128'), (1, 'e128'), (1, 'e64')):
+        for (h, ci, co) in [(128, 256, 256)]:
+            for packed, force in ((0, 'e128'), (1, 'e128'), (0, 'p128'), (1, 'p128')):
                 fn, out, keep = problem(h, ci, co, packed, 0)
                 os.environ['EVK_X3_FORCE'] = force
                 row = []
-                for dbg in (0, 1, 2, 3, 4, 8, 12, 7, 11):
+                for dbg in (0, 8, 11, 43, 43+64, 43+128, 43+192, 43+16, 43+16+192):
                     os.environ['EVK_C1_DMA_DBG'] = str(dbg)
                     row.append(f'dbg{dbg}={timeit(fn):.0f}')
                 os.environ['EVK_C1_DMA_DBG'] = '0'
@@ -75,7 +75,7 @@ def main():
                 base = timeit(fn)
                 ref = out.clone()
                 res = {}
-                for cfg in ('d256', 'd128', 'd64', 'e128', 'e64'):
+                for cfg in ('d256', 'd128', 'd64', 'e128', 'e64', 'p128'):
                     os.environ['EVK_X3_FORCE'] = cfg
                     t = timeit(fn)
                     err = float((out - ref).abs().max() / ref.abs().max())
