@@ -270,6 +270,13 @@ int launch_conv1x1_dma(IGemmArgs& a, hipStream_t stream) {
   // EVK_C1_DMA: 0 never; 1 (default) where measured faster; 2 wherever the shape allows
   static const int mode = getenv("EVK_C1_DMA") ? atoi(getenv("EVK_C1_DMA")) : 1;
   if (mode == 0 || !conv1x1_dma_applicable(a)) return 1;
+  // the persistent form with a store role (conv1x1_ps.hip) where a workgroup gets at least four tiles of at least 128
+  // outputs: measured ahead on the 128^2-map layers (64 -> 256: 107 -> 90 us, 256 -> 128: 104 -> 94, 256 -> 256: 175 -> 170),
+  // level or behind below that.  EVK_C1_PS: 0 never, 1 (default) by that rule, 2 wherever it applies (tests)
+  static const int ps_mode = getenv("EVK_C1_PS") ? atoi(getenv("EVK_C1_PS")) : 1;
+  if (ps_mode != 0 && conv1x1_ps_applicable(a) && a.Cd >= 128 &&
+      (ps_mode == 2 || ((long long)ceil_div(a.M, 128) * ceil_div(a.Cd, 128) >= 2048 && ceil_div(a.M, 128) >= 1024)))
+    return launch_conv1x1_ps(a, stream);
   if (mode == 2) return launch_conv1x1_dma_forced(a, a.Cd >= 128 ? 2128 : 2064, stream);
   // Measured on the FarSeg-R50 one-tap shapes, fp32 and packed operands, with and without the statistics epilogue
   // (tools/ab_c1dma.py, us, register-staged default -> this kernel): the two-stage ring with TWO workgroups per CU (one's
