@@ -205,10 +205,41 @@ _WGRAD_PASS = {'pending': False, 'gid': None}     # gid: the backward pass (grap
 _WGRAD_HOLD = []                 # tensors of the main stream's pool that a pending weight gradient reads or writes
 _WGRAD_OWNED = {}                # id(leaf) -> (leaf, storage address of the gradient the side stream wrote), this pass
 _WGRAD_HOLD_BYTES = [0]
-_WGRAD_HOLD_CAP = int(float(os.environ.get('EVK_WGRAD_HOLD_GB', '64')) * 2 ** 30)
+# operand bytes held for pending weight gradients beyond which the backward joins the side stream in mid-pass:
+# EVK_WGRAD_HOLD_GB, default a quarter of the device's memory (a fixed 64 GB was the whole of a smaller part)
+_WGRAD_HOLD_CAP = [int(float(os.environ['EVK_WGRAD_HOLD_GB']) * 2 ** 30) if 'EVK_WGRAD_HOLD_GB' in os.environ else None]
 _WGRAD_MAIN = {}                 # device -> the stream the pending weight gradients forked from (joins go there)
 _cuda_get_stream = getattr(torch._C, '_cuda_getCurrentStream', None)
 _cuda_set_stream = getattr(torch._C, '_cuda_setStream', None)
+
+
+_WGRAD_QUEUE = []                # (device, launch closure) of weight gradients not issued yet
+_WGRAD_BATCH = max(1, int(os.environ.get('EVK_WGRAD_BATCH', '1')))   # (8, 16, 32 measured: 524 vs 531 tiles/s for 1, same box)
+
+
+def flush_wgrad_queue():
+    """issue the queued weight gradients on the side stream, behind ONE event recorded on the backward's stream now"""
+    if not _WGRAD_QUEUE:
+        return
+    batch = list(_WGRAD_QUEUE)
+    del _WGRAD_QUEUE[:]
+    by_dev = {}
+    for dev, fn in batch:
+        by_dev.setdefault(dev, []).append(fn)
+    for dev, fns in by_dev.items():
+        side = _WGRAD_SIDE[dev]
+        main_id = _cuda_get_stream(dev.index)
+        main = _WGRAD_MAIN.get(dev)
+        if main is None or main.stream_id != main_id[0]:
+            main = _WGRAD_MAIN[dev] = torch.cuda.current_stream(dev)
+        _C.call('evk_stream_fork', main.cuda_stream, side.cuda_stream)
+        # torch's current stream by the raw setter (the Python context manager costs 20 us)
+        _cuda_set_stream(stream_id=side.stream_id, device_index=side.device_index, device_type=side.device_type)
+        try:
+            for fn in fns:
+                fn(side.cuda_stream)
+        finally:
+            _cuda_set_stream(stream_id=main_id[0], device_index=main_id[1], device_type=main_id[2])
 
 
 def _wgrad_hold(*tensors):
@@ -284,7 +315,9 @@ def _wgrad_side_stream(dev, weight, bias=None):
         wgrad_stream_stats['main'] += 1
         return None
     wgrad_stream_stats['side'] += 1
-    if _WGRAD_HOLD_BYTES[0] > _WGRAD_HOLD_CAP:
+    if _WGRAD_HOLD_CAP[0] is None:
+        _WGRAD_HOLD_CAP[0] = torch.cuda.mem_get_info(dev)[1] // 4
+    if _WGRAD_HOLD_BYTES[0] > _WGRAD_HOLD_CAP[0]:
         wait_wgrad_stream()
     s = _WGRAD_SIDE.get(dev)
     if s is None:
@@ -370,6 +403,7 @@ def _wgrad_pass_done():
 def wait_wgrad_stream():
     """the current stream — and the stream the weight gradients forked from, whose pool the held tensors go back to —
     waits for every weight gradient launched on the side stream"""
+    flush_wgrad_queue()
     if _WGRAD_PASS['pending']:
         for dev, s in _WGRAD_SIDE.items():
             if s is False:
@@ -386,6 +420,7 @@ def wait_wgrad_stream():
 
 def wgrad_side_stream_of(dev):
     """FlatGradDDP: the stream its bucket pack has to follow (None when no weight gradient is pending there)"""
+    flush_wgrad_queue()
     return (_WGRAD_SIDE.get(dev) or None) if _WGRAD_PASS['pending'] else None
 
 
@@ -853,20 +888,12 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False,
         wstr = cs.w_stride
         contract = tuple(wstr) == (taps * cin, 1, kw * cin, cin) or (taps == 1 and wstr[0] == cin and wstr[1] == 1)
         side = _wgrad_side_stream(dev, cs.weight, cs.bias_leaf if need_db else None) if contract else None
-        if side is not None:
-            # the weight gradient beside the rest of the backward (see _WGRAD_STREAM above): fork by a pooled event, switch
-            # torch's current stream by the raw setter (the Python context manager costs 20 us per layer)
-            main_id = _cuda_get_stream(dev.index)
-            main = _WGRAD_MAIN.get(dev)
-            if main is None or main.stream_id != main_id[0]:
-                main = _WGRAD_MAIN[dev] = torch.cuda.current_stream(dev)
-            _C.call('evk_stream_fork', st, side.cuda_stream)
-            _wgrad_hold(xk, dyk, dwk, dbk)
-            _cuda_set_stream(stream_id=side.stream_id, device_index=side.device_index, device_type=side.device_type)
-            st = side.cuda_stream
-        try:
+
+        def launch(st):
+            """the weight-gradient launches of this layer on stream `st` (torch's current stream when this runs)"""
             ws = workspace(dev, ws_bytes)
             h2 = x3 and _f16x2()
+            dy_pk_ = dy_pk
             sp = timing.span('conv_wgrad' if x3 else 'conv_wgrad_f32', cs.flops, cs.abytes, cs.scope)
             if h2:
                 xbits, dybits = absmax_bits(xk, st), absmax_bits(dyk, st)
@@ -875,13 +902,13 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False,
                 x_pk = _is_packed(xk)
                 xw_ptr, dyw_ptr, _tmp = xk.data_ptr(), dy_ptr, None
                 planar = 0
-                if cout_p == cout and cin_p == cin and not x_pk and not dy_pk and _wgrad_planar_pays(dk, need_db):
+                if cout_p == cout and cin_p == cin and not x_pk and not dy_pk_ and _wgrad_planar_pays(dk, need_db):
                     xq, dq = torch.empty_like(xk), torch.empty_like(dyk)
                     _C.call('evk_pack_planar_f16x2', xk.data_ptr(), xk.numel(), xbits.data_ptr(), xq.data_ptr(), st)
                     _C.call('evk_pack_planar_f16x2', dy_ptr, dyk.numel(), dybits.data_ptr(), dq.data_ptr(), st)
                     xw_ptr, dyw_ptr, _tmp, planar = xq.data_ptr(), dq.data_ptr(), [xq, dq], 8 | 16
                 elif _PACKED and not need_db and cout_p == cout and _wgrad_pack_pays(cs.flops, 0 if x_pk else xk.numel(),
-                                                                                 0 if dy_pk else dyk.numel()):
+                                                                                 0 if dy_pk_ else dyk.numel()):
                     # the kernel's bound is the split of its operands while staging (each element is staged by many
                     # workgroups): where the matrix work per byte is high, one streaming pass that stores them split first
                     _tmp = []
@@ -890,41 +917,49 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False,
                         _C.call('evk_pack_f16x2', xk.data_ptr(), xk.numel(), xbits.data_ptr(), xp.data_ptr(), st)
                         xw_ptr, x_pk = xp.data_ptr(), True
                         _tmp.append(xp)
-                    if not dy_pk:
+                    if not dy_pk_:
                         dp = torch.empty_like(dyk)
                         _C.call('evk_pack_f16x2', dy_ptr, dyk.numel(), dybits.data_ptr(), dp.data_ptr(), st)
-                        dyw_ptr, dy_pk = dp.data_ptr(), True
+                        dyw_ptr, dy_pk_ = dp.data_ptr(), True
                         _tmp.append(dp)
                 _C.call('evk_conv2d_wgrad_f16x2_ex', ctypes.byref(dk), xw_ptr, xbits.data_ptr(), dyw_ptr, dybits.data_ptr(),
                         dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes,
-                        planar if planar else ((2 if x_pk else 0) | (4 if dy_pk else 0)), st)
+                        planar if planar else ((2 if x_pk else 0) | (4 if dy_pk_ else 0)), st)
             else:
                 _C.call(_entry('evk_conv2d_wgrad_x3') if x3 else 'evk_conv2d_wgrad', ctypes.byref(dk), xk.data_ptr(), dy_ptr,
                         dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes, st)
             if sp is not None:
                 sp.stop()
-            if need_dw:
-                if cin_p != cin:
-                    dw2 = torch.empty((cout_p * taps, cin), device=dev, dtype=torch.float32)
-                    _C.call('evk_unpad_channels', dwk.data_ptr(), dw2.data_ptr(), cout_p * taps, cin_p, cin, st)
-                    dwk = dw2.reshape(cout_p, taps, cin)
-                # logical OIHW view over OHWI memory (matches a channels_last parameter)
-                dw = dwk[:cout].reshape(cout, kh, kw, cin).permute(0, 3, 1, 2)
-                wstr = cs.w_stride
-                if kh * kw == 1 and dw.stride() != wstr and wstr[0] == cin and wstr[1] == 1:
-                    # 1x1 kernels: the size-1 dims make the stride tuple ambiguous; present exactly the
-                    # parameter's strides so AccumulateGrad / DDP bucket views alias instead of copying
-                    dw = dw.as_strided(dw.shape, wstr)
+            if dw2 is not None:
+                _C.call('evk_unpad_channels', dwk.data_ptr(), dw2.data_ptr(), cout_p * taps, cin_p, cin, st)
+
+        # the tensors autograd gets are fixed now; the launches that fill them may come later (side stream, in batches)
+        dw2 = torch.empty((cout_p * taps, cin), device=dev, dtype=torch.float32) if (need_dw and cin_p != cin) else None
+        if need_dw:
+            dwv = dw2.reshape(cout_p, taps, cin) if dw2 is not None else dwk
+            # logical OIHW view over OHWI memory (matches a channels_last parameter)
+            dw = dwv[:cout].reshape(cout, kh, kw, cin).permute(0, 3, 1, 2)
+            wstr = cs.w_stride
+            if kh * kw == 1 and dw.stride() != wstr and wstr[0] == cin and wstr[1] == 1:
+                # 1x1 kernels: the size-1 dims make the stride tuple ambiguous; present exactly the
+                # parameter's strides so AccumulateGrad / DDP bucket views alias instead of copying
+                dw = dw.as_strided(dw.shape, wstr)
+        if need_db:
+            db = dbk[:cout]
+        if side is None:
+            launch(st)
+        else:
+            # the weight gradient beside the rest of the backward (see _WGRAD_STREAM above).  Its launches are QUEUED and
+            # issued in batches: one fork event, one switch of torch's current stream and back per batch instead of per
+            # layer (host time), and a captured step has a handful of edges between its two branches instead of 2 x 53
+            _wgrad_hold(xk, dyk, dwk, dbk, dw2)
+            _WGRAD_QUEUE.append((dev, launch))
+            if need_dw:              # what AccumulateGrad has to store as it is (checked at the end of the pass)
+                _WGRAD_OWNED[id(cs.weight)] = (cs.weight, dw.untyped_storage().data_ptr())
             if need_db:
-                db = dbk[:cout]
-            if side is not None:     # what AccumulateGrad has to store as it is (checked at the end of the pass)
-                if need_dw:
-                    _WGRAD_OWNED[id(cs.weight)] = (cs.weight, dw.untyped_storage().data_ptr())
-                if need_db:
-                    _WGRAD_OWNED[id(cs.bias_leaf)] = (cs.bias_leaf, db.untyped_storage().data_ptr())
-        finally:
-            if side is not None:
-                _cuda_set_stream(stream_id=main_id[0], device_index=main_id[1], device_type=main_id[2])
+                _WGRAD_OWNED[id(cs.bias_leaf)] = (cs.bias_leaf, db.untyped_storage().data_ptr())
+            if len(_WGRAD_QUEUE) >= _WGRAD_BATCH:
+                flush_wgrad_queue()
     return dx, dw, db
 
 
@@ -1938,7 +1973,10 @@ class _BnReluDotFn(Function):
         dz = torch.empty_like(z)
         dgamma = torch.empty((c,), device=dev, dtype=torch.float32) if gamma is not None else None
         dbeta = torch.empty((c,), device=dev, dtype=torch.float32) if gamma is not None else None
-        dw = torch.empty_like(w, memory_format=torch.channels_last)
+        # (OHWI memory = [k][c] for a 1x1 kernel, presented with exactly the parameter's strides: the size-1 dims make the
+        # stride tuple ambiguous, and a gradient in "another layout" costs AccumulateGrad / the bucket pack a copy)
+        dw = torch.empty_strided(w.shape, w.stride(), device=dev, dtype=torch.float32) if (
+            w.stride(0) == c and w.stride(1) == 1) else torch.empty_like(w, memory_format=torch.channels_last)
         dbias = torch.empty((k,), device=dev, dtype=torch.float32) if ctx.has_bias else None
         w2 = _weight_ohwi(w.detach()).reshape(k, c)
         # algorithmic bytes: read z twice, write dz

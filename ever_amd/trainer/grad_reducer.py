@@ -164,8 +164,13 @@ class FlatGradDDP(nn.Module):
         if side is not None:
             for p in b.params:
                 HF.check_side_stream_gradient(p)
+        # the gradients as autograd stored them: a layout copy below READS them on the side stream, and .grad is replaced by the
+        # bucket view a few lines down — without this list the source would go back to the main stream's pool (and to the next
+        # main-stream allocation) before the copy has run.  (Found by tests/world2_gpu_worker.py: the commuted decoder's
+        # classifier weight, the one gradient that arrives in another layout, was zero or half its value in 1 run of 2.)
+        stored = [p.grad for p in b.params]
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-            grads = [None if p.grad is None else self._dense_like_param(p.grad, p) for p in b.params]
+            grads = [None if g is None else self._dense_like_param(g, p) for g, p in zip(stored, b.params)]
         if self._cuda:
             # addresses go up from a persistent pinned table, and only when one changed (the caching allocator hands
             # the same blocks back step after step): no pageable H2D copy per bucket on the backward's critical path
@@ -176,7 +181,7 @@ class FlatGradDDP(nn.Module):
                 ptrs = b.ptr_table.upload([0 if g is None else g.data_ptr() for g in grads])
                 _C.call('evk_pack_multi', ptrs.data_ptr(), b.sizes_dev.data_ptr(), b.offsets_dev.data_ptr(), len(grads),
                         scale, b.flat.data_ptr(), torch.cuda.current_stream().cuda_stream)
-            b._keep = grads  # alive until the pack has run
+            b._keep = (grads, stored)  # alive until the pack has run
         else:
             for g, v in zip(grads, b.views):
                 if g is None:

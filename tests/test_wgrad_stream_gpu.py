@@ -199,12 +199,12 @@ def test_join_in_mid_pass_beyond_the_hold_cap_and_no_overlapping_stream(cuda):
     def rel(a, b):
         return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
     skip = lambda k: k.endswith('.0.bias') and ('content_encoders' in k or 'feature_reencoders' in k)
-    cap = HF._WGRAD_HOLD_CAP
-    HF._WGRAD_HOLD_CAP = 1 << 20            # 1 MB: exceeded after the first layer or two
+    cap = HF._WGRAD_HOLD_CAP[0]
+    HF._WGRAD_HOLD_CAP[0] = 1 << 20         # 1 MB: exceeded after the first layer or two
     try:
         g1, _ = _train(cuda, True, steps=1)
     finally:
-        HF._WGRAD_HOLD_CAP = cap
+        HF._WGRAD_HOLD_CAP[0] = cap
     bad = [(k, rel(g1[k], g0[k])) for k in g0 if not skip(k) and rel(g1[k], g0[k]) > 2e-4]
     assert not bad, bad[:5]
     saved = dict(HF._WGRAD_SIDE)
