@@ -101,7 +101,6 @@ SIGNATURES = {
                                                  P, c_size_t, P, P]),
     'evk_bn_relu_pool_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, P, c_size_t, P, P]),
     'evk_bn_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_i64, c_i32, c_u32, c_i32, P, c_size_t, P, P]),
-    'evk_bn_fused_stream_claim': (c_int, [P]),
     'evk_stream_fork': (c_int, [P, P]),
     'evk_streams_overlap': (c_int, [P, P, c_i32, P]),
     'evk_bn_relu_dot_fwd': (c_int, [P, P, P, P, P, c_i64, c_i32, c_i32, P]),

@@ -12,8 +12,6 @@ What had to become graph-resident:
     refreshed from `param_groups` before every replay — a captured float argument would freeze the schedule;
   * the zeroed operand-scale pools of hip/functional.py: emptied before the capture so that their fill launches are
     INSIDE the graph (the slots are raised with atomic max and must start from zero in every replay), and again after it;
-  * the one-launch BatchNorm backward (one owning stream per device, csrc/bn.hip) is handed to the recording stream for the
-    capture (evk_bn_fused_stream_claim) and back afterwards; its grid barrier resets itself, nothing host-side to replay.
 Host-side bookkeeping that a replay skips is redone after it: BatchNorm `num_batches_tracked` counters, the weight-plane
 epoch (an eager forward after a replay must re-split the updated weights).
 
@@ -62,6 +60,10 @@ class GraphedTrainStep:
         if not isinstance(optimizer, FusedSGD):
             raise TypeError('GraphedTrainStep: the captured update needs FusedSGD (learning rate from a device word); '
                             f'got {type(optimizer).__name__}')
+        if int(eager_steps) < 1:
+            # the capture bakes the step's host-side branches in: FusedSGD's first step CREATES the momentum buffers (a flag
+            # of the kernel), so at least one eager step has to come first
+            raise ValueError('GraphedTrainStep: eager_steps must be at least 1 (momentum buffers are created by the first step)')
         self.step_fn, self.optimizer = step_fn, optimizer
         self.eager_steps = int(eager_steps)
         self.calls = 0
@@ -76,6 +78,8 @@ class GraphedTrainStep:
         from .. import _C
         flat = []
         self._spec = _flatten(data, flat)
+        if not flat:
+            raise ValueError('GraphedTrainStep: the step takes no tensor input to make static')
         dev = flat[0].device
         self.optimizer.use_device_lr(dev)
         self._static = [t.clone() for t in flat]
@@ -86,16 +90,11 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         self._stream = torch.cuda.Stream(dev)
-        home = torch.cuda.current_stream(dev).cuda_stream
-        # the one-launch BatchNorm backward belongs to one stream per device: the recording stream takes it over, else the
-        # graph would hold the three-launch form (slower, and its sums fold in another order than the eager steps')
-        _C.call('evk_bn_fused_stream_claim', self._stream.cuda_stream)
         try:
             with torch.cuda.graph(self.graph, stream=self._stream):     # records the launches, executes nothing
                 out = self.step_fn(*static_data)
         finally:
             torch.cuda.synchronize()
-            _C.call('evk_bn_fused_stream_claim', home)
         HF._ZERO_POOL.clear()
         for m, n in zip(self._bns, pending):   # the host-side counters of the recording pass are not a step
             if hasattr(m, '_nbt_pending'):

@@ -6,10 +6,7 @@
 // workgroup, fp64 finalisation) so results do not depend on the launch grid.
 #include "x3_common.hpp"
 #include <stdlib.h>
-#include <mutex>
-#include <unordered_map>
 
-static uint32_t* fused_counter(hipStream_t st, bool take_over = false);   // (defined with the one-launch backward, below)
 
 namespace evk {
 
@@ -901,237 +898,17 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* __r
   if (amax) block_absmax(out, valid, amax);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Backward of SMALL maps in ONE launch (tensors up to 33.5 MB: layer 3 / 4 of the encoder, the coarse pyramid levels).
-// The three-launch form above reads dy and x twice (5 tensor-sized transfers) and its launches cost more than its
-// bytes there: 16.8 MB maps ran at 2.3 TB/s.  Here every thread keeps its slice of g = dy * mask and x in REGISTERS
-// (8 rows x 16 bytes of each) across two grid-wide barriers:
-//   phase 1  load, mask, per-channel partial sums (+ maxima for a packed dx) -> partial[workgroup]
-//   phase 2  workgroup b finalises channels [b * cpw, (b + 1) * cpw): fp64 sums in workgroup order, dgamma / dbeta,
-//            coefficients, the bound of |dx| (packed) — the same arithmetic as bn_bwd_final_kernel
-//   phase 3  dx from the registers (fp32 or packed), max|dx| slots as the apply kernel
-// 3 transfers instead of 5, one launch instead of three.  All workgroups must be resident: the grid never exceeds the
-// 256 CUs (1024 threads, <= 128 VGPRs: one workgroup fits on a CU whatever else runs there).
-constexpr int kFusedRows = 8;       // rows (16-byte elements) per thread and tensor
-constexpr int kFusedThreads = 1024;
-
-// What crosses workgroups inside the kernel (partial sums, coefficients: a few KB) is written and read with
-// agent-scope accesses (sc1: through the XCD's L2 to the fabric) and ordered by vmcnt(0) + the counter — NOT by
-// device-scope fences: a release fence writes back every dirty line of the L2 (the previous kernels' outputs) and an
-// acquire invalidates it, ~10 us each here (first form of this kernel: 48 us on an 8 MB map against 25 us for the
-// three launches).
-__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent4(float* p, const f32x4 v) {
-  st_agent(p, v.x); st_agent(p + 1, v.y); st_agent(p + 2, v.z); st_agent(p + 3, v.w);
-}
-__device__ __forceinline__ f32x4 ld_agent4(const float* p) {
-  const f32x4 v = {ld_agent(p), ld_agent(p + 1), ld_agent(p + 2), ld_agent(p + 3)};
-  return v;
-}
-// Two-level arrival: workgroup b adds to the word of group b % 8 (8 words on 8 cache lines — same-address atomics are
-// served one per ~20 ns, 256 arrivals on ONE word cost the 5 us the first form of the barrier showed), the last
-// arrival of a group adds to the top word, the last group bumps a GENERATION word that everybody polls.  The barrier
-// is self-resetting: the last arriver of a level zeroes that level's word before it passes the arrival on, so the words
-// hold no history — nothing is reserved on the host (a failed launch cannot desynchronise later ones, and a captured
-// launch replays correctly).  A workgroup reads the generation BEFORE it arrives: it cannot advance until it has.
-// The spin is bounded: a grid that is not resident as a whole (another barrier kernel of another process sharing the
-// device) traps after a few seconds instead of hanging the GPU.
-constexpr int kBarStride = 32;   // words between the counters (128 bytes)
-constexpr int kBarWords = 10 * kBarStride;
-constexpr uint32_t kBarSpinLimit = 1u << 23;
-__device__ __forceinline__ void grid_barrier(uint32_t* __restrict__ words, int nwg) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's agent-scope stores have been performed
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int g = blockIdx.x & 7;
-    const uint32_t members = (uint32_t)((nwg - g + 7) / 8), ngroups = (uint32_t)(nwg < 8 ? nwg : 8);
-    uint32_t* gen = &words[9 * kBarStride];
-    const uint32_t my_gen = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t old = __hip_atomic_fetch_add(&words[g * kBarStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old + 1u == members) {
-      (void)__hip_atomic_exchange(&words[g * kBarStride], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the reset is performed before the arrival moves up
-      const uint32_t t = __hip_atomic_fetch_add(&words[8 * kBarStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t + 1u == ngroups) {
-        (void)__hip_atomic_exchange(&words[8 * kBarStride], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    uint32_t spins = 0;
-    while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_gen) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > kBarSpinLimit) __builtin_trap();
-    }
-  }
-  __syncthreads();
-}
-
-template <bool PK>
-__global__ __launch_bounds__(kFusedThreads) void bn_bwd_fused_kernel(
-    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
-    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float* __restrict__ dx, float* __restrict__ d_residual,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ partial, float* __restrict__ coef,
-    float* __restrict__ pmax, int64_t rows, int C, int rows_per_wg, int tpc, int rl, int cpw, int relu, int train,
-    double inv_rows, uint32_t* __restrict__ amax, uint32_t* __restrict__ counter,
-    const uint32_t* __restrict__ bits) {
-  __shared__ f32x4 red[2][kFusedThreads];
-  const int nwg = gridDim.x;
-  const int tc = threadIdx.x % tpc, tr = threadIdx.x / tpc;   // tpc = C / 4: one channel chunk per thread
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
-  const int64_t r1 = min(rows, r0 + rows_per_wg);
-  const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
-  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + tc * 4);
-  const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + tc * 4);
-  f32x4 sc = one4, sh = zero4;
-  if (relu == 2) {   // the forward's pre-activation, same arithmetic as bn_bwd_partial_kernel
-    sc = (gamma ? *reinterpret_cast<const f32x4*>(gamma + tc * 4) : one4) * is;
-    sh = (beta ? *reinterpret_cast<const f32x4*>(beta + tc * 4) : zero4) - mu * sc;
-  }
-  // ---- phase 1
-  f32x4 gv[kFusedRows], xv[kFusedRows];
-  f32x4 s = zero4, q = zero4, gm = zero4, xm = zero4;
-#pragma unroll
-  for (int k = 0; k < kFusedRows; ++k) {
-    const int64_t r = r0 + tr + (int64_t)k * rl;
-    const bool ok = tr < rl && r < r1;
-    const size_t off = ok ? (size_t)r * C + tc * 4 : 0;
-    gv[k] = ok ? *reinterpret_cast<const f32x4*>(dy + off) : zero4;
-    xv[k] = ok ? *reinterpret_cast<const f32x4*>(x + off) : mu;
-    if (relu == 3) {
-      if (ok) gv[k] = relu_bits_mask(gv[k], bits, off >> 2);
-    } else if (relu) {
-      const f32x4 yy = (relu == 1) ? (ok ? *reinterpret_cast<const f32x4*>(y + off) : zero4) : xv[k] * sc + sh;
-      gv[k].x = yy.x > 0.f ? gv[k].x : 0.f; gv[k].y = yy.y > 0.f ? gv[k].y : 0.f;
-      gv[k].z = yy.z > 0.f ? gv[k].z : 0.f; gv[k].w = yy.w > 0.f ? gv[k].w : 0.f;
-    }
-    if (ok && d_residual) *reinterpret_cast<f32x4*>(d_residual + off) = gv[k];
-  }
-#pragma unroll
-  for (int k = 0; k < kFusedRows; ++k) {
-    const f32x4 xh = (xv[k] - mu) * is;
-    s += gv[k];
-    q += gv[k] * xh;
-    if constexpr (PK) {
-      gm.x = fmaxf(gm.x, fabsf(gv[k].x)); gm.y = fmaxf(gm.y, fabsf(gv[k].y));
-      gm.z = fmaxf(gm.z, fabsf(gv[k].z)); gm.w = fmaxf(gm.w, fabsf(gv[k].w));
-      xm.x = fmaxf(xm.x, fabsf(xh.x)); xm.y = fmaxf(xm.y, fabsf(xh.y));
-      xm.z = fmaxf(xm.z, fabsf(xh.z)); xm.w = fmaxf(xm.w, fabsf(xh.w));
-    }
-  }
-  red[0][threadIdx.x] = s;
-  red[1][threadIdx.x] = q;
-  __syncthreads();
-  if (tr == 0) {
-    for (int k = 1; k < rl; ++k) {
-      s += red[0][k * tpc + tc];
-      q += red[1][k * tpc + tc];
-    }
-    float* o = partial + (size_t)blockIdx.x * 2 * C;
-    st_agent4(o + tc * 4, s);
-    st_agent4(o + C + tc * 4, q);
-  }
-  if constexpr (PK) {
-    __syncthreads();
-    red[0][threadIdx.x] = gm;
-    red[1][threadIdx.x] = xm;
-    __syncthreads();
-    if (tr == 0) {
-      for (int k = 1; k < rl; ++k) {
-        const f32x4 a = red[0][k * tpc + tc], b = red[1][k * tpc + tc];
-        gm.x = fmaxf(gm.x, a.x); gm.y = fmaxf(gm.y, a.y); gm.z = fmaxf(gm.z, a.z); gm.w = fmaxf(gm.w, a.w);
-        xm.x = fmaxf(xm.x, b.x); xm.y = fmaxf(xm.y, b.y); xm.z = fmaxf(xm.z, b.z); xm.w = fmaxf(xm.w, b.w);
-      }
-      float* o = pmax + (size_t)blockIdx.x * 2 * C;
-      st_agent4(o + tc * 4, gm);
-      st_agent4(o + C + tc * 4, xm);
-    }
-  }
-  if (!PK && amax && blockIdx.x == 0 && threadIdx.x < kAmaxSlots)
-    __hip_atomic_store(&amax[threadIdx.x * kAmaxStride], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  grid_barrier(counter, nwg);
-
-  // ---- phase 2: channels [blockIdx * cpw, +cpw), one 32-lane group per channel (cpw <= 32)
-  {
-    const int j = threadIdx.x >> 5, l = threadIdx.x & 31;
-    const int c = blockIdx.x * cpw + j;
-    if (j < cpw && c < C) {
-      double ds = 0.0, dq = 0.0;
-      float g1 = 0.f, x1 = 0.f;
-      for (int b = l; b < nwg; b += 32) {
-        ds += (double)ld_agent(partial + (size_t)b * 2 * C + c);
-        dq += (double)ld_agent(partial + (size_t)b * 2 * C + C + c);
-        if constexpr (PK) {
-          g1 = fmaxf(g1, ld_agent(pmax + (size_t)b * 2 * C + c));
-          x1 = fmaxf(x1, ld_agent(pmax + (size_t)b * 2 * C + C + c));
-        }
-      }
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) {   // (fixed order: the result does not depend on timing)
-        ds += __shfl_xor(ds, o, 64);
-        dq += __shfl_xor(dq, o, 64);
-        if constexpr (PK) {
-          g1 = fmaxf(g1, __shfl_xor(g1, o, 64));
-          x1 = fmaxf(x1, __shfl_xor(x1, o, 64));
-        }
-      }
-      if (l == 0) {
-        if (dbeta) dbeta[c] = (float)ds;
-        if (dgamma) dgamma[c] = (float)dq;
-        const float k0 = (gamma ? gamma[c] : 1.f) * invstd[c];
-        const float k1 = train ? (float)(ds * inv_rows) : 0.f, k2 = train ? (float)(dq * inv_rows) : 0.f;
-        st_agent(coef + c, k0);
-        st_agent(coef + C + c, k1);
-        st_agent(coef + 2 * C + c, k2);
-        if constexpr (PK) {
-          const float bound = fabsf(k0) * (g1 + fabsf(k1) + x1 * fabsf(k2));
-          uint32_t bits = __builtin_bit_cast(uint32_t, bound);
-          if (bound != bound) bits = 0x7fc00000u;
-          if (bits) atomicMax(&amax[0], bits);
-        }
-      }
-    }
-  }
-  grid_barrier(counter, nwg);
-
-  // ---- phase 3
-  const f32x4 k0 = ld_agent4(coef + tc * 4), k1 = ld_agent4(coef + C + tc * 4), k2 = ld_agent4(coef + 2 * C + tc * 4);
-  float pk_inv = 1.f;
-  if constexpr (PK) pk_inv = op_scale(__hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)).inv;
-  uint32_t m = 0;
-#pragma unroll
-  for (int k = 0; k < kFusedRows; ++k) {
-    const int64_t r = r0 + tr + (int64_t)k * rl;
-    if (!(tr < rl && r < r1)) continue;
-    const f32x4 xh = (xv[k] - mu) * is;
-    const f32x4 out = k0 * (gv[k] - k1 - xh * k2);
-    const size_t off = (size_t)r * C + tc * 4;
-    if constexpr (PK) {
-      *reinterpret_cast<u32x4*>(dx + off) = pack_hl4(out, pk_inv);
-    } else {
-      *reinterpret_cast<f32x4*>(dx + off) = out;
-      uint32_t t = __builtin_bit_cast(uint32_t, fmaxf(fmaxf(fabsf(out.x), fabsf(out.y)), fmaxf(fabsf(out.z), fabsf(out.w))));
-      if (out.x != out.x || out.y != out.y || out.z != out.z || out.w != out.w) t = 0x7fc00000u;
-      m = max(m, t);
-    }
-  }
-  if (!PK && amax) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(&amax[(blockIdx.x & (kAmaxSlots - 1)) * kAmaxStride], m);
-  }
-}
+// (A one-launch backward for small maps — every thread's rows in registers across two grid-wide barriers, 3 tensor transfers
+// instead of 5 — lived here in rounds 2 and 3.  Its grid had to be resident as a whole, so it was off beside the weight-
+// gradient side stream, under RCCL and on any stream but one; at the end it ran on ~1 call in 30 of the default path.
+// Removed in round 4: EVK_BN_FUSED=1 vs 0 measured 547.7 / 547.4 tiles/s on the default path, 524.4 / 519.4 single-stream,
+// 521.6 / 521.2 captured, same box — and with it went the spin barrier, its device words and the stream ownership.)
 
 static unsigned oneshot_grid(size_t n4) { return (unsigned)((n4 + 255) / 256); }
 
 static void launch_parts_final(hipStream_t st, const float* parts, int nparts, int C, double rows, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                float* save_mean, float* save_invstd, float* scale_shift, uint32_t* amax, int pack) {
-  // the one-launch backward belongs to ONE stream per device (fused_counter): claimed here, by the stream of the first
-  // training-mode forward (the encoder's), not by whichever stream happens to run the first backward node
-  (void)fused_counter(st);
   if (nparts >= 512)
     hipLaunchKernelGGL((bn_parts_final_kernel<2, 128>), dim3((C + 1) / 2), dim3(256), 0, st, parts, nparts, C, rows, gamma, beta,
                        running_mean, running_var, momentum, eps, save_mean, save_invstd, scale_shift, amax, pack);
@@ -1311,67 +1088,6 @@ extern "C" int evk_bn_fwd_eval(const float* x, const float* residual, const floa
 }
 
 
-// one-launch backward for small maps (bn_bwd_fused_kernel): plan, or nwg = 0 when the map does not fit
-struct FusedPlan { int nwg, rows_per_wg, tpc, rl, cpw; };
-static FusedPlan fused_plan(int64_t rows, int C) {
-  FusedPlan p{0, 0, 0, 0, 0};
-  static const int on = getenv("EVK_BN_FUSED") ? atoi(getenv("EVK_BN_FUSED")) : 1;
-  const int c4 = C / 4;
-  if (!on || c4 > kFusedThreads || kFusedThreads % c4 != 0) return p;
-  p.tpc = c4;
-  p.rl = kFusedThreads / c4;
-  // every workgroup must be resident at the barriers and one fills a CU: never more workgroups than the device has CUs
-  static const int ncu = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    return n < 256 ? n : 256;
-  }();
-  const int64_t cap = (int64_t)kFusedRows * p.rl;              // rows one workgroup can hold
-  int64_t nwg = (rows + cap - 1) / cap;
-  if (nwg > ncu) return p;
-  // spread over the chip: as many workgroups as give each at least one full row-lane set, up to the CU count
-  int64_t want = (rows + p.rl - 1) / p.rl;
-  if (want > ncu) want = ncu;
-  if (nwg < want) nwg = want;
-  int64_t rpw = (rows + nwg - 1) / nwg;
-  rpw = ((rpw + p.rl - 1) / p.rl) * p.rl;
-  if (rpw > cap) return p;
-  p.rows_per_wg = (int)rpw;
-  p.nwg = (int)((rows + rpw - 1) / rpw);
-  p.cpw = (C + p.nwg - 1) / p.nwg;
-  if (p.cpw > 32) { p.nwg = 0; return p; }
-  return p;
-}
-// The barrier words of a device (device memory owned by the library, zeroed once; the barrier resets itself).  The
-// kernel's grid must be resident as a whole, so two such grids must never run concurrently: the one-launch form is given
-// to ONE stream per device (the first that asks); any other stream gets nullptr = the three-launch form.
-static uint32_t* fused_counter(hipStream_t st, bool take_over) {
-  struct Entry { hipStream_t stream; uint32_t* words; };
-  static std::mutex mu;
-  static std::unordered_map<int, Entry> by_dev;
-  std::lock_guard<std::mutex> lock(mu);
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  auto it = by_dev.find(dev);
-  if (it == by_dev.end()) {
-    uint32_t* w = nullptr;
-    const size_t bytes = (size_t)kBarWords * sizeof(uint32_t);
-    if (hipMalloc((void**)&w, bytes) != hipSuccess || hipMemset(w, 0, bytes) != hipSuccess) return nullptr;
-    it = by_dev.emplace(dev, Entry{st, w}).first;
-  }
-  if (take_over) it->second.stream = st;
-  return it->second.stream == st ? it->second.words : nullptr;
-}
-
-// Hand the one-launch backward of the current device to `stream` (hipGraph capture runs on a stream of its own:
-// ever_amd/core/graph.py claims it for the capture and gives it back afterwards).  The CALLER guarantees that the previous
-// owner has no such kernel in flight or queued — synchronise the device first.
-extern "C" int evk_bn_fused_stream_claim(void* stream) {
-  EVK_REQUIRE(fused_counter((hipStream_t)stream, true) != nullptr, EVK_E_LAUNCH, "bn_fused_stream_claim: no barrier words");
-  return EVK_OK;
-}
-
 extern "C" int evk_bn_bwd_bits(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
                                const float* save_mean, const float* save_invstd, float* dx, float* d_residual,
                                float* dgamma, float* dbeta, int64_t rows, int32_t C, uint32_t flags, int32_t train,
@@ -1395,24 +1111,6 @@ extern "C" int evk_bn_bwd_bits(const float* dy, const float* x, const float* y, 
   const bool pack = (flags & EVK_BN_PACK_DX) != 0;
   EVK_REQUIRE(!pack || dx_absmax, EVK_E_INVALID, "bn_bwd: EVK_BN_PACK_DX needs dx_absmax (slots zero on entry)");
   float* pmax = pack ? coef + 8 * (size_t)C : nullptr;
-  FusedPlan fp = fused_plan(rows, C);
-  if (flags & EVK_BN_NO_FUSE) fp.nwg = 0;
-  if (fp.nwg > 0) {
-    uint32_t* counter = fused_counter(st);
-    if (!counter) fp.nwg = 0;   // another stream of this device owns the one-launch form
-  }
-  if (fp.nwg > 0) {
-    uint32_t* counter = fused_counter(st);
-    if (pack)
-      hipLaunchKernelGGL(bn_bwd_fused_kernel<true>, dim3(fp.nwg), dim3(kFusedThreads), 0, st, dy, x, y, save_mean,
-                         save_invstd, gamma, beta, dx, d_residual, dgamma, dbeta, partial, coef, pmax, rows, C,
-                         fp.rows_per_wg, fp.tpc, fp.rl, fp.cpw, relu, train ? 1 : 0, 1.0 / (double)rows, dx_absmax, counter, relu_bits);
-    else
-      hipLaunchKernelGGL(bn_bwd_fused_kernel<false>, dim3(fp.nwg), dim3(kFusedThreads), 0, st, dy, x, y, save_mean,
-                         save_invstd, gamma, beta, dx, d_residual, dgamma, dbeta, partial, coef, pmax, rows, C,
-                         fp.rows_per_wg, fp.tpc, fp.rl, fp.cpw, relu, train ? 1 : 0, 1.0 / (double)rows, dx_absmax, counter, relu_bits);
-    return check_launch("bn_bwd_fused");
-  }
   if (pack)
     hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(pl.nblk), dim3(256), 0, st, dy, x, y, save_mean, save_invstd,
                        gamma, beta, d_residual, partial, rows, C, pl.rows_per_blk, pl.tpc, pl.rl, relu, pmax, relu_bits);

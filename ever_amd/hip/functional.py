@@ -195,10 +195,8 @@ _PACKED = os.environ.get('EVK_PACKED', '1') != '0'
 #    the weight gradient's own temporaries belong to the side stream;
 #  * the main stream waits for the side stream at the END of the backward pass (autograd final callback), so everything
 #    after backward() — optimiser, clipping, .grad readers — is ordered as before;
-#  * the one-launch BatchNorm backward (a grid that must be resident as a whole) is not used while weight gradients are
-#    pending (EVK_BN_NO_FUSE, as under RCCL);
 #  * under a hipGraph capture the side stream forks from the capturing stream by the same event and joins it again in the
-#    end-of-backward callback, so a replay has the same overlap (and the same BatchNorm form) as the eager step.
+#    end-of-backward callback, so a replay holds the same two branches as the eager step.
 _WGRAD_STREAM = [os.environ.get('EVK_WGRAD_STREAM', '1') != '0']
 _WGRAD_SIDE = {}
 _WGRAD_PASS = {'pending': False, 'gid': None}     # gid: the backward pass (graph task) whose end-of-pass join is queued
@@ -432,14 +430,6 @@ def _dist_initialized():
 def _collectives_world():
     import torch.distributed as dist
     return dist.get_world_size() if _dist_initialized() else 1
-
-
-def _collectives_in_flight():
-    """RCCL kernels may share the device with the backward (gradient buckets reduced while it runs): the one-launch
-    BatchNorm backward, whose grid has to be resident as a whole, is not used then (EVK_BN_NO_FUSE)."""
-    if _WGRAD_PASS['pending']:
-        return True      # a weight gradient may hold CUs while this backward runs: same rule
-    return _collectives_world() > 1
 
 
 def _mark_packed(t, bits):
@@ -1033,7 +1023,11 @@ def grouped_dense_weight(weight, groups):
     if groups == 1:
         return weight
     _require_cuda(weight, 'grouped convolution weight')
-    return _GroupDenseFn.apply(weight, int(groups))
+    dense = _GroupDenseFn.apply(weight, int(groups))
+    # a fresh tensor every call: not a weight the plane cache should register (a new slot, planes allocation and job table
+    # per step — ADVICE r3); the convolution splits it into the shared workspace instead (weight_planes.planes_for)
+    dense._evk_transient = True
+    return dense
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, bn_stats=False):
@@ -1489,7 +1483,7 @@ class _BatchNormActFn(Function):
             relu_bits_stats['masked_bn'] += 1
         _timed_call('bn', nb, 'evk_bn_bwd_bits', dy.data_ptr(), x.data_ptr(), _ptr(y), _ptr(weight), _ptr(bias),
                     save_mean.data_ptr(), save_invstd.data_ptr(), dx.data_ptr(), _ptr(dres), _ptr(dgamma), _ptr(dbeta), rows, c,
-                    (1 if ctx.relu else 0) | (2 if pack else 0) | (8 if _collectives_in_flight() else 0),
+                    (1 if ctx.relu else 0) | (2 if pack else 0),
                     1 if ctx.training else 0, ws.data_ptr(), ws_bytes, _ptr(abits), _ptr(mask_bits), st)
         if lazy:
             # the identity branch's gradient = dy where the block's output was positive: handed on unmasked with the bits

@@ -204,7 +204,7 @@ def planes_for(weight, w_dense, d, for_dgrad, stream, f16x2=False):
     the bit image of max|w|) — or None when the cache does not apply (disabled, or `w_dense` — the OHWI memory the
     kernels read — is a transient re-laid-out copy of `weight`)."""
     global _table
-    if not _ENABLED or w_dense.data_ptr() != weight.data_ptr():
+    if not _ENABLED or w_dense.data_ptr() != weight.data_ptr() or getattr(weight, '_evk_transient', False):
         return None
     kind = 'h' if f16x2 else 'b'
     with _lock:

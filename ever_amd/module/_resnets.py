@@ -46,10 +46,23 @@ def _fork(block, x):
     return h, block.downsample[1](s)
 
 
-def _lazy_ok(bn):
-    """the block's last BatchNorm is this package's own (layers.BatchNorm2d: the only one that takes lazy_res)"""
+def _lazy_ok(block, bn):
+    """May the block's last BatchNorm hand the shortcut's gradient on UNMASKED with its ReLU bits (hip/functional.py:
+    batch_norm_act, lazy_res)?  Only when both possible readers of that gradient are known to understand the bits: the
+    block input's fork node (conv1 [+ the shortcut convolution]) and, with a shortcut convolution, ITS BatchNorm — so the
+    last BatchNorm and the shortcut's must be this package's own plain BatchNorm2d (a SyncBatchNorm or another norm put
+    there by hand would read an unmasked gradient as if it were masked), and no forward hook may sit on the modules in
+    between (a hook can hang a tensor hook on the shortcut, which would see the unmasked values).  ADVICE r3."""
     from .layers import BatchNorm2d
-    return type(bn) is BatchNorm2d
+    if type(bn) is not BatchNorm2d or bn._forward_hooks:
+        return False
+    mods = [block.conv1]
+    ds = block.downsample
+    if ds is not None:
+        if len(ds) != 2 or type(ds[1]) is not BatchNorm2d:
+            return False
+        mods += [ds, ds[0], ds[1]]
+    return not any(m._forward_hooks or m._forward_pre_hooks for m in mods)
 
 
 class BasicBlock(nn.Module):
@@ -79,7 +92,7 @@ class BasicBlock(nn.Module):
         h, shortcut = _fork(self, x)
         out = self.bn1(h, relu=True, conv_only=True)       # read by conv2 alone
         # (the shortcut's gradient reaches only the fork node or the down-sampling BatchNorm: lazy_res)
-        return conv_bn(self.conv2, self.bn2, out, residual=shortcut, relu=True, lazy_res=_lazy_ok(self.bn2))
+        return conv_bn(self.conv2, self.bn2, out, residual=shortcut, relu=True, lazy_res=_lazy_ok(self, self.bn2))
 
 
 class Bottleneck(nn.Module):
@@ -109,7 +122,7 @@ class Bottleneck(nn.Module):
         h, shortcut = _fork(self, x)
         out = self.bn1(h, relu=True, conv_only=True)       # read by conv2 alone
         out = conv_bn(self.conv2, self.bn2, out, relu=True, conv_only=True)   # ... and this by conv3 alone
-        return conv_bn(self.conv3, self.bn3, out, residual=shortcut, relu=True, lazy_res=_lazy_ok(self.bn3))
+        return conv_bn(self.conv3, self.bn3, out, residual=shortcut, relu=True, lazy_res=_lazy_ok(self, self.bn3))
 
 
 class ResNet(nn.Module):

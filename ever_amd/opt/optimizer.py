@@ -27,16 +27,35 @@ class FusedSGD(SGD):
     def use_device_lr(self, device):
         """From now on the update kernel reads each group's learning rate from a device word, so that a launch captured
         into a hipGraph follows the schedule on replay; `sync_device_lr()` refreshes the words from `param_groups`."""
-        self._lr_host = torch.empty((len(self.param_groups),), dtype=torch.float32).pin_memory()
-        self._lr_dev = torch.empty((len(self.param_groups),), dtype=torch.float32, device=device)
+        # a RING of pinned rows: the host runs ahead of the GPU when nothing synchronises per step (a replayed graph costs
+        # it ~0.3 ms), and a single pinned word rewritten for step k + 1 could be read by step k's copy (ADVICE r3).  Each row
+        # carries the event of the copy that last read it; a row is rewritten only after that copy has run.
+        n = len(self.param_groups)
+        self._lr_ring = [torch.empty((n,), dtype=torch.float32).pin_memory() for _ in range(4)]
+        self._lr_events = [None] * len(self._lr_ring)
+        self._lr_slot = 0
+        self._lr_last = None
+        self._lr_dev = torch.empty((n,), dtype=torch.float32, device=device)
         self.sync_device_lr()
 
     def sync_device_lr(self):
         if self._lr_dev is None:
             return
-        for i, g in enumerate(self.param_groups):
-            self._lr_host[i] = float(g['lr'])
-        self._lr_dev.copy_(self._lr_host, non_blocking=True)
+        lrs = [float(g['lr']) for g in self.param_groups]
+        if lrs == self._lr_last:
+            return               # the device words already hold these values
+        k = self._lr_slot
+        self._lr_slot = (k + 1) % len(self._lr_ring)
+        if self._lr_events[k] is not None:
+            self._lr_events[k].synchronize()
+        row = self._lr_ring[k]
+        for i, v in enumerate(lrs):
+            row[i] = v
+        self._lr_dev.copy_(row, non_blocking=True)
+        ev = self._lr_events[k] or torch.cuda.Event()
+        ev.record()
+        self._lr_events[k] = ev
+        self._lr_last = lrs
 
     # ERModule.clip_grad calls this instead of torch's clip_grad_norm_ (reference module.py:96-108)
     def fused_clip(self, max_norm=35, norm_type=2):

@@ -284,10 +284,9 @@ int evk_nhwc_to_nchw(const float* src, float* dst, int32_t N, int32_t C, int32_t
  * (EVK_CONV_X_PACKED in its forward and weight gradient) and nothing else.  y_absmax as for EVK_BN_PACK_DX: zero on entry,
  * slot 0 raised by the finalisation to a bound of |y| derived from the statistics records (2-3x the true maximum). */
 #define EVK_BN_PACK_Y 4u
-/* evk_bn_bwd runs maps of up to 33.5 MB as ONE launch whose workgroups meet at two grid-wide barriers (dy and x stay in
- * registers in between: 3 tensor transfers instead of 5).  Its grid (<= 256 workgroups that each fill a CU) must become
- * resident as a whole; a caller that keeps other long-running kernels on the device (RCCL collectives overlapping the
- * backward) passes EVK_BN_NO_FUSE and gets the three-launch form. */
+/* (ABI <= 19: EVK_BN_NO_FUSE = 8 asked evk_bn_bwd for its three-launch form instead of a one-launch form whose grid met at
+ * device-wide barriers.  That form was removed in ABI 20 — measured level with the three launches on the default path — and
+ * the bit is ignored.) */
 #define EVK_BN_NO_FUSE 8u
 size_t evk_bn_workspace_bytes(int64_t rows, int32_t C);
 int evk_bn_fwd_train(const float* x, const float* residual, const float* gamma, const float* beta,
@@ -355,14 +354,6 @@ int evk_bn_bwd_bits(const float* dy, const float* x, const float* y, const float
                     const float* save_mean, const float* save_invstd, float* dx, float* d_residual,
                     float* dgamma, float* dbeta, int64_t rows, int32_t C, uint32_t flags, int32_t train,
                     void* workspace, size_t workspace_bytes, uint32_t* dx_absmax, const uint32_t* relu_bits, void* stream);
-
-/* The one-launch form of evk_bn_bwd* synchronises its workgroups through a device-wide barrier, so only ONE stream per
- * device may use it (the stream of the first training-mode forward); other streams get the three-launch form, whose
- * partial sums fold in another order (last-bit differences).  A training step captured into a hipGraph runs on a stream of
- * its own (ever_amd/core/graph.py): it claims the one-launch form for the capture and hands it back afterwards.  The
- * caller guarantees the previous owner has no BatchNorm backward in flight (synchronise the device first).
- * No reference counterpart (torch's batch_norm backward has no stream affinity). */
-int evk_bn_fused_stream_claim(void* stream);
 
 /* `to` waits for everything enqueued on `from` so far (an event of a per-device ring recorded on `from`, waited for on
  * `to`): the fork of the weight-gradient side stream from the backward's stream, once per convolution layer

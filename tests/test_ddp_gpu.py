@@ -134,6 +134,7 @@ def test_flat_grad_ddp_world1_matches_plain_training(cuda, side_stream):
         y = (torch.rand(2, 128, 128, device=cuda) < 0.3).long()
         opt_a = er.opt.FusedSGD(ref.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
         opt_b = er.opt.FusedSGD(wrapped.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+        strict = True
         for _ in range(2):
             la = ref(x, y)
             sum(la.values()).backward()
@@ -148,7 +149,7 @@ def test_flat_grad_ddp_world1_matches_plain_training(cuda, side_stream):
             for k in la:
                 assert torch.equal(la[k], lb[k]) or (not strict and float((la[k] - lb[k]).abs()) < 1e-5 * float(la[k].abs())), k
 
-        strict = not side_stream or os.environ.get('EVK_BN_FUSED') == '0'     # (both BatchNorm forms pinned to the same one)
+        strict = True     # (since ABI 20 there is ONE BatchNorm backward form: with or without the side stream, bit for bit)
 
         def same(a, b):
             if strict or not a.dtype.is_floating_point:

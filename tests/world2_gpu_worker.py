@@ -3,7 +3,7 @@
 RCCL refuses two ranks on one device, so the process group is gloo over DEVICE tensors (gloo stages them through the host;
 everything on this package's side of the collective — evk_pack_multi, the communication stream, the weight-gradient side
 stream's hand-off, SyncBatchNorm's staged kernels, the dice statistics buffers — is the product path).  Two processes
-sharing the device is also exactly the co-residency hazard of the one-launch BatchNorm backward (it must stay off).
+sharing the device was also exactly the co-residency hazard of the one-launch BatchNorm backward (removed in ABI 20).
 
 Reference: ever/trainer/th_ddp_trainer.py:13-30 (env:// group, DDP wrap), ever/module/loss.py:20-23,46-48 (dice statistics
 all-reduce), ever/core/launcher.py:196,317-321 (forward_times without no_sync).
@@ -192,12 +192,11 @@ def case_dice_two_ranks(rank, dev):
 def case_trainer_three_steps(rank, dev):
     """THDDPTrainer -> FlatGradDDP -> Launcher, FarSeg-R18 through the registry, three iterations with forward_times=2 on a
     toy loader sharded by StepDistributedSampler: runs (no hang with two processes on one device), logs finite losses, the
-    one-launch BatchNorm backward stays off, replicas end bit-identical."""
+    replicas end bit-identical."""
     import tempfile
     import ever_amd as er
     from ever_amd.hip import functional as HF
     from tests.plumbing_common import ToyTilesLoader  # noqa: F401  (registers the loader)
-    assert HF._collectives_in_flight(), 'world 2 must rule the one-launch BatchNorm backward out'
     work = tempfile.mkdtemp(prefix=f'w2_rank{rank}_')
     cfg_path = os.path.join(work, 'cfg.py')
     with open(cfg_path, 'w') as f:
