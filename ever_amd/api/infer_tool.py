@@ -1,6 +1,8 @@
 """Build a model from a config and load a training checkpoint for inference (API of reference
-ever/api/infer_tool.py:16-74; checkpoint layout of ever/core/checkpoint.py).  `export_model` (TorchScript
-tracing) is not offered: the HIP layers are ctypes calls, not traceable ATen ops."""
+ever/api/infer_tool.py:16-74; checkpoint layout of ever/core/checkpoint.py).  `export_model` traces the eval-mode forward with
+`torch.jit.trace` as the reference does: the no-grad forward of every HIP layer kind is a registered `ever_amd::` operator
+(hip/oplib.py), so the TorchScript file holds those operator calls and the weights; loading it needs `import ever_amd`
+(operator registration) and the GPU — there is no CPU path to fall back to."""
 import os
 from pathlib import Path
 
@@ -10,7 +12,7 @@ from ..core import checkpoint, config
 from ..core.builder import make_model
 from ..core.logger import info
 
-__all__ = ['build_from_file', 'build_and_load_from_file', 'build_from_model_dir']
+__all__ = ['build_from_file', 'build_and_load_from_file', 'build_from_model_dir', 'export_model', 'trace_model']
 
 
 def build_from_file(config_path):
@@ -59,3 +61,25 @@ def build_from_model_dir(model_dir, checkpoint_name=None):
             raise FileNotFoundError(f'no checkpoint-*.pth in {model_dir}')
         checkpoint_name = fps[-1].name
     return build_and_load_from_file(cfg_path, os.path.join(model_dir, checkpoint_name))
+
+
+def trace_model(model, example, fold=True):
+    """`torch.jit.trace` of an eval-mode HIP model (reference infer_tool.py:72).  fold: BatchNorm folded into the preceding
+    convolutions first (module/fold.py) — the traced graph then holds `ever_amd::conv2d_folded` nodes with the folded weights
+    as constants; the model's own parameters are left as they are."""
+    from ..module.fold import fold_batchnorm
+    model = model.eval()
+    if fold:
+        fold_batchnorm(model)
+    with torch.no_grad():
+        return torch.jit.trace(model, example, check_trace=False)
+
+
+def export_model(config_path, checkpoint_path, input_shape, output_path, device='cuda'):
+    """reference infer_tool.py:70-74: build, load, trace on an all-ones input of `input_shape`, save as TorchScript."""
+    model, gs = build_and_load_from_file(config_path, checkpoint_path)
+    model = model.to(device)
+    traced = trace_model(model, torch.ones(input_shape, device=device))
+    torch.jit.save(traced, output_path)
+    info('[export model] to {}'.format(output_path))
+    return traced

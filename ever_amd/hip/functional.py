@@ -2352,3 +2352,71 @@ def confusion_matrix_update(cm, y_true, y_pred=None, logits=None):
             raise ValueError('confusion_matrix: y_true and y_pred sizes differ')
         _C.call('evk_confusion_matrix', yt.data_ptr(), yp.data_ptr(), yt.numel(), c, cm.data_ptr(), _stream())
     return cm
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The no-grad forward of every layer kind as a dispatcher-level operator (hip/oplib.py): what `torch.jit.trace`
+# (reference api/infer_tool.py:70-74: export_model) and a compiler's shape pass record instead of an opaque Python call.
+# Eager calls keep the direct path; the names below are what the modules (and this file) call from here on.
+from . import oplib as _oplib  # noqa: E402
+
+
+def _conv_out(h, k, s, p, d):
+    return (h + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+def _l2(v):
+    return [int(e) for e in _pair(v)]
+
+
+_conv2d_plain = conv2d
+conv2d = _oplib.traceable(
+    'conv2d', '(Tensor x, Tensor weight, Tensor? bias, int[] stride, int[] padding, int[] dilation, bool relu) -> Tensor',
+    _conv2d_plain, impl_fn=lambda x, w, b, s, p, d, relu: _conv2d_plain(x, w, b, tuple(s), tuple(p), tuple(d), relu=relu),
+    adapt=lambda x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, bn_stats=False:
+        (x, weight, bias, _l2(stride), _l2(padding), _l2(dilation), bool(relu)),
+    fake=lambda x, w, b, s, p, d, relu: _oplib.nhwc_like(
+        x, x.shape[0], w.shape[0], _conv_out(x.shape[2], w.shape[2], s[0], p[0], d[0]), _conv_out(x.shape[3], w.shape[3], s[1], p[1], d[1])))
+
+_bn_act_plain = batch_norm_act
+batch_norm_act = _oplib.traceable(
+    'batch_norm_eval', '(Tensor x, Tensor? weight, Tensor? bias, Tensor running_mean, Tensor running_var, float eps, '
+                       'Tensor? residual, bool relu) -> Tensor',
+    _bn_act_plain, impl_fn=lambda x, w, b, rm, rv, eps, res, relu: _bn_act_plain(x, w, b, rm, rv, False, 0.1, eps, residual=res, relu=relu),
+    adapt=lambda x, weight, bias, running_mean, running_var, training, momentum, eps, residual=None, relu=False, pack_out=False,
+        lazy_res=False: (x, weight, bias, running_mean, running_var, float(eps), residual, bool(relu)),
+    fake=lambda x, w, b, rm, rv, eps, res, relu: _oplib.nhwc_like(x, *x.shape),
+    applies=lambda x, weight, bias, running_mean, running_var, training, *a, **k: not training and running_mean is not None)
+
+
+def _same_shape_fake(x, *rest):
+    return _oplib.nhwc_like(x, *x.shape) if x.dim() == 4 else torch.empty_like(x)
+
+
+_relu_plain, _add_plain, _max_pool_plain, _nearest_add_plain = relu, add, max_pool3x3s2, upsample_nearest2x_add
+_bilinear_plain, _gap_plain, _relation_plain, _mean4_plain, _stem_plain = upsample_bilinear, global_avg_pool, fs_relation, mean4, stem_conv7x7s2
+relu = _oplib.traceable('relu', '(Tensor x) -> Tensor', _relu_plain, adapt=lambda x: (x,), fake=_same_shape_fake)
+add = _oplib.traceable('add', '(Tensor a, Tensor b) -> Tensor', _add_plain, adapt=lambda a, b: (a, b), fake=_same_shape_fake)
+max_pool3x3s2 = _oplib.traceable(
+    'max_pool3x3s2', '(Tensor x) -> Tensor', _max_pool_plain, adapt=lambda x: (x,),
+    fake=lambda x: _oplib.nhwc_like(x, x.shape[0], x.shape[1], _conv_out(x.shape[2], 3, 2, 1, 1), _conv_out(x.shape[3], 3, 2, 1, 1)))
+upsample_nearest2x_add = _oplib.traceable(
+    'upsample_nearest2x_add', '(Tensor top, Tensor lateral) -> Tensor', _nearest_add_plain, adapt=lambda top, lateral: (top, lateral),
+    fake=lambda top, lateral: _oplib.nhwc_like(lateral, *lateral.shape))
+upsample_bilinear = _oplib.traceable(
+    'upsample_bilinear', '(Tensor x, float scale_h, float scale_w) -> Tensor',
+    _bilinear_plain, impl_fn=lambda x, sh, sw: _bilinear_plain(x, (sh, sw)),
+    adapt=lambda x, scale_factor: (x,) + tuple(float(s) for s in ((scale_factor, scale_factor) if not isinstance(
+        scale_factor, (tuple, list)) else scale_factor)),
+    fake=lambda x, sh, sw: _oplib.nhwc_like(x, x.shape[0], x.shape[1], int(x.shape[2] * sh), int(x.shape[3] * sw)))
+global_avg_pool = _oplib.traceable('global_avg_pool', '(Tensor x) -> Tensor', _gap_plain, adapt=lambda x: (x,),
+                                   fake=lambda x: _oplib.nhwc_like(x, x.shape[0], x.shape[1], 1, 1))
+fs_relation = _oplib.traceable('fs_relation', '(Tensor scene, Tensor content, Tensor feat) -> Tensor', _relation_plain,
+                               adapt=lambda scene, content, feat: (scene, content, feat),
+                               fake=lambda scene, content, feat: _oplib.nhwc_like(feat, *feat.shape))
+mean4 = _oplib.traceable('mean4', '(Tensor a, Tensor b, Tensor c, Tensor d) -> Tensor', _mean4_plain,
+                         adapt=lambda a, b, c, d: (a, b, c, d), fake=lambda a, b, c, d: _oplib.nhwc_like(a, *a.shape))
+stem_conv7x7s2 = _oplib.traceable(
+    'stem_conv7x7s2', '(Tensor x, Tensor weight) -> Tensor', _stem_plain, impl_fn=lambda x, w: _stem_plain(x, w, False),
+    adapt=lambda x, weight, bn_stats=False: (x, weight),
+    fake=lambda x, w: _oplib.nhwc_like(x, x.shape[0], w.shape[0], _conv_out(x.shape[2], 7, 2, 3, 1), _conv_out(x.shape[3], 7, 2, 3, 1)))

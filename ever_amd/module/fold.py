@@ -129,21 +129,49 @@ def conv_bn(conv, bn, x, residual=None, relu=False, conv_only=False, lazy_res=Fa
     return bn(conv(x, bn_stats=_takes_epilogue_stats(bn)), residual=residual, relu=relu, conv_only=conv_only)
 
 
-def folded_conv2d(x, conv, residual=None, relu=False):
-    f = conv._folded
-    # (a training-mode BatchNorm in front of a folded pair may have stored its result packed: ADVICE r2)
+# split planes of folded weights, per (weight memory, input geometry, arithmetic): constant at inference.  Keyed by the
+# weight's address and version so that the tensor-level operator below (which a TorchScript trace replays with the folded
+# weight as a graph constant) finds them again without a module to hang them on.
+_PLANES = {}
+
+
+def _folded_planes(weight, d, n, h, w, h2, st, dev):
+    key = (weight.data_ptr(), weight._version, n, h, w, h2)
+    hit = _PLANES.get(key)
+    if hit is None:
+        if len(_PLANES) > 4096:
+            _PLANES.clear()
+        lib = _C.load()
+        planes = torch.empty((lib.evk_conv2d_split_weight_bytes(ctypes.byref(d), 0),), dtype=torch.uint8, device=dev)
+        wbits = None
+        if h2:
+            wbits = HF.absmax_bits(weight, st)
+            _C.call('evk_conv2d_split_weight_f16x2', ctypes.byref(d), weight.data_ptr(), 0, planes.data_ptr(), wbits.data_ptr(), st)
+        else:
+            _C.call('evk_conv2d_split_weight', ctypes.byref(d), weight.data_ptr(), 0, planes.data_ptr(), st)
+        hit = _PLANES[key] = (planes, wbits, weight)     # (the weight kept alive: its address is the key)
+    return hit[0], hit[1]
+
+
+def _folded_conv(x, weight, bias, residual, stride, padding, dilation, relu):
+    """y = conv(x, weight) + bias (+ residual) (ReLU) with `weight` = the folded [Cout][kh][kw][Cin_p] tensor of _fold_pair
+    (channel-padded K axis), tensors only: the body of the `ever_amd::conv2d_folded` operator."""
     x = HF.unpacked(HF.as_nhwc(x, 'folded conv'))
     n, cin, h, w = x.shape
-    if cin != f.cin:
-        raise ValueError(f'folded conv: input has {cin} channels, expected {f.cin}')
+    # the folded weight is either a channels_last OIHW tensor (cin == cin_p) or a plain [cout, kh, kw, cin_p] one (padded K)
+    if weight.dim() == 4 and weight.shape[1] == cin and weight.stride(1) == 1:
+        cout, kh, kw, cin_p = weight.shape[0], weight.shape[2], weight.shape[3], cin
+    else:
+        cout, kh, kw, cin_p = weight.shape
+    if HF._pad4(cin) != cin_p:
+        raise ValueError(f'folded conv: input has {cin} channels, the folded weight expects {cin_p} (padded)')
     dev, st = x.device, HF._stream()
-    cout, kh, kw = f.weight.shape[0], conv.kernel_size[0], conv.kernel_size[1]
-    if f.cin_p != cin:
-        xk = HF._pad_last(x.data_ptr(), n * h * w, cin, f.cin_p, dev)
+    if cin_p != cin:
+        xk = HF._pad_last(x.data_ptr(), n * h * w, cin, cin_p, dev)
         x_ptr = xk.data_ptr()
     else:
         x_ptr = x.data_ptr()
-    d = HF._conv_desc(n, h, w, f.cin_p, cout, kh, kw, HF._pair(conv.stride), HF._pair(conv.padding), HF._pair(conv.dilation))
+    d = HF._conv_desc(n, h, w, cin_p, cout, kh, kw, HF._pair(stride), HF._pair(padding), HF._pair(dilation))
     y = HF.empty_nhwc(n, cout, d.Ho, d.Wo, dev)
     res_ptr = None
     if residual is not None:
@@ -153,28 +181,45 @@ def folded_conv2d(x, conv, residual=None, relu=False):
         res_ptr = residual.data_ptr()
     flags = 1 if relu else 0
     math = HF.get_conv_math()
-    if math in ('f16x2', 'bf16x3', 'bf16') and f.cin_p == cin and cin % 8 == 0:
+    if math in ('f16x2', 'bf16x3', 'bf16') and cin_p == cin and cin % 8 == 0:
         # constant at inference: split once per input geometry and arithmetic (the plane layout follows the kernel the
         # descriptor selects)
         h2 = math == 'f16x2'
-        if f.planes is None or f.planes_key != (n, h, w, h2):
-            f.planes_key = (n, h, w, h2)
-            lib = _C.load()
-            f.planes = torch.empty((lib.evk_conv2d_split_weight_bytes(ctypes.byref(d), 0),), dtype=torch.uint8, device=dev)
-            if h2:
-                f.wbits = HF.absmax_bits(f.weight, st)
-                _C.call('evk_conv2d_split_weight_f16x2', ctypes.byref(d), f.weight.data_ptr(), 0, f.planes.data_ptr(),
-                        f.wbits.data_ptr(), st)
-            else:
-                _C.call('evk_conv2d_split_weight', ctypes.byref(d), f.weight.data_ptr(), 0, f.planes.data_ptr(), st)
+        planes, wbits = _folded_planes(weight, d, n, h, w, h2, st, dev)
         if h2:
             xbits = HF.absmax_bits(x, st)
-            _C.call('evk_conv2d_fwd_f16x2', ctypes.byref(d), x_ptr, xbits.data_ptr(), f.planes.data_ptr(), f.wbits.data_ptr(),
-                    f.bias.data_ptr(), res_ptr, y.data_ptr(), flags, None, 0, ctypes.byref(ctypes.c_int32(0)), None, st)
+            _C.call('evk_conv2d_fwd_f16x2', ctypes.byref(d), x_ptr, xbits.data_ptr(), planes.data_ptr(), wbits.data_ptr(),
+                    bias.data_ptr(), res_ptr, y.data_ptr(), flags, None, 0, ctypes.byref(ctypes.c_int32(0)), None, st)
         else:
-            _C.call('evk_conv2d_fwd_x3_res', ctypes.byref(d), x_ptr, f.planes.data_ptr(), f.bias.data_ptr(), res_ptr,
+            _C.call('evk_conv2d_fwd_x3_res', ctypes.byref(d), x_ptr, planes.data_ptr(), bias.data_ptr(), res_ptr,
                     y.data_ptr(), flags, st)
     else:
-        _C.call('evk_conv2d_fwd_res', ctypes.byref(d), x_ptr, f.weight.data_ptr(), f.bias.data_ptr(), res_ptr, y.data_ptr(),
+        _C.call('evk_conv2d_fwd_res', ctypes.byref(d), x_ptr, weight.data_ptr(), bias.data_ptr(), res_ptr, y.data_ptr(),
                 flags, st)
     return y
+
+
+def _folded_fake(x, weight, bias, residual, stride, padding, dilation, relu):
+    if weight.dim() == 4 and weight.shape[1] == x.shape[1] and weight.stride(1) == 1:
+        cout, kh, kw = weight.shape[0], weight.shape[2], weight.shape[3]
+    else:
+        cout, kh, kw, _ = weight.shape
+    ho = (x.shape[2] + 2 * padding[0] - dilation[0] * (kh - 1) - 1) // stride[0] + 1
+    wo = (x.shape[3] + 2 * padding[1] - dilation[1] * (kw - 1) - 1) // stride[1] + 1
+    return HF._oplib.nhwc_like(x, x.shape[0], cout, ho, wo)
+
+
+_folded_conv_op = HF._oplib.traceable(
+    'conv2d_folded', '(Tensor x, Tensor weight, Tensor bias, Tensor? residual, int[] stride, int[] padding, int[] dilation, '
+                     'bool relu) -> Tensor',
+    _folded_conv, impl_fn=lambda x, w, b, r, s, p, d, relu: _folded_conv(x, w, b, r, tuple(s), tuple(p), tuple(d), relu),
+    adapt=lambda x, w, b, r, s, p, d, relu: (x, w, b, r, [int(e) for e in HF._pair(s)], [int(e) for e in HF._pair(p)],
+                                             [int(e) for e in HF._pair(d)], bool(relu)),
+    fake=_folded_fake)
+
+
+def folded_conv2d(x, conv, residual=None, relu=False):
+    f = conv._folded
+    if x.shape[1] != f.cin:
+        raise ValueError(f'folded conv: input has {x.shape[1]} channels, expected {f.cin}')
+    return _folded_conv_op(x, f.weight, f.bias, residual, conv.stride, conv.padding, conv.dilation, relu)

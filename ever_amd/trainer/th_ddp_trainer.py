@@ -50,11 +50,6 @@ class THDDPTrainer(trainer.Trainer):
             model = nn.parallel.DistributedDataParallel(model, **ddp_kwargs)
         return self.torch_compile(model)
 
-    def torch_compile(self, model):
-        if 'torch_compile' in self.config.train:
-            raise NotImplementedError('torch_compile: the HIP path launches hand-written kernels; there is no '
-                                      'tracing compiler in ever_amd')
-        return model
 
     def build_launcher(self, model_fn=None, optimizer_fn=None, lr_fn=None):
         model = self.make_model(model_fn=model_fn)

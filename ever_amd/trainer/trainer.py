@@ -89,6 +89,18 @@ class Trainer:
         kwargs.update(self.make_lr_optimizer(model.custom_param_groups(), lr_fn=lr_fn, optimizer_fn=optimizer_fn))
         return dict(config=self.config, launcher=Launcher(**kwargs))
 
+    def torch_compile(self, model):
+        """`config.train.torch_compile = dict(...)` -> `torch.compile(model, **that)` (reference trainer.py:241-243).  The HIP
+        layers are hand-written kernels behind ctypes: they are marked opaque to the compiler first (hip/__init__.py:
+        compiler_opaque), as are the modules of this package that carry Python-side state from layer to layer, so what Dynamo
+        captures and may optimise is the user's own module code around them; the step computes exactly what the eager step
+        computes (tests/test_inference_api_gpu.py)."""
+        if 'torch_compile' in self.config.train:
+            from ..hip import compiler_opaque
+            compiler_opaque(model)
+            model = torch.compile(model, **dict(self.config.train.torch_compile))
+        return model
+
     def build_callbacks(self):
         return [make_callback(c) for c in getattr(self.config.train, 'callbacks', [])]
 

@@ -74,3 +74,100 @@ def test_infer_tool_round_trip_and_sliding_window_inference(cuda, tmp_path):
             cnt[:, :, y0:y1, x0:x1] += 1
     assert float(cnt.min()) >= 1
     assert torch.allclose(out, acc / cnt, atol=1e-5)
+
+
+def _r18(cuda, seed=0):
+    import ever_amd as er
+    torch.manual_seed(seed)
+    widths = (64, 128, 256, 512)
+    m = er.module.FarSeg(dict(encoder=dict(resnet_type='resnet18', in_channels=4),
+                              head=dict(fpn=dict(in_channels_list=widths, out_channels=256),
+                                        fs_relation=dict(scene_embedding_channels=512))))
+    # (random running statistics: an eval-mode BatchNorm with the initial 0 / 1 would hide a wrong fold)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.2)
+            mod.running_var.uniform_(0.5, 1.5)
+    return m.to(cuda).eval()
+
+
+@pytest.mark.parametrize('fold', [False, True], ids=['bn-layers', 'bn-folded'])
+def test_export_model_torchscript_round_trip_equals_eager(cuda, tmp_path, fold):
+    """reference api/infer_tool.py:70-74 (export_model = torch.jit.trace + torch.jit.save).  The no-grad forward of every HIP
+    layer kind is a registered `ever_amd::` operator (hip/oplib.py), so the trace holds operator calls instead of opaque Python:
+    the traced module, and the module loaded back from the file, give the eager output BIT FOR BIT (same kernels, same
+    operands), also on a second input of the traced shape."""
+    from ever_amd.api import infer_tool
+    from ever_amd.module.fold import fold_batchnorm, unfold_batchnorm
+    m = _r18(cuda)
+    x = torch.randn(2, 4, 64, 64, device=cuda)
+    x2 = torch.randn(2, 4, 64, 64, device=cuda)
+    traced = infer_tool.trace_model(m, torch.ones(2, 4, 64, 64, device=cuda), fold=fold)
+    kinds = {n.kind() for n in traced.graph.nodes()} | {n.kind() for n in traced.inlined_graph.nodes()}
+    assert any(k.startswith('ever_amd::') for k in kinds), kinds
+    assert not any('PythonOp' in k for k in kinds), kinds
+    assert ('ever_amd::conv2d_folded' in kinds) == fold
+    if not fold:
+        unfold_batchnorm(m)
+    with torch.no_grad():
+        want, want2 = m(x), m(x2)
+        got, got2 = traced(x), traced(x2)
+    assert torch.equal(got, want) and torch.equal(got2, want2)
+    path = str(tmp_path / 'farseg_r18.pt')
+    torch.jit.save(traced, path)
+    back = torch.jit.load(path)
+    with torch.no_grad():
+        assert torch.equal(back(x2), want2)
+
+
+def test_export_model_from_config_and_checkpoint(cuda, tmp_path):
+    """the reference's call: export_model(config_path, checkpoint_path, input_shape, output_path)"""
+    import ever_amd as er
+    from ever_amd.api import infer_tool
+    cfg = tmp_path / 'cfg.py'
+    cfg.write_text("config = dict(model=dict(type='FarSeg', params=dict(encoder=dict(resnet_type='resnet18', in_channels=4), "
+                   "head=dict(fpn=dict(in_channels_list=(64, 128, 256, 512), out_channels=256), "
+                   "fs_relation=dict(scene_embedding_channels=512)))))\n")
+    m = _r18(cuda, seed=3)
+    torch.save({'model': m.state_dict(), 'opt': {}, 'global_step': 7}, tmp_path / 'checkpoint-7.pth')
+    out = str(tmp_path / 'exported.pt')
+    infer_tool.export_model(str(cfg), str(tmp_path / 'checkpoint-7.pth'), (1, 4, 64, 64), out)
+    back = torch.jit.load(out)
+    x = torch.randn(1, 4, 64, 64, device=cuda)
+    from ever_amd.module.fold import fold_batchnorm
+    with torch.no_grad():
+        unfolded = m(x)
+        folded = fold_batchnorm(m)(x)       # export_model folds BatchNorm into the convolutions before tracing
+        got = back(x)
+    assert torch.equal(got, folded)
+    assert float((got - unfolded).abs().max()) < 1e-5
+
+
+def test_torch_compile_hook_trains_like_eager(cuda):
+    """reference trainer.py:241-243: `config.train.torch_compile` -> torch.compile(model, **kwargs).  The HIP entry points are
+    opaque to the compiler (hip.compiler_opaque); two SGD steps through the compiled model equal the eager ones bit for bit."""
+    import ever_amd as er
+    from ever_amd.trainer.trainer import Trainer
+
+    class _T(Trainer):
+        def __init__(self):
+            self._cfg = er.AttrDict.from_dict(dict(train=dict(torch_compile=dict(dynamic=False))))
+    a, b = _r18(cuda, seed=5).train(), _r18(cuda, seed=5).train()
+    b.load_state_dict(a.state_dict())
+    cb = _T().torch_compile(b)
+    assert cb is not b
+    oa = er.opt.FusedSGD(a.parameters(), lr=0.01, momentum=0.9)
+    ob = er.opt.FusedSGD(b.parameters(), lr=0.01, momentum=0.9)
+    x = torch.randn(2, 4, 64, 64, device=cuda)
+    y = (torch.rand(2, 64, 64, device=cuda) < 0.3).long()
+    for _ in range(2):
+        la = a(x, y)
+        sum(la.values()).backward()
+        oa.step(); oa.zero_grad(set_to_none=True)
+        lb = cb(x, y)
+        sum(lb.values()).backward()
+        ob.step(); ob.zero_grad(set_to_none=True)
+        for k in la:
+            assert torch.equal(la[k], lb[k]), k
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(p, q), k
