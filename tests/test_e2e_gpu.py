@@ -155,8 +155,12 @@ def test_farseg_matches_reference_golden(cuda, name, conv_math):
         for kk in worst:
             bound = TIGHT_FACTOR * noise[kk] + TIGHT_ABS
             assert worst[kk] <= bound, f'{name}: gradient {kk} deviation {worst[kk]:.2e} > {bound:.2e}'
-    for kk in worst:   # every fixture: within a small multiple of what fp32 rounding does to the reference itself
-        lim = max(2e-2, 6.0 * noise[kk])
+    for kk in worst:   # every fixture: within a small multiple of what fp32 rounding does to the reference itself.  (Round 4:
+        # 4 x noise + 5e-3 instead of max(2e-2, 6 x noise).  The 64^2 / 128^2 fixtures cannot take the 256^2 fixture's 2 x noise:
+        # their deepest BatchNorms see 2 x 2 .. 4 x 4 maps, where ONE ReLU decision that falls differently under another
+        # summation order moves a tensor's gradient by more than the reference's own fp32-vs-fp64 distance — measured worst
+        # case over the three arithmetics: r50_3band_64 norm 4.4e-2 against a noise of 1.2e-2.)
+        lim = 4.0 * noise[kk] + 5e-3
         assert worst[kk] <= lim, f'{name}: gradient {kk} deviation {worst[kk]:.2e} > {lim:.2e}'
     # running statistics after one step, then eval-mode logits
     sd = m.state_dict()
@@ -169,7 +173,7 @@ def test_farseg_matches_reference_golden(cuda, name, conv_math):
     _check_masks(lg_eval, gold['logits_eval'], meta['num_classes'], name + ' (eval)', pinned=0)   # observed 0, all three
 
 
-def test_farseg_matches_oracle_larger_tile(cuda):
+def test_farseg_matches_oracle_larger_tile(cuda, conv_math):
     """R50, 3x256x256, batch 2: HIP path vs the oracle run on this box's CPU in fp32 AND fp64.
 
     Forward: 1e-3 relative + masks.  Backward: for this random-init network the gradient is badly
@@ -198,7 +202,11 @@ def test_farseg_matches_oracle_larger_tile(cuda):
     sum(out.values()).backward()
     lg = lg.detach().cpu().contiguous().numpy()
     assert _rel_err(lg, logits[torch.float32]) < 1e-3
-    _check_masks(lg, logits[torch.float32], 1, 'oracle256', pinned=8)   # 217 pixels inside the margin (min 3.8e-6): 4 flipped
+    # NATURAL classifier bias (nothing placed in a gap of the reference's logits): 217 of 131072 pixels lie inside the 1e-3 tie
+    # margin (smallest reference margin 3.8e-6 of the range).  Flips observed per arithmetic are pinned with a little room for a
+    # changed summation order (a new kernel choice moves one or two): masks are identical OUTSIDE the tie band, and inside it
+    # this many pixels decide differently from the fp32 CPU reference — not "bit-exact masks" on an un-engineered input.
+    _check_masks(lg, logits[torch.float32], 1, f'oracle256[{conv_math}]', pinned={'f16x2': 7, 'bf16x3': 7, 'f32': 4}[conv_math])   # observed 5 / 5 / 2
     e_hip, e_o32 = _rel_err(lg, logits[torch.float64]), _rel_err(logits[torch.float32], logits[torch.float64])
     print(f'logits vs fp64 truth: HIP {e_hip:.2e}, fp32 oracle {e_o32:.2e}')
     for k, v in losses[torch.float32].items():
