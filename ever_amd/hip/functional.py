@@ -265,6 +265,13 @@ def _note_param_use(*params):
     outside this package, e.g. an explicit L2 term in the loss; set EVK_WGRAD_STREAM=0 for such models.)"""
     if not _WGRAD_STREAM[0]:
         return
+    if _SIDE_SELFTEST[0] is None:
+        p0 = next((p for p in params if p is not None and p.is_cuda), None)
+        if p0 is not None and torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing():
+            _SIDE_SELFTEST[0] = _side_stream_selftest(p0.device)
+            if not _SIDE_SELFTEST[0]:
+                _WGRAD_STREAM[0] = False
+                return
     for p in params:
         if p is not None and p.requires_grad and p.is_leaf:
             n = p.__dict__.get('_evk_uses', 0)
@@ -286,9 +293,61 @@ def _leaf_ok(t):
     return not getattr(t, '_post_accumulate_grad_hooks', None) or getattr(t, '_evk_flat_ddp', False)
 
 
+_SIDE_SELFTEST = [None]          # None: not run yet; True / False: what the engine of this torch build does
+_SIDE_TESTED_TORCH = ('2.10',)   # builds the side stream's assumptions about the autograd engine were developed against
+
+
+def _side_stream_selftest(dev):
+    """The side stream leans on engine behaviour that is not a public contract: the id of the running
+    graph task, final callbacks queued from inside a backward node, AccumulateGrad STORING a first gradient as it is (same
+    storage, no read), the raw current-stream setter.  Checked once per process on a four-element problem before the first
+    weight gradient goes to the side stream; on any other answer the side stream is switched off, loudly, and training goes on
+    single-stream (bit-identical results, ~5 % slower)."""
+    import warnings
+    try:
+        if _cuda_get_stream is None or _cuda_set_stream is None or not hasattr(torch._C, '_current_graph_task_id'):
+            raise RuntimeError('torch._C._cuda_{get,set}Stream / _current_graph_task_id missing')
+        seen = {}
+
+        class _Probe(Function):
+            @staticmethod
+            def forward(ctx, w):
+                return w * 2.0
+
+            @staticmethod
+            def backward(ctx, g):
+                seen['gid'] = torch._C._current_graph_task_id()
+                torch.autograd.Variable._execution_engine.queue_callback(lambda: seen.__setitem__('cb', True))
+                out = g * 2.0
+                seen['ptr'] = out.untyped_storage().data_ptr()
+                return out
+        w = torch.ones(4, device=dev, requires_grad=True)
+        cur = _cuda_get_stream(dev.index)
+        _Probe.apply(w).sum().backward()
+        if seen.get('gid', -1) < 0:
+            raise RuntimeError('no graph task id inside a backward node')
+        if not seen.get('cb'):
+            raise RuntimeError('a final callback queued inside a backward node did not run')
+        if w.grad is None or w.grad.untyped_storage().data_ptr() != seen['ptr']:
+            raise RuntimeError('AccumulateGrad copied a first gradient instead of storing it')
+        if _cuda_get_stream(dev.index)[0] != cur[0]:
+            raise RuntimeError('the current stream changed across a backward pass')
+        ok = True
+    except Exception as e:       # noqa: BLE001 (anything unexpected = do not trust the mechanism)
+        warnings.warn(f'ever_amd: weight-gradient side stream disabled — this torch build ({torch.__version__}) does not behave '
+                      f'as the mechanism needs ({e}); training continues single-stream (set EVK_WGRAD_STREAM=0 to silence)')
+        ok = False
+    if ok and not torch.__version__.startswith(_SIDE_TESTED_TORCH):
+        warnings.warn(f'ever_amd: the weight-gradient side stream was developed against torch {_SIDE_TESTED_TORCH[0]}.x; this is '
+                      f'{torch.__version__} — its engine self-test passed, the end-of-pass ownership check stays on')
+    return ok
+
+
 def _wgrad_side_stream(dev, weight, bias=None):
     """the side stream for this weight gradient, or None (see the rules above)"""
     if not _WGRAD_STREAM[0] or dev.type != 'cuda' or weight is None:
+        return None
+    if not _SIDE_SELFTEST[0]:        # (the probe runs from the forward, _note_param_use; never passed = no side stream)
         return None
     leaves = (weight,) if bias is None else (weight, bias)
     flat_ddp = all(getattr(t, '_evk_flat_ddp', False) for t in leaves)

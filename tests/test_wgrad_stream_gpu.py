@@ -260,3 +260,25 @@ def test_foreign_consumer_of_a_weight_is_loud_and_other_layouts_stay_on_the_main
     torch.cuda.synchronize()
     assert HF.wgrad_stream_stats['side'] == before['side']
     assert float((conv.weight.grad.double() - ref.weight.grad).abs().max() / ref.weight.grad.abs().max()) < 3e-6
+
+
+def test_engine_self_test_gates_the_side_stream(cuda):
+    """the side stream relies on engine behaviour that is no public contract.  The one-time probe passes on
+    this torch build, and a build on which it fails gets the single-stream path with a warning instead of a silent race."""
+    import warnings
+    from ever_amd.hip import functional as HF
+    assert HF._side_stream_selftest(cuda) is True
+    saved = (HF._SIDE_SELFTEST[0], HF._WGRAD_STREAM[0], HF._cuda_set_stream)
+    try:
+        HF._SIDE_SELFTEST[0] = None
+        HF._WGRAD_STREAM[0] = True
+        HF._cuda_set_stream = None            # "a torch build without the raw stream setter"
+        before = dict(HF.wgrad_stream_stats)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            g, _ = _train(cuda, True, steps=1)
+        assert any('side stream disabled' in str(x.message) for x in w)
+        assert HF.wgrad_stream_stats['side'] == before['side']       # nothing went to the side stream
+        assert all(torch.isfinite(v).all() for v in g.values())
+    finally:
+        HF._SIDE_SELFTEST[0], HF._WGRAD_STREAM[0], HF._cuda_set_stream = saved
