@@ -65,6 +65,21 @@ def main():
                 os.environ['EVK_C1_DMA_DBG'] = '0'
                 print(f'{ci:4d}->{co:4d} @{h:3d}^2 packed={packed} {force}: ' + ' '.join(row), flush=True)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'khalf':
+        # timing probe (EVK_C1_DMA_DBG bit 16): every tile twice, each copy running one half of the K loop = what two
+        # co-resident workgroups per tile (a split of the reduction) would take per half
+        for (h, ci, co) in [(64, 512, 128), (64, 512, 256), (32, 256, 1024), (32, 1024, 256), (32, 1024, 512), (16, 512, 2048), (16, 2048, 512)]:
+            for packed in (0, 1):
+                fn, out, keep = problem(h, ci, co, packed, 0)
+                row = []
+                for force in ('e128', 'd128', 'e64'):
+                    os.environ['EVK_X3_FORCE'] = force
+                    for dbg in (0, 16):
+                        os.environ['EVK_C1_DMA_DBG'] = str(dbg)
+                        row.append(f'{force}/dbg{dbg}={timeit(fn):.1f}')
+                os.environ['EVK_C1_DMA_DBG'] = '0'
+                print(f'{ci:4d}->{co:4d} @{h:3d}^2 packed={packed}: ' + ' '.join(row), flush=True)
+        return
     tot = {}
     for (h, ci, co) in SHAPES:
         for packed in (0, 1):
