@@ -266,8 +266,12 @@ def _note_param_use(*params):
     if not _WGRAD_STREAM[0]:
         return
     if _SIDE_SELFTEST[0] is None:
-        p0 = next((p for p in params if p is not None and p.is_cuda), None)
-        if p0 is not None and torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing():
+        # (no test of torch.is_grad_enabled() here: most callers are autograd.Function.forward bodies, which always run with
+        # grad mode off — they only come here when an input needs a gradient; the probe enables grad mode for itself.  With
+        # that test in place the probe only ever ran from the one plain-Python caller, bn_relu_dot, and models without a
+        # commuted decoder classifier silently trained single-stream: ChangeStar -5 %, FreeNet -10 % on one box)
+        p0 = next((p for p in params if p is not None and p.is_cuda and p.requires_grad), None)
+        if p0 is not None and not torch.cuda.is_current_stream_capturing():
             _SIDE_SELFTEST[0] = _side_stream_selftest(p0.device)
             if not _SIDE_SELFTEST[0]:
                 _WGRAD_STREAM[0] = False
@@ -321,9 +325,10 @@ def _side_stream_selftest(dev):
                 out = g * 2.0
                 seen['ptr'] = out.untyped_storage().data_ptr()
                 return out
-        w = torch.ones(4, device=dev, requires_grad=True)
         cur = _cuda_get_stream(dev.index)
-        _Probe.apply(w).sum().backward()
+        with torch.enable_grad():        # (the caller is usually inside a Function.forward: grad mode is off there)
+            w = torch.ones(4, device=dev, requires_grad=True)
+            _Probe.apply(w).sum().backward()
         if seen.get('gid', -1) < 0:
             raise RuntimeError('no graph task id inside a backward node')
         if not seen.get('cb'):

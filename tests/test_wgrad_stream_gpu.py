@@ -282,3 +282,28 @@ def test_engine_self_test_gates_the_side_stream(cuda):
         assert all(torch.isfinite(v).all() for v in g.values())
     finally:
         HF._SIDE_SELFTEST[0], HF._WGRAD_STREAM[0], HF._cuda_set_stream = saved
+
+
+def test_side_stream_engages_without_a_commuted_classifier(cuda):
+    """The engine self-test that gates the side stream must run from the convolution entry points themselves (bodies of
+    autograd.Function.forward, where grad mode is always off): in round 4 it only ran from bn_relu_dot, the one plain-Python
+    caller, and every model without a commuted decoder classifier (ChangeStar, FreeNet, a bare conv stack) trained
+    single-stream without a word — found as a 5-10 % regression of bench.py --config c4 / c5.  Fresh process: the gate is
+    process-wide state."""
+    code = (
+        "import torch, ever_amd as er\n"
+        "from ever_amd.hip import functional as HF\n"
+        "from ever_amd.module.layers import Conv2d, BatchNorm2d, HipSequential, ReLU\n"
+        "dev = torch.device('cuda:0')\n"
+        "m = HipSequential(Conv2d(8, 16, 3, 1, 1, bias=False), BatchNorm2d(16), ReLU(True), Conv2d(16, 16, 1, bias=False)).to(dev).train()\n"
+        "x = torch.randn(2, 8, 32, 32, device=dev)\n"
+        "for _ in range(2):\n"
+        "    m(x).sum().backward()\n"
+        "    for p in m.parameters(): p.grad = None\n"
+        "torch.cuda.synchronize()\n"
+        "assert HF._SIDE_SELFTEST[0] is True, HF._SIDE_SELFTEST\n"
+        "assert HF.wgrad_stream_stats['side'] >= 4, HF.wgrad_stream_stats\n"
+        "print('ok', HF.wgrad_stream_stats)\n")
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                         env=dict(os.environ, EVK_WGRAD_STREAM='1'))
+    assert out.returncode == 0 and 'ok' in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
