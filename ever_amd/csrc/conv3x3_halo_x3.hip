@@ -304,7 +304,9 @@ __global__ __launch_bounds__(256 + 64 * MW) void conv3x3_halo_x3_kernel(const IG
     for (int a = 0; a < MB; ++a) {
       const int m = wm * WMR + a * 32 + li;
       const int gy = Y0 + (m >> 4), gx = X0 + (m & 15);
-      const size_t roff = (((size_t)n * p.Hd + (size_t)(gy * p.dsh + p.doy)) * p.Wd + (size_t)(gx * p.dsw + p.dox)) * p.Cd;
+      // (a patch may hang over the bottom / right edge of the map: those rows are computed — from zero halo — and dropped)
+      const size_t roff = (gy < p.Hm && gx < p.Wm)
+          ? (((size_t)n * p.Hd + (size_t)(gy * p.dsh + p.doy)) * p.Wd + (size_t)(gx * p.dsw + p.dox)) * p.Cd : ~(size_t)0;
       igemm_store_rows_stats<NB, WN>(p, acc[a], roff, n0, wn, li, lh, scratch, st);
     }
     bn_part_write<WN, MWM, 2>(p, st, (n * tiles_y + ty) * tiles_x + tx, n0, wm, wn, lh * 32 + li, xch);
@@ -315,6 +317,7 @@ __global__ __launch_bounds__(256 + 64 * MW) void conv3x3_halo_x3_kernel(const IG
   for (int a = 0; a < MB; ++a) {
     const int m = wm * WMR + a * 32 + li;
     const int gy = Y0 + (m >> 4), gx = X0 + (m & 15);
+    if (gy >= p.Hm || gx >= p.Wm) continue;   // outside the map (ragged last patch row / column)
     const size_t roff = (((size_t)n * p.Hd + (size_t)(gy * p.dsh + p.doy)) * p.Wd + (size_t)(gx * p.dsw + p.dox)) * p.Cd;
     igemm_store_rows<NB, WN>(p, acc[a], roff, n0, wn, lh, amax_l);
   }
@@ -327,13 +330,21 @@ bool conv3x3_halo_applies(const IGemmArgs& a) {
   if (!on) return false;
   if (a.kh != 3 || a.kw != 3 || a.ash != 1 || a.asw != 1) return false;
   if (!((a.oys == 1 || a.oys == -1) && a.oy0 == -a.oys && (a.oxs == 1 || a.oxs == -1) && a.ox0 == -a.oxs)) return false;
-  if (a.Hm != a.Hs || a.Wm != a.Ws || (a.Hm % 8) != 0 || (a.Wm % kPW) != 0) return false;
+  if (a.Hm != a.Hs || a.Wm != a.Ws) return false;
+  // patches of 8 (or 16) x 16 output pixels; the last row / column of patches may hang over the edge of the map (the halo
+  // loads zeros there, the epilogue drops those rows) as long as at least 3/4 of the patch grid is map
+  // (round 4: H % 8 == 0 and W % 16 == 0 were required until then — a 616 x 344 scene, or the stride-4 map of a 416-wide
+  // tile, fell back to the implicit-GEMM kernels)
+  {
+    const long long cover = (long long)ceil_div(a.Hm, 8) * 8 * ceil_div(a.Wm, kPW) * kPW;
+    if (a.Hm < 4 || a.Wm < 8 || 4LL * a.Hm * a.Wm < 3 * cover) return false;
+  }
   if ((a.Cs % kCh) != 0 || a.Cd < 64 || (!a.dense_dst && (a.dsh != 1 || a.dsw != 1))) return false;
   // enough workgroups for the 256 CUs, if necessary with the 64-wide N tile
   // (EVK_X3_HALO_MIN_WG=0 makes the choice independent of the batch size: tests/test_linearity_pinned_gpu.py pins the
   // accumulation order — chunk-major here, tap-major in the implicit-GEMM kernels — for a batch and its halves)
   static const long long min_wg = getenv("EVK_X3_HALO_MIN_WG") ? atoll(getenv("EVK_X3_HALO_MIN_WG")) : 256;
-  const long long patches = (long long)a.N * (a.Hm / 8) * (a.Wm / kPW);
+  const long long patches = (long long)a.N * ceil_div(a.Hm, 8) * ceil_div(a.Wm, kPW);
   return patches * ceil_div(a.Cd, 64) >= min_wg;
 }
 
@@ -362,7 +373,7 @@ template <int BN, int PH, int NPX, bool WDMA = false, int MW = 4>
 static int launch_halo_np(IGemmArgs& a, hipStream_t stream) {
   constexpr int NP = X3Mode<NPX>::NP;
   a.tiles_n = ceil_div(a.Cd, BN);
-  const int tiles_y = a.Hm / PH, tiles_x = a.Wm / kPW;
+  const int tiles_y = ceil_div(a.Hm, PH), tiles_x = ceil_div(a.Wm, kPW);
   a.tiles_m = a.N * tiles_y * tiles_x;
   bn_stats_setup(a, PH * kPW, BN, 2, a.tiles_m);   // two row waves per patch; the ring (>= 100 KB) is the scratch
   constexpr int PL = NP == 2 ? 2 : 3;
@@ -403,12 +414,12 @@ int launch_conv3x3_halo(IGemmArgs& a, hipStream_t stream) {
     if (f && *f) {
       if (!strcmp(f, "h64x8")) return launch_halo<64, 8>(a, stream);
       if (!strcmp(f, "h128x8") && a.Cd > 64) return launch_halo<128, 8>(a, stream);
-      if (!strcmp(f, "h128x16") && a.Cd > 64 && (a.Hm % 16) == 0) return launch_halo<128, 16>(a, stream);
+      if (!strcmp(f, "h128x16") && a.Cd > 64) return launch_halo<128, 16>(a, stream);
       if (!strcmp(f, "m128x8") && a.Cd > 64) return launch_halo<128, 8, 8>(a, stream);
-      if (!strcmp(f, "m128x16") && a.Cd > 64 && (a.Hm % 16) == 0) return launch_halo<128, 16, 8>(a, stream);
+      if (!strcmp(f, "m128x16") && a.Cd > 64) return launch_halo<128, 16, 8>(a, stream);
     }
   }
-  if (a.Cd <= 64 || (long long)a.N * (a.Hm / 8) * (a.Wm / kPW) * ceil_div(a.Cd, 128) < 256)
+  if (a.Cd <= 64 || (long long)a.N * ceil_div(a.Hm, 8) * ceil_div(a.Wm, kPW) * ceil_div(a.Cd, 128) < 256)
     return launch_halo<64, 8>(a, stream);   // small maps (16^2 .. 32^2): 64-wide tiles keep every CU busy
   // 16 x 16 patches (256 GEMM rows) halve the weight bytes per MFMA, the larger share of the staging traffic now;
   // taken when they still fill the chip.  With the weights fed by DMA (f16x2) the staging waves no longer hold the matrix
@@ -418,7 +429,9 @@ int launch_conv3x3_halo(IGemmArgs& a, hipStream_t stream) {
   static const bool m8 = !(getenv("EVK_HALO_WDMA") && atoi(getenv("EVK_HALO_WDMA")) == 0) &&
                          !(getenv("EVK_HALO_M8") && atoi(getenv("EVK_HALO_M8")) == 0);
   const bool wide8 = m8 && a.planes == 2;
-  if (tall && (a.Hm % 16) == 0 && (long long)a.N * (a.Hm / 16) * (a.Wm / kPW) * ceil_div(a.Cd, 128) >= 256)
+  // (16-row patches unless they would add a mostly empty last patch row: H % 16 in 1..8 is served better by 8-row patches)
+  const bool tall_fits = (a.Hm % 16) == 0 || (a.Hm % 16) > 8;
+  if (tall && tall_fits && (long long)a.N * ceil_div(a.Hm, 16) * ceil_div(a.Wm, kPW) * ceil_div(a.Cd, 128) >= 256)
     return wide8 ? launch_halo<128, 16, 8>(a, stream) : launch_halo<128, 16>(a, stream);
   return wide8 ? launch_halo<128, 8, 8>(a, stream) : launch_halo<128, 8>(a, stream);
 }

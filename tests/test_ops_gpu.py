@@ -41,6 +41,9 @@ CONV_CASES = [
     (4, 32, 128, 128, 128, 3, 1, 1, 1, True),   # LDS-halo kernel, 16x16 patches
     (3, 32, 72, 256, 64, 3, 1, 1, 1, False),    # LDS-halo kernel, non-square, H % 16 != 0 (8-row patches only)
     (3, 16, 96, 320, 128, 3, 1, 1, 1, True),    # LDS-halo kernel, one channel chunk, 16-row patches, W = 20 patches
+    (8, 32, 77, 43, 128, 3, 1, 1, 1, True),     # LDS-halo kernel, patches hanging over both edges (H % 8 = 5, W % 16 = 11)
+    (2, 96, 154, 86, 128, 3, 1, 1, 1, False),   # LDS-halo kernel, ragged patches, 128-wide tile (the FreeNet scene at stride 4)
+    (8, 64, 60, 104, 160, 3, 1, 1, 1, False),   # LDS-halo kernel, 16-row patches with a ragged last row (H % 16 = 12), ragged N tile
 ]
 
 
@@ -435,6 +438,8 @@ BN_EPI_CASES = [
     # the R18 / 64x64 plumbing configuration: a handful of row tiles, one row tile, strided, fewer rows than a tile
     (2, 16, 16, 64, 64, 3, 1, 1, False), (2, 8, 8, 128, 128, 3, 1, 1, False), (2, 16, 16, 64, 128, 3, 2, 1, False),
     (2, 16, 16, 64, 128, 1, 2, 0, False), (2, 6, 6, 64, 64, 3, 1, 1, False),
+    # LDS-halo kernel with patches hanging over the edges of the map: the dropped rows must not enter the records
+    (16, 77, 43, 64, 64, 3, 1, 1, False), (2, 154, 86, 32, 128, 3, 1, 1, False),
 ]
 
 
