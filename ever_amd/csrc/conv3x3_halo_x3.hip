@@ -413,6 +413,9 @@ int launch_conv3x3_halo(IGemmArgs& a, hipStream_t stream) {
     const char* f = getenv("EVK_X3_HALO_FORCE");
     if (f && *f) {
       if (!strcmp(f, "h64x8")) return launch_halo<64, 8>(a, stream);
+      if (!strcmp(f, "m64x8")) return launch_halo<64, 8, 8>(a, stream);
+      if (!strcmp(f, "h64x16")) return launch_halo<64, 16>(a, stream);
+      if (!strcmp(f, "m64x16")) return launch_halo<64, 16, 8>(a, stream);
       if (!strcmp(f, "h128x8") && a.Cd > 64) return launch_halo<128, 8>(a, stream);
       if (!strcmp(f, "h128x16") && a.Cd > 64) return launch_halo<128, 16>(a, stream);
       if (!strcmp(f, "m128x8") && a.Cd > 64) return launch_halo<128, 8, 8>(a, stream);
