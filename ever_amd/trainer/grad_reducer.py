@@ -27,7 +27,7 @@ class _Bucket:
 
 
 class FlatGradDDP(nn.Module):
-    def __init__(self, module, bucket_cap_mb=64, process_group=None, broadcast_buffers=True):
+    def __init__(self, module, bucket_cap_mb=64, process_group=None, broadcast_buffers=True, tail_caps_mb=(4, 32)):
         super().__init__()
         self.module = module
         self.process_group = process_group
@@ -41,17 +41,26 @@ class FlatGradDDP(nn.Module):
             if p.dtype != torch.float32 or p.device != self.device:
                 raise ValueError('FlatGradDDP: parameters must be fp32 on one device')
         self._cuda = self.device.type == 'cuda'
-        # gradients become ready roughly in reverse registration order
-        cap = int(bucket_cap_mb * 1024 * 1024) // 4
-        self.buckets = []
-        cur, cur_n = [], 0
-        for p in reversed(params):
-            if cur and cur_n + p.numel() > cap:
-                self.buckets.append(self._make_bucket(cur))
+        # Gradients become ready roughly in reverse registration order, so buckets are cut from the FRONT of the registration
+        # order and reduced back to front.  The bucket that closes LAST (the first-registered parameters: stem, layer 1 ...) is
+        # the one whose all-reduce nothing can hide — it starts when the backward pass ends — so it is kept small
+        # (`tail_caps_mb[0]`), the one before it medium (its reduction runs under the last, most expensive encoder stage), the
+        # rest at the full cap (xGMI rings are per-link bound: few large collectives).  With one uniform 64 MB cap FarSeg-R50's
+        # 126 MB of gradients made two buckets and the second — 60 MB — closed with the stem's weight gradient: its whole
+        # all-reduce was exposed.  Now: 4 MB exposed, 32 MB under layers 2 / 1, then 64 MB buckets.
+        cap = max(1, int(bucket_cap_mb * 1024 * 1024) // 4)
+        caps = [max(1, min(cap, int(mb * 1024 * 1024) // 4)) for mb in (tail_caps_mb or ())]
+        groups, cur, cur_n = [], [], 0
+        for p in params:
+            this_cap = caps[len(groups)] if len(groups) < len(caps) else cap
+            if cur and cur_n + p.numel() > this_cap:
+                groups.append(cur)
                 cur, cur_n = [], 0
             cur.append(p)
             cur_n += p.numel()
-        self.buckets.append(self._make_bucket(cur))
+        groups.append(cur)
+        # bucket 0 = the last-registered parameters (first to be complete); inside a bucket, readiness order as well
+        self.buckets = [self._make_bucket(list(reversed(g))) for g in reversed(groups)]
         self._bucket_of = {}
         for bi, b in enumerate(self.buckets):
             for pi, p in enumerate(b.params):

@@ -75,3 +75,36 @@ def test_flat_grad_ddp_equals_torch_ddp_two_ranks_gloo():
         assert p.exitcode == 0
     assert res[0][1] and res[1][1], 'FlatGradDDP and torch DDP diverged'
     assert res[0][2] == res[1][2], 'replicas diverged across ranks'
+
+
+def test_the_bucket_that_closes_last_is_small():
+    """Bucket layout (no process group: world 1): cut from the front of the registration order, reduced back to front; the
+    last-closing bucket — the first-registered parameters, whose all-reduce starts when the backward pass ends and nothing
+    hides — stays under tail_caps_mb[0], the one before it under tail_caps_mb[1], the others under the cap; every
+    parameter sits in exactly one bucket and buckets follow the readiness order.  Sizes of a FarSeg-R50-like profile."""
+    sys.path.insert(0, ROOT)
+    from ever_amd.trainer.grad_reducer import FlatGradDDP
+
+    class _Prof(nn.Module):
+        def __init__(self):
+            super().__init__()
+            # floats per "stage" in registration order (stem, layer1..4, head), as 1-D parameters
+            for i, n in enumerate([9_408, 215_808, 1_219_584, 7_098_368, 14_964_736, 8_000_000]):
+                for j in range(4):
+                    self.register_parameter(f's{i}_{j}', nn.Parameter(torch.zeros(n // 4)))
+
+    m = _Prof()
+    flat = FlatGradDDP(m, bucket_cap_mb=64)
+    sizes_mb = [sum(p.numel() for p in b.params) * 4 / 2 ** 20 for b in flat.buckets]
+    assert len(flat.buckets) >= 3, sizes_mb
+    assert sizes_mb[-1] <= 4.0 + 1e-6, sizes_mb            # closes last: exposed
+    assert sizes_mb[-2] <= 32.0 + 1e-6, sizes_mb
+    assert all(s <= 64.0 + 1e-6 for s in sizes_mb), sizes_mb
+    params = list(m.parameters())
+    order = [p for b in flat.buckets for p in b.params]
+    assert len(order) == len(params) and {id(p) for p in order} == {id(p) for p in params}
+    assert [id(p) for p in order] == [id(p) for p in reversed(params)]      # readiness order, bucket after bucket
+    # a uniform cap (the layout until round 4) for comparison: its last bucket held everything below layer 4
+    uniform = FlatGradDDP(_Prof(), bucket_cap_mb=64, tail_caps_mb=())
+    last_mb = sum(p.numel() for p in uniform.buckets[-1].params) * 4 / 2 ** 20
+    assert last_mb > 8 * sizes_mb[-1], (last_mb, sizes_mb)
