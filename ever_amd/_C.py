@@ -112,8 +112,6 @@ SIGNATURES = {
     'evk_relation_bn_workspace_bytes': (c_size_t, [c_i32, c_i32, c_i32]),
     'evk_relation_bn_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, c_i32, c_i32, c_i32, P, c_size_t, P]),
     'evk_bn_bwd_from_partials': (c_int, [P, P, P, P, P, P, P, c_i32, P, P, P, c_i64, c_i32, c_u32, c_i32, P, c_size_t, P, P]),
-    'evk_bn_bwd_from_partials_ex': (c_int, [P, P, P, P, P, P, P, P, c_i32, P, P, P, c_i64, c_i32, c_u32, c_i32, P, c_size_t, P, P]),
-    'evk_conv2d_dgrad_f16x2_bnb': (c_int, [_DP, P, P, P, P, P, P, c_u32, P, P, P, P, P, c_i32, P, P, c_i32, C.POINTER(c_i32), P]),
     'evk_bn_bwd_bits': (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_i64, c_i32, c_u32, c_i32, P, c_size_t, P, P, P]),
     'evk_relu_fwd': (c_int, [P, P, c_i64, P]),
     'evk_relu_bwd': (c_int, [P, P, P, c_i64, P]),

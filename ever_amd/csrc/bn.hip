@@ -1166,16 +1166,6 @@ extern "C" int evk_bn_bwd_from_partials(const float* g, const float* x, const fl
                                         float* dx, float* dgamma, float* dbeta, int64_t rows, int32_t C, uint32_t flags,
                                         int32_t train, void* workspace, size_t workspace_bytes, uint32_t* dx_absmax,
                                         void* stream) {
-  return evk_bn_bwd_from_partials_ex(g, x, gamma, nullptr, save_mean, save_invstd, partial, maxima, nparts, dx, dgamma, dbeta,
-                                     rows, C, flags & ~(uint32_t)EVK_BN_RELU, train, workspace, workspace_bytes, dx_absmax, stream);
-}
-// ... with EVK_BN_RELU: g arrives UNMASKED (a data gradient that left the sums from its epilogue, evk_conv2d_dgrad_f16x2_bnb)
-// and the apply pass rebuilds the mask from x as evk_bn_bwd does without a residual (beta needed for it).
-extern "C" int evk_bn_bwd_from_partials_ex(const float* g, const float* x, const float* gamma, const float* beta,
-                                           const float* save_mean, const float* save_invstd, const float* partial,
-                                           const float* maxima, int32_t nparts, float* dx, float* dgamma, float* dbeta,
-                                           int64_t rows, int32_t C, uint32_t flags, int32_t train, void* workspace,
-                                           size_t workspace_bytes, uint32_t* dx_absmax, void* stream) {
   EVK_REQUIRE(g && x && save_mean && save_invstd && partial && dx && nparts > 0, EVK_E_INVALID, "bn_bwd_from_partials: null pointer");
   EVK_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 2048, EVK_E_UNSUPPORTED, "bn_bwd_from_partials: rows=%lld C=%d",
               (long long)rows, C);
@@ -1192,13 +1182,12 @@ extern "C" int evk_bn_bwd_from_partials_ex(const float* g, const float* x, const
   int rc = check_launch("bn_bwd_final");
   if (rc) return rc;
   const size_t n4 = (size_t)rows * C / 4;
-  const int relu = (flags & EVK_BN_RELU) ? 2 : 0;
   if (pack)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(oneshot_grid(n4)), dim3(256), 0, st, g, x, (const float*)nullptr, save_mean,
-                       save_invstd, coef, gamma, beta, dx, n4, C, relu, dx_absmax, (const uint32_t*)nullptr);
+                       save_invstd, coef, gamma, (const float*)nullptr, dx, n4, C, 0, dx_absmax, (const uint32_t*)nullptr);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(oneshot_grid(n4)), dim3(256), 0, st, g, x, (const float*)nullptr, save_mean,
-                       save_invstd, coef, gamma, beta, dx, n4, C, relu, dx_absmax, (const uint32_t*)nullptr);
+                       save_invstd, coef, gamma, (const float*)nullptr, dx, n4, C, 0, dx_absmax, (const uint32_t*)nullptr);
   return check_launch("bn_bwd_apply");
 }
 

@@ -219,7 +219,7 @@ static int launch_c1(IGemmArgs& a, hipStream_t stream, int dbg) {
   a.tiles_n = ceil_div(a.Cd, BN);
   bn_stats_setup(a, BM, BN, WAVES_M, a.tiles_m);
   size_t lds = (size_t)NST * (BM * kC1Row + 2 * BN * kRowBytes);
-  const size_t scratch = ((size_t)2 * WAVES_M * 32 * (BN / 2 + 4) + (size_t)(WAVES_M - 1) * 2 * kBnXch * (BN / 2)) * sizeof(float);
+  const size_t scratch = ((size_t)2 * WAVES_M * 32 * (BN / 2 + 4) + (size_t)3 * 2 * 3 * (BN / 2)) * sizeof(float);
   if (lds < scratch) lds = scratch;
   static bool attr_set = false;
   if (!attr_set) {

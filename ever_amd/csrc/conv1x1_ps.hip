@@ -481,8 +481,7 @@ bool conv1x1_ps_applicable(const IGemmArgs& a) {
   const int nk = a.Kpad / BK3;
   // (accumulate epilogues and strided destinations stay on conv1x1_dma.hip: the store waves may not read global memory)
   const int tn = ceil_div(a.Cd, kPsBN);
-  // (its store waves take the statistics from the staging image and may not read global memory: no BatchNorm-backward sums)
-  return nk >= 2 && (a.Cd & 3) == 0 && a.Cd >= 64 && a.dense_dst && !a.accum && tn <= 32 && a.bnb_z == nullptr;
+  return nk >= 2 && (a.Cd & 3) == 0 && a.Cd >= 64 && a.dense_dst && !a.accum && tn <= 32;
 }
 
 int launch_conv1x1_ps(IGemmArgs& a, hipStream_t stream) {

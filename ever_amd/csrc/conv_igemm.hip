@@ -444,19 +444,10 @@ extern "C" int evk_conv2d_fwd_x3_res(const evk_conv_desc* d, const float* x, con
   return conv_fwd_any(d, x, nullptr, reinterpret_cast<const uint16_t*>(wsplit), bias, y, flags, stream, residual);
 }
 
-// BatchNorm-backward sums wanted from a data gradient's epilogue (IGemmArgs::bnb_z, igemm_common.hpp)
-struct BnbRequest {
-  const float *z, *mean, *invstd, *gamma, *beta;
-  int relu;
-  float *partial, *maxima;
-  int cap;
-  int parts;   // out: row tiles that left a record (0 = the kernel this shape runs on cannot)
-};
-
 static int conv_dgrad_any(const evk_conv_desc* d, const float* dy, const float* wt, const uint16_t* wt3,
                           const float* accum, float* dx, void* stream, int planes = 3,
                           const uint32_t* a_scale = nullptr, const uint32_t* w_scale = nullptr, uint32_t* out_amax = nullptr,
-                          int dy_packed = 0, const uint32_t* accum_bits = nullptr, BnbRequest* bnb = nullptr) {
+                          int dy_packed = 0, const uint32_t* accum_bits = nullptr) {
   int rc = check_desc(d);
   if (rc) return rc;
   EVK_REQUIRE(dy && (wt || wt3) && dx, EVK_E_INVALID, "conv2d_dgrad: null pointer");
@@ -506,18 +497,9 @@ static int conv_dgrad_any(const evk_conv_desc* d, const float* dy, const float* 
         a.dense_dst = (sh == 1 && sw == 1) ? 1 : 0;
         a.relu = 0;
         a.Kpad = kpad32(a.Ktot);
-        if (bnb && wt3 && a.dense_dst && !accum && d->Cin % 4 == 0) {
-          a.bn_want = 1;
-          a.bn_buf = bnb->partial;
-          a.bn_cap = bnb->cap;
-          a.bnb_z = bnb->z; a.bnb_mean = bnb->mean; a.bnb_invstd = bnb->invstd; a.bnb_gamma = bnb->gamma; a.bnb_beta = bnb->beta;
-          a.bnb_max = bnb->maxima;
-          a.bnb_relu = bnb->relu;
-        }
         rc = wt3 ? launch_conv3x3_halo(a, st) : 1;
         if (rc == 1) rc = wt3 ? launch_igemm_x3(a, st) : launch_igemm(a, st);
         if (rc) return rc;
-        if (bnb) bnb->parts = a.bn_parts;
       }
       woff += wsize;
       woff3 += (size_t)3 * d->Cin * kpad32(py.nt * px.nt * d->Cout);
@@ -564,26 +546,6 @@ extern "C" int evk_conv2d_dgrad_f16x2_masked(const evk_conv_desc* d, const void*
               "conv2d_dgrad_f16x2_masked: stride-1 convolutions with Cin %% 4 == 0, accum distinct from dx");
   return conv_dgrad_any(d, reinterpret_cast<const float*>(dy), nullptr, reinterpret_cast<const uint16_t*>(wsplit_t), accum, dx,
                         stream, 2, dy_absmax, w_absmax, dx_absmax, (flags & EVK_CONV_DY_PACKED) ? 1 : 0, accum_bits);
-}
-
-// The data gradient of a stride-1 convolution whose input came from a BatchNorm (+ ReLU) of this package and has no other
-// reader: beside dx the epilogue leaves the partial sums that BatchNorm's backward starts with (see ever_hip.h).
-extern "C" int evk_conv2d_dgrad_f16x2_bnb(const evk_conv_desc* d, const void* dy, const uint32_t* dy_absmax,
-                                          const void* wsplit_t, const uint32_t* w_absmax, float* dx, uint32_t* dx_absmax,
-                                          uint32_t flags, const float* bn_x, const float* bn_mean, const float* bn_invstd,
-                                          const float* bn_gamma, const float* bn_beta, int32_t bn_relu, float* partial,
-                                          float* maxima, int32_t capacity, int32_t* nparts, void* stream) {
-  EVK_REQUIRE(wsplit_t && dy_absmax && w_absmax && bn_x && bn_mean && bn_invstd && partial && maxima && nparts, EVK_E_INVALID,
-              "conv2d_dgrad_f16x2_bnb: null pointer");
-  EVK_REQUIRE((flags & ~EVK_CONV_DY_PACKED) == 0, EVK_E_INVALID, "conv2d_dgrad_f16x2_bnb: unknown flag 0x%x", flags);
-  EVK_REQUIRE(d && d->stride_h == 1 && d->stride_w == 1, EVK_E_UNSUPPORTED, "conv2d_dgrad_f16x2_bnb: stride-1 convolutions");
-  BnbRequest req{bn_x, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_relu ? 1 : 0, partial, maxima, capacity, 0};
-  *nparts = 0;
-  const int rc = conv_dgrad_any(d, reinterpret_cast<const float*>(dy), nullptr, reinterpret_cast<const uint16_t*>(wsplit_t),
-                                nullptr, dx, stream, 2, dy_absmax, w_absmax, dx_absmax, (flags & EVK_CONV_DY_PACKED) ? 1 : 0,
-                                nullptr, &req);
-  if (rc == EVK_OK) *nparts = req.parts;
-  return rc;
 }
 
 extern "C" int evk_conv2d_dgrad_x3(const evk_conv_desc* d, const float* dy, const void* wsplit_t, const float* accum,

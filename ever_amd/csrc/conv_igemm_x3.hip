@@ -246,7 +246,7 @@ static int launch_cfg3_np(IGemmArgs& a, hipStream_t stream) {
   bn_stats_setup(a, BM, BN, WAVES_M, a.tiles_m);
   size_t lds = (size_t)NBUF * 3 * (BM + BN) * kRowBytes;
   // statistics epilogue: per-wave scratch + the row waves' exchange area
-  const size_t scratch = ((size_t)4 * 32 * (BN / WAVES_N + 4) + (size_t)(WAVES_M - 1) * kBnXch * BN) * sizeof(float);
+  const size_t scratch = ((size_t)4 * 32 * (BN / WAVES_N + 4) + (size_t)3 * BN) * sizeof(float);
   if (lds < scratch) lds = scratch;
   static bool attr_set = false;
   if (!attr_set) {

@@ -43,21 +43,6 @@ struct IGemmArgs {
   // BatchNorm + add + ReLU, the identity branch's gradient is accum where the block's output was positive — masked here, in
   // the epilogue that adds it, instead of being written and re-read as a tensor of its own (evk_bn_bwd: EVK_BN_LAZY_RES)
   const uint32_t* accum_bits;
-  // BatchNorm-BACKWARD partial sums of the OUTPUT from the epilogue (round 4).  A data gradient whose only reader is the
-  // backward of the BatchNorm + ReLU that produced this convolution's input (the two inner activations of a bottleneck):
-  // that backward starts with a reduce pass over (dy, z) for sum g and sum g * xhat per channel, g = dy * (y > 0) — a
-  // latency-bound launch on the backward's critical chain (44 us on average, 32 of them per FarSeg-R50 step).  With
-  // bnb_z set the statistics epilogue (bn_part != nullptr, same conditions) reads the matching tile of z instead, rebuilds
-  // mask and xhat from the BatchNorm's saved statistics exactly as evk_bn_bwd does, and leaves per row tile
-  //   bn_part[tile][2][Cd] = (sum g, sum g * xhat),   bnb_max[tile][2][Cd] = (max |g|, max |xhat|)
-  // — the layout of evk_bn_bwd's own partial pass, consumed by evk_bn_bwd_from_partials_ex.  dst itself is written unmasked.
-  const float* bnb_z;
-  const float* bnb_mean;
-  const float* bnb_invstd;
-  const float* bnb_gamma;   // may be null (no affine)
-  const float* bnb_beta;
-  float* bnb_max;
-  int bnb_relu;             // the BatchNorm was followed by a ReLU (mask from z * sc + sh > 0)
 };
 
 // f16x2 arithmetic: the accumulators hold (x / s_a) * (w / s_w) sums; multiply by s_a * s_w before the epilogue
@@ -213,13 +198,11 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
 struct BnLaneStat {
   float n;
   f32x4 piv, s, q;
-  f32x4 xm;     // BatchNorm-backward mode (IGemmArgs::bnb_z): s = sum g, q = sum g * xhat, piv = max |g|, xm = max |xhat|
 };
 __device__ __forceinline__ void bn_stat_init(BnLaneStat& st) {
   st.n = 0.f;
-  st.piv = st.s = st.q = st.xm = f32x4{0.f, 0.f, 0.f, 0.f};
+  st.piv = st.s = st.q = f32x4{0.f, 0.f, 0.f, 0.f};
 }
-constexpr int kBnXch = 4;   // f32x4 slots per record in the row waves' LDS exchange (3 in statistics mode, 4 in backward mode)
 
 // roff: element offset of THIS lane's row (row li of the block) in dst, or ~0 when the row is outside the tensor
 template <int NB, int WN>
@@ -240,47 +223,6 @@ __device__ __forceinline__ void igemm_store_rows_stats(const IGemmArgs& p, f32x1
   f32x4 bias = {0.f, 0.f, 0.f, 0.f};
   if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + col);
   const uint32_t ro_lo = (uint32_t)roff, ro_hi = (uint32_t)(roff >> 32);
-  if (p.bnb_z != nullptr) {
-    // ---- BatchNorm-backward sums of this block (see IGemmArgs::bnb_z).  The z loads of a chunk of rows are issued before
-    // its stores: gfx9 counts loads and stores in one in-order vmcnt, a load behind a store waits for that store.
-    const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 mu = *reinterpret_cast<const f32x4*>(p.bnb_mean + col), is = *reinterpret_cast<const f32x4*>(p.bnb_invstd + col);
-    const f32x4 sc = (p.bnb_gamma ? *reinterpret_cast<const f32x4*>(p.bnb_gamma + col) : one4) * is;
-    const f32x4 sh = (p.bnb_beta ? *reinterpret_cast<const f32x4*>(p.bnb_beta + col) : zero4) - mu * sc;
-    constexpr int NIT = 32 / RPI, CH = NIT < 8 ? NIT : 8;
-#pragma unroll
-    for (int it0 = 0; it0 < NIT; it0 += CH) {
-      size_t ros[CH];
-      f32x4 zt[CH];
-#pragma unroll
-      for (int u = 0; u < CH; ++u) {
-        const int r = (it0 + u) * RPI + rsub;
-        ros[u] = ((size_t)(uint32_t)__shfl((int)ro_hi, r, 64) << 32) | (uint32_t)__shfl((int)ro_lo, r, 64);
-        zt[u] = ros[u] != ~(size_t)0 ? *reinterpret_cast<const f32x4*>(p.bnb_z + ros[u] + col) : zero4;
-      }
-#pragma unroll
-      for (int u = 0; u < CH; ++u) {
-        const int r = (it0 + u) * RPI + rsub;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + r * P + c4) + bias;
-        if (ros[u] == ~(size_t)0) continue;
-        *reinterpret_cast<f32x4*>(p.dst + ros[u] + col) = v;
-        f32x4 g = v;
-        if (p.bnb_relu) {
-          const f32x4 yy = zt[u] * sc + sh;
-          g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
-          g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
-        }
-        const f32x4 xh = (zt[u] - mu) * is;
-        st.s += g;
-        st.q += g * xh;
-        st.piv.x = fmaxf(st.piv.x, fabsf(g.x)); st.piv.y = fmaxf(st.piv.y, fabsf(g.y));
-        st.piv.z = fmaxf(st.piv.z, fabsf(g.z)); st.piv.w = fmaxf(st.piv.w, fabsf(g.w));
-        st.xm.x = fmaxf(st.xm.x, fabsf(xh.x)); st.xm.y = fmaxf(st.xm.y, fabsf(xh.y));
-        st.xm.z = fmaxf(st.xm.z, fabsf(xh.z)); st.xm.w = fmaxf(st.xm.w, fabsf(xh.w));
-      }
-    }
-    return;
-  }
 #pragma unroll
   for (int it = 0; it < 32 / RPI; ++it) {
     const int r = it * RPI + rsub;
@@ -306,55 +248,6 @@ __device__ __forceinline__ void bn_part_write(const IGemmArgs& p, const BnLaneSt
                                               int lane, float* xch) {
   constexpr int LPR = WN / 4;
   static_assert(WAVES_M == 1 || WAVES_M == 2 || WAVES_M == 4, "row waves per tile");
-  if (p.bnb_z != nullptr) {
-    // ---- BatchNorm-backward mode: plain sums and maxima, merged in the same fixed order as the statistics records
-    f32x4 s = st.s, q = st.q, gm = st.piv, xm = st.xm;
-    auto mx4 = [](f32x4 a, const f32x4 b) {
-      a.x = fmaxf(a.x, b.x); a.y = fmaxf(a.y, b.y); a.z = fmaxf(a.z, b.z); a.w = fmaxf(a.w, b.w);
-      return a;
-    };
-#pragma unroll
-    for (int off = LPR; off < 64; off <<= 1) {
-      f32x4 s2, q2, g2, x2;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        s2[e] = __shfl_xor(s[e], off, 64); q2[e] = __shfl_xor(q[e], off, 64);
-        g2[e] = __shfl_xor(gm[e], off, 64); x2[e] = __shfl_xor(xm[e], off, 64);
-      }
-      s += s2; q += q2; gm = mx4(gm, g2); xm = mx4(xm, x2);
-    }
-    if (WAVES_M > 1) {
-      float* x = xch + ((wm > 0 ? wm - 1 : 0) * WAVES_N + wn) * kBnXch * WN + lane * 4;
-      if (wm >= 1 && lane < LPR) {
-        *reinterpret_cast<f32x4*>(x) = s;
-        *reinterpret_cast<f32x4*>(x + WN) = q;
-        *reinterpret_cast<f32x4*>(x + 2 * WN) = gm;
-        *reinterpret_cast<f32x4*>(x + 3 * WN) = xm;
-      }
-      __syncthreads();
-      if (wm >= 1) return;
-      if (lane < LPR) {
-#pragma unroll
-        for (int o = 0; o < WAVES_M - 1; ++o) {
-          const float* y = xch + (o * WAVES_N + wn) * kBnXch * WN + lane * 4;
-          s += *reinterpret_cast<const f32x4*>(y);
-          q += *reinterpret_cast<const f32x4*>(y + WN);
-          gm = mx4(gm, *reinterpret_cast<const f32x4*>(y + 2 * WN));
-          xm = mx4(xm, *reinterpret_cast<const f32x4*>(y + 3 * WN));
-        }
-      }
-    }
-    if (lane < LPR) {
-      const int col = n0 + wn * WN + lane * 4;
-      float* rec = p.bn_part + (size_t)tile * 2 * p.Cd + col;
-      *reinterpret_cast<f32x4*>(rec) = s;
-      *reinterpret_cast<f32x4*>(rec + p.Cd) = q;
-      float* rmx = p.bnb_max + (size_t)tile * 2 * p.Cd + col;
-      *reinterpret_cast<f32x4*>(rmx) = gm;
-      *reinterpret_cast<f32x4*>(rmx + p.Cd) = xm;
-    }
-    return;
-  }
   float n = st.n;
   const float inv = n > 0.f ? 1.f / n : 0.f;
   f32x4 mean = st.piv + st.s * inv;
@@ -379,7 +272,7 @@ __device__ __forceinline__ void bn_part_write(const IGemmArgs& p, const BnLaneSt
     merge(n2, mean2, m22);
   }
   if (WAVES_M == 2) {
-    float* x = xch + wn * kBnXch * WN + lane * 4;
+    float* x = xch + wn * 3 * WN + lane * 4;
     if (wm == 1 && lane < LPR) {
       *reinterpret_cast<f32x4*>(x) = f32x4{n, n, n, n};
       *reinterpret_cast<f32x4*>(x + WN) = mean;
@@ -390,7 +283,7 @@ __device__ __forceinline__ void bn_part_write(const IGemmArgs& p, const BnLaneSt
     if (lane < LPR) merge(x[0], *reinterpret_cast<const f32x4*>(x + WN), *reinterpret_cast<const f32x4*>(x + 2 * WN));
   }
   if (WAVES_M == 4) {   // (xch: 3 x WAVES_N x 3 x WN floats) row waves 1..3 park their record, row wave 0 merges them in order
-    float* x = xch + ((wm > 0 ? wm - 1 : 0) * WAVES_N + wn) * kBnXch * WN + lane * 4;
+    float* x = xch + ((wm > 0 ? wm - 1 : 0) * WAVES_N + wn) * 3 * WN + lane * 4;
     if (wm >= 1 && lane < LPR) {
       *reinterpret_cast<f32x4*>(x) = f32x4{n, n, n, n};
       *reinterpret_cast<f32x4*>(x + WN) = mean;
@@ -401,7 +294,7 @@ __device__ __forceinline__ void bn_part_write(const IGemmArgs& p, const BnLaneSt
     if (lane < LPR) {
 #pragma unroll
       for (int o = 0; o < 3; ++o) {
-        const float* y = xch + (o * WAVES_N + wn) * kBnXch * WN + lane * 4;
+        const float* y = xch + (o * WAVES_N + wn) * 3 * WN + lane * 4;
         merge(y[0], *reinterpret_cast<const f32x4*>(y + WN), *reinterpret_cast<const f32x4*>(y + 2 * WN));
       }
     }
@@ -416,7 +309,7 @@ __device__ __forceinline__ void bn_part_write(const IGemmArgs& p, const BnLaneSt
 }
 
 // the row-linear kernels' epilogue in statistics mode (dense destination, Cd % 4 == 0, whole column blocks).
-// scratch_base: LDS area of (waves x 32 x (WN + 4) + (WAVES_M - 1) x WAVES_N x kBnXch x WN) floats, free of other use
+// scratch_base: LDS area of (waves x 32 x (WN + 4) + WAVES_N x 3 x WN) floats, free of other use
 template <int MB, int NB, int WM, int WN, int WAVES_M, int WAVES_N>
 __device__ __forceinline__ void igemm_epilogue_stats(const IGemmArgs& p, f32x16 (&acc)[MB][NB], int m0, int n0, int wm, int wn,
                                                      int li, int lh, float* scratch_base) {

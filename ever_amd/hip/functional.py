@@ -172,10 +172,6 @@ def get_conv_math():
 
 # BatchNorm statistics from the producing convolution's epilogue (EVK_BN_EPILOGUE=0: BatchNorm's own statistics pass)
 _BN_EPILOGUE = os.environ.get('EVK_BN_EPILOGUE', '1') != '0'
-# BatchNorm BACKWARD sums from the epilogue of the data gradient that produces the BatchNorm's output gradient (the inner
-# BatchNorms of a bottleneck; include/ever_hip.h: evk_conv2d_dgrad_f16x2_bnb).  EVK_BNB_DGRAD=0: BatchNorm's own reduce pass
-_BNB_DGRAD = os.environ.get('EVK_BNB_DGRAD', '1') != '0'
-bnb_stats = {'fused': 0, 'declined': 0}
 # f16x2: activations that only convolutions read are stored already split ("packed", include/ever_hip.h:
 # evk_pack_f16x2) by the BatchNorm pass that writes them (EVK_PACKED=0: fp32 everywhere, split while staging)
 _PACKED = os.environ.get('EVK_PACKED', '1') != '0'
@@ -721,7 +717,7 @@ class _ConvState:
     its own node forms no reference cycle, in-place writes to a saved tensor are caught by the version check, and
     saved-tensor hooks (activation checkpointing, offloading) see them."""
     __slots__ = ('desc', 'relu', 'cin', 'has_bias', 'flops', 'abytes', 'w_stride', 'xk', 'w_ohwi', 'y', 'weight',
-                 'w_alias', 'scope', 'bn_parts', 'bias_leaf', 'bnb')
+                 'w_alias', 'scope', 'bn_parts', 'bias_leaf')
 
 
 def _stash(states):
@@ -747,7 +743,6 @@ def _drop(states):
     caching allocator that has to grow (hipMalloc inside the step) whenever the collector is late."""
     for cs in states:
         cs.xk = cs.y = cs.weight = cs.w_ohwi = cs.bias_leaf = None
-        cs.bnb = None
 
 
 def _conv_forward(x, weight, bias, stride, padding, dilation, relu, want_stats=False):
@@ -830,10 +825,6 @@ def _conv_forward(x, weight, bias, stride, padding, dilation, relu, want_stats=F
     # xk (channel-padded copy when Cin % 4 != 0) is what wgrad reads
     cs.xk, cs.w_ohwi, cs.y, cs.weight = xk, w_ohwi, (y if relu else None), weight
     cs.bn_parts = bn_parts
-    # x is the output of a training-mode BatchNorm (+ ReLU) that this convolution alone reads (batch_norm_act(pack_out=True)):
-    # its data gradient can leave that BatchNorm's backward sums from its epilogue (_conv_backward, EVK_BNB_DGRAD)
-    src = x.__dict__.get('_evk_bn_src') if _BNB_DGRAD else None
-    cs.bnb = src if (src is not None and src[0] == x._version and src[1] == x.data_ptr()) else None
     return y, cs
 
 
@@ -903,22 +894,6 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False,
                 relu_bits_stats['masked_dgrad'] += 1
                 _C.call('evk_conv2d_dgrad_f16x2_masked', ctypes.byref(dk), dy_ptr, dybits.data_ptr(), pl_ptr, wabs_ptr,
                         acc_ptr, accum_bits.data_ptr(), dx.data_ptr(), _ptr(dxbits), 4 if dy_pk else 0, st)
-            elif (cs.bnb is not None and acc_ptr is None and not narrow8 and d.stride_h == 1 and d.stride_w == 1
-                  and not observers_active()):
-                # the only reader of dx is the backward of the BatchNorm that made x: leave its sums from this epilogue
-                _v, _p, bz, bmean, binv, bgamma, bbeta, brelu = cs.bnb
-                cap = n * d.H * d.W // 64 + 1
-                part = torch.empty((2, cap * 2 * cin), device=dev, dtype=torch.float32)
-                npart = ctypes.c_int32(0)
-                _C.call('evk_conv2d_dgrad_f16x2_bnb', ctypes.byref(dk), dy_ptr, dybits.data_ptr(), pl_ptr, wabs_ptr,
-                        dx.data_ptr(), _ptr(dxbits), 4 if dy_pk else 0, bz.data_ptr(), bmean.data_ptr(), binv.data_ptr(),
-                        _ptr(bgamma), _ptr(bbeta), 1 if brelu else 0, part[0].data_ptr(), part[1].data_ptr(), cap,
-                        ctypes.byref(npart), st)
-                if npart.value > 0:
-                    bnb_stats['fused'] += 1
-                    dx._evk_bnb = (bz.data_ptr(), part, int(npart.value))
-                else:
-                    bnb_stats['declined'] += 1
             else:
                 _C.call('evk_conv2d_dgrad_f16x2_ex', ctypes.byref(dk), dy_ptr, dybits.data_ptr(), pl_ptr, wabs_ptr, acc_ptr,
                         dx.data_ptr(), _ptr(dxbits), 4 if dy_pk else 0, st)
@@ -1050,11 +1025,12 @@ class _Conv2dFn(Function):
     """
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, dilation, relu, want_stats=False):
+    def forward(ctx, x, weight, bias, stride, padding, dilation, relu, want_stats=False, slot=None):
         y, cs = _conv_forward(x, weight, bias, stride, padding, dilation, relu, want_stats)
         if any(ctx.needs_input_grad):
             _note_param_use(weight, bias)
         ctx.cs = cs
+        ctx.slot = slot
         ctx.save_for_backward(*_stash([cs]))
         _BN_HANDOFF[0] = cs.bn_parts      # picked up by conv2d() right after apply (same thread, no autograd in between)
         cs.bn_parts = None
@@ -1065,12 +1041,18 @@ class _Conv2dFn(Function):
     def backward(ctx, dy):
         cs = ctx.cs
         _unstash([cs], ctx.saved_tensors)
+        acc = None
+        if ctx.slot is not None:     # a later consumer's gradient of x, parked by _SlotOutFn: summed in the epilogue below
+            ctx.slot.consumed = True
+            acc, ctx.slot.grad = ctx.slot.grad, None
         try:
+            if acc is not None and not ctx.needs_input_grad[0]:
+                acc = None
             dx, dw, db = _conv_backward(cs, dy, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                        cs.has_bias and ctx.needs_input_grad[2])
+                                        cs.has_bias and ctx.needs_input_grad[2], accum=acc)
         finally:
             _drop([cs])
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 _BN_HANDOFF = [None, None]   # statistics records of the convolution(s) that just ran: [main, shortcut]
@@ -1119,14 +1101,21 @@ def grouped_dense_weight(weight, groups):
     return dense
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, bn_stats=False):
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, bn_stats=False, grad_slot=None):
     """bn_stats=True: the caller applies a training-mode BatchNorm to the result next; where the kernel can, the
     epilogue leaves that BatchNorm's partial statistics on the returned tensor (`_evk_bn_parts`) and
-    batch_norm_act() skips its own statistics pass over it."""
+    batch_norm_act() skips its own statistics pass over it.
+    grad_slot: a GradSlot this convolution CLAIMS — x has a second, LATER consumer that was handed slot_output(x, slot); its
+    gradient is parked there (backward runs it first) and added inside this convolution's data-gradient epilogue."""
     _require_cuda(x, 'conv2d')
     x = as_nhwc(x, 'conv2d')
     _BN_HANDOFF[0] = None
-    y = _Conv2dFn.apply(x, weight, bias, _pair(stride), _pair(padding), _pair(dilation), bool(relu), bool(bn_stats))
+    if grad_slot is not None:
+        if x.shape[1] % 8 or not _planes_math() or not (torch.is_grad_enabled() and x.requires_grad) or grad_slot.claimed:
+            grad_slot = None        # (no accumulate epilogue on this path, or nothing to differentiate)
+        else:
+            grad_slot.claimed = True
+    y = _Conv2dFn.apply(x, weight, bias, _pair(stride), _pair(padding), _pair(dilation), bool(relu), bool(bn_stats), grad_slot)
     parts, _BN_HANDOFF[0] = _BN_HANDOFF[0], None
     return _attach_parts(y, parts)
 
@@ -1525,11 +1514,8 @@ class _BatchNormActFn(Function):
             _timed_call('bn', nb, 'evk_bn_fwd_eval', x.data_ptr(), _ptr(residual), _ptr(weight), _ptr(bias), running_mean.data_ptr(),
                     running_var.data_ptr(), float(eps), y.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(),
                     rows, c, flags, ws.data_ptr(), ws_bytes, _ptr(abits), st)
-        global _AMAX_HANDOFF, _BNB_HANDOFF
+        global _AMAX_HANDOFF
         _AMAX_HANDOFF = (abits, pack)
-        # (a convolution that is this output's only reader may leave this BatchNorm's backward sums from its data gradient)
-        _BNB_HANDOFF = (x, save_mean, save_invstd, weight, bias, bool(relu)) if (
-            _BNB_DGRAD and pack_out and training and residual is None and not observers_active()) else None
         ctx.training = training
         ctx.pack_dx = bool(parts is not None and len(parts) > 2 and parts[2])
         ctx.relu = relu
@@ -1573,21 +1559,6 @@ class _BatchNormActFn(Function):
         mask_bits = rbits if rbits is not None else in_bits
         if in_bits is not None:
             relu_bits_stats['masked_bn'] += 1
-        rec = dy.__dict__.get('_evk_bnb')
-        if (rec is not None and rec[0] == x.data_ptr() and mask_bits is None and y is None and dres is None
-                and not ctx.has_res):
-            # the data gradient that wrote dy left (sum g, sum g xhat) and the maxima per row tile: no reduce pass
-            _timed_call('bn', 4.0 * x.numel() * 3, 'evk_bn_bwd_from_partials_ex', dy.data_ptr(), x.data_ptr(), _ptr(weight),
-                        _ptr(bias), save_mean.data_ptr(), save_invstd.data_ptr(), rec[1][0].data_ptr(), rec[1][1].data_ptr(),
-                        rec[2], dx.data_ptr(), _ptr(dgamma), _ptr(dbeta), rows, c,
-                        (1 if ctx.relu else 0) | (2 if pack else 0), 1 if ctx.training else 0, ws.data_ptr(), ws_bytes,
-                        _ptr(abits), st)
-            if pack:
-                _mark_packed(dx, abits)
-            elif abits is not None:
-                _note_amax(dx, abits)
-            return (dx, None, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None,
-                    None, None, None, None, None, None, None, None, None)
         _timed_call('bn', nb, 'evk_bn_bwd_bits', dy.data_ptr(), x.data_ptr(), _ptr(y), _ptr(weight), _ptr(bias),
                     save_mean.data_ptr(), save_invstd.data_ptr(), dx.data_ptr(), _ptr(dres), _ptr(dgamma), _ptr(dbeta), rows, c,
                     (1 if ctx.relu else 0) | (2 if pack else 0),
@@ -1625,9 +1596,8 @@ def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentu
     parts = getattr(x, '_evk_bn_parts', None) if use_batch_stats else None
     if parts is not None:
         del x._evk_bn_parts
-    global _AMAX_HANDOFF, _BNB_HANDOFF
+    global _AMAX_HANDOFF
     _AMAX_HANDOFF = None
-    _BNB_HANDOFF = None
     if use_batch_stats and running_mean is not None:
         weight_planes.note_running_stats_changed()
     y = _BatchNormActFn.apply(x, residual, weight, bias, running_mean, running_var, bool(use_batch_stats),
@@ -1639,15 +1609,10 @@ def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentu
         elif abits is not None:
             _note_amax(y, abits)
         _AMAX_HANDOFF = None
-    if _BNB_HANDOFF is not None:
-        if y.requires_grad:
-            y._evk_bn_src = (y._version, y.data_ptr()) + _BNB_HANDOFF
-        _BNB_HANDOFF = None
     return y
 
 
 _AMAX_HANDOFF = None
-_BNB_HANDOFF = None
 
 
 class _BnReluPoolFn(Function):
@@ -2486,7 +2451,7 @@ _conv2d_plain = conv2d
 conv2d = _oplib.traceable(
     'conv2d', '(Tensor x, Tensor weight, Tensor? bias, int[] stride, int[] padding, int[] dilation, bool relu) -> Tensor',
     _conv2d_plain, impl_fn=lambda x, w, b, s, p, d, relu: _conv2d_plain(x, w, b, tuple(s), tuple(p), tuple(d), relu=relu),
-    adapt=lambda x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, bn_stats=False:
+    adapt=lambda x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, bn_stats=False, grad_slot=None:
         (x, weight, bias, _l2(stride), _l2(padding), _l2(dilation), bool(relu)),
     fake=lambda x, w, b, s, p, d, relu: _oplib.nhwc_like(
         x, x.shape[0], w.shape[0], _conv_out(x.shape[2], w.shape[2], s[0], p[0], d[0]), _conv_out(x.shape[3], w.shape[3], s[1], p[1], d[1])))

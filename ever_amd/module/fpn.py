@@ -58,12 +58,32 @@ class FPN(nn.Module):
     def forward(self, x):
         """x: feature maps, highest resolution first -> tuple of FPN maps, highest resolution first."""
         last_inner = getattr(self, self.inner_blocks[-1])(x[-1])
-        results = [getattr(self, self.layer_blocks[-1])(last_inner)]
-        for feat, inner, layer in zip(x[:-1][::-1], self.inner_blocks[:-1][::-1], self.layer_blocks[:-1][::-1]):
+        out, top = self._output_conv(self.layer_blocks[-1], last_inner, len(self.inner_blocks) > 1)
+        results = [out]
+        names = list(zip(x[:-1][::-1], self.inner_blocks[:-1][::-1], self.layer_blocks[:-1][::-1]))
+        for i, (feat, inner, layer) in enumerate(names):
             lateral = getattr(self, inner)(feat)
-            last_inner = HF.upsample_nearest2x_add(last_inner, lateral)  # lateral + nearest_x2(top), one pass
-            results.insert(0, getattr(self, layer)(last_inner))
+            last_inner = HF.upsample_nearest2x_add(top, lateral)  # lateral + nearest_x2(top), one pass
+            out, top = self._output_conv(layer, last_inner, i + 1 < len(names))
+            results.insert(0, out)
         return tuple(results)
+
+    def _output_conv(self, layer, last_inner, has_finer_level):
+        """(P_k, the tensor to hand to the next finer level).  last_inner_k feeds its 3x3 output convolution AND, later in the
+        forward, the top-down path of level k - 1; backward runs that later consumer first, so its gradient is parked in a
+        GradSlot and added inside the output convolution's data-gradient epilogue (hip/functional.py: GradSlot) instead of by
+        autograd's own add pass over a 256-channel map — which also left a tensor without an operand scale behind, i.e. a
+        stand-alone absmax pass in front of the two gradient kernels that read it."""
+        block = getattr(self, layer)
+        conv = block[0] if isinstance(block, nn.Sequential) and len(block) == 3 else None
+        plain = (conv is not None and type(conv) is Conv2d and isinstance(block[1], nn.Identity) and isinstance(block[2], nn.Identity)
+                 and conv.groups == 1 and not (block._forward_hooks or block._forward_pre_hooks or conv._forward_hooks
+                                               or conv._forward_pre_hooks))
+        if not (has_finer_level and plain and HF.grad_slots_enabled() and last_inner.requires_grad):
+            return block(last_inner), last_inner
+        slot = HF.GradSlot()
+        out = HF.conv2d(last_inner, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, grad_slot=slot)
+        return out, (HF.slot_output(last_inner, slot) if slot.claimed else last_inner)
 
 
 class AssymetricDecoder(nn.Module):

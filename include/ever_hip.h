@@ -196,21 +196,6 @@ int evk_conv2d_dgrad_f16x2_ex(const evk_conv_desc* d, const void* dy, const uint
 int evk_conv2d_dgrad_f16x2_masked(const evk_conv_desc* d, const void* dy, const uint32_t* dy_absmax, const void* wsplit_t,
                                   const uint32_t* w_absmax, const float* accum, const uint32_t* accum_bits, float* dx,
                                   uint32_t* dx_absmax, uint32_t flags, void* stream);
-/* dx = dgrad(dy) of a stride-1 convolution whose INPUT was the output of a training-mode BatchNorm (+ ReLU) and has no other
- * reader (the two inner activations of a bottleneck: reference ever/module/_resnets.py:95-108, `bn1 -> relu -> conv2`,
- * `bn2 -> relu -> conv3`).  Autograd would hand dx to native_batch_norm_backward, whose first act is a reduction over (dx, x_bn)
- * for sum g and sum g * xhat per channel, g = dx * (y > 0): a latency-bound launch on the backward's critical chain.  Here the
- * epilogue that writes dx reads the matching tile of bn_x (the BatchNorm's input), rebuilds mask and xhat from the saved
- * statistics exactly as evk_bn_bwd does (bn_relu: y = bn_x * gamma * invstd + (beta - mean * gamma * invstd) > 0) and leaves,
- * per row tile, partial[tile][2][Cin] = (sum g, sum g * xhat) and maxima[tile][2][Cin] = (max |g|, max |xhat|) — the layout of
- * evk_bn_bwd's own partial pass, to be consumed by evk_bn_bwd_from_partials_ex(..., EVK_BN_RELU, ...).  dx itself is written
- * UNMASKED.  *nparts = row tiles written, 0 when the kernel this shape runs on cannot (the caller then runs evk_bn_bwd);
- * capacity: records that fit `partial` / `maxima` (N H W / 64 + 1 is always enough).  bn_gamma / bn_beta may be NULL. */
-int evk_conv2d_dgrad_f16x2_bnb(const evk_conv_desc* d, const void* dy, const uint32_t* dy_absmax, const void* wsplit_t,
-                               const uint32_t* w_absmax, float* dx, uint32_t* dx_absmax, uint32_t flags, const float* bn_x,
-                               const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
-                               int32_t bn_relu, float* partial, float* maxima, int32_t capacity, int32_t* nparts,
-                               void* stream);
 int evk_conv2d_wgrad_f16x2_ex(const evk_conv_desc* d, const void* x, const uint32_t* x_absmax, const void* dy,
                               const uint32_t* dy_absmax, float* dw, float* dbias, void* workspace,
                               size_t workspace_bytes, uint32_t flags, void* stream);
@@ -606,12 +591,6 @@ int evk_bn_bwd_from_partials(const float* g, const float* x, const float* gamma,
                              const float* save_invstd, const float* partial, const float* maxima, int32_t nparts, float* dx,
                              float* dgamma, float* dbeta, int64_t rows, int32_t C, uint32_t flags, int32_t train,
                              void* workspace, size_t workspace_bytes, uint32_t* dx_absmax, void* stream);
-/* the same from records a data gradient left (evk_conv2d_dgrad_f16x2_bnb): with EVK_BN_RELU in flags g arrives UNMASKED and
- * the apply pass rebuilds the ReLU mask from x, gamma, beta and the saved statistics as evk_bn_bwd does without a residual. */
-int evk_bn_bwd_from_partials_ex(const float* g, const float* x, const float* gamma, const float* beta, const float* save_mean,
-                                const float* save_invstd, const float* partial, const float* maxima, int32_t nparts, float* dx,
-                                float* dgamma, float* dbeta, int64_t rows, int32_t C, uint32_t flags, int32_t train,
-                                void* workspace, size_t workspace_bytes, uint32_t* dx_absmax, void* stream);
 
 /* BatchNorm + ReLU + a narrow 1x1 convolution as ONE consumer of a convolution output z (the decoder's classifier applied
  * per branch: reference fpn.py:163-170 `conv3x3 -> BN -> ReLU`, :179-193 the 1x1 classifier; ever_amd/module/fpn.py runs the
