@@ -1,3 +1,9 @@
+"""dev tool (GPU box): one workload's step time in THIS tree, to be run from two trees on one box — the comparison that an
+in-build switch cannot make (a change to a shared epilogue alters the registers of every kernel that instantiates it, on
+both sides of the switch: DESIGN 2.9).  Workflow (build container):
+    git worktree add -f _r03 <older commit>; make -C _r03/ever_amd/csrc -j; cp tools/ab_tree.py _r03/tools/
+    gpurun -- 'for c in c2 c5; do (cd _r03 && python tools/ab_tree.py $c); python tools/ab_tree.py $c; done'
+(_r03/ is in .git/info/exclude; its built library travels with the snapshot.)  usage: python tools/ab_tree.py c2|c3|c4|c5"""
 import sys, os, torch, time
 sys.path.insert(0, os.getcwd())
 import bench, ever_amd as er
