@@ -212,6 +212,7 @@ _cuda_set_stream = getattr(torch._C, '_cuda_setStream', None)
 
 
 _WGRAD_QUEUE = []                # (device, launch closure) of weight gradients not issued yet
+_WGRAD_EARLY = os.environ.get('EVK_WGRAD_EARLY', '0') == '1'
 _WGRAD_BATCH = max(1, int(os.environ.get('EVK_WGRAD_BATCH', '1')))   # (8, 16, 32 measured: 524 vs 531 tiles/s for 1, same box)
 
 
@@ -872,148 +873,164 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False,
                      d.dil_h, d.dil_w)
     dx = dw = db = None
     taps = kh * kw
-    if need_dx and x3 and cin_p == cin and (narrow8 or (cout_p == cout and cout % 8 == 0)):
-        if narrow8:     # zero rows appended to the (tiny) weight: a transient copy, split on every call
-            w_src = torch.zeros((cout_p, taps, cin), device=dev, dtype=torch.float32)
-            w_src[:cout].copy_(w_ohwi.permute(0, 2, 3, 1).reshape(cout, taps, cin))
-        else:
-            w_src = w_ohwi
-        pl_ptr, wabs_ptr, _keep = _weight_planes(cs.weight, w_src, w_src.data_ptr(), dk, 1, st, dev)
-        acc_ptr = None
-        if accum is not None:
-            accum = as_nhwc(accum, 'conv2d.backward.accum')
-            acc_ptr = accum.data_ptr()
-        dx = accum if (inplace and accum is not None) else empty_nhwc(n, cin, d.H, d.W, dev)
-        dybits = absmax_bits(dyk, st) if wabs_ptr is not None else None
-        sp = timing.span('conv_igemm', cs.flops, cs.abytes, cs.scope)
-        if wabs_ptr is not None:
-            # in place: the slots the main branch's launch raised stay (an upper bound is all a scale needs)
-            hit = getattr(dx, '_evk_amax', None) if inplace else None
-            dxbits = hit[2] if hit is not None else _amax_zeroed(dev)
-            if accum_bits is not None and acc_ptr is not None:
-                relu_bits_stats['masked_dgrad'] += 1
-                _C.call('evk_conv2d_dgrad_f16x2_masked', ctypes.byref(dk), dy_ptr, dybits.data_ptr(), pl_ptr, wabs_ptr,
-                        acc_ptr, accum_bits.data_ptr(), dx.data_ptr(), _ptr(dxbits), 4 if dy_pk else 0, st)
-            else:
-                _C.call('evk_conv2d_dgrad_f16x2_ex', ctypes.byref(dk), dy_ptr, dybits.data_ptr(), pl_ptr, wabs_ptr, acc_ptr,
-                        dx.data_ptr(), _ptr(dxbits), 4 if dy_pk else 0, st)
-            if dxbits is not None:
-                _note_amax(dx, dxbits)
-        else:
-            _C.call(_entry('evk_conv2d_dgrad_x3'), ctypes.byref(dk), dy_ptr, pl_ptr, acc_ptr, dx.data_ptr(), st)
-        if sp is not None:
-            sp.stop()
-    elif need_dx:
-        # weights as [cout_p][taps][cin_p]
-        if cin_p != cin or cout_p != cout:
-            wfull = torch.zeros((cout_p, taps, cin_p), device=dev, dtype=torch.float32)
-            tmp = (_pad_last(w_ohwi.data_ptr(), cout * taps, cin, cin_p, dev) if cin_p != cin
-                   else w_ohwi.permute(0, 2, 3, 1))  # OHWI memory order
-            wfull[:cout].copy_(tmp.reshape(cout, taps, cin_p))
-            w_src = wfull
-        else:
-            w_src = w_ohwi
-        wt = torch.empty((cin_p, taps, cout_p), device=dev, dtype=torch.float32)
-        _C.call('evk_conv2d_pack_dgrad_weight', ctypes.byref(dk), w_src.data_ptr(), wt.data_ptr(), st)
-        acc_ptr = None
-        if accum is not None:
-            if cin_p != cin:
-                raise HipPathError('conv2d.backward: accum with channel-padded inputs is not supported')
-            accum = as_nhwc(accum, 'conv2d.backward.accum')
-            acc_ptr = accum.data_ptr()
-        dxk = empty_nhwc(n, cin_p, d.H, d.W, dev)
-        sp = timing.span('conv_igemm_f32', cs.flops, cs.abytes, cs.scope)
-        _C.call('evk_conv2d_dgrad', ctypes.byref(dk), dy_ptr, wt.data_ptr(), acc_ptr, dxk.data_ptr(), st)
-        if sp is not None:
-            sp.stop()
-        if cin_p != cin:
-            dx = empty_nhwc(n, cin, d.H, d.W, dev)
-            _C.call('evk_unpad_channels', dxk.data_ptr(), dx.data_ptr(), n * d.H * d.W, cin_p, cin, st)
-        else:
-            dx = dxk
-    if need_dw or need_db:
-        lib = _C.load()
-        ws_bytes = (lib.evk_conv2d_wgrad_x3_workspace_bytes if x3 else lib.evk_conv2d_wgrad_workspace_bytes)(
-            ctypes.byref(dk))
-        dwk = torch.empty((cout_p, taps, cin_p), device=dev, dtype=torch.float32)
-        dbk = torch.empty((cout_p,), device=dev, dtype=torch.float32) if need_db else None
-        # (the gradient comes in OHWI memory order: a parameter laid out otherwise gets a deep copy from AccumulateGrad —
-        # a read of dw on the backward's stream — so its weight gradient stays there)
-        wstr = cs.w_stride
-        contract = tuple(wstr) == (taps * cin, 1, kw * cin, cin) or (taps == 1 and wstr[0] == cin and wstr[1] == 1)
-        side = _wgrad_side_stream(dev, cs.weight, cs.bias_leaf if need_db else None) if contract else None
 
-        def launch(st):
-            """the weight-gradient launches of this layer on stream `st` (torch's current stream when this runs)"""
-            ws = workspace(dev, ws_bytes)
-            h2 = x3 and _f16x2()
-            dy_pk_ = dy_pk
-            sp = timing.span('conv_wgrad' if x3 else 'conv_wgrad_f32', cs.flops, cs.abytes, cs.scope)
-            if h2:
-                xbits, dybits = absmax_bits(xk, st), absmax_bits(dyk, st)
-                if side is not None:     # (slices of a pooled buffer of the main stream: keep the pool block until this has run)
-                    _wgrad_hold(xbits, dybits)
-                x_pk = _is_packed(xk)
-                xw_ptr, dyw_ptr, _tmp = xk.data_ptr(), dy_ptr, None
-                planar = 0
-                if cout_p == cout and cin_p == cin and not x_pk and not dy_pk_ and _wgrad_planar_pays(dk, need_db):
-                    xq, dq = torch.empty_like(xk), torch.empty_like(dyk)
-                    _C.call('evk_pack_planar_f16x2', xk.data_ptr(), xk.numel(), xbits.data_ptr(), xq.data_ptr(), st)
-                    _C.call('evk_pack_planar_f16x2', dy_ptr, dyk.numel(), dybits.data_ptr(), dq.data_ptr(), st)
-                    xw_ptr, dyw_ptr, _tmp, planar = xq.data_ptr(), dq.data_ptr(), [xq, dq], 8 | 16
-                elif _PACKED and not need_db and cout_p == cout and _wgrad_pack_pays(cs.flops, 0 if x_pk else xk.numel(),
-                                                                                 0 if dy_pk_ else dyk.numel()):
-                    # the kernel's bound is the split of its operands while staging (each element is staged by many
-                    # workgroups): where the matrix work per byte is high, one streaming pass that stores them split first
-                    _tmp = []
-                    if not x_pk:
-                        xp = torch.empty_like(xk)
-                        _C.call('evk_pack_f16x2', xk.data_ptr(), xk.numel(), xbits.data_ptr(), xp.data_ptr(), st)
-                        xw_ptr, x_pk = xp.data_ptr(), True
-                        _tmp.append(xp)
-                    if not dy_pk_:
-                        dp = torch.empty_like(dyk)
-                        _C.call('evk_pack_f16x2', dy_ptr, dyk.numel(), dybits.data_ptr(), dp.data_ptr(), st)
-                        dyw_ptr, dy_pk_ = dp.data_ptr(), True
-                        _tmp.append(dp)
-                _C.call('evk_conv2d_wgrad_f16x2_ex', ctypes.byref(dk), xw_ptr, xbits.data_ptr(), dyw_ptr, dybits.data_ptr(),
-                        dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes,
-                        planar if planar else ((2 if x_pk else 0) | (4 if dy_pk_ else 0)), st)
+    def _dgrad():
+        nonlocal dx, accum, accum_bits
+        if need_dx and x3 and cin_p == cin and (narrow8 or (cout_p == cout and cout % 8 == 0)):
+            if narrow8:     # zero rows appended to the (tiny) weight: a transient copy, split on every call
+                w_src = torch.zeros((cout_p, taps, cin), device=dev, dtype=torch.float32)
+                w_src[:cout].copy_(w_ohwi.permute(0, 2, 3, 1).reshape(cout, taps, cin))
             else:
-                _C.call(_entry('evk_conv2d_wgrad_x3') if x3 else 'evk_conv2d_wgrad', ctypes.byref(dk), xk.data_ptr(), dy_ptr,
-                        dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes, st)
+                w_src = w_ohwi
+            pl_ptr, wabs_ptr, _keep = _weight_planes(cs.weight, w_src, w_src.data_ptr(), dk, 1, st, dev)
+            acc_ptr = None
+            if accum is not None:
+                accum = as_nhwc(accum, 'conv2d.backward.accum')
+                acc_ptr = accum.data_ptr()
+            dx = accum if (inplace and accum is not None) else empty_nhwc(n, cin, d.H, d.W, dev)
+            dybits = absmax_bits(dyk, st) if wabs_ptr is not None else None
+            sp = timing.span('conv_igemm', cs.flops, cs.abytes, cs.scope)
+            if wabs_ptr is not None:
+                # in place: the slots the main branch's launch raised stay (an upper bound is all a scale needs)
+                hit = getattr(dx, '_evk_amax', None) if inplace else None
+                dxbits = hit[2] if hit is not None else _amax_zeroed(dev)
+                if accum_bits is not None and acc_ptr is not None:
+                    relu_bits_stats['masked_dgrad'] += 1
+                    _C.call('evk_conv2d_dgrad_f16x2_masked', ctypes.byref(dk), dy_ptr, dybits.data_ptr(), pl_ptr, wabs_ptr,
+                            acc_ptr, accum_bits.data_ptr(), dx.data_ptr(), _ptr(dxbits), 4 if dy_pk else 0, st)
+                else:
+                    _C.call('evk_conv2d_dgrad_f16x2_ex', ctypes.byref(dk), dy_ptr, dybits.data_ptr(), pl_ptr, wabs_ptr, acc_ptr,
+                            dx.data_ptr(), _ptr(dxbits), 4 if dy_pk else 0, st)
+                if dxbits is not None:
+                    _note_amax(dx, dxbits)
+            else:
+                _C.call(_entry('evk_conv2d_dgrad_x3'), ctypes.byref(dk), dy_ptr, pl_ptr, acc_ptr, dx.data_ptr(), st)
             if sp is not None:
                 sp.stop()
-            if dw2 is not None:
-                _C.call('evk_unpad_channels', dwk.data_ptr(), dw2.data_ptr(), cout_p * taps, cin_p, cin, st)
+        elif need_dx:
+            # weights as [cout_p][taps][cin_p]
+            if cin_p != cin or cout_p != cout:
+                wfull = torch.zeros((cout_p, taps, cin_p), device=dev, dtype=torch.float32)
+                tmp = (_pad_last(w_ohwi.data_ptr(), cout * taps, cin, cin_p, dev) if cin_p != cin
+                       else w_ohwi.permute(0, 2, 3, 1))  # OHWI memory order
+                wfull[:cout].copy_(tmp.reshape(cout, taps, cin_p))
+                w_src = wfull
+            else:
+                w_src = w_ohwi
+            wt = torch.empty((cin_p, taps, cout_p), device=dev, dtype=torch.float32)
+            _C.call('evk_conv2d_pack_dgrad_weight', ctypes.byref(dk), w_src.data_ptr(), wt.data_ptr(), st)
+            acc_ptr = None
+            if accum is not None:
+                if cin_p != cin:
+                    raise HipPathError('conv2d.backward: accum with channel-padded inputs is not supported')
+                accum = as_nhwc(accum, 'conv2d.backward.accum')
+                acc_ptr = accum.data_ptr()
+            dxk = empty_nhwc(n, cin_p, d.H, d.W, dev)
+            sp = timing.span('conv_igemm_f32', cs.flops, cs.abytes, cs.scope)
+            _C.call('evk_conv2d_dgrad', ctypes.byref(dk), dy_ptr, wt.data_ptr(), acc_ptr, dxk.data_ptr(), st)
+            if sp is not None:
+                sp.stop()
+            if cin_p != cin:
+                dx = empty_nhwc(n, cin, d.H, d.W, dev)
+                _C.call('evk_unpad_channels', dxk.data_ptr(), dx.data_ptr(), n * d.H * d.W, cin_p, cin, st)
+            else:
+                dx = dxk
 
-        # the tensors autograd gets are fixed now; the launches that fill them may come later (side stream, in batches)
-        dw2 = torch.empty((cout_p * taps, cin), device=dev, dtype=torch.float32) if (need_dw and cin_p != cin) else None
-        if need_dw:
-            dwv = dw2.reshape(cout_p, taps, cin) if dw2 is not None else dwk
-            # logical OIHW view over OHWI memory (matches a channels_last parameter)
-            dw = dwv[:cout].reshape(cout, kh, kw, cin).permute(0, 3, 1, 2)
+    def _wgrad():
+        nonlocal dw, db
+        if need_dw or need_db:
+            lib = _C.load()
+            ws_bytes = (lib.evk_conv2d_wgrad_x3_workspace_bytes if x3 else lib.evk_conv2d_wgrad_workspace_bytes)(
+                ctypes.byref(dk))
+            dwk = torch.empty((cout_p, taps, cin_p), device=dev, dtype=torch.float32)
+            dbk = torch.empty((cout_p,), device=dev, dtype=torch.float32) if need_db else None
+            # (the gradient comes in OHWI memory order: a parameter laid out otherwise gets a deep copy from AccumulateGrad —
+            # a read of dw on the backward's stream — so its weight gradient stays there)
             wstr = cs.w_stride
-            if kh * kw == 1 and dw.stride() != wstr and wstr[0] == cin and wstr[1] == 1:
-                # 1x1 kernels: the size-1 dims make the stride tuple ambiguous; present exactly the
-                # parameter's strides so AccumulateGrad / DDP bucket views alias instead of copying
-                dw = dw.as_strided(dw.shape, wstr)
-        if need_db:
-            db = dbk[:cout]
-        if side is None:
-            launch(st)
-        else:
-            # the weight gradient beside the rest of the backward (see _WGRAD_STREAM above).  Its launches are QUEUED and
-            # issued in batches: one fork event, one switch of torch's current stream and back per batch instead of per
-            # layer (host time), and a captured step has a handful of edges between its two branches instead of 2 x 53
-            _wgrad_hold(xk, dyk, dwk, dbk, dw2)
-            _WGRAD_QUEUE.append((dev, launch))
-            if need_dw:              # what AccumulateGrad has to store as it is (checked at the end of the pass)
-                _WGRAD_OWNED[id(cs.weight)] = (cs.weight, dw.untyped_storage().data_ptr())
+            contract = tuple(wstr) == (taps * cin, 1, kw * cin, cin) or (taps == 1 and wstr[0] == cin and wstr[1] == 1)
+            side = _wgrad_side_stream(dev, cs.weight, cs.bias_leaf if need_db else None) if contract else None
+
+            def launch(st):
+                """the weight-gradient launches of this layer on stream `st` (torch's current stream when this runs)"""
+                ws = workspace(dev, ws_bytes)
+                h2 = x3 and _f16x2()
+                dy_pk_ = dy_pk
+                sp = timing.span('conv_wgrad' if x3 else 'conv_wgrad_f32', cs.flops, cs.abytes, cs.scope)
+                if h2:
+                    xbits, dybits = absmax_bits(xk, st), absmax_bits(dyk, st)
+                    if side is not None:     # (slices of a pooled buffer of the main stream: keep the pool block until this has run)
+                        _wgrad_hold(xbits, dybits)
+                    x_pk = _is_packed(xk)
+                    xw_ptr, dyw_ptr, _tmp = xk.data_ptr(), dy_ptr, None
+                    planar = 0
+                    if cout_p == cout and cin_p == cin and not x_pk and not dy_pk_ and _wgrad_planar_pays(dk, need_db):
+                        xq, dq = torch.empty_like(xk), torch.empty_like(dyk)
+                        _C.call('evk_pack_planar_f16x2', xk.data_ptr(), xk.numel(), xbits.data_ptr(), xq.data_ptr(), st)
+                        _C.call('evk_pack_planar_f16x2', dy_ptr, dyk.numel(), dybits.data_ptr(), dq.data_ptr(), st)
+                        xw_ptr, dyw_ptr, _tmp, planar = xq.data_ptr(), dq.data_ptr(), [xq, dq], 8 | 16
+                    elif _PACKED and not need_db and cout_p == cout and _wgrad_pack_pays(cs.flops, 0 if x_pk else xk.numel(),
+                                                                                     0 if dy_pk_ else dyk.numel()):
+                        # the kernel's bound is the split of its operands while staging (each element is staged by many
+                        # workgroups): where the matrix work per byte is high, one streaming pass that stores them split first
+                        _tmp = []
+                        if not x_pk:
+                            xp = torch.empty_like(xk)
+                            _C.call('evk_pack_f16x2', xk.data_ptr(), xk.numel(), xbits.data_ptr(), xp.data_ptr(), st)
+                            xw_ptr, x_pk = xp.data_ptr(), True
+                            _tmp.append(xp)
+                        if not dy_pk_:
+                            dp = torch.empty_like(dyk)
+                            _C.call('evk_pack_f16x2', dy_ptr, dyk.numel(), dybits.data_ptr(), dp.data_ptr(), st)
+                            dyw_ptr, dy_pk_ = dp.data_ptr(), True
+                            _tmp.append(dp)
+                    _C.call('evk_conv2d_wgrad_f16x2_ex', ctypes.byref(dk), xw_ptr, xbits.data_ptr(), dyw_ptr, dybits.data_ptr(),
+                            dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes,
+                            planar if planar else ((2 if x_pk else 0) | (4 if dy_pk_ else 0)), st)
+                else:
+                    _C.call(_entry('evk_conv2d_wgrad_x3') if x3 else 'evk_conv2d_wgrad', ctypes.byref(dk), xk.data_ptr(), dy_ptr,
+                            dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes, st)
+                if sp is not None:
+                    sp.stop()
+                if dw2 is not None:
+                    _C.call('evk_unpad_channels', dwk.data_ptr(), dw2.data_ptr(), cout_p * taps, cin_p, cin, st)
+
+            # the tensors autograd gets are fixed now; the launches that fill them may come later (side stream, in batches)
+            dw2 = torch.empty((cout_p * taps, cin), device=dev, dtype=torch.float32) if (need_dw and cin_p != cin) else None
+            if need_dw:
+                dwv = dw2.reshape(cout_p, taps, cin) if dw2 is not None else dwk
+                # logical OIHW view over OHWI memory (matches a channels_last parameter)
+                dw = dwv[:cout].reshape(cout, kh, kw, cin).permute(0, 3, 1, 2)
+                wstr = cs.w_stride
+                if kh * kw == 1 and dw.stride() != wstr and wstr[0] == cin and wstr[1] == 1:
+                    # 1x1 kernels: the size-1 dims make the stride tuple ambiguous; present exactly the
+                    # parameter's strides so AccumulateGrad / DDP bucket views alias instead of copying
+                    dw = dw.as_strided(dw.shape, wstr)
             if need_db:
-                _WGRAD_OWNED[id(cs.bias_leaf)] = (cs.bias_leaf, db.untyped_storage().data_ptr())
-            if len(_WGRAD_QUEUE) >= _WGRAD_BATCH:
-                flush_wgrad_queue()
+                db = dbk[:cout]
+            if side is None:
+                launch(st)
+            else:
+                # the weight gradient beside the rest of the backward (see _WGRAD_STREAM above).  Its launches are QUEUED and
+                # issued in batches: one fork event, one switch of torch's current stream and back per batch instead of per
+                # layer (host time), and a captured step has a handful of edges between its two branches instead of 2 x 53
+                _wgrad_hold(xk, dyk, dwk, dbk, dw2)
+                _WGRAD_QUEUE.append((dev, launch))
+                if need_dw:              # what AccumulateGrad has to store as it is (checked at the end of the pass)
+                    _WGRAD_OWNED[id(cs.weight)] = (cs.weight, dw.untyped_storage().data_ptr())
+                if need_db:
+                    _WGRAD_OWNED[id(cs.bias_leaf)] = (cs.bias_leaf, db.untyped_storage().data_ptr())
+                if len(_WGRAD_QUEUE) >= _WGRAD_BATCH:
+                    flush_wgrad_queue()
+
+    # EVK_WGRAD_EARLY=1 (A/B): the weight gradient is forked BEFORE the data gradient is enqueued, so that it may start
+    # beside it instead of behind it; the operand scale of dy is fixed first (both read it, from different streams)
+    if _WGRAD_EARLY and need_dx and (need_dw or need_db) and _f16x2() and x3:
+        absmax_bits(dyk, st)
+        _wgrad()
+        _dgrad()
+    else:
+        _dgrad()
+        _wgrad()
     return dx, dw, db
 
 
