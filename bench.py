@@ -458,12 +458,14 @@ def main():
                                                    if args.ddp == 'flat' else 'torch DistributedDataParallel') + \
                 (' (world 1, forced by EVK_BENCH_FORCE_DDP)' if world == 1 else '')
         if timer is not None:
-            fam = timer.summary()
             x3 = conv_math in ('f16x2', 'bf16x3', 'bf16')
             passes = {'f16x2': 3, 'bf16x3': X3_PASSES, 'bf16': 1}.get(conv_math, 1)
             # split kernels: every algorithmic fp32 FLOP costs X3_PASSES bf16 MFMA FLOPs, so the roofline for
             # algorithmic FLOP/s is the dense bf16 MFMA peak / X3_PASSES
             peak = PEAK_BF16_MFMA_TFLOPS / passes if x3 else PEAK_FP32_MFMA_TFLOPS
+            fam = timer.summary(peak_flops=peak * 1e12, peak_bytes=8.0e12)
+            own = ('sum over the launches of each one\'s own roofline time, max(FLOP / MFMA peak of the arithmetic, algorithmic '
+                   'bytes / 8 TB/s), over their measured time: the one-tap layers of stages 1-2 are bound by their bytes')
             peak_note = (f'dense bf16/fp16 MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} TF / {passes} partial product(s) per product'
                          if x3 else 'dense f32-input MFMA peak (v_mfma_f32_32x32x2_f32)')
             convs = [fam[k] for k in ('conv_igemm', 'conv_wgrad', 'conv_igemm_f32', 'conv_wgrad_f32') if k in fam]
@@ -498,7 +500,8 @@ def main():
                     'algorithmic_bytes_per_launch': round(ig['bytes'] / ig['launches']),
                     'launches_per_step': ig['launches'] // max(1, sampled), 'sampled_steps': sampled,
                     'avg_launch_us': round(ig['seconds'] / ig['launches'] * 1e6, 2),
-                    'algorithmic_gflop_per_launch': round(ig['flops'] / ig['launches'] / 1e9, 3)}
+                    'algorithmic_gflop_per_launch': round(ig['flops'] / ig['launches'] / 1e9, 3),
+                    'frac_of_launch_bounds': round(ig['bound_seconds'] / ig['seconds'], 4), 'frac_of_launch_bounds_note': own}
                 if conv_math == 'f16x2' and args.config == 'c2':
                     busy, busy_file = pmc_busy('conv_igemm')
                     line['roofline']['mfma_busy'] = busy
@@ -515,7 +518,8 @@ def main():
                                           'algorithmic_bytes_per_launch': round(wg['bytes'] / wg['launches']),
                                           'launches_per_step': wg['launches'] // max(1, sampled),
                                           'avg_launch_us': round(wg['seconds'] / wg['launches'] * 1e6, 2),
-                                          'algorithmic_gflop_per_launch': round(wg['flops'] / wg['launches'] / 1e9, 3)}
+                                          'algorithmic_gflop_per_launch': round(wg['flops'] / wg['launches'] / 1e9, 3),
+                                          'frac_of_launch_bounds': round(wg['bound_seconds'] / wg['seconds'], 4)}
                 if conv_math == 'f16x2' and args.config == 'c2':
                     line['roofline_wgrad']['mfma_busy'] = pmc_busy('conv_wgrad')[0]
             # the ResNet-50 encoder's convolutions alone (BASELINE.json north_star: >= 0.6 x MFMA roofline on this
@@ -525,6 +529,7 @@ def main():
             enc = [e for e in enc if e]
             if enc:
                 fl, sec = sum(e['flops'] for e in enc), sum(e['seconds'] for e in enc)
+                bsec = sum(e['bound_seconds'] for e in enc)
                 parts = {}
                 for k in ('conv_igemm', 'conv_wgrad', 'conv_igemm_f32', 'conv_wgrad_f32'):
                     e = fam.get('encoder/' + k)
@@ -537,6 +542,7 @@ def main():
                                                '+ weight gradient of en.*)',
                     'achieved': round(fl / sec / 1e12, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                     'frac': round(fl / sec / 1e12 / peak, 4),
+                    'frac_of_launch_bounds': round(bsec / sec, 4),
                     'gflop_per_step': round(fl / max(1, sampled) / 1e9, 1),
                     'ms_per_step': round(sec / max(1, sampled) * 1e3, 3), 'families': parts}
             if overlapped is not None:

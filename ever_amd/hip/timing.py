@@ -41,18 +41,22 @@ class KernelTimer:
         global _active
         _active = None
 
-    def summary(self):
+    def summary(self, peak_flops=None, peak_bytes=None):
         """{family: dict(launches, flops, bytes, seconds)}, plus the same under '<scope>/<family>' for launches issued
-        inside a `scope` — call after torch.cuda.synchronize()."""
+        inside a `scope` — call after torch.cuda.synchronize().  With peak_flops / peak_bytes (per second) also
+        `bound_seconds`: the sum over the launches of each one's OWN roofline time, max(flops / peak_flops, bytes / peak_bytes)
+        — a one-tap convolution with 64 reduction channels is bound by its bytes, not by the matrix pipe."""
         out = {}
         for fam, flops, nbytes, s, e, sc in self.records:
             sec = s.elapsed_time(e) * 1e-3
+            bound = max(flops / peak_flops if peak_flops else 0.0, nbytes / peak_bytes if peak_bytes else 0.0)
             for key in ((fam,) if not sc else (fam, f'{sc}/{fam}')):
-                d = out.setdefault(key, dict(launches=0, flops=0.0, bytes=0.0, seconds=0.0))
+                d = out.setdefault(key, dict(launches=0, flops=0.0, bytes=0.0, seconds=0.0, bound_seconds=0.0))
                 d['launches'] += 1
                 d['flops'] += flops
                 d['bytes'] += nbytes
                 d['seconds'] += sec
+                d['bound_seconds'] += bound
         return out
 
 
