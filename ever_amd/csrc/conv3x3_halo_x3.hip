@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256 + 64 * MW) void conv3x3_halo_x3_kernel(const IG
   const int ty = t % tiles_y;
   const int n = t / tiles_y;
   const int Y0 = ty * kPH, X0 = tx * kPW, n0 = tile_n * BN;
-  const int nchunk = p.Cs / kCh;
+  const int nchunk = (p.Cs + kCh - 1) / kCh;   // (a partial last chunk: its missing channels are zero in both operands)
   const int niter = nchunk * 3;
   const int tid = threadIdx.x;
 
@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256 + 64 * MW) void conv3x3_halo_x3_kernel(const IG
     const int ptid = tid - 64 * MW;
     // halo items: (pixel 0..179, float4 q 0..3); three per thread, the last pass partially filled
     int a_src[AI], a_lds[AI];
-    bool a_ok[AI], a_has[AI];
+    bool a_ok[AI], a_has[AI], a_okc[AI];   // a_okc: a_ok for the chunk last loaded (channels past Cs in a partial last chunk)
+    const int tail_ch = p.Cs % kCh;        // 0: every chunk is whole
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int e = ptid + 256 * i;
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256 + 64 * MW) void conv3x3_halo_x3_kernel(const IG
       const int hy = pix / (kPW + 2), hx = pix - hy * (kPW + 2);
       const int sy = Y0 - 1 + hy, sx = X0 - 1 + hx;
       a_ok[i] = a_has[i] && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
+      a_okc[i] = a_ok[i];
       a_src[i] = a_ok[i] ? ((n * p.Hs + sy) * p.Ws + sx) * p.Cs + q * 4 : 0;
       const int hr = hy * kHP + hx;
       a_lds[i] = hr * kRB + (((q >> 1) ^ ((hr >> 3) & 1)) << 4) + ((q & 1) << 3);
@@ -116,8 +118,12 @@ __global__ __launch_bounds__(256 + 64 * MW) void conv3x3_halo_x3_kernel(const IG
     float a_inv = 1.f;   // f16x2: 1 / activation scale
     if constexpr (NP == 2) a_inv = op_scale(act_absmax(p.a_scale)).inv;
     auto load_a = [&](int c) {
+      const bool partial = tail_ch != 0 && c == nchunk - 1;
 #pragma unroll
-      for (int i = 0; i < AI; ++i) ra[i] = *reinterpret_cast<const f32x4*>(p.src + a_src[i] + (a_ok[i] ? c * kCh : 0));
+      for (int i = 0; i < AI; ++i) {
+        a_okc[i] = a_ok[i] && (!partial || ((ptid + 256 * i) & 3) * 4 < tail_ch);
+        ra[i] = *reinterpret_cast<const f32x4*>(p.src + (a_okc[i] ? a_src[i] + c * kCh : 0));
+      }
     };
     auto store_a = [&](int stage) {
       unsigned char* A = Abase + stage * kAStage;
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(256 + 64 * MW) void conv3x3_halo_x3_kernel(const IG
       for (int i = 0; i < AI; ++i) {
         if (!a_has[i]) continue;
         const f32x4 v = ra[i];
-        const bool ok = a_ok[i];
+        const bool ok = a_okc[i];
         uint32_t h0, m0 = 0, l0 = 0, h1, m1 = 0, l1 = 0;
         split_op<NP, PK>(ok ? v.x : 0.f, ok ? v.y : 0.f, a_inv, h0, m0, l0);
         split_op<NP, PK>(ok ? v.z : 0.f, ok ? v.w : 0.f, a_inv, h1, m1, l1);
@@ -339,7 +345,9 @@ bool conv3x3_halo_applies(const IGemmArgs& a) {
     const long long cover = (long long)ceil_div(a.Hm, 8) * 8 * ceil_div(a.Wm, kPW) * kPW;
     if (a.Hm < 4 || a.Wm < 8 || 4LL * a.Hm * a.Wm < 3 * cover) return false;
   }
-  if ((a.Cs % kCh) != 0 || a.Cd < 64 || (!a.dense_dst && (a.dsh != 1 || a.dsw != 1))) return false;
+  // (reduction channels: whole 16-channel chunks, or a partial last one as long as three quarters of the chunks' slots are
+  // channels — Cin = 200 = 12.5 chunks; pairs of channels are split together, so Cs must be even: % 8 keeps the 16-byte loads)
+  if ((a.Cs % 8) != 0 || 4 * a.Cs < 3 * ceil_div(a.Cs, kCh) * kCh || a.Cd < 64 || (!a.dense_dst && (a.dsh != 1 || a.dsw != 1))) return false;
   // enough workgroups for the 256 CUs, if necessary with the 64-wide N tile
   // (EVK_X3_HALO_MIN_WG=0 makes the choice independent of the batch size: tests/test_linearity_pinned_gpu.py pins the
   // accumulation order — chunk-major here, tap-major in the implicit-GEMM kernels — for a batch and its halves)
@@ -452,7 +460,7 @@ __global__ void split_weight_halo_kernel(const float* __restrict__ w, uint16_t* 
 int launch_split_weight_halo(const float* w, uint16_t* out, int Cout, int Cin, int for_dgrad, hipStream_t st,
                              const uint32_t* wscale) {
   const int rows = for_dgrad ? Cin : Cout, K = for_dgrad ? Cout : Cin;
-  const size_t total = (size_t)9 * (K / kCh) * rows * (kCh / 2);
+  const size_t total = (size_t)9 * ((K + kCh - 1) / kCh) * rows * (kCh / 2);
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipLaunchKernelGGL(split_weight_halo_kernel, dim3(blocks), dim3(256), 0, st, w, out, Cout, Cin, for_dgrad, wscale);
   return check_launch("split_weight_halo");

@@ -359,7 +359,17 @@ using namespace evk;
 
 extern "C" size_t evk_conv2d_split_weight_bytes(const evk_conv_desc* d, int32_t for_dgrad) {
   if (!d) return 0;
-  if (!for_dgrad) return (size_t)3 * d->Cout * kpad32(d->kh * d->kw * d->Cin) * sizeof(uint16_t);
+  // (3x3: the LDS-halo kernel's layout pads the reduction channels to 16 per tap, the generic one the whole row to 32:
+  // with channels % 16 != 0 the first can be the larger)
+  auto k3 = [&](int K) { return d->kh == 3 && d->kw == 3 ? 9 * ((K + 15) / 16 * 16) : 0; };
+  if (!for_dgrad) {
+    const int kp = kpad32(d->kh * d->kw * d->Cin);
+    return (size_t)3 * d->Cout * (kp > k3(d->Cin) ? kp : k3(d->Cin)) * sizeof(uint16_t);
+  }
+  if (d->stride_h == 1 && d->stride_w == 1 && d->kh == 3 && d->kw == 3) {
+    const int kp = kpad32(9 * d->Cout);
+    return (size_t)3 * d->Cin * (kp > k3(d->Cout) ? kp : k3(d->Cout)) * sizeof(uint16_t);
+  }
   size_t total = 0;
   for (int cy = 0; cy < d->stride_h; ++cy)
     for (int cx = 0; cx < d->stride_w; ++cx) {

@@ -76,7 +76,7 @@ __device__ __forceinline__ void split_dgrad_body(const float* __restrict__ w, ui
 __device__ __forceinline__ void split_halo_body(const float* __restrict__ w, uint16_t* __restrict__ out, int Cout,
                                                 int Cin, int for_dgrad, size_t t0, size_t nthreads, const uint32_t* wscale = nullptr) {
   const int rows = for_dgrad ? Cin : Cout, K = for_dgrad ? Cout : Cin;  // K = reduction channels
-  const int nchunk = K / kHaloCh;
+  const int nchunk = (K + kHaloCh - 1) / kHaloCh;   // (a partial last chunk is zero-filled: K % 16 != 0, K even)
   const size_t total = (size_t)9 * nchunk * rows * (kHaloCh / 2);
   const size_t plane = (size_t)9 * nchunk * rows * kHaloCh;
   for (size_t i = t0; i < total; i += nthreads) {
@@ -87,13 +87,15 @@ __device__ __forceinline__ void split_halo_body(const float* __restrict__ w, uin
     const int ch = (int)(r % nchunk);
     const int tap = (int)(r / nchunk);
     const int kc = ch * kHaloCh + 2 * k2;
-    float x0, x1;
-    if (for_dgrad) {
-      x0 = w[((size_t)kc * 9 + tap) * Cin + row];
-      x1 = w[((size_t)(kc + 1) * 9 + tap) * Cin + row];
-    } else {
-      x0 = w[((size_t)row * 9 + tap) * Cin + kc];
-      x1 = w[((size_t)row * 9 + tap) * Cin + kc + 1];
+    float x0 = 0.f, x1 = 0.f;
+    if (kc + 1 < K) {
+      if (for_dgrad) {
+        x0 = w[((size_t)kc * 9 + tap) * Cin + row];
+        x1 = w[((size_t)(kc + 1) * 9 + tap) * Cin + row];
+      } else {
+        x0 = w[((size_t)row * 9 + tap) * Cin + kc];
+        x1 = w[((size_t)row * 9 + tap) * Cin + kc + 1];
+      }
     }
     split_put(x0, x1, reinterpret_cast<uint32_t*>(out + (((size_t)tap * nchunk + ch) * rows + row) * kHaloCh + 2 * k2), plane, wscale);
   }
@@ -106,7 +108,7 @@ static inline size_t split_job_pairs(const evk_split_job& j) {
     case kSplitDgrad: return (size_t)j.arg[3] * (j.arg[10] >> 1);
     default: {
       const int rows = j.arg[2] ? j.arg[1] : j.arg[0], K = j.arg[2] ? j.arg[0] : j.arg[1];
-      return (size_t)9 * (K / kHaloCh) * rows * (kHaloCh / 2);
+      return (size_t)9 * ((K + kHaloCh - 1) / kHaloCh) * rows * (kHaloCh / 2);
     }
   }
 }

@@ -43,6 +43,8 @@ CONV_CASES = [
     (3, 16, 96, 320, 128, 3, 1, 1, 1, True),    # LDS-halo kernel, one channel chunk, 16-row patches, W = 20 patches
     (8, 32, 77, 43, 128, 3, 1, 1, 1, True),     # LDS-halo kernel, patches hanging over both edges (H % 8 = 5, W % 16 = 11)
     (2, 96, 154, 86, 128, 3, 1, 1, 1, False),   # LDS-halo kernel, ragged patches, 128-wide tile (the FreeNet scene at stride 4)
+    (4, 200, 96, 88, 96, 3, 1, 1, 1, False),    # LDS-halo kernel, 12.5 channel chunks (the FreeNet input convolution), ragged patches
+    (8, 24, 64, 64, 64, 3, 1, 1, 1, True),      # LDS-halo kernel, 1.5 channel chunks
     (8, 64, 60, 104, 160, 3, 1, 1, 1, False),   # LDS-halo kernel, 16-row patches with a ragged last row (H % 16 = 12), ragged N tile
 ]
 
