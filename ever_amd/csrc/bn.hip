@@ -909,7 +909,12 @@ static unsigned oneshot_grid(size_t n4) { return (unsigned)((n4 + 255) / 256); }
 static void launch_parts_final(hipStream_t st, const float* parts, int nparts, int C, double rows, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                float* save_mean, float* save_invstd, float* scale_shift, uint32_t* amax, int pack) {
-  if (nparts >= 512)
+  // EVK_BN_FIN1 (A/B, default on): one channel per workgroup above 1024 records — eight records per lane, all in flight at once
+  static const bool fin1 = !(getenv("EVK_BN_FIN1") && atoi(getenv("EVK_BN_FIN1")) == 0);
+  if (nparts >= 1024 && fin1)
+    hipLaunchKernelGGL((bn_parts_final_kernel<1, 256>), dim3(C), dim3(256), 0, st, parts, nparts, C, rows, gamma, beta,
+                       running_mean, running_var, momentum, eps, save_mean, save_invstd, scale_shift, amax, pack);
+  else if (nparts >= 512)
     hipLaunchKernelGGL((bn_parts_final_kernel<2, 128>), dim3((C + 1) / 2), dim3(256), 0, st, parts, nparts, C, rows, gamma, beta,
                        running_mean, running_var, momentum, eps, save_mean, save_invstd, scale_shift, amax, pack);
   else
