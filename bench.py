@@ -179,6 +179,33 @@ def host_cores():
     return n
 
 
+def library_gemm_yardstick(dev):
+    """What the vendor library's dense fp16 GEMM (torch.matmul = hipBLASLt) sustains on THIS box, after the timed region: the
+    practical ceiling of the matrix pipe under this part's power limit, beside the nominal 2500 TF the roofline divides by.
+    The f16x2 arithmetic needs three such products per fp32 product (tools/probes/gemm_yardstick.py has the per-layer shapes)."""
+    out = {}
+    try:
+        for name, (m, n, k) in (('8192x8192x8192', (8192, 8192, 8192)), ('262144x256x2304 (3x3x256 @128^2 as a plain GEMM)', (262144, 256, 2304))):
+            a = torch.randn(m, k, device=dev, dtype=torch.float16)
+            b = torch.randn(k, n, device=dev, dtype=torch.float16)
+            for _ in range(3):
+                a @ b
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(10):
+                a @ b
+            e.record()
+            torch.cuda.synchronize()
+            tf = 2.0 * m * n * k / (s.elapsed_time(e) / 10 * 1e-3) / 1e12
+            out[name] = {'tflops': round(tf, 1), 'frac_of_nominal_2500': round(tf / PEAK_BF16_MFMA_TFLOPS, 3),
+                         'algorithmic_tflops_at_3_products': round(tf / 3, 1)}
+            del a, b
+    except Exception as ex:       # noqa: BLE001 (a yardstick, never a reason to lose the line)
+        out['error'] = str(ex)[:200]
+    return out
+
+
 def graph_replay_line(args):
     """The same workload with the step captured once as a hipGraph and replayed (`bench.py --graph`, ever_amd/core/graph.py;
     bit-identical to the eager step: tests/test_graph_gpu.py), measured in a CHILD process after the timed region — a capture
@@ -577,6 +604,8 @@ def main():
                         g1 = a['bytes'] / a['seconds'] / 1e9
                         line['roofline_hbm_' + fam_name].update({'achieved_overlapped': round(g1, 1),
                                                                  'frac_overlapped': round(g1 / PEAK_HBM_GBS, 4)})
+        if world == 1 and not args.graph and 'roofline' in line:
+            line['roofline']['library_fp16_gemm'] = library_gemm_yardstick(dev)
         if world == 1 and not use_ddp and not args.graph and not args.no_graph_line and conv_math == 'f16x2':
             line['hip_graph_replay'] = graph_replay_line(args)
         if world == 1 and not args.no_cpu_baseline:
