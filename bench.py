@@ -510,7 +510,7 @@ def main():
                     line['roofline_cin200'] = {'bound': 'mfma', 'kernel': 'first convolution, 3x3, Cin 200 -> 96 @616x344 '
                                                '(forward + weight gradient launches)', 'achieved': round(ach, 2),
                                                'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                                               'launches_per_step': len(recs) // max(1, sampled),
+                                               'launches_per_step': len(recs) // max(1, sampled), 'sampled_steps': sampled,
                                                'avg_launch_us': round(sec / len(recs) * 1e6, 2)}
             ig = fam.get('conv_igemm' if x3 else 'conv_igemm_f32')
             if ig:
@@ -519,7 +519,7 @@ def main():
                 traffic, traffic_file = pmc_traffic('conv_igemm') if (conv_math == 'f16x2' and args.config == 'c2') else (None, None)
                 line['roofline'] = {
                     'bound': 'mfma',
-                    'kernel': ('evk::conv3x3_halo_x3_kernel / conv1x1_dma_kernel / conv_igemm_x3ws_kernel / conv_igemm_x3_kernel' if x3
+                    'kernel': ('evk::conv3x3_halo_x3_kernel / conv1x1_dma_kernel / conv1x1_ps_kernel / conv_igemm_x3ws_kernel / conv_igemm_x3_kernel' if x3
                                else 'evk::conv_igemm_kernel') + ' (conv forward + data-gradient launches)',
                     'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'peak_note': peak_note,
                     'frac': round(ach / peak, 4), 'traffic': traffic,
@@ -543,7 +543,7 @@ def main():
                                           'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                                           'frac': round(ach / peak, 4), 'traffic': wtraffic,
                                           'algorithmic_bytes_per_launch': round(wg['bytes'] / wg['launches']),
-                                          'launches_per_step': wg['launches'] // max(1, sampled),
+                                          'launches_per_step': wg['launches'] // max(1, sampled), 'sampled_steps': sampled,
                                           'avg_launch_us': round(wg['seconds'] / wg['launches'] * 1e6, 2),
                                           'algorithmic_gflop_per_launch': round(wg['flops'] / wg['launches'] / 1e9, 3),
                                           'frac_of_launch_bounds': round(wg['bound_seconds'] / wg['seconds'], 4)}
@@ -570,7 +570,7 @@ def main():
                     'achieved': round(fl / sec / 1e12, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                     'frac': round(fl / sec / 1e12 / peak, 4),
                     'frac_of_launch_bounds': round(bsec / sec, 4),
-                    'gflop_per_step': round(fl / max(1, sampled) / 1e9, 1),
+                    'gflop_per_step': round(fl / max(1, sampled) / 1e9, 1), 'sampled_steps': sampled,
                     'ms_per_step': round(sec / max(1, sampled) * 1e3, 3), 'families': parts}
             if overlapped is not None:
                 for key, fname in (('roofline', 'conv_igemm' if x3 else 'conv_igemm_f32'),
@@ -594,10 +594,12 @@ def main():
                         'bound': 'hbm', 'kernel': label, 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                         'frac': round(gbs / PEAK_HBM_GBS, 4),
                         # PMC bytes are per KERNEL launch (a call is 2-3 kernels): compare with algorithmic_bytes_per_kernel
-                        'traffic': (pmc_traffic('bn')[0] if (fam_name == 'bn' and conv_math == 'f16x2' and args.config == 'c2') else None),
+                        'traffic': (pmc_traffic(fam_name)[0] if (conv_math == 'f16x2' and args.config == 'c2') else None),
+                        'traffic_unit': f'HBM bytes per KERNEL launch (PMC, {pmc_traffic(fam_name)[1]}; kernels listed there)',
                         'algorithmic_bytes_per_call': round(hb['bytes'] / hb['launches']),
-                        'algorithmic_bytes_per_kernel': (round(hb['bytes'] / max(1, sampled) / pmc_kernel_launches_per_step('bn'))
-                                                         if (fam_name == 'bn' and pmc_kernel_launches_per_step('bn')) else None),
+                        'algorithmic_bytes_per_kernel': (round(hb['bytes'] / max(1, sampled) / pmc_kernel_launches_per_step(fam_name))
+                                                         if pmc_kernel_launches_per_step(fam_name) else None),
+                        'calls_per_step': hb['launches'] // max(1, sampled), 'sampled_steps': sampled,
                         'avg_call_us': round(hb['seconds'] / hb['launches'] * 1e6, 2)}
                     a = overlapped.get(fam_name) if overlapped is not None else None
                     if a and a['seconds'] > 0:

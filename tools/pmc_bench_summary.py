@@ -9,9 +9,13 @@ the most time, the mean counters per dispatch and the derived ratios
   clock GHz   = GRBM_GUI_ACTIVE / 8 XCDs / duration (duration of the profiled dispatch: profiled passes clock lower)
 
 usage: python tools/pmc_bench_summary.py pass1.db pass2.db ... [top=14]"""
+import os
 import sqlite3
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import families  # noqa: E402
 
 
 def load(paths):
@@ -41,13 +45,12 @@ def main():
     if jpath:
         # machine-readable: per kernel family the time-weighted matrix-pipe occupancy (bench.py puts it into `roofline`)
         import json
-        fams = {'conv_igemm': ('conv_igemm', 'conv3x3_halo', 'conv1x1_dma'), 'conv_wgrad': ('conv_wgrad',), 'bn': ('bn_',)}
         out = {}
-        for fam, pats in fams.items():
+        for fam in ('conv_igemm', 'conv_wgrad', 'bn'):   # tools/families.py: one table for every profile tool
             num = den = 0.0
             per = {}
             for n, r in k.items():
-                if not any(p in n for p in pats):
+                if families.family_of(n) != fam:
                     continue
                 c = r['c']
                 if 'SQ_BUSY_CYCLES' not in c or 'SQ_VALU_MFMA_BUSY_CYCLES' not in c:

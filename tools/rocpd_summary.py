@@ -5,8 +5,12 @@ human-readable per-kernel table: calls, total / average / min / max duration, sh
 writes <out>.md and <out>.csv
 """
 import csv
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import families  # noqa: E402
 
 
 def main(db_path, out, steps=28, mode='two'):
@@ -22,18 +26,33 @@ def main(db_path, out, steps=28, mode='two'):
         for n, c, s, a, mn, mx in rows:
             w.writerow([n, c, round(s / 1e3, 1), round(a / 1e3, 2), round(mn / 1e3, 2), round(mx / 1e3, 2),
                         round(100.0 * s / total, 2)])
-    fams = [('conv_igemm (forward + data gradient: conv3x3_halo_x3 / conv1x1_dma / conv_igemm_x3ws / conv_igemm_x3 / conv_igemm kernels)', ('conv_igemm', 'conv3x3_halo', 'conv1x1_dma'), None),
-            ('conv_wgrad (conv_wgrad_x3ws / conv_wgrad_x3 / conv_wgrad_tr / conv_wgrad kernels)', ('conv_wgrad',), None),
-            ('conv_wgrad as bench.py brackets it (one span per C-ABI call: + splitk_reduce, colsum_*, pack_f16x2 / pack_planar kernels; '
-             '"launches" = weight-gradient kernels)', ('conv_wgrad', 'splitk_reduce', 'colsum_', 'pack_f16x2', 'pack_planar'), ('conv_wgrad',)),
-            ('BatchNorm (bn_* kernels; bench.py times C-ABI calls of 2-3 kernels each)', ('bn_',), None)]
+    # one family table for every profile tool (tools/families.py); the partition is asserted exact
+    fam, rest = families.split(rows)
+    label_of = {k: lab for k, lab, _ in families.FAMILIES}
     fam_rows = []
-    for label, pats, count_pats in fams:
-        sel = [r for r in rows if any(p in r[0] for p in pats)]
+    for key in ('conv_igemm', 'conv_wgrad'):
+        sel = fam[key]
         if sel:
-            calls = sum(r[1] for r in sel if any(p in r[0] for p in (count_pats or pats)))
             tot = sum(r[2] for r in sel)
-            fam_rows.append((label, calls, tot, tot / calls))
+            fam_rows.append((label_of[key], sum(r[1] for r in sel), tot))
+    if fam['conv_wgrad']:
+        sel = fam['conv_wgrad'] + fam['conv_wgrad_aux']
+        fam_rows.append(('conv_wgrad as bench.py brackets it (one span per C-ABI call: + splitk_reduce, colsum_*, pack_f16x2 / '
+                         'pack_planar kernels; "launches" = weight-gradient kernels)', sum(r[1] for r in fam['conv_wgrad']),
+                         sum(r[2] for r in sel)))
+    for key in ('conv_wgrad_aux', 'bn', 'resample_loss', 'pointwise', 'operand_prep', 'optimizer'):
+        sel = fam[key]
+        if sel:
+            fam_rows.append((label_of[key], sum(r[1] for r in sel), sum(r[2] for r in sel)))
+    rest_tot = sum(r[2] for r in rest)
+    fam_rows.append(('every other kernel (ATen element-wise kernels, runtime copies / fills, any evk:: kernel no family claims)',
+                     sum(r[1] for r in rest), rest_tot))
+    claimed = sum(sum(r[2] for r in v) for v in fam.values()) + rest_tot
+    assert abs(claimed - total) <= 1e-9 * total, (claimed, total)
+    # the partition the table prints: every row except the repeated "as bench.py brackets it" one
+    assert abs(sum(t for lab, c, t in fam_rows if not lab.startswith('conv_wgrad as bench.py')) - total) <= 1e-9 * total
+    fam_rows = [(lab, c, t, t / max(1, c)) for lab, c, t in fam_rows]
+    unclaimed = [r for r in rest if 'evk::' in r[0] and r[2] >= 0.003 * total]
     with open(out + '.md', 'w') as f:
         f.write('# rocprofv3 --kernel-trace --stats summary\n\n' + (
                 '**Single-stream run (`EVK_WGRAD_STREAM=0`): every kernel alone on the chip — the durations behind the `achieved` / '
@@ -53,9 +72,12 @@ def main(db_path, out, steps=28, mode='two'):
                 '| family | launches | total ms | avg us per launch | ms per step | % |\n|---|---:|---:|---:|---:|---:|\n')
         for label, calls, tot, avg in fam_rows:
             f.write(f'| {label} | {calls} | {tot / 1e6:.2f} | {avg / 1e3:.1f} | {tot / 1e6 / steps:.2f} | {100.0 * tot / total:.2f} |\n')
-        f.write('\n| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---:|---:|---:|---:|---:|---:|\n')
+        f.write('\nThe family rows partition the capture (asserted: families + rest = total; the weight-gradient row "as bench.py '
+                'brackets it" repeats the conv_wgrad row plus its auxiliaries).  `evk::` kernels above 0.3 % of the kernel time that '
+                'no family claims: ' + (', '.join(f'`{families.bare(r[0])}` {100.0 * r[2] / total:.2f} %' for r in unclaimed) or 'none') + '.\n')
+        f.write('\n| kernel | family | calls | total ms | avg us | min us | max us | % |\n|---|---|---:|---:|---:|---:|---:|---:|\n')
         for n, c, s, a, mn, mx in rows:
-            f.write(f'| `{n[:110]}` | {c} | {s / 1e6:.2f} | {a / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} | '
+            f.write(f'| `{n[:110]}` | {families.family_of(n) or "-"} | {c} | {s / 1e6:.2f} | {a / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} | '
                     f'{100.0 * s / total:.2f} |\n')
     print(f'wrote {out}.md and {out}.csv')
 

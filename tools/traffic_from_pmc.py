@@ -9,7 +9,11 @@ import sqlite3
 import sys
 from collections import defaultdict
 
-FAMILIES = {'conv_igemm': ('conv_igemm', 'conv3x3_halo', 'conv1x1_dma'), 'conv_wgrad': ('conv_wgrad',), 'bn': ('bn_',)}
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import families  # noqa: E402
+
+FAMILY_KEYS = ('conv_igemm', 'conv_wgrad', 'bn', 'resample_loss')   # tools/families.py: one table for every profile tool
 
 
 def per_dispatch(db_path, counter):
@@ -28,21 +32,23 @@ def main(fetch_db, write_db, out, steps=7):
     res = {}
     f_acc, f_name = per_dispatch(fetch_db, 'FETCH_SIZE')
     w_acc, w_name = per_dispatch(write_db, 'WRITE_SIZE')
-    for fam, pats in FAMILIES.items():
-        fsel = [v for d, v in f_acc.items() if any(p in f_name[d] for p in pats)]
-        wsel = [v for d, v in w_acc.items() if any(p in w_name[d] for p in pats)]
+    for fam in FAMILY_KEYS:
+        fsel = [v for d, v in f_acc.items() if families.family_of(f_name[d]) == fam]
+        wsel = [v for d, v in w_acc.items() if families.family_of(w_name[d]) == fam]
         if not fsel or not wsel:
             continue
         fb = 2.0 * 1024.0 * sum(fsel) / len(fsel)
         wb = 1024.0 * sum(wsel) / len(wsel)
         res[fam] = {'launches': len(fsel), 'kernel_launches_per_step': round(len(fsel) / steps, 1),
                     'fetch_bytes_per_launch': round(fb), 'write_bytes_per_launch': round(wb),
-                    'hbm_bytes_per_launch': round(fb + wb)}
+                    'hbm_bytes_per_launch': round(fb + wb),
+                    'kernels': sorted({families.bare(f_name[d]) for d in f_acc if families.family_of(f_name[d]) == fam})}
     res['method'] = __doc__.split('\n\n')[0] if False else (
         'rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE on `python bench.py --steps 3 '
         '--warmup 1 --no-cpu-baseline --no-kernel-timer`; counters are KB summed over the 8 XCDs per dispatch; FETCH_SIZE '
-        'doubled (gfx950 reports half of a wide coalesced stream, guide §HBM); families: every conv_igemm* / conv3x3_halo* / conv1x1_dma* kernel '
-        '(fp32, x3, x3ws, halo; forward + data gradient), every conv_wgrad* kernel, every bn_* kernel; tools/traffic_from_pmc.py')
+        'doubled (gfx950 reports half of a wide coalesced stream, guide §HBM); families as tools/families.py defines them (conv_igemm = every forward / data-gradient '
+        'convolution kernel incl. conv1x1_ps; conv_wgrad; bn_*; resample_loss = bilinear_* / nearest2x_* / bce_* / dice_* / ce_*), the kernels '
+        'counted are listed per family; tools/traffic_from_pmc.py')
     with open(out, 'w') as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res, indent=1)[:1200])
