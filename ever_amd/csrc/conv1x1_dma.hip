@@ -279,6 +279,16 @@ int launch_conv1x1_dma(IGemmArgs& a, hipStream_t stream) {
   // outputs: measured ahead on the 128^2-map layers (64 -> 256: 107 -> 90 us, 256 -> 128: 104 -> 94, 256 -> 256: 175 -> 170),
   // level or behind below that.  EVK_C1_PS: 0 never, 1 (default) by that rule, 2 wherever it applies (tests)
   static const int ps_mode = getenv("EVK_C1_PS") ? atoi(getenv("EVK_C1_PS")) : 1;
+  // Round 5: the three-role persistent form (conv1x1_ps2.hip: loader / compute / store waves, software-pipelined K step) takes
+  // those layers from it and the short-reduction layers of the 64^2 maps as well — measured (tools/ab_c1sp.py, us, best other
+  // form -> this): 64 -> 256 @128^2 93 -> 78, 256 -> 256 173 -> 152, 256 -> 128 98 -> 83, 128 -> 512 @64^2 52 -> 46; level on
+  // the longer reductions of the 64^2 / 32^2 maps, behind on 2048 -> 512 @16^2 (one tile per workgroup: nothing to overlap).
+  // EVK_C1_PS2: 0 never, 1 (default) by that rule, 2 wherever it applies (tests)
+  static const int ps2_mode = getenv("EVK_C1_PS2") ? atoi(getenv("EVK_C1_PS2")) : 1;
+  if (ps2_mode != 0 && ps_mode != 2 && conv1x1_ps2_applicable(a) && a.Cd >= 128) {
+    const int tm = ceil_div(a.M, 128), nk = a.Kpad / BK3;
+    if (ps2_mode == 2 || tm >= 1024 || (tm >= 512 && nk <= 4)) return launch_conv1x1_ps2(a, stream);
+  }
   if (ps_mode != 0 && conv1x1_ps_applicable(a) && a.Cd >= 128 &&
       (ps_mode == 2 || ((long long)ceil_div(a.M, 128) * ceil_div(a.Cd, 128) >= 2048 && ceil_div(a.M, 128) >= 1024)))
     return launch_conv1x1_ps(a, stream);

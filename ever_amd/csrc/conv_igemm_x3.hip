@@ -296,6 +296,11 @@ int launch_igemm_x3(IGemmArgs& a, hipStream_t stream) {
       if (!strcmp(f, "e128") && conv1x1_dma_applicable(a)) return launch_conv1x1_dma_forced(a, 2128, stream);
       if (!strcmp(f, "e64") && conv1x1_dma_applicable(a)) return launch_conv1x1_dma_forced(a, 2064, stream);
       if (!strcmp(f, "p128") && conv1x1_ps_applicable(a)) return launch_conv1x1_ps(a, stream);
+      if (!strcmp(f, "q128") && conv1x1_ps2_applicable(a)) return launch_conv1x1_ps2(a, stream);
+      if (!strcmp(f, "s128") && conv1x1_sp_applicable(a)) return launch_conv1x1_sp_forced(a, 128, stream);
+      if (!strcmp(f, "s64") && conv1x1_sp_applicable(a)) return launch_conv1x1_sp_forced(a, 64, stream);
+      if (!strcmp(f, "t128") && conv1x1_sp_applicable(a)) return launch_conv1x1_sp_forced(a, 3128, stream);
+      if (!strcmp(f, "t64") && conv1x1_sp_applicable(a)) return launch_conv1x1_sp_forced(a, 3064, stream);
       if (!strcmp(f, "c128x128")) return launch_cfg3<128, 128, 2, 2, 1>(a, stream);
       if (!strcmp(f, "c64x128")) return launch_cfg3<64, 128, 2, 2, 1>(a, stream);
       if (!strcmp(f, "c128x64")) return launch_cfg3<128, 64, 2, 2, 1>(a, stream);

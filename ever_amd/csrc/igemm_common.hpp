@@ -347,6 +347,10 @@ int launch_conv1x1_dma_forced(IGemmArgs& a, int bn, hipStream_t stream);
 bool conv1x1_dma_applicable(const IGemmArgs& a);
 int launch_conv1x1_ps(IGemmArgs& a, hipStream_t stream);   // persistent form with a store role (conv1x1_ps.hip)
 bool conv1x1_ps_applicable(const IGemmArgs& a);
+int launch_conv1x1_sp_forced(IGemmArgs& a, int bn, hipStream_t stream);   // software-pipelined, loader waves (conv1x1_sp.hip)
+bool conv1x1_sp_applicable(const IGemmArgs& a);
+int launch_conv1x1_ps2(IGemmArgs& a, hipStream_t stream);  // persistent, loader + compute + store waves (conv1x1_ps2.hip)
+bool conv1x1_ps2_applicable(const IGemmArgs& a);
 int launch_conv3x3_halo(IGemmArgs& a, hipStream_t stream);  // 1 = not applicable
 bool conv_desc_uses_halo(const evk_conv_desc* d, int for_dgrad);
 int launch_split_weight_halo(const float* w, uint16_t* out, int Cout, int Cin, int for_dgrad, hipStream_t st,
