@@ -27,7 +27,9 @@ static BnPlan bn_plan(int64_t rows, int C) {
   const int c4 = C / 4;
   p.tpc = c4 < 256 ? c4 : 256;
   p.rl = 256 / p.tpc;
-  int64_t nb = (rows * (int64_t)C + 65535) / 65536;  // ~64K elements per workgroup
+  // ~64K elements per workgroup (EVK_BN_ELEMS: A/B switch, read once)
+  static const int64_t per = getenv("EVK_BN_ELEMS") ? atoll(getenv("EVK_BN_ELEMS")) : 65536;
+  int64_t nb = (rows * (int64_t)C + per - 1) / per;
   if (nb > kMaxStatBlocks) nb = kMaxStatBlocks;
   if (nb < 1) nb = 1;
   int64_t rpb = (rows + nb - 1) / nb;

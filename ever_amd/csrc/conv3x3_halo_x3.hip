@@ -19,9 +19,22 @@
 #include "lds_dma.hpp"
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
+
+#ifndef EVK_HALO_PIPE
+#define EVK_HALO_PIPE 0   // round 5, NEGATIVE RESULT kept for the record (tools/build_variant.sh -DEVK_HALO_PIPE=1 builds it):
+// explicitly software-pipelined matrix loops — fragment reads of tap u+1 interleaved with the MFMAs of tap u, across the
+// iteration's barrier — whose ISA has no exposed LDS wait left.  Same box, us, 3x3x256 @128^2 (tools/autotune_convs.py):
+// 16 x 16 patches, 8 matrix waves (the production form): 762-781 -> 797-810; 8 x 16 patches: 875-904 -> 857-891; the
+// four-matrix-wave and 64-wide forms 5-25 % behind (two fragment sets cost them a workgroup per CU).  The loop is not
+// latency-bound: the same launch takes 1023 us on zero-mean random activations, 743 on an all-zero activation tensor and 712
+// on constant operands (tools/probes/power_probe.py) — it runs against the chip's power cap (PMC: matrix pipe 0.69 busy at
+// 1.76 GHz), and a schedule with fewer stalls returns its gain as a lower clock.
+#endif
 
 namespace evk {
 
+constexpr bool kHaloPipe = EVK_HALO_PIPE != 0;
 constexpr int kPW = 16;                        // output patch width; height PH = 8 or 16 (template)
 // halo row pitch in slots: 32 (>= 18, multiple of 16: every 16-lane group of a ds_read_b128 covers 16 distinct row
 // residues) for the 8-row patch; 18 for the 16-row patch, whose halo would not fit twice otherwise (2 of 16 lanes
@@ -266,37 +279,219 @@ __global__ __launch_bounds__(256 + 64 * MW) void conv3x3_halo_x3_kernel(const IG
     for (int it = 0; it < niter; ++it) __syncthreads();
     return;
   }
-  for (int it = 0; it < niter; ++it) {
-    const int c = it / 3, jy = it - 3 * c;
-    const unsigned char* A = Abase + (c & 1) * kAStage;
-    const unsigned char* B = Bbase + (BDMA ? it % 3 : (it & 1)) * kBStage;
-    const int dy = p.oy0 + jy * p.oys;
+  if constexpr (kHaloPipe && NP == 2 && MB == 2 && NB == 2) {
+    // Round 5, the 64 x 64 wave tile (the 16 x 16-patch form that serves the 3x3x256 layers): two whole fragment sets do not
+    // fit its 168 registers (64 accumulators + 2 x 32), so the prefetch follows the LIFETIMES inside a tap.  The three
+    // partial products of a tap are  l x h | h x l | h x h  (x3_common.hpp): the A fragments' l plane is dead after the first
+    // four MFMAs, the B fragments' l plane after the next four.  So a tap is
+    //     read next A.h, B.h (spare set) + MFMA Al x Bh | read next A.l INTO Al + MFMA Ah x Bl | read next B.l INTO Bl + MFMA Ah x Bh
+    // with one spare set of h planes (16 registers) instead of a second whole set; every fragment has >= 8 MFMAs (256 cycles)
+    // between its read and its first use, and the accumulation order is the reference loop's (t6, a, b): bit-identical.
+    // The iteration's barrier sits in front of its third tap, whose prefetches are the next iteration's first tap.
+    struct HSet {
+      bf16x8 ah[2], bh[2];
+    };
+    bf16x8 Al[2], Bl[2];
+    auto a_ptr = [&](int it, int jx, int a) {
+      const int c = it / 3, jy = it - 3 * c;
+      const int dy = p.oy0 + jy * p.oys, dx = p.ox0 + jx * p.oxs;
+      return Abase + (c & 1) * kAStage + half_off(hb[a] + dy * kHP + dx, lh);
+    };
+    auto b_ptr = [&](int it, int jx, int b) {
+      return Bbase + (BDMA ? it % 3 : (it & 1)) * kBStage + jx * PL * BN * kRB + fb[b];
+    };
+    auto ld = [&](const unsigned char* q) { return *reinterpret_cast<const bf16x8*>(q); };
+    auto interleave = [&](int reads) {     // reads behind the first MFMAs of the phase, one each
 #pragma unroll
-    for (int jx = 0; jx < 3; ++jx) {
-      const int dx = p.ox0 + jx * p.oxs;
-      bf16x8 fa[MB][3], fbv[NB][3];
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i < reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    };
+    auto tap = [&](int it, int jx, HSet& X, HSet& Y, auto has_next) {
+      constexpr bool NX = decltype(has_next)::value;
+      const int nit = jx == 2 ? it + 1 : it, njx = jx == 2 ? 0 : jx + 1;
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NX) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) Y.ah[a] = ld(a_ptr(nit, njx, a));
+#pragma unroll
+        for (int b = 0; b < 2; ++b) Y.bh[b] = ld(b_ptr(nit, njx, b));
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = mfma_np<2>(X.bh[b], Al[a], acc[a][b]);
+      interleave(NX ? 4 : 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NX) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) Al[a] = ld(a_ptr(nit, njx, a) + kHSlots * kRB);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = mfma_np<2>(Bl[b], X.ah[a], acc[a][b]);
+      interleave(NX ? 2 : 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NX) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) Bl[b] = ld(b_ptr(nit, njx, b) + BN * kRB);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = mfma_np<2>(X.bh[b], X.ah[a], acc[a][b]);
+      interleave(NX ? 2 : 0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto iter = [&](int it, HSet& SA, HSet& SB, auto has_next) {
+      tap(it, 0, SA, SB, std::true_type{});
+      tap(it, 1, SB, SA, std::true_type{});
+      __syncthreads();
+      tap(it, 2, SA, SB, has_next);
+    };
+    HSet S0, S1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      S0.ah[a] = ld(a_ptr(0, 0, a));
+      Al[a] = ld(a_ptr(0, 0, a) + kHSlots * kRB);
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      S0.bh[b] = ld(b_ptr(0, 0, b));
+      Bl[b] = ld(b_ptr(0, 0, b) + BN * kRB);
+    }
+    int it = 0;
+    for (; it + 2 < niter; it += 2) {
+      iter(it, S0, S1, std::true_type{});
+      iter(it + 1, S1, S0, std::true_type{});
+    }
+    if (niter - it == 2) {
+      iter(it, S0, S1, std::true_type{});
+      iter(it + 1, S1, S0, std::false_type{});
+    } else {
+      iter(it, S0, S1, std::false_type{});
+    }
+  } else if constexpr (kHaloPipe && NP == 2 && MB * NB <= 2 && MW == 8 && BN == 128) {
+    // Round 5: the fragment registers double-buffered ACROSS taps and across the iteration's barrier (conv1x1_sp.hip has the
+    // ISA argument).  The loop below this block reads a tap's eight fragments and multiplies them right away — in its ISA each
+    // tap opens with an exposed LDS wait (reads, s_waitcnt, MFMAs; eight waves reading at once), and the barrier adds its
+    // own: ~3900 cycles per iteration against 2304 of matrix work for the two waves of a SIMD (profiles/r05_floor_table_c2.txt:
+    // 3x3x256 @128^2 takes 555 us with ONE product per fragment pair, 779 with three).  Here tap u+1 is read while tap u
+    // multiplies, and the iteration's barrier sits between the MFMAs of its second tap and the reads of the NEXT iteration's
+    // first tap:   read T1 | MFMA T0 | read T2 | MFMA T1 | barrier | read T0' | MFMA T2
+    // All reads of iteration `it` are issued before its barrier, so the staging waves' protocol (which stage is free after
+    // which barrier, csrc header) is unchanged: they still see one barrier per iteration.
+    struct TapFrag {
+      bf16x8 a[MB][2], b[NB][2];
+    };
+    auto read_tap = [&](int it, int jx, TapFrag& f) {
+      const int c = it / 3, jy = it - 3 * c;
+      const unsigned char* A = Abase + (c & 1) * kAStage;
+      const unsigned char* B = Bbase + (BDMA ? it % 3 : (it & 1)) * kBStage;
+      const int dy = p.oy0 + jy * p.oys, dx = p.ox0 + jx * p.oxs;
 #pragma unroll
       for (int a = 0; a < MB; ++a) {
-        const int hr = hb[a] + dy * kHP + dx;
-        const int off = half_off(hr, lh);
+        const int off = half_off(hb[a] + dy * kHP + dx, lh);
 #pragma unroll
-        for (int pt = 0; pt < NP; ++pt) fa[a][pt] = *reinterpret_cast<const bf16x8*>(A + pt * kHSlots * kRB + off);
+        for (int pt = 0; pt < 2; ++pt) f.a[a][pt] = *reinterpret_cast<const bf16x8*>(A + pt * kHSlots * kRB + off);
       }
 #pragma unroll
       for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int pt = 0; pt < NP; ++pt)
-          fbv[b][pt] = *reinterpret_cast<const bf16x8*>(B + (jx * PL + pt) * BN * kRB + fb[b]);
+        for (int pt = 0; pt < 2; ++pt) f.b[b][pt] = *reinterpret_cast<const bf16x8*>(B + (jx * PL + pt) * BN * kRB + fb[b]);
+    };
+    auto mma_tap = [&](const TapFrag& f) {
 #pragma unroll
-      for (int t6 = 0; t6 < X3Prod<NP>::N; ++t6)
+      for (int t6 = 0; t6 < 3; ++t6)
 #pragma unroll
         for (int a = 0; a < MB; ++a)
 #pragma unroll
-          for (int b = 0; b < NB; ++b)
-            acc[a][b] = mfma_np<NP>(fbv[b][x3_pb(NP, t6)], fa[a][x3_pa(NP, t6)], acc[a][b]);
+          for (int b = 0; b < NB; ++b) acc[a][b] = mfma_np<2>(f.b[b][x3_pb(2, t6)], f.a[a][x3_pa(2, t6)], acc[a][b]);
+    };
+    // one iteration; on entry f0 holds (the reads of) its first tap, on exit f1 holds the next iteration's first tap
+    // reads of the next tap INTERLEAVED with the MFMAs of the current one (one ds_read behind each MFMA): issued as a block
+    // in front of them they cost the wave their own issue time with the matrix pipe idle (measured: the four-matrix-wave
+    // forms fell from 928 to 1196 us on 3x3x256 @128^2 that way)
+    constexpr int kReads = (MB + NB) * 2, kMfma = 3 * MB * NB;
+    auto overlap = [&]() {
+#pragma unroll
+      for (int i = 0; i < kReads; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read
+      }
+      if (kMfma > kReads) __builtin_amdgcn_sched_group_barrier(0x008, kMfma - kReads, 0);
+    };
+    auto iter = [&](int it, TapFrag& f0, TapFrag& f1, auto has_next) {
+      __builtin_amdgcn_sched_barrier(0);
+      read_tap(it, 1, f1);
+      mma_tap(f0);
+      overlap();
+      __builtin_amdgcn_sched_barrier(0);
+      read_tap(it, 2, f0);
+      mma_tap(f1);
+      overlap();
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      if constexpr (decltype(has_next)::value) {
+        read_tap(it + 1, 0, f1);
+        mma_tap(f0);
+        overlap();
+      } else {
+        mma_tap(f0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    TapFrag F0, F1;
+    read_tap(0, 0, F0);
+    int it = 0;
+    // (pairs of iterations: three taps per iteration swap the roles of the two register sets; the tail is peeled so that no
+    // read behind a barrier is conditional — a conditional one makes hipcc wait for the reads just issued)
+    for (; it + 2 < niter; it += 2) {
+      iter(it, F0, F1, std::true_type{});
+      iter(it + 1, F1, F0, std::true_type{});
     }
-    __syncthreads();
-  }
+    if (niter - it == 2) {
+      iter(it, F0, F1, std::true_type{});
+      iter(it + 1, F1, F0, std::false_type{});
+    } else {
+      iter(it, F0, F1, std::false_type{});
+    }
+  } else {
+  for (int it = 0; it < niter; ++it) {
+      const int c = it / 3, jy = it - 3 * c;
+      const unsigned char* A = Abase + (c & 1) * kAStage;
+      const unsigned char* B = Bbase + (BDMA ? it % 3 : (it & 1)) * kBStage;
+      const int dy = p.oy0 + jy * p.oys;
+  #pragma unroll
+      for (int jx = 0; jx < 3; ++jx) {
+        const int dx = p.ox0 + jx * p.oxs;
+        bf16x8 fa[MB][3], fbv[NB][3];
+  #pragma unroll
+        for (int a = 0; a < MB; ++a) {
+          const int hr = hb[a] + dy * kHP + dx;
+          const int off = half_off(hr, lh);
+  #pragma unroll
+          for (int pt = 0; pt < NP; ++pt) fa[a][pt] = *reinterpret_cast<const bf16x8*>(A + pt * kHSlots * kRB + off);
+        }
+  #pragma unroll
+        for (int b = 0; b < NB; ++b)
+  #pragma unroll
+          for (int pt = 0; pt < NP; ++pt)
+            fbv[b][pt] = *reinterpret_cast<const bf16x8*>(B + (jx * PL + pt) * BN * kRB + fb[b]);
+  #pragma unroll
+        for (int t6 = 0; t6 < X3Prod<NP>::N; ++t6)
+  #pragma unroll
+          for (int a = 0; a < MB; ++a)
+  #pragma unroll
+            for (int b = 0; b < NB; ++b)
+              acc[a][b] = mfma_np<NP>(fbv[b][x3_pb(NP, t6)], fa[a][x3_pa(NP, t6)], acc[a][b]);
+      }
+      __syncthreads();
+    }
+  
+}
 
   if constexpr (NP == 2) igemm_scale_acc<MB, NB>(acc, op_scale(act_absmax(p.a_scale)).s * op_scale(*p.w_scale).s);
   if (p.bn_part) {

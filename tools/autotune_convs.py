@@ -19,7 +19,7 @@ from ever_amd import _C  # noqa: E402
 
 FIELDS = [f[0] for f in _C.ConvDesc._fields_]
 GENERIC = ['c128x128', 'c64x128', 'c128x64', 'c64x64', 'w256', 'w128', 'w64', 'd256', 'd128', 'd64', 'e128', 'e64']
-HALO = ['h64x8', 'h128x8', 'h128x16', 'm128x8', 'm128x16']
+HALO = ['h64x8', 'm64x8', 'm64x16', 'h128x8', 'h128x16', 'm128x8', 'm128x16']
 B = int(os.environ.get('BATCH', 16))
 
 
@@ -75,6 +75,10 @@ def main():
     for (kind, key), count in sorted(probs.items(), key=lambda kv: -kv[1]):
         d = _C.ConvDesc(*key)
         n, h, w, cin, ho, wo, cout, kh, kw = key[:9]
+        if os.environ.get('AUTOTUNE_ONLY') == 'k3' and kh != 3:
+            continue
+        if os.environ.get('AUTOTUNE_ONLY') == 'k1' and kh != 1:
+            continue
         g = torch.Generator().manual_seed(1)
         x = (torch.randn(n, h, w, cin, generator=g) + 0.5).to(dev)
         wt = (torch.randn(cout, kh, kw, cin, generator=g) * 0.05).to(dev)
