@@ -500,16 +500,22 @@ int launch_conv1x1_ps(IGemmArgs& a, hipStream_t stream) {
     a.bn_part = a.bn_buf;
     a.bn_parts = 2 * a.tiles_m;
   }
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    set_error("conv1x1_ps: cannot query the device");
+    return EVK_E_LAUNCH;
+  }
+  static int cus_of[64];                 // per device id (one process may drive devices of different sizes)
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (!cus_of[dev]) {
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
       set_error("conv1x1_ps: cannot query the device");
       return EVK_E_LAUNCH;
     }
-    cus = prop.multiProcessorCount;
+    cus_of[dev] = prop.multiProcessorCount;
   }
+  const int cus = cus_of[dev];
   const long long items = (long long)a.tiles_m * a.tiles_n;
   if (items <= 0 || items > 0x7fffffffLL) {
     set_error("conv1x1_ps: bad grid %lld", items);

@@ -15,10 +15,21 @@ def compiler_opaque(model=None):
     Idempotent; called by Trainer.torch_compile (reference trainer.py:241-243)."""
     import torch
     if model is not None:
+        # per CLASS, not per instance (ADVICE r4): an instance attribute `forward` bound to the original module is copied by
+        # reference by copy.deepcopy (an EMA / SWA copy would silently run the ORIGINAL's weights) and breaks torch.save(model)
         for m in model.modules():
-            if type(m).__module__.startswith('ever_amd.') and not getattr(m, '_evk_opaque', False):
-                m.forward = torch.compiler.disable(m.forward, recursive=True)
-                m._evk_opaque = True
+            cls = type(m)
+            if cls.__module__.startswith('ever_amd.') and not cls.__dict__.get('_evk_opaque', False):
+                cls.forward = torch.compiler.disable(cls.forward, recursive=True)
+                cls._evk_opaque = True
+        if not getattr(model, '_evk_opaque_logged', False):
+            import logging
+            logging.getLogger('EVER').info('torch_compile: the built-in HIP layers run eagerly (hand-written kernels behind '
+                                           'ctypes: nothing to trace); only user module code around them is compiled')
+            try:
+                model._evk_opaque_logged = True
+            except Exception:
+                pass
     if _OPAQUE[0]:
         return
     import types

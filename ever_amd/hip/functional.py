@@ -211,34 +211,40 @@ _cuda_get_stream = getattr(torch._C, '_cuda_getCurrentStream', None)
 _cuda_set_stream = getattr(torch._C, '_cuda_setStream', None)
 
 
-_WGRAD_QUEUE = []                # (device, launch closure) of weight gradients not issued yet
+_WGRAD_QUEUE = {}                # device -> launch closures of weight gradients not issued yet (one list per
+                                 # device — autograd runs one engine thread per device, and a shared list lost appends)
 _WGRAD_EARLY = os.environ.get('EVK_WGRAD_EARLY', '0') == '1'
 _WGRAD_BATCH = max(1, int(os.environ.get('EVK_WGRAD_BATCH', '1')))   # (8, 16, 32 measured: 524 vs 531 tiles/s for 1, same box)
 
 
-def flush_wgrad_queue():
-    """issue the queued weight gradients on the side stream, behind ONE event recorded on the backward's stream now"""
-    if not _WGRAD_QUEUE:
-        return
-    batch = list(_WGRAD_QUEUE)
-    del _WGRAD_QUEUE[:]
-    by_dev = {}
-    for dev, fn in batch:
-        by_dev.setdefault(dev, []).append(fn)
-    for dev, fns in by_dev.items():
-        side = _WGRAD_SIDE[dev]
-        main_id = _cuda_get_stream(dev.index)
-        main = _WGRAD_MAIN.get(dev)
-        if main is None or main.stream_id != main_id[0]:
-            main = _WGRAD_MAIN[dev] = torch.cuda.current_stream(dev)
-        _C.call('evk_stream_fork', main.cuda_stream, side.cuda_stream)
-        # torch's current stream by the raw setter (the Python context manager costs 20 us)
-        _cuda_set_stream(stream_id=side.stream_id, device_index=side.device_index, device_type=side.device_type)
-        try:
-            for fn in fns:
-                fn(side.cuda_stream)
-        finally:
-            _cuda_set_stream(stream_id=main_id[0], device_index=main_id[1], device_type=main_id[2])
+def flush_wgrad_queue(dev=None):
+    """issue the queued weight gradients on the side stream, behind ONE event recorded on the backward's stream now.
+    dev: that device's queue only (the backward thread of a device flushes its own); None: every device's."""
+    for d in ([dev] if dev is not None else list(_WGRAD_QUEUE.keys())):
+        fns = _WGRAD_QUEUE.pop(d, None)      # (atomic under the GIL: an append racing with it starts a fresh list)
+        if not fns:
+            continue
+        if d.index is not None and d.index != torch.cuda.current_device():
+            with torch.cuda.device(d):       # another device's queue (flushed from the main thread at the end of a pass)
+                _issue_wgrads(d, fns)
+        else:
+            _issue_wgrads(d, fns)
+
+
+def _issue_wgrads(d, fns):
+    side = _WGRAD_SIDE[d]
+    main_id = _cuda_get_stream(d.index)
+    main = _WGRAD_MAIN.get(d)
+    if main is None or main.stream_id != main_id[0]:
+        main = _WGRAD_MAIN[d] = torch.cuda.current_stream(d)
+    _C.call('evk_stream_fork', main.cuda_stream, side.cuda_stream)
+    # torch's current stream by the raw setter (the Python context manager costs 20 us)
+    _cuda_set_stream(stream_id=side.stream_id, device_index=side.device_index, device_type=side.device_type)
+    try:
+        for fn in fns:
+            fn(side.cuda_stream)
+    finally:
+        _cuda_set_stream(stream_id=main_id[0], device_index=main_id[1], device_type=main_id[2])
 
 
 def _wgrad_hold(*tensors):
@@ -950,6 +956,14 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False,
             contract = tuple(wstr) == (taps * cin, 1, kw * cin, cin) or (taps == 1 and wstr[0] == cin and wstr[1] == 1)
             side = _wgrad_side_stream(dev, cs.weight, cs.bias_leaf if need_db else None) if contract else None
 
+            # with BATCHED side-stream launches (graph capture: EVK_WGRAD_BATCH = 32) the closure would look at host-side
+            # tensor state — the operand-scale caches, the packed flag — up to 32 layers after this layer's backward ran; what it
+            # needs is resolved here, when the launch is queued.  (A batch of one runs the closure right away: nothing to resolve,
+            # and a missing scale is then computed on the side stream, off the backward's chain.)
+            pre = None
+            if side is not None and _WGRAD_BATCH > 1 and x3 and _f16x2():
+                pre = (absmax_bits(xk, st), absmax_bits(dyk, st), _is_packed(xk))
+
             def launch(st):
                 """the weight-gradient launches of this layer on stream `st` (torch's current stream when this runs)"""
                 ws = workspace(dev, ws_bytes)
@@ -957,10 +971,12 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False,
                 dy_pk_ = dy_pk
                 sp = timing.span('conv_wgrad' if x3 else 'conv_wgrad_f32', cs.flops, cs.abytes, cs.scope)
                 if h2:
-                    xbits, dybits = absmax_bits(xk, st), absmax_bits(dyk, st)
+                    if pre is not None:
+                        xbits, dybits, x_pk = pre
+                    else:
+                        xbits, dybits, x_pk = absmax_bits(xk, st), absmax_bits(dyk, st), _is_packed(xk)
                     if side is not None:     # (slices of a pooled buffer of the main stream: keep the pool block until this has run)
                         _wgrad_hold(xbits, dybits)
-                    x_pk = _is_packed(xk)
                     xw_ptr, dyw_ptr, _tmp = xk.data_ptr(), dy_ptr, None
                     planar = 0
                     if cout_p == cout and cin_p == cin and not x_pk and not dy_pk_ and _wgrad_planar_pays(dk, need_db):
@@ -1014,13 +1030,13 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False,
                 # issued in batches: one fork event, one switch of torch's current stream and back per batch instead of per
                 # layer (host time), and a captured step has a handful of edges between its two branches instead of 2 x 53
                 _wgrad_hold(xk, dyk, dwk, dbk, dw2)
-                _WGRAD_QUEUE.append((dev, launch))
+                _WGRAD_QUEUE.setdefault(dev, []).append(launch)
                 if need_dw:              # what AccumulateGrad has to store as it is (checked at the end of the pass)
                     _WGRAD_OWNED[id(cs.weight)] = (cs.weight, dw.untyped_storage().data_ptr())
                 if need_db:
                     _WGRAD_OWNED[id(cs.bias_leaf)] = (cs.bias_leaf, db.untyped_storage().data_ptr())
-                if len(_WGRAD_QUEUE) >= _WGRAD_BATCH:
-                    flush_wgrad_queue()
+                if len(_WGRAD_QUEUE.get(dev, ())) >= _WGRAD_BATCH:
+                    flush_wgrad_queue(dev)
 
     # EVK_WGRAD_EARLY=1 (A/B): the weight gradient is forked BEFORE the data gradient is enqueued, so that it may start
     # beside it instead of behind it; the operand scale of dy is fixed first (both read it, from different streams)

@@ -9,6 +9,9 @@ folded parameters next to the original ones (training is unaffected); the call s
 blocks and the Sequential peephole) use them whenever the BatchNorm is in eval mode."""
 import ctypes
 
+import collections
+import weakref
+
 import torch
 
 from .. import _C
@@ -18,7 +21,7 @@ __all__ = ['fold_batchnorm', 'unfold_batchnorm', 'conv_bn']
 
 
 class _Folded(object):
-    __slots__ = ('weight', 'bias', 'planes', 'planes_key', 'cin', 'cin_p', 'stamp', 'wbits')
+    __slots__ = ('weight', 'bias', 'planes', 'planes_key', 'cin', 'cin_p', 'stamp', 'wbits', '__weakref__')
 
 
 def _stamp(conv, bn):
@@ -53,6 +56,7 @@ def _fold_pair(conv, bn):
         f.planes = None
         f.planes_key = None
         f.stamp = _stamp(conv, bn)
+        weakref.finalize(f, _drop_planes_of, f.weight)   # a deleted model releases its planes
     return f
 
 
@@ -70,6 +74,8 @@ def fold_batchnorm(model):
         if isinstance(conv, Conv2d) and isinstance(bn, torch.nn.BatchNorm2d) and not isinstance(bn, torch.nn.SyncBatchNorm):
             f = _fold_pair(conv, bn)
             if f is not None:
+                if getattr(conv, '_folded', None) is not None:
+                    _drop_planes_of(conv._folded.weight)
                 conv._folded, bn._folded_into = f, conv
                 n += 1
     for m in model.modules():
@@ -94,6 +100,7 @@ def fold_batchnorm(model):
 def unfold_batchnorm(model):
     for m in model.modules():
         if hasattr(m, '_folded'):
+            _drop_planes_of(getattr(m._folded, 'weight', None))
             del m._folded
         if hasattr(m, '_folded_into'):
             del m._folded_into
@@ -109,6 +116,7 @@ def _use_folded(conv, bn):
         f = _fold_pair(conv, bn)
         if f is None:
             return False
+        _drop_planes_of(conv._folded.weight)
         conv._folded = f
     return True
 
@@ -132,15 +140,25 @@ def conv_bn(conv, bn, x, residual=None, relu=False, conv_only=False, lazy_res=Fa
 # split planes of folded weights, per (weight memory, input geometry, arithmetic): constant at inference.  Keyed by the
 # weight's address and version so that the tensor-level operator below (which a TorchScript trace replays with the folded
 # weight as a graph constant) finds them again without a module to hang them on.
-_PLANES = {}
+# The entry keeps its weight alive (the address is the key: it must not be reused while the entry exists), so the cache is
+# a small LRU — every new input geometry of a live weight adds an entry — and the module path evicts a weight's entries
+# when it replaces or drops the folded copy (`_use_folded` after training, `fold_batchnorm` again, `unfold_batchnorm`):
+# ADVICE r4 — the unbounded dict grew by one entry per folded convolution at every train / eval alternation.
+_PLANES = collections.OrderedDict()     # key -> (planes, wbits, weight)
+_PLANES_MAX = 256
+
+
+def _drop_planes_of(weight):
+    if weight is None:
+        return
+    for key in [k for k, v in _PLANES.items() if v[2] is weight]:
+        del _PLANES[key]
 
 
 def _folded_planes(weight, d, n, h, w, h2, st, dev):
     key = (weight.data_ptr(), weight._version, n, h, w, h2)
     hit = _PLANES.get(key)
     if hit is None:
-        if len(_PLANES) > 4096:
-            _PLANES.clear()
         lib = _C.load()
         planes = torch.empty((lib.evk_conv2d_split_weight_bytes(ctypes.byref(d), 0),), dtype=torch.uint8, device=dev)
         wbits = None
@@ -149,7 +167,11 @@ def _folded_planes(weight, d, n, h, w, h2, st, dev):
             _C.call('evk_conv2d_split_weight_f16x2', ctypes.byref(d), weight.data_ptr(), 0, planes.data_ptr(), wbits.data_ptr(), st)
         else:
             _C.call('evk_conv2d_split_weight', ctypes.byref(d), weight.data_ptr(), 0, planes.data_ptr(), st)
-        hit = _PLANES[key] = (planes, wbits, weight)     # (the weight kept alive: its address is the key)
+        hit = _PLANES[key] = (planes, wbits, weight)
+        while len(_PLANES) > _PLANES_MAX:
+            _PLANES.popitem(last=False)
+    else:
+        _PLANES.move_to_end(key)
     return hit[0], hit[1]
 
 

@@ -264,3 +264,25 @@ def test_folded_batchnorm_inference_matches_unfolded_and_reference(cuda, conv_ma
         plain2 = m.head(m.en(x)).cpu().contiguous().numpy()
     assert _rel_err(plain2, plain) > 1e-4                     # the statistics did move
     assert _rel_err(refolded, plain2) < 2e-5, _rel_err(refolded, plain2)
+    # the plane cache of the folded weights is bounded — a re-derived fold evicts the planes of the copy it
+    # replaces, unfold_batchnorm evicts everything it drops (it grew by one entry per folded convolution and re-fold before)
+    import gc
+    from ever_amd.module import fold as _fold
+    gc.collect()                                              # (models of earlier tests: their folded copies die with them)
+    mine = lambda: sum(1 for v in _fold._PLANES.values() if v[2].device == x.device and any(
+        getattr(c, '_folded', None) is not None and c._folded.weight is v[2] for c in m.modules()))
+    assert mine() == 0                                        # unfold_batchnorm above dropped every folded copy
+    base = len(_fold._PLANES)
+    fold_batchnorm(m)
+    with torch.no_grad():
+        m.head(m.en(x))
+    n0 = len(_fold._PLANES)
+    assert n0 - base <= m._folded_pairs and mine() == n0 - base
+    assert n0 > base or conv_math == 'f32'                    # (the exact-fp32 kernels read the folded weight itself: no planes)
+    for _ in range(3):                                        # train / eval alternation: every eval re-derives every fold
+        m.train()
+        m.head(m.en(x))
+        m.eval()
+        with torch.no_grad():
+            m.head(m.en(x))
+        assert len(_fold._PLANES) == n0, (len(_fold._PLANES), n0)
