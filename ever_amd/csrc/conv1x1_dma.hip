@@ -305,6 +305,10 @@ int launch_conv1x1_dma(IGemmArgs& a, hipStream_t stream) {
   int bn = 2128;
   if (tm * ceil_div(a.Cd, 128) < 224) {
     if (tm * ceil_div(a.Cd, 64) < 224) return 1;   // cannot fill the chip
+    // long reductions on the 16^2 maps (2048 -> 512: 64 steps, one 128 x 64 tile per CU): the software-pipelined form with
+    // loader waves (conv1x1_sp.hip, ring of four) — 42.9 -> 32.8 us, 43.3 -> 33.6 with the statistics epilogue (tools/ab_c1sp.py)
+    static const int sp_mode = getenv("EVK_C1_SP") ? atoi(getenv("EVK_C1_SP")) : 1;
+    if (sp_mode && a.Kpad / BK3 >= 32 && conv1x1_sp_applicable(a)) return launch_conv1x1_sp_forced(a, 64, stream);
     bn = 2064;
   }
   return launch_conv1x1_dma_forced(a, bn, stream);

@@ -20,7 +20,8 @@
 //   loader : after B(g-1): issue stage g+2 into the slot stage g-1 has left; wait for stage g+1; B(g);
 //   store  : tile j's image is complete after B(first step of tile j+1) and is overwritten after B(last step of tile j+1):
 //            nk - 1 slices between those barriers; the last tile after E1.
-// Compile-time ablations (tools/build_variant.sh -DEVK_PS2_ABL=bits): 1 no loader DMA, 4 no compute, 8 no stores.
+// Compile-time ablations (tools/build_variant.sh -DEVK_PS2_ABL=bits): 1 no loader DMA, 4 no compute, 8 no global stores,
+// 16 store waves idle, 32 no staging writes.
 #include "igemm_common.hpp"
 #include "x3_common.hpp"
 #include "lds_dma.hpp"
@@ -49,6 +50,11 @@ constexpr int kP2Instr = 16;                         // store instructions (4 ro
 __device__ __forceinline__ void p2_dma16s(i32x4 rsrc, uint32_t lds_byte, uint32_t voff, uint32_t soff) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
                :: "v"(voff), "s"(lds_byte), "s"(rsrc), "s"(soff) : "memory", "m0");
+}
+// (ablation bit 64: no barrier at all — the loop's own speed; results are garbage)
+__device__ __forceinline__ void p2_barrier() {
+  if (EVK_PS2_ABL & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  else ring_barrier();
 }
 __device__ __forceinline__ u32x4 p2_lds_read16(uint32_t lds_byte) {
   return *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)lds_byte;
@@ -145,11 +151,11 @@ __global__ __launch_bounds__(64 * kP2Waves) void conv1x1_ps2_kernel(const IGemmA
     issue_next();                                      // stage 0
     if (G > 1) issue_next();                           // stage 1
     if (G > 1) wait_vmcnt<PER>(); else wait_vmcnt<0>();
-    ring_barrier();                                    // P0: stage 0 has landed
+    p2_barrier();                                    // P0: stage 0 has landed
     for (int g = 0; g < G; ++g) {
       if (g + 2 < G) issue_next();                     // stage g + 2 into the slot stage g - 1 has left
       if (g + 2 < G) wait_vmcnt<PER>(); else wait_vmcnt<0>();   // stage g + 1 has landed
-      ring_barrier();                                  // B(g)
+      p2_barrier();                                  // B(g)
     }
     return;                                            // (E1: an ended wave is not waited for)
   }
@@ -202,6 +208,14 @@ __global__ __launch_bounds__(64 * kP2Waves) void conv1x1_ps2_kernel(const IGemmA
       bf16x8 b[NB][2];         // weight planes h, l
     };
     auto read_frag = [&](uint32_t S, int kk, Frag& f) {
+      if (EVK_PS2_ABL & 128) {       // (ablation: no fragment reads — the registers keep whatever they hold, made opaque)
+        asm volatile("" : "+v"(f.a0), "+v"(f.a1));
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt) asm volatile("" : "+v"(f.b[b][pt]));
+        return;
+      }
 #pragma unroll
       for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -215,10 +229,14 @@ __global__ __launch_bounds__(64 * kP2Waves) void conv1x1_ps2_kernel(const IGemmA
       const f32x4 w0 = __builtin_bit_cast(f32x4, f.a0), w1 = __builtin_bit_cast(f32x4, f.a1);
       u32x4 H, L;
       uint32_t h, l, unused = 0;
+      if (EVK_PS2_ABL & 256) {       // (ablation: no operand split — the raw words go to the matrix pipe)
+        H = f.a0; L = f.a1;
+      } else {
       split_op<2, PK>(w0.x, w0.y, a_inv, h, l, unused); H[0] = h; L[0] = l;
       split_op<2, PK>(w0.z, w0.w, a_inv, h, l, unused); H[1] = h; L[1] = l;
       split_op<2, PK>(w1.x, w1.y, a_inv, h, l, unused); H[2] = h; L[2] = l;
       split_op<2, PK>(w1.z, w1.w, a_inv, h, l, unused); H[3] = h; L[3] = l;
+      }
       const bf16x8 fa[2] = {__builtin_bit_cast(bf16x8, H), __builtin_bit_cast(bf16x8, L)};
 #pragma unroll
       for (int t = 0; t < 3; ++t)
@@ -227,6 +245,14 @@ __global__ __launch_bounds__(64 * kP2Waves) void conv1x1_ps2_kernel(const IGemmA
     };
     uint32_t amax_m = 0;
     auto park_tile = [&]() {           // accumulators -> staging image, then start the next tile from zero
+      if (EVK_PS2_ABL & 32) {          // (ablation: keep the accumulators live without the LDS writes)
+        float sum = 0.f;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sum += acc[b][r];
+        amax_m = max(amax_m, __builtin_bit_cast(uint32_t, sum));
+      } else
 #pragma unroll
       for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -244,7 +270,7 @@ __global__ __launch_bounds__(64 * kP2Waves) void conv1x1_ps2_kernel(const IGemmA
     };
 
     Frag fx, fy;
-    ring_barrier();                                    // P0: stage 0 has landed
+    p2_barrier();                                    // P0: stage 0 has landed
     uint32_t S_c = lds0;
     int kt = 0;
     if (!(EVK_PS2_ABL & 4)) read_frag(opaque(S_c), 0, fx);
@@ -256,7 +282,7 @@ __global__ __launch_bounds__(64 * kP2Waves) void conv1x1_ps2_kernel(const IGemmA
       const bool last_of_tile = ++kt == nk;
       if (last_of_tile) kt = 0;
       if (EVK_PS2_ABL & 4) {
-        ring_barrier();
+        p2_barrier();
         if (last_of_tile) park_tile();
         continue;
       }
@@ -264,7 +290,7 @@ __global__ __launch_bounds__(64 * kP2Waves) void conv1x1_ps2_kernel(const IGemmA
       __builtin_amdgcn_sched_barrier(0);
       mma(fx);
       __builtin_amdgcn_sched_barrier(0);
-      ring_barrier();                                  // B(g): stage g + 1 has landed; fy returned long ago
+      p2_barrier();                                  // B(g): stage g + 1 has landed; fy returned long ago
       read_frag(Sn, 0, fx);
       __builtin_amdgcn_sched_barrier(0);
       mma(fy);
@@ -272,17 +298,17 @@ __global__ __launch_bounds__(64 * kP2Waves) void conv1x1_ps2_kernel(const IGemmA
       if (last_of_tile) park_tile();                   // complete at B(g + 1): ring_barrier waits for the ds_writes
     }
     if (EVK_PS2_ABL & 4) {
-      ring_barrier();
+      p2_barrier();
     } else {
       read_frag(opaque(S_c), 1, fy);
       __builtin_amdgcn_sched_barrier(0);
       mma(fx);
       __builtin_amdgcn_sched_barrier(0);
-      ring_barrier();                                  // B(G - 1)
+      p2_barrier();                                  // B(G - 1)
       mma(fy);
     }
     park_tile();
-    ring_barrier();                                    // E1: the last tile is staged
+    p2_barrier();                                    // E1: the last tile is staged
     if (p.out_amax) {
       // |acc + bias| <= |acc| + max|bias|; ReLU only lowers it: an upper bound is all the consumer's operand scale needs
       amax_m = __builtin_bit_cast(uint32_t, __builtin_bit_cast(float, amax_m) + bias_max);
@@ -381,21 +407,21 @@ __global__ __launch_bounds__(64 * kP2Waves) void conv1x1_ps2_kernel(const IGemmA
 
   // slices of tile j-1 in the nk - 1 intervals between B(first step of tile j) and B(last step of tile j)
   const int per = (kP2Instr + nk - 2) / (nk - 1);
-  ring_barrier();                                    // P0
-  for (int k = 0; k < nk; ++k) ring_barrier();       // tile 0: B(0) .. B(nk - 1), nothing to drain yet
+  p2_barrier();                                    // P0
+  for (int k = 0; k < nk; ++k) p2_barrier();       // tile 0: B(0) .. B(nk - 1), nothing to drain yet
   for (int j = 1; j < nmine; ++j) {
-    ring_barrier();                                  // B(first step of tile j): tile j-1 is staged
+    p2_barrier();                                  // B(first step of tile j): tile j-1 is staged
     set_drain_tile(grp + (j - 1) * ngroups);
     for (int k = 1; k < nk; ++k) {
       const int count = min(per, kP2Instr - d_i);
-      if (count > 0) drain(count);
-      ring_barrier();                                // B(j nk + k)   (waits for this wave's LDS reads: lgkmcnt(0))
+      if (count > 0 && !(EVK_PS2_ABL & 16)) drain(count);
+      p2_barrier();                                // B(j nk + k)   (waits for this wave's LDS reads: lgkmcnt(0))
     }
     close_tile();
   }
-  ring_barrier();                                    // E1: the last tile is staged
+  p2_barrier();                                    // E1: the last tile is staged
   set_drain_tile(grp + (nmine - 1) * ngroups);
-  drain(kP2Instr);
+  if (!(EVK_PS2_ABL & 16)) drain(kP2Instr);
   close_tile();
 }
 
