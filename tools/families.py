@@ -7,18 +7,19 @@ A family is (key, label, substrings).  A kernel belongs to the FIRST family one 
 totals plus the rest add up to the capture's total."""
 
 # forward + data gradient convolution kernels (bench.py family `conv_igemm`)
-CONV_IGEMM = ('conv_igemm', 'conv3x3_halo', 'conv1x1_dma', 'conv1x1_ps', 'conv1x1_smallm', 'conv1x1_big', 'conv_gemm256')
+# every one-tap form starts with conv1x1_ (dma, ps, ps2, sp, smallm): ONE prefix, so that the next one cannot be forgotten
+CONV_IGEMM = ('conv_igemm', 'conv3x3_halo', '^conv1x1_')
 CONV_WGRAD = ('conv_wgrad',)
 # what a weight-gradient C-ABI call launches besides its matrix kernel
 CONV_WGRAD_AUX = ('splitk_reduce', 'colsum_', 'pack_f16x2', 'pack_planar')
 BN = ('bn_',)
 # the memory-bound kernels north_star names, as bench.py's `resample_loss` spans bracket them (hip/functional.py: the
 # bilinear forward / backward and the bce / dice / ce calls with their tiny finalisation kernels)
-RESAMPLE_LOSS = ('^bilinear_', '^mean_loss', '^finalize_partials', '^bce_', '^dice_', '^ce_', '^focal_', '^prob_stats', '^ohem_')   # '^' = the bare name starts with it
+RESAMPLE_LOSS = ('^bilinear_', '^mean_loss', '^finalize_partials', '^bce_', '^dice_', '^ce_', '^focal_', '^prob_stats', '^ohem_', '^soft_ce_', '^sum_loss', '^nr_finalize')   # '^' = the bare name starts with it
 
 FAMILIES = (
-    ('conv_igemm', 'conv_igemm (forward + data gradient: conv3x3_halo_x3 / conv1x1_dma / conv1x1_ps / conv_igemm_x3ws / '
-                   'conv_igemm_x3 / conv_igemm / conv1x1_smallm kernels)', CONV_IGEMM),
+    ('conv_igemm', 'conv_igemm (forward + data gradient: conv3x3_halo_x3 / conv1x1_* (dma, ps, ps2, sp, smallm) / conv_igemm_x3ws / '
+                   'conv_igemm_x3 / conv_igemm kernels)', CONV_IGEMM),
     ('conv_wgrad', 'conv_wgrad (conv_wgrad_x3ws / conv_wgrad_x3 / conv_wgrad_tr / conv_wgrad kernels)', CONV_WGRAD),
     ('conv_wgrad_aux', 'weight-gradient auxiliaries (splitk_reduce, colsum_*, pack_f16x2 / pack_planar): part of a '
                        'weight-gradient C-ABI call as bench.py brackets it', CONV_WGRAD_AUX),
@@ -26,10 +27,11 @@ FAMILIES = (
     ('resample_loss', 'bilinear resampling + pixel losses (bilinear_* / bce_* / dice_* / ce_* kernels and their finalisation)', RESAMPLE_LOSS),
     ('pointwise', 'other streaming kernels of the model (relation_* / nearest2x_* / gap_* / mean4 / ew / stem_s2d / maxpool / gn_* / concat / '
                   'channel_scale / confusion)', ('^relation_', '^nearest2x_', '^gap_', '^mean4', '^ew_', '^stem_s2d_kernel', '^maxpool', '^gn_', '^concat2',
-                                                '^split2', '^channel_scale', '^confusion', '^nchw_', '^nhwc_')),
+                                                '^split2', '^channel_scale', '^confusion', '^nchw_', '^nhwc_', '^bias_rows', '^pad_channels', '^unpad_channels',
+                                                '^relu_bits_apply', '^scale_store')),
     ('operand_prep', 'operand preparation of the f16x2 arithmetic (absmax* scale words, split_weight* planes)',
-     ('^absmax', '^split_weight', '^pack_dgrad_weight', '^stem_s2d_weight')),
-    ('optimizer', 'fused optimizer / gradient-bucket kernels (sgd_multi, sqnorm_multi, pack_multi, clip)', ('^sgd_', '^sqnorm_', '^pack_multi', '^clip_', '^unpack_multi', '^scale_multi')),
+     ('^absmax', '^split_weight', '^pack_dgrad_weight', '^stem_s2d_weight', '^group_weight')),
+    ('optimizer', 'fused optimizer / gradient-bucket kernels (sgd_multi, sqnorm_multi, pack_multi, clip)', ('^sgd_', '^adam_', '^sqnorm_', '^pack_multi', '^clip_', '^unpack_multi', '^scale_multi')),
 )
 
 
