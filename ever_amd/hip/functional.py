@@ -213,7 +213,8 @@ _cuda_set_stream = getattr(torch._C, '_cuda_setStream', None)
 
 _WGRAD_QUEUE = {}                # device -> launch closures of weight gradients not issued yet (one list per
                                  # device — autograd runs one engine thread per device, and a shared list lost appends)
-_WGRAD_EARLY = os.environ.get('EVK_WGRAD_EARLY', '0') == '1'
+_WGRAD_EARLY_MODE = int(os.environ.get('EVK_WGRAD_EARLY', '0'))
+_WGRAD_EARLY = _WGRAD_EARLY_MODE == 1
 _WGRAD_BATCH = max(1, int(os.environ.get('EVK_WGRAD_BATCH', '1')))   # (8, 16, 32 measured: 524 vs 531 tiles/s for 1, same box)
 
 
@@ -1040,7 +1041,14 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False,
 
     # EVK_WGRAD_EARLY=1 (A/B): the weight gradient is forked BEFORE the data gradient is enqueued, so that it may start
     # beside it instead of behind it; the operand scale of dy is fixed first (both read it, from different streams)
-    if _WGRAD_EARLY and need_dx and (need_dw or need_db) and _f16x2() and x3:
+    # EVK_WGRAD_EARLY=2 (round 5): only the layers whose weight gradient is the nine-tap planar kernel (3x3x256 on the 128^2
+    # maps: one 686 us workgroup per CU at 244 registers x 2 waves per SIMD — NOTHING co-resides with it).  Forked behind its
+    # data gradient it runs beside the short HBM-bound kernels that follow on the backward's stream and holds every one of them
+    # off the chip (profiles/r05_stream_timeline.txt: a 5 us finalisation kernel "running" 180 us); forked in front, it time-slices
+    # with its own layer's 780 us halo data gradient — two long matrix-bound kernels, where nothing short waits.
+    early = _WGRAD_EARLY_MODE == 1 or (_WGRAD_EARLY_MODE == 2 and need_dw and cout_p == cout and cin_p == cin and not dy_pk
+                                       and _wgrad_planar_pays(dk, need_db))
+    if early and need_dx and (need_dw or need_db) and _f16x2() and x3:
         absmax_bits(dyk, st)
         _wgrad()
         _dgrad()
