@@ -33,7 +33,7 @@ X = os.path.join(P, f'{tag}_experiments')
 os.makedirs(X, exist_ok=True)
 for name in ('final/power_probe.txt', 'final/dma_patterns.txt', 'final/dma_issue.txt', 'final/ab_c1sp.txt', 'sp_abl.txt', 'ab_c1_small.txt',
              'at_halo_pipe.txt', 'at_halo_old.txt', 'at_k1.txt', 'ab_bn_elems.txt', 'bn_big.txt', 'reduce_patterns.txt', 'kstats_ps2.md',
-             'kstats_ps2off.md'):
+             'kstats_ps2off.md', 'power_phase.txt', 'power_step.txt', 'host_profile.txt', 'train_sanity.txt'):
     s = os.path.join(G, name)
     if os.path.exists(s) and os.path.getsize(s) > 0:
         shutil.copyfile(s, os.path.join(X, os.path.basename(name)))
