@@ -206,6 +206,55 @@ def library_gemm_yardstick(dev):
     return out
 
 
+def board_power_line(step, seconds=2.5):
+    """Board power while the SAME training step keeps running after the timed region (rocm-smi sampled every ~0.4 s from a
+    thread; DESIGN 2.10: every phase of this step runs at 73-100 % of the part's power cap, so the step is bounded by its
+    energy, not by a kernel schedule).  None when rocm-smi is not on the box.  Never part of the timed region."""
+    import shutil
+    import subprocess
+    import threading
+    if shutil.which('rocm-smi') is None:
+        return None
+    samples, stop = [], [False]
+
+    def sampler():
+        time.sleep(0.5)
+        while not stop[0]:
+            try:
+                out = subprocess.run(['rocm-smi', '--showpower', '--showclocks', '--json'], capture_output=True, text=True,
+                                     timeout=10).stdout
+                d = json.loads(out)
+                card = d.get('card0') or next(iter(d.values()))
+                w = next((float(v) for k, v in card.items() if 'Power (W)' in k), None)
+                clk = next((int(''.join(c for c in v if c.isdigit())) for k, v in card.items() if k.startswith('sclk clock speed')), None)
+                if w is not None:
+                    samples.append((w, clk))
+            except Exception:      # noqa: BLE001 (a probe, never a reason to lose the line)
+                pass
+            time.sleep(0.3)
+
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        n += 10
+    elapsed = time.perf_counter() - t0
+    stop[0] = True
+    th.join(timeout=15)
+    if not samples:
+        return None
+    w = sum(s[0] for s in samples) / len(samples)
+    clks = [s[1] for s in samples if s[1]]
+    return {'avg_board_power_w': round(w, 1), 'power_cap_w': 1400, 'frac_of_cap': round(w / 1400.0, 3),
+            'avg_sclk_mhz': round(sum(clks) / len(clks)) if clks else None, 'samples': len(samples),
+            'joules_per_step': round(w * elapsed / n, 2), 'ms_per_step_during_probe': round(elapsed / n * 1e3, 3),
+            'note': 'rocm-smi during extra steps after the timed region; by phase (profiles/r05_experiments/power_phase.txt): 3x3 halo '
+                    'convolution 1380 W, one-tap 256->256 @128^2 1400 W, BatchNorm backward 1217 W, device copy 1018 W, idle 283 W'}
+
+
 def graph_replay_line(args):
     """The same workload with the step captured once as a hipGraph and replayed (`bench.py --graph`, ever_amd/core/graph.py;
     bit-identical to the eager step: tests/test_graph_gpu.py), measured in a CHILD process after the timed region — a capture
@@ -608,6 +657,8 @@ def main():
                                                                  'frac_overlapped': round(g1 / PEAK_HBM_GBS, 4)})
         if world == 1 and not args.graph and 'roofline' in line:
             line['roofline']['library_fp16_gemm'] = library_gemm_yardstick(dev)
+        if world == 1 and not args.graph and not args.no_graph_line and not use_ddp:
+            line['board_power'] = board_power_line(step)
         if world == 1 and not use_ddp and not args.graph and not args.no_graph_line and conv_math == 'f16x2':
             line['hip_graph_replay'] = graph_replay_line(args)
         if world == 1 and not args.no_cpu_baseline:
