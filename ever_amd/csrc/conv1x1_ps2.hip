@@ -51,6 +51,18 @@ __device__ __forceinline__ void p2_dma16s(i32x4 rsrc, uint32_t lds_byte, uint32_
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
                :: "v"(voff), "s"(lds_byte), "s"(rsrc), "s"(soff) : "memory", "m0");
 }
+// the activation stream with the non-temporal hint: a row tile is read by tiles_n workgroups of one XCD — with one or two
+// column tiles the hint is ahead (same box, us: 256 -> 256 @128^2 197 -> 187, 64 -> 256 92 -> 87, 256 -> 128 94 -> 90), with
+// four it evicts what the neighbours are about to read (128 -> 512 @64^2 51 -> 58): the launcher decides (template NT)
+template <bool NT>
+__device__ __forceinline__ void p2_dma16s_a(i32x4 rsrc, uint32_t lds_byte, uint32_t voff, uint32_t soff) {
+  if constexpr (NT) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen nt lds"
+                 :: "v"(voff), "s"(lds_byte), "s"(rsrc), "s"(soff) : "memory", "m0");
+  } else {
+    p2_dma16s(rsrc, lds_byte, voff, soff);
+  }
+}
 // (ablation bit 64: no barrier at all — the loop's own speed; results are garbage)
 __device__ __forceinline__ void p2_barrier() {
   if (EVK_PS2_ABL & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -68,7 +80,7 @@ __device__ __forceinline__ uint32_t p2_out_off(int row, int c) { return (uint32_
 
 }  // namespace
 
-template <bool PK, bool STATS>
+template <bool PK, bool STATS, bool NT>
 __global__ __launch_bounds__(64 * kP2Waves) void conv1x1_ps2_kernel(const IGemmArgs p, uint32_t src_bytes, uint32_t wgt_bytes) {
   constexpr int BM = kP2BM, BN = kP2BN, WM = 32, WN = 64, NB = 2, NST = kP2NST;
   constexpr int AI = kP2AStage / 1024 / kP2LW;        // activation DMA instructions per loader wave and stage (8 rows each)
@@ -136,7 +148,7 @@ __global__ __launch_bounds__(64 * kP2Waves) void conv1x1_ps2_kernel(const IGemmA
       if (!(EVK_PS2_ABL & 1)) {
         const uint32_t ka = (uint32_t)i_kt * kP2Row, kb = (uint32_t)i_kt * kRowBytes;
 #pragma unroll
-        for (int t = 0; t < AI; ++t) p2_dma16s(rs_a, S_i + (AI * lw + t) * 1024, a_voff[t], ka);
+        for (int t = 0; t < AI; ++t) p2_dma16s_a<NT>(rs_a, S_i + (AI * lw + t) * 1024, a_voff[t], ka);
 #pragma unroll
         for (int t = 0; t < BI; ++t) p2_dma16s(rs_b, S_i + kP2AStage + (BI * lw + t) * 1024, b_voff[t], kb);
       }
@@ -478,16 +490,22 @@ int launch_conv1x1_ps2(IGemmArgs& a, hipStream_t stream) {
   const unsigned long long sb = (unsigned long long)a.N * a.Hs * a.Ws * a.Cs * 4ull;
   const unsigned long long wb = 2ull * a.Cd * a.Kpad * 2ull;
   const dim3 g((unsigned)grid), b(64 * kP2Waves);
-  const int which = (a.a_packed ? 2 : 0) | (a.bn_part != nullptr ? 1 : 0);
+  // non-temporal activation loads where at most two workgroups read a row tile (EVK_C1_PS2_NT=0: never; A/B switch)
+  static const bool nt_on = !(getenv("EVK_C1_PS2_NT") && atoi(getenv("EVK_C1_PS2_NT")) == 0);
+  const int which = (a.a_packed ? 2 : 0) | (a.bn_part != nullptr ? 1 : 0) | ((nt_on && a.tiles_n <= 2) ? 4 : 0);
   auto go = [&](auto kern) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kP2Lds);
     hipLaunchKernelGGL(kern, g, b, kP2Lds, stream, a, (uint32_t)sb, (uint32_t)wb);
   };
   switch (which) {
-    case 0: go(&conv1x1_ps2_kernel<false, false>); break;
-    case 1: go(&conv1x1_ps2_kernel<false, true>); break;
-    case 2: go(&conv1x1_ps2_kernel<true, false>); break;
-    default: go(&conv1x1_ps2_kernel<true, true>); break;
+    case 0: go(&conv1x1_ps2_kernel<false, false, false>); break;
+    case 1: go(&conv1x1_ps2_kernel<false, true, false>); break;
+    case 2: go(&conv1x1_ps2_kernel<true, false, false>); break;
+    case 3: go(&conv1x1_ps2_kernel<true, true, false>); break;
+    case 4: go(&conv1x1_ps2_kernel<false, false, true>); break;
+    case 5: go(&conv1x1_ps2_kernel<false, true, true>); break;
+    case 6: go(&conv1x1_ps2_kernel<true, false, true>); break;
+    default: go(&conv1x1_ps2_kernel<true, true, true>); break;
   }
   return check_launch("conv1x1_ps2");
 }
