@@ -10,6 +10,21 @@
 
 namespace evk {
 
+#ifndef EVK_BN_NT
+#define EVK_BN_NT 1
+#endif
+// streaming loads of the one-element-per-thread apply passes with the non-temporal hint (round 5): they are the LAST reader of
+// what they stream for a long while (the forward apply of z until the backward; the backward apply of g and z for good), so the
+// lines need not stay in L2 / the memory-side cache: 536.2 -> 539.6 tiles/s, three interleaved rounds on one box
+// (tools/ab_lib.sh; -DEVK_BN_NT=0 builds the plain loads).  The reduce pass keeps plain loads: the apply pass re-reads its data.
+__device__ __forceinline__ f32x4 bn_ld(const float* p, size_t i) {
+#if EVK_BN_NT
+  return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + i);
+#else
+  return reinterpret_cast<const f32x4*>(p)[i];
+#endif
+}
+
 constexpr int kMaxStatBlocks = 2048;
 
 // the slots of an output's operand-scale buffer start empty (block_absmax below fills them)
@@ -245,8 +260,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     const int cb = chunk_of(base, c4);
     const f32x4 sc = reinterpret_cast<const f32x4*>(scale_shift)[cb];
     const f32x4 sh = reinterpret_cast<const f32x4*>(scale_shift + C)[cb];
-    v = reinterpret_cast<const f32x4*>(x)[i] * sc + sh;
-    if (residual) v += reinterpret_cast<const f32x4*>(residual)[i];
+    v = bn_ld(x, i) * sc + sh;
+    if (residual) v += bn_ld(residual, i);
   }
   // the backward's mask, one bit per element (common.hpp: relu_bits_*): every lane of the wave takes part (v = 0 where
   // the element does not exist), i >> 6 is this wave's chunk
@@ -472,8 +487,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const f32x4 k2 = reinterpret_cast<const f32x4*>(coef + 2 * C)[c];
     const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c];
     const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[c];
-    f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
-    const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+    f32x4 g = bn_ld(dy, i);
+    const f32x4 xv = bn_ld(x, i);
     if (relu == 3) {
       g = relu_bits_mask(g, bits, i);
     } else if (relu) {

@@ -178,6 +178,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGradArgs p) {
     }
 }
 
+#ifndef EVK_SK_NT
+#define EVK_SK_NT 1   // (528.2 -> 528.6 tiles/s over three interleaved rounds: inside the noise, kept as the right hint)
+#endif
+#if EVK_SK_NT
+#define SK_LD(p) __builtin_nontemporal_load(p)   // the partials' last reader
+#else
+#define SK_LD(p) (*(p))
+#endif
 // out[i] = sum_z ws[z][i]  (fixed order)
 // `lanes` threads share one 16-byte element: lane l sums the splits z = l, l + lanes, ... (fixed order), the lanes are
 // folded through LDS in index order => the result depends on (splitk, lanes) only, never on timing.  With one thread
@@ -196,11 +204,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     if (i < n4) {
       int z = l;
       for (; z + 3 * lanes < splitk; z += 4 * lanes) {  // four independent 16-byte loads in flight
-        const f32x4 a = w4[(size_t)z * stride4 + i], b = w4[(size_t)(z + lanes) * stride4 + i];
-        const f32x4 c = w4[(size_t)(z + 2 * lanes) * stride4 + i], d = w4[(size_t)(z + 3 * lanes) * stride4 + i];
+        const f32x4 a = SK_LD(w4 + (size_t)z * stride4 + i), b = SK_LD(w4 + (size_t)(z + lanes) * stride4 + i);
+        const f32x4 c = SK_LD(w4 + (size_t)(z + 2 * lanes) * stride4 + i), d = SK_LD(w4 + (size_t)(z + 3 * lanes) * stride4 + i);
         s += (a + b) + (c + d);
       }
-      for (; z < splitk; z += lanes) s += w4[(size_t)z * stride4 + i];
+      for (; z < splitk; z += lanes) s += SK_LD(w4 + (size_t)z * stride4 + i);
     }
     if (lanes > 1) {
       red[threadIdx.x] = s;
