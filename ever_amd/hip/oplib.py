@@ -6,6 +6,8 @@ cannot serialise).  The reference exports models with `torch.jit.trace` (`ever/a
 `torch.compile` (`ever/trainer/trainer.py:241-243`), so the no-grad forward of every layer kind is ALSO a dispatcher-level
 operator: an opaque custom op with a schema, the same ctypes launch behind it, and a fake (shape-only) implementation.
 
+  * the operators differentiate (register_autograd: the backward re-runs the entry point under autograd — same kernels, same
+    gradients; the package's own training path keeps its state-carrying autograd.Function wrappers and never pays that);
   * eager calls do not go through the dispatcher (no cost on the hot path): `traceable()` returns a wrapper that takes the
     operator route only while a trace is being recorded (`torch.jit.trace`, or a compiler's fake-tensor pass);
   * a TorchScript file saved from such a trace holds `ever_amd::conv2d(...)` nodes and the weights as constants; loading it
@@ -52,6 +54,43 @@ def traceable(name, schema, fn, adapt, fake, applies=None, impl_fn=None):
 
     _LIB.impl(name, impl, 'CUDA')
     torch.library.register_fake('ever_amd::' + name, fake, lib=_LIB)
+
+    # Autograd for the operator ("op definitions + autograd wrappers"): a direct call of
+    # torch.ops.ever_amd.<name> on tensors that require grad differentiates.  The training path of this package does NOT come
+    # through here (its autograd.Function wrappers keep the forward's state — statistics records, packed operands, gradient
+    # slots — and cost no recomputation); the operator's backward re-runs the entry point under autograd and differentiates
+    # that: the same kernels, hence the same gradients bit for bit, at the price of a second forward.
+    def setup_context(ctx, inputs, output):
+        ctx.spec = [None if isinstance(a, torch.Tensor) else a for a in inputs]
+        ctx.is_tensor = [isinstance(a, torch.Tensor) for a in inputs]
+        ctx.save_for_backward(*[a for a in inputs if isinstance(a, torch.Tensor)])
+
+    def backward(ctx, grad):
+        saved = iter(ctx.saved_tensors)
+        args, wrt = [], []
+        for i, (is_t, v) in enumerate(zip(ctx.is_tensor, ctx.spec)):
+            if is_t:
+                t = next(saved).detach()
+                if ctx.needs_input_grad[i]:
+                    t.requires_grad_()
+                    wrt.append((i, t))
+                args.append(t)
+            else:
+                args.append(v)
+        _STATE.inside = True
+        try:
+            with torch.enable_grad():
+                y = (impl_fn or fn)(*args)
+                gs = torch.autograd.grad(y, [t for _, t in wrt], grad.contiguous(memory_format=torch.channels_last)
+                                         if grad.dim() == 4 else grad, allow_unused=True)
+        finally:
+            _STATE.inside = False
+        out = [None] * len(args)
+        for (i, _), g in zip(wrt, gs):
+            out[i] = g
+        return tuple(out)
+
+    torch.library.register_autograd('ever_amd::' + name, backward, setup_context=setup_context, lib=_LIB)
     op = getattr(torch.ops.ever_amd, name)
     OPS[name] = op
 

@@ -171,3 +171,63 @@ def test_torch_compile_hook_trains_like_eager(cuda):
             assert torch.equal(la[k], lb[k]), k
     for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
         assert torch.equal(p, q), k
+
+
+def test_library_operators_differentiate(cuda):
+    """SURVEY 8 b4 / VERDICT r4 weak 12: the `ever_amd::*` operators carry autograd.  A direct call on tensors that require grad
+    gives the gradients of the package's own autograd.Function path — the operator's backward re-runs the entry point under
+    autograd (hip/oplib.py), the same kernels in the same order: bit for bit."""
+    from ever_amd.hip import functional as HF
+    ops = torch.ops.ever_amd
+    g = torch.Generator().manual_seed(11)
+    cl = torch.channels_last
+
+    def leaf(*shape, scale=1.0):
+        t = (torch.randn(*shape, generator=g) * scale).to(cuda)
+        return (t.contiguous(memory_format=cl) if t.dim() == 4 else t).requires_grad_()
+
+    def same(a, b):
+        assert len(a) == len(b)
+        for u, v in zip(a, b):
+            assert (u is None) == (v is None)
+            if u is not None:
+                assert torch.equal(u, v), float((u - v).abs().max())
+
+    # convolution (3x3, bias, fused ReLU): x, weight and bias gradients
+    x, w, b = leaf(2, 32, 24, 20), leaf(48, 32, 3, 3, scale=0.1), leaf(48)
+    dy = torch.randn(2, 48, 24, 20, generator=g).to(cuda).contiguous(memory_format=cl)
+    y1 = ops.conv2d(x, w, b, [1, 1], [1, 1], [1, 1], True)
+    g1 = torch.autograd.grad(y1, (x, w, b), dy)
+    y2 = HF._conv2d_plain(x, w, b, (1, 1), (1, 1), (1, 1), relu=True)
+    g2 = torch.autograd.grad(y2, (x, w, b), dy)
+    assert torch.equal(y1, y2)
+    same(g1, g2)
+    # one-tap convolution without bias, only the input needs a gradient
+    w1 = (torch.randn(64, 32, 1, 1, generator=g) * 0.1).to(cuda).contiguous(memory_format=cl)
+    y1 = ops.conv2d(x, w1, None, [1, 1], [0, 0], [1, 1], False)
+    y2 = HF._conv2d_plain(x, w1, None, (1, 1), (0, 0), (1, 1), relu=False)
+    d1 = torch.randn_like(y1)
+    same(torch.autograd.grad(y1, (x,), d1), torch.autograd.grad(y2, (x,), d1))
+    # element-wise / pooling / resampling operators
+    a, c = leaf(2, 16, 12, 12), leaf(2, 16, 12, 12)
+    for op, plain, args in ((ops.relu, HF._relu_plain, (a,)), (ops.add, HF._add_plain, (a, c)),
+                            (ops.max_pool3x3s2, HF._max_pool_plain, (a,)), (ops.global_avg_pool, HF._gap_plain, (a,))):
+        o1, o2 = op(*args), plain(*args)
+        d = torch.randn_like(o1)
+        assert torch.equal(o1, o2)
+        same(torch.autograd.grad(o1, args, d), torch.autograd.grad(o2, args, d))
+    o1, o2 = ops.upsample_bilinear(a, 2.0, 2.0), HF._bilinear_plain(a, (2.0, 2.0))
+    d = torch.randn_like(o1)
+    same(torch.autograd.grad(o1, (a,), d), torch.autograd.grad(o2, (a,), d))
+    top, lat = leaf(2, 16, 6, 6), leaf(2, 16, 12, 12)
+    o1, o2 = ops.upsample_nearest2x_add(top, lat), HF._nearest_add_plain(top, lat)
+    d = torch.randn_like(o1)
+    same(torch.autograd.grad(o1, (top, lat), d), torch.autograd.grad(o2, (top, lat), d))
+    # eval-mode BatchNorm (+ residual, ReLU): input, affine parameters and residual
+    gam, bet, res = leaf(16), leaf(16), leaf(2, 16, 12, 12)
+    rm, rv = torch.randn(16, generator=g).to(cuda), (torch.rand(16, generator=g) + 0.5).to(cuda)
+    o1 = ops.batch_norm_eval(a, gam, bet, rm, rv, 1e-5, res, True)
+    o2 = HF._bn_act_plain(a, gam, bet, rm, rv, False, 0.1, 1e-5, residual=res, relu=True)
+    d = torch.randn_like(o1)
+    assert torch.equal(o1, o2)
+    same(torch.autograd.grad(o1, (a, gam, bet, res), d), torch.autograd.grad(o2, (a, gam, bet, res), d))
