@@ -69,6 +69,10 @@ def parse():
                         'MFMA products, fp32 grade; bf16x3 = 3-term bf16 split, 6 products, fp32 grade; f32 = exact fp32 '
                         'MFMA; bf16 = plain bf16 operands, the --mixed_precision bf16 mode: NOT the headline configuration)')
     p.add_argument('--no-kernel-timer', action='store_true')
+    p.add_argument('--host-cores', type=int, default=None,
+                   help='CPUs this rank\'s enqueuing threads are kept on (ever_amd.core.device.pin_host_threads): default '
+                        'EVK_HOST_CORES, else 4 (the inputs are resident in HBM, there are no loader workers to squeeze); '
+                        '0 = only restore the launch mask if the HIP runtime widened it')
     p.add_argument('--graph', action='store_true',
                    help='run the step as one captured hipGraph (ever_amd/core/graph.py; N = 1, no per-kernel event timer): '
                         'what the host costs then is in host_*_ms_per_step')
@@ -382,6 +386,11 @@ def main():
                                 device_id=dev)   # RCCL over xGMI, communicator bound to this rank's GPU
     import ever_amd as er
     from ever_amd import _C
+    from ever_amd.core.device import pin_host_threads
+    torch.cuda.init()
+    if args.host_cores is None:
+        args.host_cores = int(os.environ.get('EVK_HOST_CORES', '4') or 0)
+    pin_host_threads(local_rank, args.host_cores)   # (after the runtime is up: its initialisation may reset the mask)
     from ever_amd.hip import timing
     from ever_amd.hip import functional as HF
     if args.conv_math:

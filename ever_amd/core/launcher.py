@@ -32,7 +32,7 @@ from ..interface.learning_rate import LearningRateBase
 from . import to
 from .checkpoint import CheckPoint
 from .config import AttrDict
-from .device import auto_device
+from .device import auto_device, pin_host_threads
 from .dist import get_world_size, is_main_process
 from .iterator import get_iterator
 from .logger import Logger
@@ -116,6 +116,10 @@ class Launcher:
             self._logger = Logger('EVER', use_tensorboard=False, tensorboard_logdir=model_dir)
             self._logger.on()
         self._device = auto_device()
+        if self._device.type == 'cuda' and os.environ.get('EVK_HOST_CORES'):
+            # opt-in (loader workers inherit the mask): keep the enqueuing threads of this rank on a few CPUs (core/device.py)
+            torch.cuda.init()
+            pin_host_threads(int(os.environ.get('LOCAL_RANK', 0)))
         self._ckpt = CheckPoint(self)
         self._training = False
         self._buffer = dict()

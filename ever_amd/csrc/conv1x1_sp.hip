@@ -43,6 +43,8 @@ __device__ __forceinline__ void sp_dma16s(i32x4 rsrc, uint32_t lds_byte, uint32_
 __device__ __forceinline__ u32x4 sp_lds_read16(uint32_t lds_byte) {
   return *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)lds_byte;
 }
+// (ablations 16: no barrier; 32: the fragments are read once, in front of the loop; 64: no operand split / byte permutes)
+__device__ __forceinline__ void sp_barrier() { if (!(EVK_SP_ABL & 16)) ring_barrier(); }
 __device__ __forceinline__ int sp_arow_off(int row, int c) { return row * kSpRow + ((c ^ ((row >> 1) & 7)) << 4); }
 
 }  // namespace
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(64 * (kSpCW + LW)) void conv1x1_sp_kernel(const IGe
     // stage 0 landed: at most the later prologue stages outstanding (fewer than NST - 2 of them exist when nk is short: the
     // count is then an over-estimate of what may stay in flight only if nk - 1 < NST - 2, handled by the full wait)
     if (nk - 1 >= NST - 2) wait_vmcnt<(NST - 2) * PER>(); else wait_vmcnt<0>();
-    ring_barrier();                                   // P0
+    sp_barrier();                                   // P0
     uint32_t S_i = lds0 + (NST - 1) * kStage;         // slot of stage kt + NST - 1 (= the slot stage kt - 1 has left)
     for (int kt = 0; kt < nk; ++kt) {
       if (kt + NST - 1 < nk) issue(kt + NST - 1, S_i);
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(64 * (kSpCW + LW)) void conv1x1_sp_kernel(const IGe
       if (younger >= NST - 2) wait_vmcnt<(NST - 2) * PER>();
       else if (NST > 3 && younger == 1) wait_vmcnt<PER>();
       else wait_vmcnt<0>();
-      ring_barrier();                                 // B(kt)
+      sp_barrier();                                 // B(kt)
     }
     return;
   }
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(64 * (kSpCW + LW)) void conv1x1_sp_kernel(const IGe
     u32x4 a0, a1;            // raw activation words: 8 consecutive k of this lane's row
     bf16x8 b[NB][2];         // weight planes h, l
   };
-  auto read_frag = [&](uint32_t S, int kk, Frag& f) {
+  auto read_frag_now = [&](uint32_t S, int kk, Frag& f) {
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -169,11 +171,22 @@ __global__ __launch_bounds__(64 * (kSpCW + LW)) void conv1x1_sp_kernel(const IGe
     f.a0 = sp_lds_read16(S + fa_off[kk][0]);
     f.a1 = sp_lds_read16(S + fa_off[kk][1]);
   };
+  auto read_frag = [&](uint32_t S, int kk, Frag& f) {
+    if (!(EVK_SP_ABL & 32)) read_frag_now(S, kk, f);
+  };
   auto mma = [&](const Frag& f) {
     // (read as floats: a bit_cast of an ext-vector ELEMENT is miscompiled by this hipcc; conv1x1_dma.hip)
     const f32x4 w0 = __builtin_bit_cast(f32x4, f.a0), w1 = __builtin_bit_cast(f32x4, f.a1);
     u32x4 H, L;
     uint32_t h, l, unused = 0;
+    if (EVK_SP_ABL & 64) {
+      const bf16x8 fr[2] = {__builtin_bit_cast(bf16x8, f.a0), __builtin_bit_cast(bf16x8, f.a1)};
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[0][b] = mfma_np<2>(f.b[b][kHB[t]], fr[kHA[t]], acc[0][b]);
+      return;
+    }
     split_op<2, PK>(w0.x, w0.y, a_inv, h, l, unused); H[0] = h; L[0] = l;
     split_op<2, PK>(w0.z, w0.w, a_inv, h, l, unused); H[1] = h; L[1] = l;
     split_op<2, PK>(w1.x, w1.y, a_inv, h, l, unused); H[2] = h; L[2] = l;
@@ -186,9 +199,10 @@ __global__ __launch_bounds__(64 * (kSpCW + LW)) void conv1x1_sp_kernel(const IGe
   };
 
   Frag fx, fy;
-  ring_barrier();                                     // P0: stage 0 has landed
+  sp_barrier();                                     // P0: stage 0 has landed
   uint32_t S_c = lds0;
-  if (!(EVK_SP_ABL & 4)) read_frag(opaque(S_c), 0, fx);
+  if (!(EVK_SP_ABL & 4)) read_frag_now(opaque(S_c), 0, fx);
+  if (EVK_SP_ABL & 32) read_frag_now(opaque(S_c), 1, fy);
   // (the last step is peeled: a conditional read of the next stage would merge two LDS-counter states behind the barrier and
   // make hipcc wait for the reads just issued — seen in the ISA as lgkmcnt(1) in front of the second MFMA group)
   for (int kt = 0; kt + 1 < nk; ++kt) {
@@ -196,27 +210,27 @@ __global__ __launch_bounds__(64 * (kSpCW + LW)) void conv1x1_sp_kernel(const IGe
     S_c = S_c == lds0 + (NST - 1) * kStage ? lds0 : S_c + kStage;
     const uint32_t Sn = opaque(S_c);
     if (EVK_SP_ABL & 4) {
-      ring_barrier();
+      sp_barrier();
       continue;
     }
     read_frag(S, 1, fy);
     __builtin_amdgcn_sched_barrier(0);
     mma(fx);
     __builtin_amdgcn_sched_barrier(0);
-    ring_barrier();                                   // B(kt): stage kt + 1 has landed; fy has returned long ago
+    sp_barrier();                                   // B(kt): stage kt + 1 has landed; fy has returned long ago
     read_frag(Sn, 0, fx);
     __builtin_amdgcn_sched_barrier(0);
     mma(fy);
     __builtin_amdgcn_sched_barrier(0);
   }
   if (EVK_SP_ABL & 4) {
-    ring_barrier();
+    sp_barrier();
   } else {
     read_frag(opaque(S_c), 1, fy);
     __builtin_amdgcn_sched_barrier(0);
     mma(fx);
     __builtin_amdgcn_sched_barrier(0);
-    ring_barrier();                                   // B(nk - 1): the loader waves' last barrier
+    sp_barrier();                                   // B(nk - 1): the loader waves' last barrier
     mma(fy);
   }
   if (EVK_SP_ABL & 8) {   // (every accumulator register stays live: nothing of the loop may be optimised away)

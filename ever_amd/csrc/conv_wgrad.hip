@@ -287,7 +287,10 @@ WGradPlan plan_wgrad(const evk_conv_desc* d, int x3, int planes, int tr) {
   // (its gathers are raw buffer loads: 32-bit byte offsets, so both tensors must stay below 2 GiB)
   const bool fits32 = (long long)d->N * d->H * d->W * d->Cin * 4 < 0x7fffffffLL &&
                       (long long)d->N * d->Ho * d->Wo * d->Cout * 4 < 0x7fffffffLL;
-  pl.ws = (x3 && ws_mode && d->Cout >= 128 && Ktot >= 256 && fits32) ? 1 : 0;
+  // (Cout below 128 leaves rows of the 128-row tile empty; EVK_WG_WS_MINCOUT: from which width the wide tile still wins)
+  static const int ws_min0 = getenv("EVK_WG_WS_MINCOUT") ? atoi(getenv("EVK_WG_WS_MINCOUT")) : 128;
+  const int ws_min = knob("EVK_WG_WS_MINCOUT", ws_min0);
+  pl.ws = (x3 && ws_mode && d->Cout >= ws_min && Ktot >= 256 && fits32) ? 1 : 0;
   if (tr) { pl.ws = 1; pl.bm = 128; }
   if (pl.ws) pl.bn = 256;
   pl.tiles_co = ceil_div(d->Cout, pl.bm);

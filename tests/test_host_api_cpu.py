@@ -348,3 +348,25 @@ def test_weight_scale_slots_are_reused_when_weights_die():
         wp.clear()
         wp._SLOTS, wp._next_slot[0] = saved[0], saved[1]
         wp._free_slots.extend(saved[2])
+
+
+def test_pin_host_threads_groups_by_rank_and_restores_launch_mask():
+    """core/device.py: rank r takes the r-th group of the launch CPU set; cores=0 restores the launch mask (the HIP runtime may
+    widen it when it initialises); threads started afterwards inherit it."""
+    import os
+    import threading
+    from ever_amd.core.device import launch_affinity, pin_host_threads
+    if not hasattr(os, 'sched_setaffinity'):
+        pytest.skip('no affinity call on this OS')
+    allowed = sorted(launch_affinity())
+    try:
+        if len(allowed) >= 4:
+            a, b = pin_host_threads(0, 2), pin_host_threads(1, 2)
+            assert sorted(a) == allowed[0:2] and sorted(b) == allowed[2:4]
+            seen = []
+            t = threading.Thread(target=lambda: seen.append(frozenset(os.sched_getaffinity(0))))
+            t.start(); t.join()
+            assert seen[0] == b
+        assert sorted(pin_host_threads(0, len(allowed) + 3)) == allowed      # more than there are: the whole launch set
+    finally:
+        assert sorted(pin_host_threads(0, 0)) == allowed

@@ -15,21 +15,28 @@ from ever_amd import _C  # noqa: E402
 
 FIELDS = [f[0] for f in _C.ConvDesc._fields_]
 B = int(os.environ.get('BATCH', 16))
-KNOBS = [dict(EVK_WG_WS=w, EVK_WG_ROUNDS=r, EVK_WG_MINCHUNK=c) for w, r, c in
-         itertools.product(('1', '0'), ('1', '2'), ('256', '1024'))]
+MODEL = os.environ.get('MODEL', 'farseg')     # 'freenet': the C5 scene (batch 1, 200 bands, 616 x 344)
+KNOB_NAMES = ('EVK_WG_WS', 'EVK_WG_ROUNDS', 'EVK_WG_MINCHUNK', 'EVK_WG_WS_MINCOUT')
+KNOBS = [dict(zip(KNOB_NAMES, v)) for v in itertools.product(('1', '0'), ('1', '2'), ('256', '1024'), ('128', '64'))
+         if not (v[0] == '0' and v[3] == '64')]
 
 
 def record():
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
-    m = er.module.FarSeg(dict()).to(dev).train()
-    x = torch.randn(B, 3, 512, 512, device=dev)
-    y = (torch.rand(B, 512, 512, device=dev) > 0.5).long()
+    if MODEL == 'freenet':
+        m = er.module.FreeNet(dict()).to(dev).train()
+        x = torch.randn(1, 200, 616, 344, device=dev)
+        y = torch.randint(0, 17, (1, 616, 344), device=dev)
+    else:
+        m = er.module.FarSeg(dict()).to(dev).train()
+        x = torch.randn(B, 3, 512, 512, device=dev)
+        y = (torch.rand(B, 512, 512, device=dev) > 0.5).long()
     probs = collections.Counter()
     orig = _C.call
 
     def spy(name, *args):
-        if name in ('evk_conv2d_wgrad_x3', 'evk_conv2d_wgrad_f16x2'):
+        if name in ('evk_conv2d_wgrad_x3', 'evk_conv2d_wgrad_f16x2', 'evk_conv2d_wgrad_f16x2_ex'):
             d = args[0]._obj
             probs[tuple(getattr(d, f) for f in FIELDS)] += 1
         return orig(name, *args)
@@ -58,7 +65,7 @@ def timeit(fn, iters):
 
 
 def setk(k):
-    for n in ('EVK_WG_WS', 'EVK_WG_ROUNDS', 'EVK_WG_MINCHUNK'):
+    for n in KNOB_NAMES:
         os.environ[n] = k.get(n, '') if k else ''
 
 
@@ -97,7 +104,7 @@ def main():
             try:
                 t = run()
                 err = float((dw - ref).abs().max() / (ref.abs().max() + 1e-30))
-                res[(k['EVK_WG_WS'], k['EVK_WG_ROUNDS'], k['EVK_WG_MINCHUNK'])] = t if err < 1e-4 else float('inf')
+                res[tuple(k[n] for n in KNOB_NAMES)] = t if err < 1e-4 else float('inf')
             except Exception:
                 pass
         setk(None)
@@ -111,7 +118,7 @@ def main():
         n, h, w, cin, ho, wo, cout, kh, kw, sh = key[:10]
         top = sorted(res.items(), key=lambda kv: kv[1])[:4]
         print(f'x{count:2d} {cin:4d}->{cout:4d} k{kh} s{sh} {h:3d}x{w:<3d} {gf:7.1f} GF default {base:7.1f} us ({gf/base*1e3:6.1f} TF) '
-              f'best ws/rounds/minchunk {best} {tbest:7.1f} us gain/step {(base-tbest)*count:7.1f} | ' +
+              f'best ws/rounds/minchunk/mincout {best} {tbest:7.1f} us gain/step {(base-tbest)*count:7.1f} | ' +
               ' '.join(f'{k}={v:.0f}' for k, v in top))
 
 
