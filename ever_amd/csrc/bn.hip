@@ -10,6 +10,19 @@
 
 namespace evk {
 
+// Traversal direction of the streaming passes (round 5).  The apply passes, forward and backward, walk the map from
+// its END: the pass in front of them (the convolution that wrote z; the reduce pass that has just read g and z) finished there,
+// so the lines most recently touched come first, and what the pass writes is in turn met head-first by the next convolution.
+// Same arithmetic, same bits.  Six interleaved rounds on one box: 538.49 -> 539.65 tiles/s (+0.22 %, ahead in every round);
+// the forward alone +0.13 %, the reduce pass reversed as well +0.19 % (tools/ab_libs.sh, profiles/r05_experiments/ab_bn_rev*.txt).
+// Bits: 1 bn_apply, 2 bn_bwd_apply, 4 bn_bwd_partial.
+#ifndef EVK_BN_REV
+#define EVK_BN_REV 3
+#endif
+template <int BIT>
+__device__ __forceinline__ unsigned bn_blk() { return (EVK_BN_REV & BIT) ? gridDim.x - 1u - blockIdx.x : blockIdx.x; }
+
+
 #ifndef EVK_BN_NT
 #define EVK_BN_NT 1
 #endif
@@ -249,7 +262,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ scale_shift, float* __restrict__ y,
                                                        size_t n4, int C, int relu, uint32_t* __restrict__ amax,
                                                        uint32_t* __restrict__ relu_bits = nullptr) {
-  const size_t base = (size_t)blockIdx.x * 256;
+  const size_t base = (size_t)bn_blk<1>() * 256;
   const size_t i = base + threadIdx.x;
   const bool valid = i < n4;
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -284,7 +297,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 // Optionally writes g to d_residual.
 // PK (dx will be written packed, EVK_BN_PACK_DX): also pmax[blk][0][C] = max |g|, [1][C] = max |xhat| — what the
 // finalisation needs to bound |dx| per channel BEFORE the apply pass writes it under that scale.
-template <bool PK>
+template <bool NTL>
+__device__ __forceinline__ f32x4 bp_ld(const float* p) {
+  if constexpr (NTL) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  else return *reinterpret_cast<const f32x4*>(p);
+}
+// NTL: the loads carry the non-temporal hint — for maps too large to be found in a cache by the apply pass anyway (the launcher
+// decides by size, EVK_BN_PART_NT_MB): a plain read of more than ~256 MB that a plain-store producer has just written streams at
+// 4.1 TB/s, the same read with the hint at 6.8 (tools/probes/mall_direction.hip)
+template <bool PK, bool NTL = false>
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ y,
                                                              const float* __restrict__ mean,
@@ -302,7 +323,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   __shared__ f32x4 red[2][256];
   const int c4 = C >> 2;
   const int tc = threadIdx.x % tpc, tr = threadIdx.x / tpc;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+  const int64_t r0 = (int64_t)bn_blk<4>() * rows_per_blk;
   const int64_t r1 = min(rows, r0 + rows_per_blk);
   for (int cb = tc; cb < c4; cb += tpc) {
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + cb * 4);
@@ -345,16 +366,16 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
       for (; r + 3 * st < r1; r += 4 * st) {
         const size_t o0 = (size_t)r * C + cb * 4, o1 = (size_t)(r + st) * C + cb * 4;
         const size_t o2 = (size_t)(r + 2 * st) * C + cb * 4, o3 = (size_t)(r + 3 * st) * C + cb * 4;
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(dy + o0), g1 = *reinterpret_cast<const f32x4*>(dy + o1);
-        const f32x4 g2 = *reinterpret_cast<const f32x4*>(dy + o2), g3 = *reinterpret_cast<const f32x4*>(dy + o3);
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + o0), x1 = *reinterpret_cast<const f32x4*>(x + o1);
-        const f32x4 x2 = *reinterpret_cast<const f32x4*>(x + o2), x3 = *reinterpret_cast<const f32x4*>(x + o3);
+        const f32x4 g0 = bp_ld<NTL>(dy + o0), g1 = bp_ld<NTL>(dy + o1);
+        const f32x4 g2 = bp_ld<NTL>(dy + o2), g3 = bp_ld<NTL>(dy + o3);
+        const f32x4 x0 = bp_ld<NTL>(x + o0), x1 = bp_ld<NTL>(x + o1);
+        const f32x4 x2 = bp_ld<NTL>(x + o2), x3 = bp_ld<NTL>(x + o3);
         f32x4 y0 = zero4, y1 = zero4, y2 = zero4, y3 = zero4;
         if (relu == 1) {
-          y0 = *reinterpret_cast<const f32x4*>(y + o0);
-          y1 = *reinterpret_cast<const f32x4*>(y + o1);
-          y2 = *reinterpret_cast<const f32x4*>(y + o2);
-          y3 = *reinterpret_cast<const f32x4*>(y + o3);
+          y0 = bp_ld<NTL>(y + o0);
+          y1 = bp_ld<NTL>(y + o1);
+          y2 = bp_ld<NTL>(y + o2);
+          y3 = bp_ld<NTL>(y + o3);
         }
         one(g0, x0, y0, o0);
         one(g1, x1, y1, o1);
@@ -363,9 +384,9 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
       }
       for (; r < r1; r += st) {
         const size_t o0 = (size_t)r * C + cb * 4;
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(dy + o0);
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + o0);
-        const f32x4 y0 = (relu == 1) ? *reinterpret_cast<const f32x4*>(y + o0) : zero4;
+        const f32x4 g0 = bp_ld<NTL>(dy + o0);
+        const f32x4 x0 = bp_ld<NTL>(x + o0);
+        const f32x4 y0 = (relu == 1) ? bp_ld<NTL>(y + o0) : zero4;
         one(g0, x0, y0, o0);
       }
     }
@@ -377,7 +398,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
         s += red[0][k * tpc + tc];
         q += red[1][k * tpc + tc];
       }
-      float* o = partial + (size_t)blockIdx.x * 2 * C;
+      float* o = partial + (size_t)bn_blk<4>() * 2 * C;
       *reinterpret_cast<f32x4*>(o + cb * 4) = s;
       *reinterpret_cast<f32x4*>(o + C + cb * 4) = q;
     }
@@ -392,7 +413,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
           gm.x = fmaxf(gm.x, a.x); gm.y = fmaxf(gm.y, a.y); gm.z = fmaxf(gm.z, a.z); gm.w = fmaxf(gm.w, a.w);
           xm.x = fmaxf(xm.x, b.x); xm.y = fmaxf(xm.y, b.y); xm.z = fmaxf(xm.z, b.z); xm.w = fmaxf(xm.w, b.w);
         }
-        float* o = pmax + (size_t)blockIdx.x * 2 * C;
+        float* o = pmax + (size_t)bn_blk<4>() * 2 * C;
         *reinterpret_cast<f32x4*>(o + cb * 4) = gm;
         *reinterpret_cast<f32x4*>(o + C + cb * 4) = xm;
       }
@@ -472,7 +493,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ beta, float* __restrict__ dx,
                                                            size_t n4, int C, int relu, uint32_t* __restrict__ amax,
                                                            const uint32_t* __restrict__ bits = nullptr) {
-  const size_t base = (size_t)blockIdx.x * 256;
+  const size_t base = (size_t)bn_blk<2>() * 256;
   const size_t i = base + threadIdx.x;
   const bool valid = i < n4;
   f32x4 out = {0.f, 0.f, 0.f, 0.f};
@@ -1133,12 +1154,14 @@ extern "C" int evk_bn_bwd_bits(const float* dy, const float* x, const float* y, 
   const bool pack = (flags & EVK_BN_PACK_DX) != 0;
   EVK_REQUIRE(!pack || dx_absmax, EVK_E_INVALID, "bn_bwd: EVK_BN_PACK_DX needs dx_absmax (slots zero on entry)");
   float* pmax = pack ? coef + 8 * (size_t)C : nullptr;
-  if (pack)
-    hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(pl.nblk), dim3(256), 0, st, dy, x, y, save_mean, save_invstd,
-                       gamma, beta, d_residual, partial, rows, C, pl.rows_per_blk, pl.tpc, pl.rl, relu, pmax, relu_bits);
-  else
-    hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(pl.nblk), dim3(256), 0, st, dy, x, y, save_mean, save_invstd,
-                       gamma, beta, d_residual, partial, rows, C, pl.rows_per_blk, pl.tpc, pl.rl, relu, pmax, relu_bits);
+  static const long long part_nt_mb = getenv("EVK_BN_PART_NT_MB") ? atoll(getenv("EVK_BN_PART_NT_MB")) : -1;   // (measured level from 128 MB up, -0.3 % below: off)
+  const bool ntl = part_nt_mb >= 0 && (long long)rows * C * 4 >= (part_nt_mb << 20);
+#define EVK_BN_PARTIAL(PKV, NTV)                                                                                              \
+  hipLaunchKernelGGL((bn_bwd_partial_kernel<PKV, NTV>), dim3(pl.nblk), dim3(256), 0, st, dy, x, y, save_mean, save_invstd, \
+                     gamma, beta, d_residual, partial, rows, C, pl.rows_per_blk, pl.tpc, pl.rl, relu, pmax, relu_bits)
+  if (pack) { if (ntl) EVK_BN_PARTIAL(true, true); else EVK_BN_PARTIAL(true, false); }
+  else { if (ntl) EVK_BN_PARTIAL(false, true); else EVK_BN_PARTIAL(false, false); }
+#undef EVK_BN_PARTIAL
   int rc = check_launch("bn_bwd_partial");
   if (rc) return rc;
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, partial, pl.nblk, C,
