@@ -22,6 +22,15 @@ namespace evk {
 template <int BIT>
 __device__ __forceinline__ unsigned bn_blk() { return (EVK_BN_REV & BIT) ? gridDim.x - 1u - blockIdx.x : blockIdx.x; }
 
+// non-temporal STORES of the apply passes (experiment): bits 1 forward y, 2 backward dx
+#ifndef EVK_BN_NTS
+#define EVK_BN_NTS 0
+#endif
+template <int BIT, typename V>
+__device__ __forceinline__ void bn_st(V* p, size_t i, V v) {
+  if (EVK_BN_NTS & BIT) __builtin_nontemporal_store(v, p + i); else p[i] = v;
+}
+
 
 #ifndef EVK_BN_NT
 #define EVK_BN_NT 1
@@ -284,9 +293,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
     if constexpr (PK) {
-      reinterpret_cast<u32x4*>(y)[i] = pack_hl4(v, pk_inv);
+      bn_st<1>(reinterpret_cast<u32x4*>(y), i, pack_hl4(v, pk_inv));
     } else {
-      reinterpret_cast<f32x4*>(y)[i] = v;
+      bn_st<1>(reinterpret_cast<f32x4*>(y), i, v);
     }
   }
   if constexpr (!PK)
@@ -527,9 +536,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const f32x4 xh = (xv - mu) * is;
     out = k0 * (g - k1 - xh * k2);
     if constexpr (PK) {
-      reinterpret_cast<u32x4*>(dx)[i] = pack_hl4(out, pk_inv);
+      bn_st<2>(reinterpret_cast<u32x4*>(dx), i, pack_hl4(out, pk_inv));
     } else {
-      reinterpret_cast<f32x4*>(dx)[i] = out;
+      bn_st<2>(reinterpret_cast<f32x4*>(dx), i, out);
     }
   }
   if constexpr (!PK)
