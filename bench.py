@@ -59,6 +59,7 @@ def parse():
     p.add_argument('--warmup', type=int, default=5)
     p.add_argument('--batch', type=int, default=BATCH, help='tiles per GPU (default: the BASELINE config)')
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-baseline-only', action='store_true', help='(internal) time the CPU oracle and print its JSON object')
     p.add_argument('--no-graph-line', action='store_true',
                    help='skip the `hip_graph_replay` object (the same step captured as one hipGraph and replayed, measured in a '
                         'child process after the timed region; never the headline value)')
@@ -312,6 +313,22 @@ def cpu_baseline(seconds_budget=20.0):
                        f'torch {torch.__version__} CPU, {cores} threads')
 
 
+def cpu_baseline_child():
+    """cpu_baseline() in a CHILD process started on the CPU set this process was launched with: the parent has narrowed its own
+    mask to a few CPUs (--host-cores) and its OpenMP workers inherited that; the child initialises no GPU runtime, so its mask
+    stays what it is given."""
+    import subprocess
+    from ever_amd.core.device import launch_affinity
+    mask = launch_affinity()
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-only'], capture_output=True, text=True,
+                             timeout=900, preexec_fn=(lambda: os.sched_setaffinity(0, mask)) if mask else None)
+        rows = [ln for ln in out.stdout.splitlines() if ln.startswith('{"value"')]
+        return json.loads(rows[-1])
+    except Exception as e:   # never at the expense of the headline line
+        return {'value': None, 'error': f'{type(e).__name__}: {str(e)[:160]}'}
+
+
 def free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
@@ -355,6 +372,9 @@ def dry_launch(args, world, rank, local_rank):
 
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline()), flush=True)
+        return
     if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or args.dry_launch):
         self_launch(args)    # does not return
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -671,7 +691,7 @@ def main():
         if world == 1 and not use_ddp and not args.graph and not args.no_graph_line and conv_math == 'f16x2':
             line['hip_graph_replay'] = graph_replay_line(args)
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline()
+            line['cpu_baseline'] = cpu_baseline_child()
         out_line = json.dumps(line)
     if use_ddp:
         torch.distributed.destroy_process_group()   # RCCL prints its version banner here: keep the JSON line last
