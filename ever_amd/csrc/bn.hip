@@ -64,8 +64,10 @@ static BnPlan bn_plan(int64_t rows, int C) {
   const int c4 = C / 4;
   p.tpc = c4 < 256 ? c4 : 256;
   p.rl = 256 / p.tpc;
-  // ~64K elements per workgroup (EVK_BN_ELEMS: A/B switch, read once)
-  static const int64_t per = getenv("EVK_BN_ELEMS") ? atoll(getenv("EVK_BN_ELEMS")) : 65536;
+  // ~32K elements per workgroup (EVK_BN_ELEMS, read once).  Round 5, three interleaved rounds on each of two boxes, tiles/s:
+  // 65536 549.1 / 525.7, 49152 - / 526.6, 40960 - / 528.1, 32768 551.2 / 528.7 (+0.4 / +0.6 %), 24576 - / 526.8, 16384 545.9 / -:
+  // twice the workgroups halve the latency-bound reduce passes on the small maps, four times cost more in the finalisation
+  static const int64_t per = getenv("EVK_BN_ELEMS") ? atoll(getenv("EVK_BN_ELEMS")) : 32768;
   int64_t nb = (rows * (int64_t)C + per - 1) / per;
   if (nb > kMaxStatBlocks) nb = kMaxStatBlocks;
   if (nb < 1) nb = 1;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
 // in flight per lane: the chain of up to 2048 partials per channel is latency bound, and a grid of C/8
 // workgroups instead of C/32 spreads it over more CUs), then fold the 32 lanes through LDS in a fixed
 // order.  Returns true on the lane that holds the totals.
-constexpr int kFinCh = 8, kFinLanes = 32;
+constexpr int kFinCh = 8;
 // Fold one value per thread over the FL lanes of a channel (thread = lane * FC + channel, FC * FL = 256): xor-shuffles
 // inside a wave (a channel's lanes sit FC apart), then the four waves' results through LDS — a fixed tree, so the result
 // is reproducible, and 4 + log2 steps where a serial fold by one thread took FL dependent LDS round trips (32 / 128 of
@@ -146,33 +148,34 @@ __device__ __forceinline__ T fold_channel_lanes(T v, T (*lds)[FC], Op op) {
   __syncthreads();
   return r;
 }
+template <int FC = kFinCh>
 __device__ __forceinline__ bool reduce_partials(const float* __restrict__ partial, int nblk, int C, int& c, double& s,
                                                 double& q) {
-  __shared__ double red[4][kFinCh];
-  const int tc = threadIdx.x % kFinCh, tl = threadIdx.x / kFinCh;
-  c = blockIdx.x * kFinCh + tc;
+  __shared__ double red[4][FC];
+  const int tc = threadIdx.x % FC, tl = threadIdx.x / FC;
+  c = blockIdx.x * FC + tc;
   s = 0.0;
   q = 0.0;
   if (c < C) {
     const float* ps = partial + c;
     const size_t st = (size_t)2 * C;
     int b = tl;
-    for (; b + 3 * kFinLanes < nblk; b += 4 * kFinLanes) {
-      const float s0 = ps[b * st], s1 = ps[(b + kFinLanes) * st], s2 = ps[(b + 2 * kFinLanes) * st],
-                  s3 = ps[(b + 3 * kFinLanes) * st];
-      const float q0 = ps[b * st + C], q1 = ps[(b + kFinLanes) * st + C], q2 = ps[(b + 2 * kFinLanes) * st + C],
-                  q3 = ps[(b + 3 * kFinLanes) * st + C];
+    for (; b + 3 * (256 / FC) < nblk; b += 4 * (256 / FC)) {
+      const float s0 = ps[b * st], s1 = ps[(b + (256 / FC)) * st], s2 = ps[(b + 2 * (256 / FC)) * st],
+                  s3 = ps[(b + 3 * (256 / FC)) * st];
+      const float q0 = ps[b * st + C], q1 = ps[(b + (256 / FC)) * st + C], q2 = ps[(b + 2 * (256 / FC)) * st + C],
+                  q3 = ps[(b + 3 * (256 / FC)) * st + C];
       s += ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
       q += ((double)q0 + (double)q1) + ((double)q2 + (double)q3);
     }
-    for (; b < nblk; b += kFinLanes) {
+    for (; b < nblk; b += (256 / FC)) {
       s += (double)ps[b * st];
       q += (double)ps[b * st + C];
     }
   }
   auto add = [](double a, double b) { return a + b; };
-  s = fold_channel_lanes<kFinCh>(s, red, add);
-  q = fold_channel_lanes<kFinCh>(q, red, add);
+  s = fold_channel_lanes<FC>(s, red, add);
+  q = fold_channel_lanes<FC>(q, red, add);
   return tl == 0 && c < C;
 }
 
@@ -432,6 +435,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 }
 
 // coef[0][C] = gamma*invstd ; coef[1][C] = mean(g) ; coef[2][C] = mean(g*xhat)  (0 when !train)
+// FC channels x 256 / FC lanes per workgroup: 8 x 32 by default; 2 x 128 (four times the workgroups) when the partials are many
+template <int FC = kFinCh>
 __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ partial, int nblk, int C,
                                                            double inv_rows, const float* __restrict__ gamma,
                                                            const float* __restrict__ invstd,
@@ -446,33 +451,33 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
   if (!pmax) zero_amax(amax);
   float gmax = 0.f, xmax = 0.f;
   if (pmax) {
-    __shared__ float mred[4][kFinCh];
-    const int tc = threadIdx.x % kFinCh, tl = threadIdx.x / kFinCh;
-    const int cc = blockIdx.x * kFinCh + tc;
+    __shared__ float mred[4][FC];
+    const int tc = threadIdx.x % FC, tl = threadIdx.x / FC;
+    const int cc = blockIdx.x * FC + tc;
     if (cc < C) {
       const float* pm = pmax + cc;
       const size_t st = (size_t)2 * C;
       int b = tl;
-      for (; b + 3 * kFinLanes < nblk; b += 4 * kFinLanes) {   // eight independent loads in flight per lane
-        const float g0 = pm[b * st], g1 = pm[(b + kFinLanes) * st], g2 = pm[(b + 2 * kFinLanes) * st],
-                    g3 = pm[(b + 3 * kFinLanes) * st];
-        const float x0 = pm[b * st + C], x1 = pm[(b + kFinLanes) * st + C], x2 = pm[(b + 2 * kFinLanes) * st + C],
-                    x3 = pm[(b + 3 * kFinLanes) * st + C];
+      for (; b + 3 * (256 / FC) < nblk; b += 4 * (256 / FC)) {   // eight independent loads in flight per lane
+        const float g0 = pm[b * st], g1 = pm[(b + (256 / FC)) * st], g2 = pm[(b + 2 * (256 / FC)) * st],
+                    g3 = pm[(b + 3 * (256 / FC)) * st];
+        const float x0 = pm[b * st + C], x1 = pm[(b + (256 / FC)) * st + C], x2 = pm[(b + 2 * (256 / FC)) * st + C],
+                    x3 = pm[(b + 3 * (256 / FC)) * st + C];
         gmax = fmaxf(gmax, fmaxf(fmaxf(g0, g1), fmaxf(g2, g3)));
         xmax = fmaxf(xmax, fmaxf(fmaxf(x0, x1), fmaxf(x2, x3)));
       }
-      for (; b < nblk; b += kFinLanes) {
+      for (; b < nblk; b += (256 / FC)) {
         gmax = fmaxf(gmax, pm[b * st]);
         xmax = fmaxf(xmax, pm[b * st + C]);
       }
     }
     auto mx = [](float a, float b) { return fmaxf(a, b); };
-    gmax = fold_channel_lanes<kFinCh>(gmax, mred, mx);
-    xmax = fold_channel_lanes<kFinCh>(xmax, mred, mx);
+    gmax = fold_channel_lanes<FC>(gmax, mred, mx);
+    xmax = fold_channel_lanes<FC>(xmax, mred, mx);
   }
   int c;
   double s, q;
-  if (!reduce_partials(partial, nblk, C, c, s, q)) return;
+  if (!reduce_partials<FC>(partial, nblk, C, c, s, q)) return;
   if (dbeta) dbeta[c] = (float)s;
   if (dgamma) dgamma[c] = (float)q;
   const float g = gamma ? gamma[c] : 1.f;
@@ -1103,7 +1108,7 @@ extern "C" int evk_bn_relu_pool_bwd(const float* dp, const uint8_t* code, const 
                        beta, partial, (int)rows, H, W, C, Ho, Wo, (int)pl.rows_per_blk, pl.tpc, pl.rl);
   int rc = check_launch("bn_pool_bwd_partial");
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, (const float*)partial, nblk, C,
+  hipLaunchKernelGGL(bn_bwd_final_kernel<kFinCh>, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, (const float*)partial, nblk, C,
                      1.0 / (double)rows, gamma, save_invstd, dgamma, dbeta, coef, train ? 1 : 0, dx_absmax,
                      (const float*)nullptr);
   rc = check_launch("bn_bwd_final");
@@ -1173,9 +1178,17 @@ extern "C" int evk_bn_bwd_bits(const float* dy, const float* x, const float* y, 
 #undef EVK_BN_PARTIAL
   int rc = check_launch("bn_bwd_partial");
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, partial, pl.nblk, C,
-                     1.0 / (double)rows, gamma, save_invstd, dgamma, dbeta, coef, train ? 1 : 0, dx_absmax,
-                     (const float*)pmax);
+  // (EVK_BN_FIN_FC=2: two channels x 128 lanes per workgroup, four times the workgroups, measured -0.2 % with it chosen from 128
+  // partials up and -2.5 % everywhere: the 8-byte pieces of a partial row it reads cost more than the shorter chains save)
+  static const int fin_fc = getenv("EVK_BN_FIN_FC") ? atoi(getenv("EVK_BN_FIN_FC")) : 8;
+  if (fin_fc == 2 || (fin_fc == 0 && pl.nblk >= 128 && C <= 1024))
+    hipLaunchKernelGGL(bn_bwd_final_kernel<2>, dim3((C + 1) / 2), dim3(256), 0, st, partial, pl.nblk, C,
+                       1.0 / (double)rows, gamma, save_invstd, dgamma, dbeta, coef, train ? 1 : 0, dx_absmax,
+                       (const float*)pmax);
+  else
+    hipLaunchKernelGGL(bn_bwd_final_kernel<kFinCh>, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, partial, pl.nblk, C,
+                       1.0 / (double)rows, gamma, save_invstd, dgamma, dbeta, coef, train ? 1 : 0, dx_absmax,
+                       (const float*)pmax);
   rc = check_launch("bn_bwd_final");
   if (rc) return rc;
   const size_t n4 = (size_t)rows * C / 4;
@@ -1230,7 +1243,7 @@ extern "C" int evk_bn_bwd_from_partials(const float* g, const float* x, const fl
               "bn_bwd_from_partials: EVK_BN_PACK_DX needs dx_absmax (slots zero on entry) and the maxima");
   hipStream_t st = (hipStream_t)stream;
   float* coef = (float*)workspace;
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, partial, nparts, C,
+  hipLaunchKernelGGL(bn_bwd_final_kernel<kFinCh>, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, partial, nparts, C,
                      1.0 / (double)rows, gamma, save_invstd, dgamma, dbeta, coef, train ? 1 : 0, dx_absmax,
                      pack ? maxima : (const float*)nullptr);
   int rc = check_launch("bn_bwd_final");
@@ -1561,7 +1574,7 @@ extern "C" int evk_bn_relu_dot_bwd(const float* dl, const float* z, const float*
 #undef EVK_DOT_PARTIAL
   int rc = check_launch("bn_relu_dot_bwd_partial");
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, (const float*)bnp, nb, C,
+  hipLaunchKernelGGL(bn_bwd_final_kernel<kFinCh>, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, st, (const float*)bnp, nb, C,
                      1.0 / (double)rows, gamma, save_invstd, dgamma, dbeta, coef, 1, dx_absmax,
                      pack ? (const float*)bnm : (const float*)nullptr);
   rc = check_launch("bn_bwd_final");
