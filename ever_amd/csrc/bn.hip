@@ -69,6 +69,11 @@ static BnPlan bn_plan(int64_t rows, int C) {
   // twice the workgroups halve the latency-bound reduce passes on the small maps, four times cost more in the finalisation
   static const int64_t per = getenv("EVK_BN_ELEMS") ? atoll(getenv("EVK_BN_ELEMS")) : 32768;
   int64_t nb = (rows * (int64_t)C + per - 1) / per;
+  // at most TWO workgroups per CU (EVK_BN_MAXBLK, <= kMaxStatBlocks): whole rounds of the chip and a quarter of the partials for
+  // the finalisation of the large maps.  Three interleaved rounds, two boxes: 2048 542.9 / 546.4, 1024 543.1, 768 - / 547.4,
+  // 640 - / 545.9, 512 546.1 / 550.0 (+0.6 / +0.65 %), 384 - / 547.4, 256 538.6
+  static const int64_t cap = getenv("EVK_BN_MAXBLK") ? atoll(getenv("EVK_BN_MAXBLK")) : 512;
+  if (nb > cap) nb = cap;
   if (nb > kMaxStatBlocks) nb = kMaxStatBlocks;
   if (nb < 1) nb = 1;
   int64_t rpb = (rows + nb - 1) / nb;
