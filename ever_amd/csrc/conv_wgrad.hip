@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
   }
 }
 
-WGradPlan plan_wgrad(const evk_conv_desc* d, int x3, int planes, int tr) {
+WGradPlan plan_wgrad(const evk_conv_desc* d, int x3, int planes, int tr, int shared) {
   WGradPlan pl;
   const int Ktot = d->kh * d->kw * d->Cin;
   const int M = d->N * d->Ho * d->Wo;
@@ -306,7 +306,15 @@ WGradPlan plan_wgrad(const evk_conv_desc* d, int x3, int planes, int tr) {
   // split kernel: single-buffered 3-plane bf16 stage (48 KB at 128x128), residency set by its VGPRs
   const int per_cu = pl.ws ? 1 : x3 ? (pl.bm + pl.bn >= 256 ? 3 : 4)
                         : (lds_kb >= 64 ? 2 : (lds_kb >= 48 ? 3 : 4));
-  const int slots = 256 * per_cu;
+  // A wide-tile kernel (one 8-wave workgroup per CU, up to 700 us long) that runs BESIDE the backward chain — the caller says
+  // so with EVK_CONV_WGRAD_SHARED — is split for HALF of the CUs: sixteen workgroups per XCD, the other sixteen CUs of every XCD
+  // stay with the main stream's kernels instead of queueing behind it.  Round 5, three interleaved rounds per box, tiles/s:
+  // 100 % 545.9 / 541.8 / 560.0, 75 % 564.7, 62 % 545.6, 56 % 544.6, 50 % 557.4 / 552.2 / 565.9 (+1.1 .. +2.1 %), 44 % 545.8,
+  // 37 % 531.2, 25 % 469.7; the nine-tap planar kernel alone at 50 %: +1.1 %, the x3ws kernels alone: +0.3 %; the 128 x 128
+  // single-role tiles (3-4 workgroups per CU) do not care (EVK_WG_SHARED_FILL, percent; 100 = as if alone).
+  static const int shared_fill0 = getenv("EVK_WG_SHARED_FILL") ? atoi(getenv("EVK_WG_SHARED_FILL")) : 50;
+  const int fill = (shared && pl.ws) ? knob("EVK_WG_SHARED_FILL", shared_fill0) : 100;
+  const int slots = 256 * per_cu * (fill > 0 && fill <= 100 ? fill : 100) / 100;
   int maxsplit = ceil_div(M, min_chunk);  // at least min_chunk pixels per split
   int sk = (rounds * slots) / tiles;      // floor: never spill into an extra, nearly empty round
   if (sk > maxsplit) sk = maxsplit;
@@ -374,11 +382,11 @@ static int conv_wgrad_any(const evk_conv_desc* d, const float* x, const float* d
                   (long long)d->N * d->Ho * d->Wo * d->Cout < 0x7fffffffLL,
               EVK_E_UNSUPPORTED, "conv2d_wgrad: tensors of 2^31 or more elements are not supported");
   hipStream_t st = (hipStream_t)stream;
-  const int planar = (pk_flags & (EVK_CONV_X_PLANAR | EVK_CONV_DY_PLANAR)) ? 1 : 0;
+  const int planar = (pk_flags & (EVK_CONV_X_PLANAR | EVK_CONV_DY_PLANAR)) ? 1 : 0;   // (workspace: sized for the unshared plan, which splits more)
   EVK_REQUIRE(!planar || ((pk_flags & EVK_CONV_X_PLANAR) && (pk_flags & EVK_CONV_DY_PLANAR) && planes == 2 && !dbias),
               EVK_E_UNSUPPORTED, "conv2d_wgrad: planar operands come in pairs (x and dy), f16x2 only, no bias gradient");
   const int nine = planar && wgrad_tr_nine_tap(d) ? 1 : 0;
-  const WGradPlan pl = plan_wgrad(d, x3, planes, planar ? 1 + nine : 0);
+  const WGradPlan pl = plan_wgrad(d, x3, planes, planar ? 1 + nine : 0, (pk_flags & EVK_CONV_WGRAD_SHARED) ? 1 : 0);
   WGradArgs a{};
   a.planes = planes;
   a.planar = planar;
@@ -460,7 +468,7 @@ extern "C" int evk_conv2d_wgrad_f16x2_ex(const evk_conv_desc* d, const void* x, 
                                          size_t workspace_bytes, uint32_t flags, void* stream) {
   EVK_REQUIRE(d && d->Cin % 4 == 0 && d->Cout % 4 == 0, EVK_E_UNSUPPORTED, "conv2d_wgrad_f16x2_ex: channels must be multiples of 4");
   EVK_REQUIRE(x_absmax && dy_absmax, EVK_E_INVALID, "conv2d_wgrad_f16x2_ex: null scales");
-  EVK_REQUIRE((flags & ~(EVK_CONV_X_PACKED | EVK_CONV_DY_PACKED | EVK_CONV_X_PLANAR | EVK_CONV_DY_PLANAR)) == 0, EVK_E_INVALID,
+  EVK_REQUIRE((flags & ~(EVK_CONV_X_PACKED | EVK_CONV_DY_PACKED | EVK_CONV_X_PLANAR | EVK_CONV_DY_PLANAR | EVK_CONV_WGRAD_SHARED)) == 0, EVK_E_INVALID,
               "conv2d_wgrad_f16x2_ex: unknown flag 0x%x", flags);
   return conv_wgrad_any(d, reinterpret_cast<const float*>(x), reinterpret_cast<const float*>(dy), dw, dbias, workspace,
                         workspace_bytes, stream, 1, 2, x_absmax, dy_absmax, flags);

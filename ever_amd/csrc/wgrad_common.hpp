@@ -33,7 +33,7 @@ struct WGradPlan {
 // x3 = 1: plan for the bf16-split kernel (different LDS footprint => different residency)
 // tr = 1 / 2: the planar-operand kernel (conv_wgrad_tr.hip), one workgroup per CU: 128 x 256 tile / nine-tap form
 // (128 output channels x 9 taps x 64 input channels per tile)
-WGradPlan plan_wgrad(const evk_conv_desc* d, int x3, int planes = 3, int tr = 0);
+WGradPlan plan_wgrad(const evk_conv_desc* d, int x3, int planes = 3, int tr = 0, int shared = 0);
 int launch_wgrad_x3(const WGradArgs& a, const WGradPlan& pl, hipStream_t stream);
 int launch_wgrad_x3ws(const WGradArgs& a, hipStream_t stream);
 bool wgrad_tr_applicable(const WGradArgs& a);

@@ -215,6 +215,18 @@ _WGRAD_QUEUE = {}                # device -> launch closures of weight gradients
                                  # device — autograd runs one engine thread per device, and a shared list lost appends)
 _WGRAD_EARLY_MODE = int(os.environ.get('EVK_WGRAD_EARLY', '0'))
 _WGRAD_EARLY = _WGRAD_EARLY_MODE == 1
+_WGRAD_SHARED = 32    # EVK_CONV_WGRAD_SHARED (include/ever_hip.h): the launch runs beside the backward chain — wide tiles on half of the CUs
+# (EVK_WGRAD_SHARED=0 / set_wgrad_shared_split(False): the side stream's launches split as if they ran alone — the same
+# accumulation order as the single-stream step, which the bit-for-bit tests of the mechanism pin; +1.1 .. +2.1 % on the step when on)
+_WGRAD_SHARED_ON = [os.environ.get('EVK_WGRAD_SHARED', '1') != '0']
+
+
+def set_wgrad_shared_split(on):
+    """runtime switch of the half-chip split of side-stream weight gradients (returns the previous setting)"""
+    prev, _WGRAD_SHARED_ON[0] = _WGRAD_SHARED_ON[0], bool(on)
+    return prev
+
+
 _WGRAD_BATCH = max(1, int(os.environ.get('EVK_WGRAD_BATCH', '1')))   # (8, 16, 32 measured: 524 vs 531 tiles/s for 1, same box)
 
 
@@ -1002,7 +1014,7 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False,
                             _tmp.append(dp)
                     _C.call('evk_conv2d_wgrad_f16x2_ex', ctypes.byref(dk), xw_ptr, xbits.data_ptr(), dyw_ptr, dybits.data_ptr(),
                             dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes,
-                            planar if planar else ((2 if x_pk else 0) | (4 if dy_pk_ else 0)), st)
+                            (planar if planar else ((2 if x_pk else 0) | (4 if dy_pk_ else 0))) | (_WGRAD_SHARED if side is not None and _WGRAD_SHARED_ON[0] else 0), st)
                 else:
                     _C.call(_entry('evk_conv2d_wgrad_x3') if x3 else 'evk_conv2d_wgrad', ctypes.byref(dk), xk.data_ptr(), dy_ptr,
                             dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes, st)

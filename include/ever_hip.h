@@ -65,6 +65,11 @@ typedef struct evk_conv_desc {
  * (csrc/conv_wgrad_tr.hip).  Needs both flags, Cin % 64 == 0, Cout % 64 == 0, dbias == NULL. */
 #define EVK_CONV_X_PLANAR 8u
 #define EVK_CONV_DY_PLANAR 16u
+/* evk_conv2d_wgrad_f16x2_ex only (round 5): the launch runs BESIDE other work on another stream (the weight-gradient side stream
+ * of hip/functional.py).  The wide-tile kernels — one 8-wave workgroup per CU — are then split for half of the CUs, so that the
+ * other stream's kernels find free CUs in every XCD instead of queueing behind a 700 us launch (+1.1 .. +2.1 % on the training
+ * step).  Same result bits as without the flag only if the split count happens to coincide; the workspace size does not change. */
+#define EVK_CONV_WGRAD_SHARED 32u
 
 /* y = conv(x, w) (+ bias).  w: [Cout][kh][kw][Cin].  bias may be NULL.
  * Implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32), im2col rows gathered to LDS. */

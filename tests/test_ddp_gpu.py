@@ -113,6 +113,7 @@ def test_flat_grad_ddp_world1_matches_plain_training(cuda, side_stream):
     from ever_amd.hip import functional as HF
     from ever_amd.trainer.grad_reducer import FlatGradDDP
     prev_stream = HF.set_wgrad_stream(side_stream)
+    prev_shared = HF.set_wgrad_shared_split(False)   # (bit-for-bit comparison of the mechanism: launches split as if alone)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29619')
     created = False
@@ -165,6 +166,7 @@ def test_flat_grad_ddp_world1_matches_plain_training(cuda, side_stream):
             assert same(sa[k], sb[k]), k       # running statistics live in the flat buffer tensor now
     finally:
         HF.set_wgrad_stream(prev_stream)
+        HF.set_wgrad_shared_split(prev_shared)
         if created:
             dist.destroy_process_group()
 

@@ -88,6 +88,16 @@ def test_planar_weight_gradient(cuda, case):
     assert torch.isfinite(a).all()
     assert (a - ref).abs().max().item() <= 1e-5 * scale, (a - ref).abs().max().item() / scale
     assert (a - dw_packed.double().cpu()).abs().max().item() <= 1e-5 * scale
+    # EVK_CONV_WGRAD_SHARED (32): the launch shares the chip with another stream — the wide-tile kernels split for half of the
+    # CUs.  Same workspace, same result to the accumulation order, both operand forms
+    for flags, src in ((8 | 16, (xq, dq)), (2 | 4, (xp, dp))):
+        dw_sh = torch.full_like(dw_planar, float('nan'))
+        _C.call('evk_conv2d_wgrad_f16x2_ex', ctypes.byref(d), src[0].data_ptr(), bx.data_ptr(), src[1].data_ptr(), bd.data_ptr(),
+                dw_sh.data_ptr(), None, ws.data_ptr(), wsb, flags | 32, st)
+        torch.cuda.synchronize()
+        b = dw_sh.double().cpu()
+        assert torch.isfinite(b).all()
+        assert (b - ref).abs().max().item() <= 1e-5 * scale, (flags, (b - ref).abs().max().item() / scale)
 
 
 def test_planar_operands_come_in_pairs(cuda):

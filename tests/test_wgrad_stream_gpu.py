@@ -22,10 +22,11 @@ def _model(cuda):
                                            fs_relation=dict(scene_embedding_channels=512)))).to(cuda).train()
 
 
-def _train(cuda, on, steps=4):
+def _train(cuda, on, steps=4, shared=True):
     import ever_amd as er
     from ever_amd.hip import functional as HF
     prev = HF.set_wgrad_stream(on)
+    prev_shared = HF.set_wgrad_shared_split(shared)
     try:
         m = _model(cuda)
         opt = er.opt.FusedSGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
@@ -46,15 +47,20 @@ def _train(cuda, on, steps=4):
         return grads, {k: v.detach().clone() for k, v in m.state_dict().items()}
     finally:
         HF.set_wgrad_stream(prev)
+        HF.set_wgrad_shared_split(prev_shared)
 
 
 def test_training_is_the_same_with_and_without_the_side_stream(cuda):
     """first-step gradients and the weights after four clipped SGD steps: bit for bit (the same kernels on the same operands;
     until ABI 19 a one-launch BatchNorm backward that the side stream ruled out made this a tolerance test)"""
-    g1, s1 = _train(cuda, True)
     g0, s0 = _train(cuda, False)
+    # the mechanism: with the side stream's launches split as if they ran alone (set_wgrad_shared_split(False)), bit for bit
+    g1, s1 = _train(cuda, True, shared=False)
     assert all(torch.equal(g1[k], g0[k]) for k in g0), [k for k in g0 if not torch.equal(g1[k], g0[k])][:5]
     assert all(torch.equal(s1[k], s0[k]) for k in s0), [k for k in s0 if not torch.equal(s1[k], s0[k])][:5]
+    # the default: wide-tile weight gradients beside the backward chain split for half of the CUs (EVK_CONV_WGRAD_SHARED) —
+    # another accumulation order for those layers, equal to fp32 rounding
+    g1, s1 = _train(cuda, True)
 
     def rel(a, b):
         return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
@@ -62,8 +68,10 @@ def test_training_is_the_same_with_and_without_the_side_stream(cuda):
     skip = lambda k: k.endswith('.0.bias') and ('content_encoders' in k or 'feature_reencoders' in k)
     bad = [(k, rel(g1[k], g0[k])) for k in g0 if not skip(k) and rel(g1[k], g0[k]) > 2e-4]
     assert not bad, bad[:5]
-    # (four steps amplify the last-bit differences of the two BatchNorm backward forms; the bitwise test below pins them)
-    bad = [(k, rel(s1[k], s0[k])) for k in s0 if s0[k].dtype.is_floating_point and rel(s1[k], s0[k]) > 5e-3]
+    # (four steps amplify the last-bit differences of the two split counts; the bitwise test below pins them)
+    # (BatchNorm biases start at zero: after four steps they are ~1e-4 and the two accumulation orders leave them ~1e-6 apart)
+    far = lambda a, b: float((a.double() - b.double()).abs().max()) > 5e-3 * float(b.double().abs().max()) + 5e-6
+    bad = [(k, rel(s1[k], s0[k])) for k in s0 if s0[k].dtype.is_floating_point and far(s1[k], s0[k])]
     assert not bad, bad[:5]
 
 
@@ -73,7 +81,7 @@ def test_bitwise_equal_when_the_batchnorm_form_is_pinned(cuda):
         "import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
         "from test_wgrad_stream_gpu import _train\n"
         "dev = torch.device('cuda:0')\n"
-        "g1, s1 = _train(dev, True); g0, s0 = _train(dev, False)\n"
+        "g1, s1 = _train(dev, True, shared=False); g0, s0 = _train(dev, False)\n"
         "bad = [k for k in g0 if not torch.equal(g1[k], g0[k])] + [k for k in s0 if not torch.equal(s1[k], s0[k])]\n"
         "print('BITWISE', len(bad), bad[:4])\n" % (ROOT, ROOT))
     out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, EVK_BN_FUSED='0'), capture_output=True, text=True,

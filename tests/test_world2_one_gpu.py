@@ -30,7 +30,8 @@ def world2_results(cuda, tmp_path_factory):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='4')
+                   HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='4',
+                   EVK_WGRAD_SHARED='0')   # (FlatGradDDP == torch DDP bit for bit: side-stream launches split as if alone)
         procs.append(subprocess.Popen([sys.executable, WORKER, str(out)] + CASES, env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     logs = []
