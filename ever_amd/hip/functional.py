@@ -415,6 +415,9 @@ def _wgrad_side_stream(dev, weight, bias=None):
 
 
 _SIDE_CANDIDATES = []
+# priority of the side stream (torch: lower = more urgent, clamped to the device's range; the backward's stream is torch's default
+# stream, priority 0): EVK_WGRAD_PRIO
+_WGRAD_PRIO = int(os.environ.get('EVK_WGRAD_PRIO', '0'))
 
 
 def _pick_side_stream(dev):
@@ -430,7 +433,7 @@ def _pick_side_stream(dev):
     main = _stream()
     took = ctypes.c_float(0.0)
     for _ in range(8):
-        cand = torch.cuda.Stream(dev)
+        cand = torch.cuda.Stream(dev, priority=_WGRAD_PRIO)
         rc = _C.load().evk_streams_overlap(main, cand.cuda_stream, 150, ctypes.byref(took))
         if rc < 0:
             _C.check(rc, 'evk_streams_overlap')
