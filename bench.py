@@ -275,7 +275,10 @@ def graph_replay_line(args):
         return {'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'],
                 'host_enqueue_ms_per_step': d['host_enqueue_ms_per_step'],
                 'how': 'python bench.py --graph (child process, same box, right after the timed region): forward + losses + '
-                       'backward + fused SGD captured once by torch.cuda.graph and replayed; EVK_GRAPH=1 in the Launcher'}
+                       'backward + fused SGD captured once by torch.cuda.graph and replayed; EVK_GRAPH=1 in the Launcher.  Behind the eager step by '
+                       '3-4 %: a replayed graph serialises its two branches at every fork, so the capture forks the weight-gradient '
+                       'branch once per 32 layers instead of once per layer (DESIGN 3; 1 / 2 / 4 / 8 / 32 launches per fork: 513.7 / '
+                       '520.8 / 529.5 / 528.7 / 550.6 tiles/s where eager is 572.4, profiles/r05_experiments/ab_graph_batch.txt)'}
     except Exception as e:   # never at the expense of the headline line
         return {'value': None, 'error': f'{type(e).__name__}: {str(e)[:160]}'}
 
