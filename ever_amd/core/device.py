@@ -24,7 +24,8 @@ def pin_host_threads(local_rank=0, cores=None):
     One training step is enqueued by ONE busy thread at a time (the Python thread forward, autograd's device thread
     backward); on a box that shows 256 logical CPUs under a 16-core quota they migrate, and the step costs the host 3-4 ms
     more than on two CPUs.  `cores` CPUs per rank (default: EVK_HOST_CORES, else 0 = only undo a widening of
-    the launch mask by the runtime), rank r taking the r-th group of the launch set; threads created afterwards (autograd's,
+    the launch mask by the runtime), rank r taking the r-th group of the launch set — if the set holds a group for every local rank
+    (LOCAL_WORLD_SIZE), otherwise nobody is narrowed; threads created afterwards (autograd's,
     the side stream's callbacks) inherit the mask.  Returns the CPU set now in force.  No-op where the OS has no affinity
     call."""
     if not hasattr(os, 'sched_setaffinity') or not _LAUNCH_AFFINITY:
@@ -32,9 +33,10 @@ def pin_host_threads(local_rank=0, cores=None):
     if cores is None:
         cores = int(os.environ.get('EVK_HOST_CORES', '0') or 0)
     allowed = sorted(_LAUNCH_AFFINITY)
-    if cores > 0 and len(allowed) > cores:
-        start = (local_rank * cores) % (len(allowed) - cores + 1) if len(allowed) >= cores * (local_rank + 1) else 0
-        want = allowed[start:start + cores]
+    # every local rank gets its OWN group, or nobody is narrowed (two ranks on the same four CPUs would be worse than none pinned)
+    ranks = max(int(os.environ.get('LOCAL_WORLD_SIZE', '1') or 1), local_rank + 1)
+    if cores > 0 and len(allowed) > cores and len(allowed) >= cores * ranks:
+        want = allowed[local_rank * cores:(local_rank + 1) * cores]
     else:
         want = allowed
     try:

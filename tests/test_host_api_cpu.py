@@ -368,5 +368,10 @@ def test_pin_host_threads_groups_by_rank_and_restores_launch_mask():
             t.start(); t.join()
             assert seen[0] == b
         assert sorted(pin_host_threads(0, len(allowed) + 3)) == allowed      # more than there are: the whole launch set
+        os.environ['LOCAL_WORLD_SIZE'] = str(len(allowed))                   # no room for a group of two per local rank: nobody narrowed
+        try:
+            assert len(allowed) < 2 or sorted(pin_host_threads(0, 2)) == allowed
+        finally:
+            del os.environ['LOCAL_WORLD_SIZE']
     finally:
         assert sorted(pin_host_threads(0, 0)) == allowed
