@@ -303,7 +303,9 @@ int launch_conv1x1_dma(IGemmArgs& a, hipStream_t stream) {
   if (a.Cd < 128) return 1;
   const long long tm = ceil_div(a.M, 128);
   int bn = 2128;
-  if (tm * ceil_div(a.Cd, 128) < 224) {
+  // (EVK_C1_FILL_WG: below how many 128-wide tiles the 64-wide ones are taken — A/B in the step, where the chip is shared)
+  static const long long fill_wg = getenv("EVK_C1_FILL_WG") ? atoll(getenv("EVK_C1_FILL_WG")) : 224;
+  if (tm * ceil_div(a.Cd, 128) < fill_wg) {
     if (tm * ceil_div(a.Cd, 64) < 224) return 1;   // cannot fill the chip
     // long reductions on the 16^2 maps (2048 -> 512: 64 steps, one 128 x 64 tile per CU): the software-pipelined form with
     // loader waves (conv1x1_sp.hip, ring of four) — 42.9 -> 32.8 us, 43.3 -> 33.6 with the statistics epilogue (tools/ab_c1sp.py)

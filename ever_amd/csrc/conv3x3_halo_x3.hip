@@ -625,7 +625,11 @@ int launch_conv3x3_halo(IGemmArgs& a, hipStream_t stream) {
       if (!strcmp(f, "m128x16") && a.Cd > 64) return launch_halo<128, 16, 8>(a, stream);
     }
   }
-  if (a.Cd <= 64 || (long long)a.N * ceil_div(a.Hm, 8) * ceil_div(a.Wm, kPW) * ceil_div(a.Cd, 128) < 256)
+  // (EVK_X3_HALO_MIN128 / EVK_X3_HALO_MINTALL: workgroup counts from which the 128-wide tile / the 16-row patch is taken — A/B in
+  // the step, where the chip is shared with the side stream)
+  static const long long min128 = getenv("EVK_X3_HALO_MIN128") ? atoll(getenv("EVK_X3_HALO_MIN128")) : 256;
+  static const long long mintall = getenv("EVK_X3_HALO_MINTALL") ? atoll(getenv("EVK_X3_HALO_MINTALL")) : 256;
+  if (a.Cd <= 64 || (long long)a.N * ceil_div(a.Hm, 8) * ceil_div(a.Wm, kPW) * ceil_div(a.Cd, 128) < min128)
     return launch_halo<64, 8>(a, stream);   // small maps (16^2 .. 32^2): 64-wide tiles keep every CU busy
   // 16 x 16 patches (256 GEMM rows) halve the weight bytes per MFMA, the larger share of the staging traffic now;
   // taken when they still fill the chip.  With the weights fed by DMA (f16x2) the staging waves no longer hold the matrix
@@ -637,7 +641,7 @@ int launch_conv3x3_halo(IGemmArgs& a, hipStream_t stream) {
   const bool wide8 = m8 && a.planes == 2;
   // (16-row patches unless they would add a mostly empty last patch row: H % 16 in 1..8 is served better by 8-row patches)
   const bool tall_fits = (a.Hm % 16) == 0 || (a.Hm % 16) > 8;
-  if (tall && tall_fits && (long long)a.N * ceil_div(a.Hm, 16) * ceil_div(a.Wm, kPW) * ceil_div(a.Cd, 128) >= 256)
+  if (tall && tall_fits && (long long)a.N * ceil_div(a.Hm, 16) * ceil_div(a.Wm, kPW) * ceil_div(a.Cd, 128) >= mintall)
     return wide8 ? launch_halo<128, 16, 8>(a, stream) : launch_halo<128, 16>(a, stream);
   return wide8 ? launch_halo<128, 8, 8>(a, stream) : launch_halo<128, 8>(a, stream);
 }
