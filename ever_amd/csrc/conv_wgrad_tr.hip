@@ -322,18 +322,20 @@ int launch_wgrad_tr(const WGradArgs& a, int nine_tap, hipStream_t stream) {
 __global__ __launch_bounds__(256) void pack_planar_f16x2_kernel(const float* __restrict__ x, size_t n8,
                                                                 const uint32_t* __restrict__ amax, uint32_t* __restrict__ H,
                                                                 uint32_t* __restrict__ L) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const float inv = op_scale(act_absmax(amax)).inv;
-  if (i >= n8) return;
-  const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + i * 8), v1 = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
-  u32x4 h, l;
-  uint32_t a, b;
-  split2h(v0.x * inv, v0.y * inv, a, b); h.x = a; l.x = b;
-  split2h(v0.z * inv, v0.w * inv, a, b); h.y = a; l.y = b;
-  split2h(v1.x * inv, v1.y * inv, a, b); h.z = a; l.z = b;
-  split2h(v1.z * inv, v1.w * inv, a, b); h.w = a; l.w = b;
-  *reinterpret_cast<u32x4*>(H + i * 4) = h;
-  *reinterpret_cast<u32x4*>(L + i * 4) = l;
+  // (grid-stride: one trip with the one-shot grid; EVK_PACK_PLANAR_WG caps the grid — the pass runs on the side stream beside
+  // HBM-bound kernels of the backward chain)
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + i * 8), v1 = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
+    u32x4 h, l;
+    uint32_t a, b;
+    split2h(v0.x * inv, v0.y * inv, a, b); h.x = a; l.x = b;
+    split2h(v0.z * inv, v0.w * inv, a, b); h.y = a; l.y = b;
+    split2h(v1.x * inv, v1.y * inv, a, b); h.z = a; l.z = b;
+    split2h(v1.z * inv, v1.w * inv, a, b); h.w = a; l.w = b;
+    *reinterpret_cast<u32x4*>(H + i * 4) = h;
+    *reinterpret_cast<u32x4*>(L + i * 4) = l;
+  }
 }
 __global__ __launch_bounds__(256) void unpack_planar_f16x2_kernel(const uint32_t* __restrict__ H, const uint32_t* __restrict__ L,
                                                                   size_t n8, const uint32_t* __restrict__ amax,
@@ -361,7 +363,10 @@ extern "C" int evk_pack_planar_f16x2(const float* x, int64_t n, const uint32_t* 
   EVK_REQUIRE(x && x_absmax && out && n > 0 && n % 8 == 0, EVK_E_INVALID, "pack_planar_f16x2: null pointer or n %% 8 != 0");
   const size_t n8 = (size_t)n / 8;
   uint32_t* H = (uint32_t*)out;
-  hipLaunchKernelGGL(pack_planar_f16x2_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n8,
+  static const long long cap = getenv("EVK_PACK_PLANAR_WG") ? atoll(getenv("EVK_PACK_PLANAR_WG")) : 0;
+  size_t grid = (n8 + 255) / 256;
+  if (cap > 0 && grid > (size_t)cap) grid = (size_t)cap;
+  hipLaunchKernelGGL(pack_planar_f16x2_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, n8,
                      x_absmax, H, H + n / 2);
   return check_launch("pack_planar_f16x2");
 }
