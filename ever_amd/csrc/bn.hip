@@ -26,6 +26,17 @@ __device__ __forceinline__ unsigned bn_blk() { return (EVK_BN_REV & BIT) ? gridD
 #ifndef EVK_BN_NTS
 #define EVK_BN_NTS 0
 #endif
+// non-temporal loads of the stem's 268 MB map in its fused BatchNorm + pool passes (experiment: a plain read of more than 256 MB
+// behind a plain-store writer streams at 4.1 TB/s, with the hint at 6.8 — tools/probes/mall_direction.hip).
+// Bits: 1 backward reduce pass, 2 forward, 4 backward apply pass
+#ifndef EVK_BN_POOL_NT
+#define EVK_BN_POOL_NT 5   // kernel times with the hint (us): backward reduce 123.4 -> 115.5, backward apply 98.1 -> 94.7, forward 82.8 -> 99.4 (off)
+#endif
+template <int BIT>
+__device__ __forceinline__ f32x4 pool_ld(const float* p) {
+  if (EVK_BN_POOL_NT & BIT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return *reinterpret_cast<const f32x4*>(p);
+}
 template <int BIT, typename V>
 __device__ __forceinline__ void bn_st(V* p, size_t i, V v) {
   if (EVK_BN_NTS & BIT) __builtin_nontemporal_store(v, p + i); else p[i] = v;
@@ -59,7 +70,7 @@ struct BnPlan {
   int64_t rows_per_blk;
   int tpc, rl;
 };
-static BnPlan bn_plan(int64_t rows, int C) {
+static BnPlan bn_plan(int64_t rows, int C, int64_t per_override = 0, int64_t cap_override = 0) {
   BnPlan p;
   const int c4 = C / 4;
   p.tpc = c4 < 256 ? c4 : 256;
@@ -68,12 +79,13 @@ static BnPlan bn_plan(int64_t rows, int C) {
   // 65536 549.1 / 525.7, 49152 - / 526.6, 40960 - / 528.1, 32768 551.2 / 528.7 (+0.4 / +0.6 %), 24576 - / 526.8, 16384 545.9 / -:
   // twice the workgroups halve the latency-bound reduce passes on the small maps, four times cost more in the finalisation
   static const int64_t per = getenv("EVK_BN_ELEMS") ? atoll(getenv("EVK_BN_ELEMS")) : 32768;
-  int64_t nb = (rows * (int64_t)C + per - 1) / per;
+  const int64_t per_e = per_override > 0 ? per_override : per;
+  int64_t nb = (rows * (int64_t)C + per_e - 1) / per_e;
   // at most TWO workgroups per CU (EVK_BN_MAXBLK, <= kMaxStatBlocks): whole rounds of the chip and a quarter of the partials for
   // the finalisation of the large maps.  Three interleaved rounds, two boxes: 2048 542.9 / 546.4, 1024 543.1, 768 - / 547.4,
   // 640 - / 545.9, 512 546.1 / 550.0 (+0.6 / +0.65 %), 384 - / 547.4, 256 538.6
   static const int64_t cap = getenv("EVK_BN_MAXBLK") ? atoll(getenv("EVK_BN_MAXBLK")) : 512;
-  if (nb > cap) nb = cap;
+  if (nb > (cap_override > 0 ? cap_override : cap)) nb = cap_override > 0 ? cap_override : cap;
   if (nb > kMaxStatBlocks) nb = kMaxStatBlocks;
   if (nb < 1) nb = 1;
   int64_t rpb = (rows + nb - 1) / nb;
@@ -681,7 +693,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __re
       for (int kx = 0; kx < 3; ++kx) {
         const int ix = ox * 2 - 1 + kx;
         if ((unsigned)ix >= (unsigned)W) continue;
-        f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)n * H + iy) * W + ix) * C + cb * 4) * sc + sh;
+        f32x4 v = pool_ld<2>(x + (((size_t)n * H + iy) * W + ix) * C + cb * 4) * sc + sh;
         v.x = v.x != v.x ? v.x : fmaxf(v.x, 0.f); v.y = v.y != v.y ? v.y : fmaxf(v.y, 0.f);   // relu keeps NaN visible
         v.z = v.z != v.z ? v.z : fmaxf(v.z, 0.f); v.w = v.w != v.w ? v.w : fmaxf(v.w, 0.f);
         const int t = ky * 3 + kx;
@@ -792,7 +804,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_partial_quad_kernel(const flo
         const float* xb = x + (((size_t)n * H + 2 * k) * W + 2 * l) * C + cb * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + ((size_t)(e >> 1) * W + (e & 1)) * C);
+          const f32x4 xv = pool_ld<1>(xb + ((size_t)(e >> 1) * W + (e & 1)) * C);
           f32x4 g = pq.g[e];
           const f32x4 yy = xv * sc + sh;
           g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
@@ -850,7 +862,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_quad_kernel(const float
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const size_t off = base + ((size_t)(e >> 1) * W + (e & 1)) * C;
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
+      const f32x4 xv = pool_ld<4>(x + off);
       f32x4 g = pq.g[e];
       const f32x4 yy = xv * sc + sh;
       g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
@@ -1095,7 +1107,9 @@ extern "C" int evk_bn_relu_pool_bwd(const float* dp, const uint8_t* code, const 
   EVK_REQUIRE(workspace && workspace_bytes >= evk_bn_workspace_bytes(rows, C), EVK_E_WORKSPACE,
               "bn_relu_pool_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  const BnPlan pl = bn_plan(rows, C);
+  // (the quad reduce pass gathers pooled gradients and codes per element: it keeps the finer split it was measured with —
+  // 1024 workgroups on the stem's map: 86 us, 123 us under the two-per-CU cap of the plain reduce passes)
+  const BnPlan pl = bn_plan(rows, C, 65536, kMaxStatBlocks);
   float* partial = (float*)workspace;
   float* coef = partial + (size_t)kMaxStatBlocks * 2 * C;
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
