@@ -4,6 +4,7 @@
 // Reference call sites are cited per entry point in include/ever_hip.h.
 // All kernels use 16-byte accesses along the channel axis (C % 4 == 0) with a scalar fallback where
 // the path has C == 1 (classifier logits).
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace evk {
@@ -751,8 +752,11 @@ __global__ __launch_bounds__(256) void relation_bn_bwd_kernel(
 }
 
 static int relation_blocks(int HW) {
-  int b = (HW + 63) / 64;
-  return b > 256 ? 256 : (b < 1 ? 1 : b);
+  // pixels per workgroup and the cap on workgroups per image (EVK_REL_PPB / EVK_REL_MAXBLK, read once)
+  static const int ppb = getenv("EVK_REL_PPB") ? atoi(getenv("EVK_REL_PPB")) : 64;
+  static const int cap = getenv("EVK_REL_MAXBLK") ? atoi(getenv("EVK_REL_MAXBLK")) : 256;
+  int b = (HW + ppb - 1) / ppb;
+  return b > cap ? cap : (b < 1 ? 1 : b);
 }
 
 }  // namespace evk
