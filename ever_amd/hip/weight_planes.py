@@ -24,7 +24,7 @@ from torch.utils.weak import WeakIdKeyDictionary
 from .. import _C
 
 _ENABLED = os.environ.get('EVK_PLANE_CACHE', '1') != '0'
-_PAIRS_PER_BLOCK = 2048          # 256 threads x 8 trips
+_PAIRS_PER_BLOCK = int(os.environ.get('EVK_SPLIT_PAIRS', '2048'))          # 256 threads x 8 trips (EVK_SPLIT_PAIRS: A/B)
 _lock = threading.RLock()        # forward (main thread) and backward (autograd engine thread) both come here
 _epoch = 0
 _by_weight = WeakIdKeyDictionary()   # weight tensor object (weakly, by identity) -> {layout signature: _Entry}
