@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 #include "../../include/ever_hip.h"
 
 namespace evk {
@@ -26,6 +27,19 @@ inline int check_launch(const char* what) {
       return (code);                     \
     }                                    \
   } while (0)
+
+// "Once per DEVICE" for hipFuncSetAttribute: a function attribute belongs to the device's copy of the code object, so a
+// process that drives several devices has to set it on each (one flag per process left the second device's kernels at the
+// 64 KB default: launch failure with a 98-160 KB ring).
+struct PerDeviceOnce {
+  std::atomic<uint64_t> mask{0};
+  bool first() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const uint64_t b = 1ull << (d & 63);
+    return !(mask.fetch_or(b) & b);
+  }
+};
 
 constexpr int kWave = 64;
 

@@ -262,11 +262,10 @@ static int launch_sp(IGemmArgs& a, hipStream_t stream) {
   size_t lds = (size_t)NST * (BM * kSpRow + 2 * BN * kRowBytes);
   const size_t scratch = ((size_t)2 * 4 * 32 * (BN / 2 + 4) + (size_t)3 * 2 * 3 * (BN / 2)) * sizeof(float);
   if (lds < scratch) lds = scratch;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_sp_kernel<BN, PK, NST, LW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   const long long nwg = (long long)a.tiles_m * a.tiles_n;
   if (nwg <= 0 || nwg > 0x7fffffffLL) {

@@ -581,11 +581,10 @@ static int launch_halo_np(IGemmArgs& a, hipStream_t stream) {
   bn_stats_setup(a, PH * kPW, BN, 2, a.tiles_m);   // two row waves per patch; the ring (>= 100 KB) is the scratch
   constexpr int PL = NP == 2 ? 2 : 3;
   const size_t lds = (size_t)2 * (PL * HaloGeom<PH, PL>::kHSlots * kRB) + (size_t)(WDMA ? 3 : 2) * (3 * PL * BN * kRB);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_x3_kernel<BN, PH, NPX, WDMA, MW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   const long long nwg = (long long)a.tiles_m * a.tiles_n;
   hipLaunchKernelGGL((conv3x3_halo_x3_kernel<BN, PH, NPX, WDMA, MW>), dim3((unsigned)nwg), dim3(256 + 64 * MW), lds, stream, a, tiles_y, tiles_x,

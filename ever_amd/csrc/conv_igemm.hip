@@ -222,11 +222,10 @@ static int launch_cfg(IGemmArgs& a, hipStream_t stream) {
   a.tiles_m = ceil_div(a.M, BM);
   a.tiles_n = ceil_div(a.Cd, BN);
   const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   const long long nwg = (long long)a.tiles_m * a.tiles_n;
   if (nwg <= 0 || nwg > 0x7fffffffLL) {
@@ -375,7 +374,8 @@ static int conv_fwd_any(const evk_conv_desc* d, const float* x, const float* w, 
   a.bn_cap = bn_cap;
   if (nparts) *nparts = 0;
   if (w3) {
-    const int hr = launch_conv3x3_halo(a, (hipStream_t)stream);   // 3x3 'same' convolutions: LDS-halo kernel
+    int hr = launch_conv3x3_wino(a, (hipStream_t)stream);         // 3x3 'same', f16x2, large maps: Winograd F(2,3) along x
+    if (hr == 1) hr = launch_conv3x3_halo(a, (hipStream_t)stream);   // 3x3 'same' convolutions: LDS-halo kernel
     if (hr != 1) {
       if (nparts && hr == EVK_OK) *nparts = a.bn_parts;
       return hr;
@@ -497,7 +497,8 @@ static int conv_dgrad_any(const evk_conv_desc* d, const float* dy, const float* 
         a.dense_dst = (sh == 1 && sw == 1) ? 1 : 0;
         a.relu = 0;
         a.Kpad = kpad32(a.Ktot);
-        rc = wt3 ? launch_conv3x3_halo(a, st) : 1;
+        rc = wt3 ? launch_conv3x3_wino(a, st) : 1;
+        if (rc == 1) rc = wt3 ? launch_conv3x3_halo(a, st) : 1;
         if (rc == 1) rc = wt3 ? launch_igemm_x3(a, st) : launch_igemm(a, st);
         if (rc) return rc;
       }

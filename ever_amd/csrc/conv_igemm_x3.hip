@@ -248,11 +248,10 @@ static int launch_cfg3_np(IGemmArgs& a, hipStream_t stream) {
   // statistics epilogue: per-wave scratch + the row waves' exchange area
   const size_t scratch = ((size_t)4 * 32 * (BN / WAVES_N + 4) + (size_t)3 * BN) * sizeof(float);
   if (lds < scratch) lds = scratch;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_x3_kernel<BM, BN, WAVES_M, WAVES_N, NBUF, NP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   const long long nwg = (long long)a.tiles_m * a.tiles_n;
   if (nwg <= 0 || nwg > 0x7fffffffLL) {
@@ -396,6 +395,8 @@ static int split_weight_any(const evk_conv_desc* d, const float* w, int32_t for_
   // 3x3 'same' convolutions served by the LDS-halo kernel take their planes in that kernel's own order (the
   // decision is a pure function of the descriptor, so the consumer makes the same one); never larger than the
   // generic layout.
+  if (wscale && conv_desc_uses_wino(d, for_dgrad ? 1 : 0))   // (12 x 2 planes of taps: inside the 9 x 3 the buffer is sized for)
+    return launch_split_weight_wino(w, out, d->Cout, d->Cin, for_dgrad ? 1 : 0, st, wscale);
   if (d->kh == 3 && d->kw == 3 && conv_desc_uses_halo(d, for_dgrad ? 1 : 0))
     return launch_split_weight_halo(w, out, d->Cout, d->Cin, for_dgrad ? 1 : 0, st, wscale);
   if (!for_dgrad) {

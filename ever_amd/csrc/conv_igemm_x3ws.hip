@@ -295,11 +295,10 @@ static int launch_ws_np(IGemmArgs& a, hipStream_t stream) {
   bn_stats_setup(a, BM, BN, WAVES_M, a.tiles_m);
   const size_t lds = (size_t)NSTAGE * 3 * (BM + BN) * kRowBytes;   // >= the statistics epilogue's scratch
   a.bn_scratch_off = 0;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_x3ws_kernel<BM, BN, WAVES_M, WAVES_N, NSTAGE, NP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   const long long nwg = (long long)a.tiles_m * a.tiles_n;
   if (nwg <= 0 || nwg > 0x7fffffffLL) {

@@ -301,11 +301,10 @@ bool wgrad_tr_nine_tap(const evk_conv_desc* d) {
 template <int NT>
 static int launch_tr(const WGradArgs& b, hipStream_t stream) {
   const size_t lds = (size_t)3 * TrGeom<NT>::kStage;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_tr_kernel<NT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   hipLaunchKernelGGL((conv_wgrad_tr_kernel<NT>), dim3(b.tiles_co * b.tiles_k * b.splitk), dim3(512), lds, stream, b);
   return check_launch("conv_wgrad_tr");

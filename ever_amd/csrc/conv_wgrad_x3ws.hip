@@ -416,11 +416,10 @@ template <int NP, bool W8, bool PKX = false, bool PKD = false>
 static int launch_wgrad_x3ws_t(const WGradArgs& b, hipStream_t stream) {
   constexpr int BM = 128, BN = 256;
   const size_t lds = (size_t)2 * 3 * (BM + BN) * kRowBytes;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x3ws_kernel<BM, BN, NP, W8, PKX, PKD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   hipLaunchKernelGGL((conv_wgrad_x3ws_kernel<BM, BN, NP, W8, PKX, PKD>), dim3(b.tiles_co * b.tiles_k * b.splitk), dim3(512), lds, stream, b);
   return check_launch("conv_wgrad_x3ws");

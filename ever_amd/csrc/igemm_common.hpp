@@ -353,6 +353,11 @@ int launch_conv1x1_ps2(IGemmArgs& a, hipStream_t stream);  // persistent, loader
 bool conv1x1_ps2_applicable(const IGemmArgs& a);
 int launch_conv3x3_halo(IGemmArgs& a, hipStream_t stream);  // 1 = not applicable
 bool conv_desc_uses_halo(const evk_conv_desc* d, int for_dgrad);
+bool conv3x3_halo_applies(const IGemmArgs& a);
+int launch_conv3x3_wino(IGemmArgs& a, hipStream_t stream);  // 1 = not applicable (conv3x3_wino_x3.hip; f16x2 only)
+bool conv_desc_uses_wino(const evk_conv_desc* d, int for_dgrad);   // geometry only: the caller knows the arithmetic
+int launch_split_weight_wino(const float* w, uint16_t* out, int Cout, int Cin, int for_dgrad, hipStream_t st,
+                             const uint32_t* wscale);
 int launch_split_weight_halo(const float* w, uint16_t* out, int Cout, int Cin, int for_dgrad, hipStream_t st,
                              const uint32_t* wscale = nullptr);
 

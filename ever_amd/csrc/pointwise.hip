@@ -919,13 +919,12 @@ extern "C" int evk_upsample_bilinear_fwd(const float* x, float* y, int32_t N, in
   const int prow = (int)((kTileR - 1) * sy) + 3, pcol = (int)((kTileC - 1) * sx) + 3;
   const size_t patch_bytes = (size_t)prow * pcol * C * sizeof(float);
   if (C % 4 == 0 && C >= 128 && patch_bytes <= 64 * 1024 && N <= 65535 && (Ho + kTileR - 1) / kTileR <= 65535) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bilinear_fwd_tile_kernel<64>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bilinear_fwd_tile_kernel<32>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-      attr_set = true;
     }
     const dim3 grid((Wo + kTileC - 1) / kTileC, (Ho + kTileR - 1) / kTileR, N);
     if (C <= 128)

@@ -101,6 +101,47 @@ __device__ __forceinline__ void split_halo_body(const float* __restrict__ w, uin
   }
 }
 
+// Planes for the Winograd F(2,3) 3x3 kernel (conv3x3_wino_x3.hip; f16x2 arithmetic only): out[pt][ky*4 + xi][chunk][row][16]
+// fp16 of U / s, U = (g0, (g0 + g1 + g2)/2, (g0 - g1 + g2)/2, g2) of kernel row ky (formed in fp64, rounded once).  That
+// kernel always correlates, so the data gradient's planes hold the transposed and flipped filter:
+// g[kx] = w[row][ky][kx][k] (forward: rows = Cout) or w[k][2 - ky][2 - kx][row] (data gradient: rows = Cin).
+__device__ __forceinline__ void split_wino_body(const float* __restrict__ w, uint16_t* __restrict__ out, int Cout,
+                                                int Cin, int for_dgrad, size_t t0, size_t nthreads, const uint32_t* wscale) {
+  const int rows = for_dgrad ? Cin : Cout, K = for_dgrad ? Cout : Cin;
+  const int nchunk = (K + kHaloCh - 1) / kHaloCh;
+  const size_t total = (size_t)3 * nchunk * rows * (kHaloCh / 2);
+  const size_t tap = (size_t)nchunk * rows * kHaloCh, plane = 12 * tap;
+  for (size_t i = t0; i < total; i += nthreads) {
+    const int k2 = (int)(i % (kHaloCh / 2));
+    size_t r = i / (kHaloCh / 2);
+    const int row = (int)(r % rows);
+    r /= rows;
+    const int ch = (int)(r % nchunk);
+    const int ky = (int)(r / nchunk);
+    const int kc = ch * kHaloCh + 2 * k2;
+    float u[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    if (kc + 1 < K) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        double g[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+          g[kx] = for_dgrad ? (double)w[(((size_t)(kc + e) * 3 + (2 - ky)) * 3 + (2 - kx)) * Cin + row]
+                            : (double)w[(((size_t)row * 3 + ky) * 3 + kx) * Cin + kc + e];
+        u[0][e] = (float)g[0];
+        u[1][e] = (float)(0.5 * (g[0] + g[1] + g[2]));
+        u[2][e] = (float)(0.5 * (g[0] - g[1] + g[2]));
+        u[3][e] = (float)g[2];
+      }
+    }
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi)
+      split_put(u[xi][0], u[xi][1],
+                reinterpret_cast<uint32_t*>(out + ((size_t)(ky * 4 + xi) * nchunk + ch) * rows * kHaloCh + (size_t)row * kHaloCh + 2 * k2),
+                plane, wscale);
+  }
+}
+
 // pairs (= threads' worth of work) of one job, for grid sizing
 static inline size_t split_job_pairs(const evk_split_job& j) {
   switch (j.kind) {

@@ -26,6 +26,8 @@ __global__ __launch_bounds__(256) void split_weight_multi_kernel(const evk_split
   else if (j.kind == kSplitDgrad)
     split_dgrad_body(w, out, j.arg[0], j.arg[1], j.arg[2], j.arg[3], j.arg[4], j.arg[5], j.arg[6], j.arg[7], j.arg[8],
                      j.arg[9], j.arg[10], t0, nt, wscale);
+  else if (wscale && j.arg[3])   // f16x2 and a shape the Winograd kernel takes (conv_desc_uses_wino)
+    split_wino_body(w, out, j.arg[0], j.arg[1], j.arg[2], t0, nt, wscale);
   else
     split_halo_body(w, out, j.arg[0], j.arg[1], j.arg[2], t0, nt, wscale);
 }
@@ -60,6 +62,7 @@ extern "C" int evk_conv2d_split_jobs(const evk_conv_desc* d, const float* w, int
   if (d->kh == 3 && d->kw == 3 && conv_desc_uses_halo(d, for_dgrad ? 1 : 0)) {
     evk_split_job& j = put(kSplitHalo, out);
     j.arg[0] = d->Cout; j.arg[1] = d->Cin; j.arg[2] = for_dgrad ? 1 : 0;
+    j.arg[3] = conv_desc_uses_wino(d, for_dgrad ? 1 : 0) ? 1 : 0;
     return n;
   }
   if (!for_dgrad) {

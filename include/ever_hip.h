@@ -107,7 +107,8 @@ int evk_conv2d_split_weight(const evk_conv_desc* d, const float* w, int32_t for_
 typedef struct evk_split_job {
   const float* w;   /* OHWI parameter */
   void* out;        /* start of this job's planes inside the convolution's wsplit buffer */
-  int32_t kind;     /* 0 forward, 1 data gradient (one residue class), 2 LDS-halo 3x3 */
+  int32_t kind;     /* 0 forward, 1 data gradient (one residue class), 2 LDS-halo 3x3 (arg[3] != 0: under the f16x2
+                     * arithmetic these planes are the Winograd F(2,3) kernel's, 12 transformed taps instead of 9) */
   int32_t arg[13];  /* layout parameters (opaque); arg[12] = workgroups assigned by the caller */
 } evk_split_job;
 int32_t evk_conv2d_split_job_count(const evk_conv_desc* d, int32_t for_dgrad);
