@@ -211,7 +211,7 @@ def library_gemm_yardstick(dev):
     return out
 
 
-def board_power_line(step, seconds=2.5):
+def board_power_line(step, seconds=2.5, device_index=0):
     """Board power while the SAME training step keeps running after the timed region (rocm-smi sampled every ~0.4 s from a
     thread; DESIGN 2.10: every phase of this step runs at 73-100 % of the part's power cap, so the step is bounded by its
     energy, not by a kernel schedule).  None when rocm-smi is not on the box.  Never part of the timed region."""
@@ -229,7 +229,7 @@ def board_power_line(step, seconds=2.5):
                 out = subprocess.run(['rocm-smi', '--showpower', '--showclocks', '--json'], capture_output=True, text=True,
                                      timeout=10).stdout
                 d = json.loads(out)
-                card = d.get('card0') or next(iter(d.values()))
+                card = d.get(f'card{device_index}') or next(iter(d.values()))
                 w = next((float(v) for k, v in card.items() if 'Power (W)' in k), None)
                 clk = next((int(''.join(c for c in v if c.isdigit())) for k, v in card.items() if k.startswith('sclk clock speed')), None)
                 if w is not None:
@@ -238,6 +238,13 @@ def board_power_line(step, seconds=2.5):
                 pass
             time.sleep(0.3)
 
+    cap = 1400.0   # (the part's default; replaced by what the board reports)
+    try:
+        d = json.loads(subprocess.run(['rocm-smi', '--showmaxpower', '--json'], capture_output=True, text=True, timeout=10).stdout)
+        card = d.get(f'card{device_index}') or next(iter(d.values()))
+        cap = next((float(v) for k, v in card.items() if 'Max Graphics Package Power' in k or 'Max' in k), cap) or cap
+    except Exception:      # noqa: BLE001
+        pass
     th = threading.Thread(target=sampler, daemon=True)
     th.start()
     t0, n = time.perf_counter(), 0
@@ -253,7 +260,7 @@ def board_power_line(step, seconds=2.5):
         return None
     w = sum(s[0] for s in samples) / len(samples)
     clks = [s[1] for s in samples if s[1]]
-    return {'avg_board_power_w': round(w, 1), 'power_cap_w': 1400, 'frac_of_cap': round(w / 1400.0, 3),
+    return {'avg_board_power_w': round(w, 1), 'power_cap_w': round(cap, 1), 'frac_of_cap': round(w / cap, 3), 'card': device_index,
             'avg_sclk_mhz': round(sum(clks) / len(clks)) if clks else None, 'samples': len(samples),
             'joules_per_step': round(w * elapsed / n, 2), 'ms_per_step_during_probe': round(elapsed / n * 1e3, 3),
             'note': 'rocm-smi during extra steps after the timed region; by phase (profiles/r05_experiments/power_phase.txt): 3x3 halo '
@@ -539,6 +546,9 @@ def main():
             'host_enqueue_ms_per_step': round(enqueued / args.steps * 1e3, 3),
             'host_unblocked_ms_per_step': round(host_unblocked_ms, 3),
             'host_cores': host_cores(), 'host_affinity': len(os.sched_getaffinity(0)),
+            'host_pinned_cores': args.host_cores,   # (bench.py pins its enqueuing threads by default; the Launcher only under EVK_HOST_CORES,
+                                                   #  because DataLoader workers inherit the mask: tiles/s is the same either way — the step is
+                                                   #  GPU-bound — only host_*_ms_per_step move, DESIGN 2.10 "Host threads")
             'hip_graph': bool(args.graph),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if conv_math == 'bf16' else 'f32', 'data': 'synthetic',
@@ -600,7 +610,7 @@ def main():
                 traffic, traffic_file = pmc_traffic('conv_igemm') if (conv_math == 'f16x2' and args.config == 'c2') else (None, None)
                 line['roofline'] = {
                     'bound': 'mfma',
-                    'kernel': ('evk::conv3x3_halo_x3_kernel / conv1x1_dma_kernel / conv1x1_ps_kernel / conv_igemm_x3ws_kernel / conv_igemm_x3_kernel' if x3
+                    'kernel': ('evk::conv3x3_wino_x3_kernel / conv3x3_halo_x3_kernel / conv1x1_ps2_kernel / conv1x1_dma_kernel / conv1x1_sp_kernel / conv_igemm_x3ws_kernel / conv_igemm_x3_kernel' if x3
                                else 'evk::conv_igemm_kernel') + ' (conv forward + data-gradient launches)',
                     'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'peak_note': peak_note,
                     'frac': round(ach / peak, 4), 'traffic': traffic,
@@ -630,6 +640,35 @@ def main():
                                           'frac_of_launch_bounds': round(wg['bound_seconds'] / wg['seconds'], 4)}
                 if conv_math == 'f16x2' and args.config == 'c2':
                     line['roofline_wgrad']['mfma_busy'] = pmc_busy('conv_wgrad')[0]
+            # traffic and algorithmic bytes on ONE denominator — per step (`traffic` is per KERNEL launch,
+            # `algorithmic_bytes_per_launch` per C-ABI call, and a strided data gradient or a split-K weight gradient is
+            # several kernels per call)
+            for key, fname, e in (('roofline', 'conv_igemm', ig), ('roofline_wgrad', 'conv_wgrad', wg)):
+                if key in line and e:
+                    per_step = e['bytes'] / max(1, sampled)
+                    line[key]['algorithmic_bytes_per_step'] = round(per_step)
+                    kl = pmc_kernel_launches_per_step(fname)
+                    if line[key].get('traffic') and kl:
+                        line[key]['traffic_per_step'] = round(line[key]['traffic'] * kl)
+                        line[key]['traffic_over_algorithmic'] = round(line[key]['traffic'] * kl / per_step, 3)
+                        line[key]['traffic_per_step_note'] = (f'PMC bytes per kernel launch x {kl} kernel launches per step of the family '
+                                                              '(profiles/r*_traffic.json); the two *_per_step fields are comparable')
+            # every convolution launch of the step as one object, and the whole step against the same peak: `roofline` alone
+            # (forward + data gradient) reads better than either
+            if ig and wg:
+                fl, sec = ig['flops'] + wg['flops'], ig['seconds'] + wg['seconds']
+                line['roofline_conv_all'] = {
+                    'bound': 'mfma', 'kernel': 'every convolution launch of the step (forward + data gradient + weight gradient, '
+                                               'incl. split-K reduce, bias column sums and pack passes)',
+                    'achieved': round(fl / sec / 1e12, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                    'frac': round(fl / sec / 1e12 / peak, 4), 'gflop_per_step': round(fl / max(1, sampled) / 1e9, 1),
+                    'ms_per_step': round(sec / max(1, sampled) * 1e3, 3), 'sampled_steps': sampled,
+                    'frac_of_launch_bounds': round((ig['bound_seconds'] + wg['bound_seconds']) / sec, 4)}
+                step_tf = fl / max(1, sampled) / (ms * 1e-3) / 1e12
+                line['roofline_step'] = {
+                    'bound': 'mfma', 'kernel': 'the whole training step (algorithmic convolution FLOP of a step over ms_per_step: '
+                                               'BatchNorm, resampling, losses, optimizer and every gap included)',
+                    'achieved': round(step_tf, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(step_tf / peak, 4)}
             # the ResNet-50 encoder's convolutions alone (BASELINE.json north_star: >= 0.6 x MFMA roofline on this
             # stack): forward + data gradient + weight gradient of every `en.*` convolution, the 7x7 stem on the
             # exact-fp32 kernel included, all priced against the default arithmetic's peak
@@ -681,7 +720,12 @@ def main():
                         'algorithmic_bytes_per_kernel': (round(hb['bytes'] / max(1, sampled) / pmc_kernel_launches_per_step(fam_name))
                                                          if pmc_kernel_launches_per_step(fam_name) else None),
                         'calls_per_step': hb['launches'] // max(1, sampled), 'sampled_steps': sampled,
-                        'avg_call_us': round(hb['seconds'] / hb['launches'] * 1e6, 2)}
+                        'avg_call_us': round(hb['seconds'] / hb['launches'] * 1e6, 2),
+                        'algorithmic_bytes_per_step': round(hb['bytes'] / max(1, sampled))}
+                    o = line['roofline_hbm_' + fam_name]
+                    if o['traffic'] and pmc_kernel_launches_per_step(fam_name):
+                        o['traffic_per_step'] = round(o['traffic'] * pmc_kernel_launches_per_step(fam_name))
+                        o['traffic_over_algorithmic'] = round(o['traffic_per_step'] / o['algorithmic_bytes_per_step'], 3)
                     a = overlapped.get(fam_name) if overlapped is not None else None
                     if a and a['seconds'] > 0:
                         g1 = a['bytes'] / a['seconds'] / 1e9
@@ -690,7 +734,7 @@ def main():
         if world == 1 and not args.graph and 'roofline' in line:
             line['roofline']['library_fp16_gemm'] = library_gemm_yardstick(dev)
         if world == 1 and not args.graph and not args.no_graph_line and not use_ddp:
-            line['board_power'] = board_power_line(step)
+            line['board_power'] = board_power_line(step, device_index=local_rank)
         if world == 1 and not use_ddp and not args.graph and not args.no_graph_line and conv_math == 'f16x2':
             line['hip_graph_replay'] = graph_replay_line(args)
         if world == 1 and not args.no_cpu_baseline:

@@ -24,6 +24,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifndef EVK_C1_DMA_ABL
+#define EVK_C1_DMA_ABL 0   // timing ablations (tools/build_variant.sh -DEVK_C1_DMA_ABL=n; wrong results): 1 no activation DMA, 2 no weight
+#endif                     // DMA, 4 no compute, 8 no stores, 16 every tile twice with half of the K loop each
 namespace evk {
 
 namespace {
@@ -47,7 +50,8 @@ __device__ __forceinline__ int c1_arow_off(int row, int c) { return row * kC1Row
 }  // namespace
 
 template <int BN, bool PK, int NST, int WAVES_M>
-__global__ __launch_bounds__(128 * WAVES_M) void conv1x1_dma_kernel(const IGemmArgs p, uint32_t src_bytes, uint32_t wgt_bytes, int dbg) {
+__global__ __launch_bounds__(128 * WAVES_M) void conv1x1_dma_kernel(const IGemmArgs p, uint32_t src_bytes, uint32_t wgt_bytes) {
+  constexpr int dbg = EVK_C1_DMA_ABL;
   constexpr int BM = 128, WAVES_N = 2, NW = WAVES_M * WAVES_N, WM = BM / WAVES_M, MB = WM / 32, WN = BN / 2, NB = WN / 32;
   static_assert(NST == 2 || NST == 3, "ring depth");
   static_assert(WAVES_M == 4 || WAVES_M == 2, "row waves");
@@ -213,7 +217,8 @@ __global__ __launch_bounds__(128 * WAVES_M) void conv1x1_dma_kernel(const IGemmA
 }
 
 template <int BN, bool PK, int NST, int WAVES_M>
-static int launch_c1(IGemmArgs& a, hipStream_t stream, int dbg) {
+static int launch_c1(IGemmArgs& a, hipStream_t stream) {
+  constexpr int dbg = EVK_C1_DMA_ABL;
   constexpr int BM = 128;
   a.tiles_m = ceil_div(a.M, BM);
   a.tiles_n = ceil_div(a.Cd, BN);
@@ -234,13 +239,13 @@ static int launch_c1(IGemmArgs& a, hipStream_t stream, int dbg) {
   const unsigned long long sb = (unsigned long long)a.N * a.Hs * a.Ws * a.Cs * 4ull;
   const unsigned long long wb = 2ull * a.Cd * a.Kpad * 2ull;
   hipLaunchKernelGGL((conv1x1_dma_kernel<BN, PK, NST, WAVES_M>), dim3((unsigned)((dbg & 16) ? 2 * nwg : nwg)), dim3(128 * WAVES_M), lds, stream, a,
-                     (uint32_t)sb, (uint32_t)wb, dbg);
+                     (uint32_t)sb, (uint32_t)wb);
   return check_launch("conv1x1_dma");
 }
 
 template <int BN, int NST, int WAVES_M = 4>
-static int launch_c1_pk(IGemmArgs& a, hipStream_t stream, int dbg) {
-  return a.a_packed ? launch_c1<BN, true, NST, WAVES_M>(a, stream, dbg) : launch_c1<BN, false, NST, WAVES_M>(a, stream, dbg);
+static int launch_c1_pk(IGemmArgs& a, hipStream_t stream) {
+  return a.a_packed ? launch_c1<BN, true, NST, WAVES_M>(a, stream) : launch_c1<BN, false, NST, WAVES_M>(a, stream);
 }
 
 bool conv1x1_dma_applicable(const IGemmArgs& a) {
@@ -255,16 +260,12 @@ int launch_conv1x1_dma_forced(IGemmArgs& a, int bn, hipStream_t stream) {
     set_error("conv1x1_dma: shape not supported (1x1, Cs %% 32 == 0, f16x2 arithmetic)");
     return EVK_E_UNSUPPORTED;
   }
-  // ablation switches (tools/ab_c1dma.py: 1 no activation DMA, 2 no weight DMA, 4 no compute, 8 no stores); read on every
-  // launch under EVK_TUNE only
-  static const bool tune = getenv("EVK_TUNE") != nullptr;
-  const int dbg = tune && getenv("EVK_C1_DMA_DBG") ? atoi(getenv("EVK_C1_DMA_DBG")) : 0;
-  if (bn == 256) return launch_c1_pk<256, 3>(a, stream, dbg);
-  if (bn == 128) return launch_c1_pk<128, 3>(a, stream, dbg);
-  if (bn == 64) return launch_c1_pk<64, 3>(a, stream, dbg);
+  if (bn == 256) return launch_c1_pk<256, 3>(a, stream);
+  if (bn == 128) return launch_c1_pk<128, 3>(a, stream);
+  if (bn == 64) return launch_c1_pk<64, 3>(a, stream);
   // two stages: two workgroups per CU (one's epilogue under the other's loop)
-  if (bn == 2128) return launch_c1_pk<128, 2>(a, stream, dbg);
-  return launch_c1_pk<64, 2>(a, stream, dbg);
+  if (bn == 2128) return launch_c1_pk<128, 2>(a, stream);
+  return launch_c1_pk<64, 2>(a, stream);
   // (four-wave forms, 2 x 2 waves of 64 x BN/2 — a third fewer LDS bytes per MFMA — measured behind the eight-wave ones on
   // every shape: 182-190 vs 178-180 us on 256->256 @128^2; instantiate launch_c1_pk<BN, NST, 2> to try them again)
 }
@@ -274,23 +275,20 @@ int launch_conv1x1_dma(IGemmArgs& a, hipStream_t stream) {
   // EVK_C1_DMA: 0 never; 1 (default) where measured faster; 2 wherever the shape allows
   static const int mode = getenv("EVK_C1_DMA") ? atoi(getenv("EVK_C1_DMA")) : 1;
   if (mode == 0 || !conv1x1_dma_applicable(a)) return 1;
-  // the persistent form with a store role (conv1x1_ps.hip) where a workgroup gets at least four tiles of at least 128
-  // outputs: measured ahead on the 128^2-map layers (64 -> 256: 107 -> 90 us, 256 -> 128: 104 -> 94, 256 -> 256: 175 -> 170),
-  // level or behind below that.  EVK_C1_PS: 0 never, 1 (default) by that rule, 2 wherever it applies (tests)
-  static const int ps_mode = getenv("EVK_C1_PS") ? atoi(getenv("EVK_C1_PS")) : 1;
-  // Round 5: the three-role persistent form (conv1x1_ps2.hip: loader / compute / store waves, software-pipelined K step) takes
-  // those layers from it and the short-reduction layers of the 64^2 maps as well — measured (tools/ab_c1sp.py, us, best other
+  // The three-role persistent form (conv1x1_ps2.hip: loader / compute / store waves, software-pipelined K step) takes the
+  // 128^2-map layers and the short-reduction layers of the 64^2 maps (round 4's two-role persistent kernel, conv1x1_ps.hip,
+  // which it superseded on every shape, was deleted in round 6) — measured (tools/ab_c1sp.py, us, best other
   // form -> this): 64 -> 256 @128^2 93 -> 78, 256 -> 256 173 -> 152, 256 -> 128 98 -> 83, 128 -> 512 @64^2 52 -> 46; level on
   // the longer reductions of the 64^2 / 32^2 maps, behind on 2048 -> 512 @16^2 (one tile per workgroup: nothing to overlap).
   // EVK_C1_PS2: 0 never, 1 (default) by that rule, 2 wherever it applies (tests)
   static const int ps2_mode = getenv("EVK_C1_PS2") ? atoi(getenv("EVK_C1_PS2")) : 1;
-  if (ps2_mode != 0 && ps_mode != 2 && conv1x1_ps2_applicable(a) && a.Cd >= 128) {
+  if (ps2_mode != 0 && conv1x1_ps2_applicable(a) && a.Cd >= 128) {
     const int tm = ceil_div(a.M, 128), nk = a.Kpad / BK3;
-    if (ps2_mode == 2 || tm >= 1024 || (tm >= 512 && nk <= 4)) return launch_conv1x1_ps2(a, stream);
+    if (ps2_mode == 2 || tm >= 1024 || (tm >= 512 && nk <= 4)) {
+      const int rc = launch_conv1x1_ps2(a, stream);   // (1: the column tiles do not fit this device's CUs per XCD — go on)
+      if (rc != 1) return rc;
+    }
   }
-  if (ps_mode != 0 && conv1x1_ps_applicable(a) && a.Cd >= 128 &&
-      (ps_mode == 2 || ((long long)ceil_div(a.M, 128) * ceil_div(a.Cd, 128) >= 2048 && ceil_div(a.M, 128) >= 1024)))
-    return launch_conv1x1_ps(a, stream);
   if (mode == 2) return launch_conv1x1_dma_forced(a, a.Cd >= 128 ? 2128 : 2064, stream);
   // Measured on the FarSeg-R50 one-tap shapes, fp32 and packed operands, with and without the statistics epilogue
   // (tools/ab_c1dma.py, us, register-staged default -> this kernel): the two-stage ring with TWO workgroups per CU (one's
@@ -302,8 +300,9 @@ int launch_conv1x1_dma(IGemmArgs& a, hipStream_t stream) {
   if (a.Cd < 128) return 1;
   const long long tm = ceil_div(a.M, 128);
   int bn = 2128;
-  // (EVK_C1_FILL_WG: below how many 128-wide tiles the 64-wide ones are taken — A/B in the step, where the chip is shared)
-  static const long long fill_wg = getenv("EVK_C1_FILL_WG") ? atoll(getenv("EVK_C1_FILL_WG")) : 224;
+  // (below how many 128-wide tiles the 64-wide ones are taken: swept in the step in round 5, where the chip is shared with the
+  // side stream — 128 / 320 / 640 / 1100 all behind or level with 224)
+  constexpr long long fill_wg = 224;
   if (tm * ceil_div(a.Cd, 128) < fill_wg) {
     if (tm * ceil_div(a.Cd, 64) < 224) return 1;   // cannot fill the chip
     // long reductions on the 16^2 maps (2048 -> 512: 64 steps, one 128 x 64 tile per CU): the software-pipelined form with

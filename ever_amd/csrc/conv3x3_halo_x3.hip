@@ -21,20 +21,14 @@
 #include <string.h>
 #include <type_traits>
 
-#ifndef EVK_HALO_PIPE
-#define EVK_HALO_PIPE 0   // round 5, NEGATIVE RESULT kept for the record (tools/build_variant.sh -DEVK_HALO_PIPE=1 builds it):
-// explicitly software-pipelined matrix loops — fragment reads of tap u+1 interleaved with the MFMAs of tap u, across the
-// iteration's barrier — whose ISA has no exposed LDS wait left.  Same box, us, 3x3x256 @128^2 (tools/autotune_convs.py):
-// 16 x 16 patches, 8 matrix waves (the production form): 762-781 -> 797-810; 8 x 16 patches: 875-904 -> 857-891; the
-// four-matrix-wave and 64-wide forms 5-25 % behind (two fragment sets cost them a workgroup per CU).  The loop is not
-// latency-bound: the same launch takes 1023 us on zero-mean random activations, 743 on an all-zero activation tensor and 712
-// on constant operands (tools/probes/power_probe.py) — it runs against the chip's power cap (PMC: matrix pipe 0.69 busy at
-// 1.76 GHz), and a schedule with fewer stalls returns its gain as a lower clock.
-#endif
+// (Round 5 negative result, removed from this file in round 6 — commit 6ed01e3 has the code: explicitly software-pipelined matrix
+// loops, fragment reads of tap u+1 interleaved with the MFMAs of tap u across the iteration's barrier, no exposed LDS wait left in
+// the ISA: 3x3x256 @128^2 762-781 -> 797-810 us.  The loop is not latency-bound, it runs against the chip's power cap — PMC:
+// matrix pipe 0.69 busy at 1.76 GHz; the same launch 1023 us on random activations, 743 on zeros — and a schedule with fewer
+// stalls returns its gain as a lower clock)
 
 namespace evk {
 
-constexpr bool kHaloPipe = EVK_HALO_PIPE != 0;
 constexpr int kPW = 16;                        // output patch width; height PH = 8 or 16 (template)
 // halo row pitch in slots: 32 (>= 18, multiple of 16: every 16-lane group of a ds_read_b128 covers 16 distinct row
 // residues) for the 8-row patch; 18 for the 16-row patch, whose halo would not fit twice otherwise (2 of 16 lanes
@@ -55,7 +49,7 @@ __device__ __forceinline__ int half_off(int row, int c16) { return row * kRB + (
 
 // MW = matrix waves: 4 (2 x 2, one per SIMD) or 8 (4 x 2, two per SIMD: one's fragment reads under the other's MFMAs)
 template <int BN, int PH, int NPX, bool WDMA, int MW>
-__global__ __launch_bounds__(256 + 64 * MW) void conv3x3_halo_x3_kernel(const IGemmArgs p, int tiles_y, int tiles_x, int dbg) {
+__global__ __launch_bounds__(256 + 64 * MW) void conv3x3_halo_x3_kernel(const IGemmArgs p, int tiles_y, int tiles_x) {
   constexpr int NP = X3Mode<NPX>::NP;
   constexpr bool PK = X3Mode<NPX>::PK;   // the activation operand arrives packed (x3_common.hpp)
   constexpr int PL = NP == 2 ? 2 : 3;
@@ -167,11 +161,6 @@ __global__ __launch_bounds__(256 + 64 * MW) void conv3x3_halo_x3_kernel(const IG
         if (b_has[i]) *reinterpret_cast<u32x4*>(B + b_lds[i]) = rbv[i];
     };
 
-    if (dbg & 1) {   // ablation (EVK_TUNE + EVK_HALO_DBG=1, tools/ab_halo.py): the staging waves only keep the barriers
-      __syncthreads();
-      for (int it = 0; it < niter; ++it) __syncthreads();
-      return;
-    }
     if constexpr (BDMA) {
       // ---- weights by DMA.  A (tap, plane) tile is BN rows x 32 B, contiguous in HBM; one instruction moves 32 rows, the
       // 16-byte halves of a row swapped on the source side where half_off() swaps them in LDS.  Iteration it + 2 is issued
@@ -275,223 +264,37 @@ __global__ __launch_bounds__(256 + 64 * MW) void conv3x3_halo_x3_kernel(const IG
   for (int b = 0; b < NB; ++b) fb[b] = half_off(wn * WN + b * 32 + li, lh);
 
   __syncthreads();
-  if (dbg & 2) {   // ablation (EVK_HALO_DBG=2): the matrix waves only keep the barriers
-    for (int it = 0; it < niter; ++it) __syncthreads();
-    return;
-  }
-  if constexpr (kHaloPipe && NP == 2 && MB == 2 && NB == 2) {
-    // Round 5, the 64 x 64 wave tile (the 16 x 16-patch form that serves the 3x3x256 layers): two whole fragment sets do not
-    // fit its 168 registers (64 accumulators + 2 x 32), so the prefetch follows the LIFETIMES inside a tap.  The three
-    // partial products of a tap are  l x h | h x l | h x h  (x3_common.hpp): the A fragments' l plane is dead after the first
-    // four MFMAs, the B fragments' l plane after the next four.  So a tap is
-    //     read next A.h, B.h (spare set) + MFMA Al x Bh | read next A.l INTO Al + MFMA Ah x Bl | read next B.l INTO Bl + MFMA Ah x Bh
-    // with one spare set of h planes (16 registers) instead of a second whole set; every fragment has >= 8 MFMAs (256 cycles)
-    // between its read and its first use, and the accumulation order is the reference loop's (t6, a, b): bit-identical.
-    // The iteration's barrier sits in front of its third tap, whose prefetches are the next iteration's first tap.
-    struct HSet {
-      bf16x8 ah[2], bh[2];
-    };
-    bf16x8 Al[2], Bl[2];
-    auto a_ptr = [&](int it, int jx, int a) {
-      const int c = it / 3, jy = it - 3 * c;
-      const int dy = p.oy0 + jy * p.oys, dx = p.ox0 + jx * p.oxs;
-      return Abase + (c & 1) * kAStage + half_off(hb[a] + dy * kHP + dx, lh);
-    };
-    auto b_ptr = [&](int it, int jx, int b) {
-      return Bbase + (BDMA ? it % 3 : (it & 1)) * kBStage + jx * PL * BN * kRB + fb[b];
-    };
-    auto ld = [&](const unsigned char* q) { return *reinterpret_cast<const bf16x8*>(q); };
-    auto interleave = [&](int reads) {     // reads behind the first MFMAs of the phase, one each
+  for (int it = 0; it < niter; ++it) {
+    const int c = it / 3, jy = it - 3 * c;
+    const unsigned char* A = Abase + (c & 1) * kAStage;
+    const unsigned char* B = Bbase + (BDMA ? it % 3 : (it & 1)) * kBStage;
+    const int dy = p.oy0 + jy * p.oys;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (i < reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-    };
-    auto tap = [&](int it, int jx, HSet& X, HSet& Y, auto has_next) {
-      constexpr bool NX = decltype(has_next)::value;
-      const int nit = jx == 2 ? it + 1 : it, njx = jx == 2 ? 0 : jx + 1;
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (NX) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a) Y.ah[a] = ld(a_ptr(nit, njx, a));
-#pragma unroll
-        for (int b = 0; b < 2; ++b) Y.bh[b] = ld(b_ptr(nit, njx, b));
-      }
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = mfma_np<2>(X.bh[b], Al[a], acc[a][b]);
-      interleave(NX ? 4 : 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (NX) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a) Al[a] = ld(a_ptr(nit, njx, a) + kHSlots * kRB);
-      }
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = mfma_np<2>(Bl[b], X.ah[a], acc[a][b]);
-      interleave(NX ? 2 : 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (NX) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b) Bl[b] = ld(b_ptr(nit, njx, b) + BN * kRB);
-      }
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = mfma_np<2>(X.bh[b], X.ah[a], acc[a][b]);
-      interleave(NX ? 2 : 0);
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    auto iter = [&](int it, HSet& SA, HSet& SB, auto has_next) {
-      tap(it, 0, SA, SB, std::true_type{});
-      tap(it, 1, SB, SA, std::true_type{});
-      __syncthreads();
-      tap(it, 2, SA, SB, has_next);
-    };
-    HSet S0, S1;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      S0.ah[a] = ld(a_ptr(0, 0, a));
-      Al[a] = ld(a_ptr(0, 0, a) + kHSlots * kRB);
-    }
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      S0.bh[b] = ld(b_ptr(0, 0, b));
-      Bl[b] = ld(b_ptr(0, 0, b) + BN * kRB);
-    }
-    int it = 0;
-    for (; it + 2 < niter; it += 2) {
-      iter(it, S0, S1, std::true_type{});
-      iter(it + 1, S1, S0, std::true_type{});
-    }
-    if (niter - it == 2) {
-      iter(it, S0, S1, std::true_type{});
-      iter(it + 1, S1, S0, std::false_type{});
-    } else {
-      iter(it, S0, S1, std::false_type{});
-    }
-  } else if constexpr (kHaloPipe && NP == 2 && MB * NB <= 2 && MW == 8 && BN == 128) {
-    // Round 5: the fragment registers double-buffered ACROSS taps and across the iteration's barrier (conv1x1_sp.hip has the
-    // ISA argument).  The loop below this block reads a tap's eight fragments and multiplies them right away — in its ISA each
-    // tap opens with an exposed LDS wait (reads, s_waitcnt, MFMAs; eight waves reading at once), and the barrier adds its
-    // own: ~3900 cycles per iteration against 2304 of matrix work for the two waves of a SIMD (profiles/r05_floor_table_c2.txt:
-    // 3x3x256 @128^2 takes 555 us with ONE product per fragment pair, 779 with three).  Here tap u+1 is read while tap u
-    // multiplies, and the iteration's barrier sits between the MFMAs of its second tap and the reads of the NEXT iteration's
-    // first tap:   read T1 | MFMA T0 | read T2 | MFMA T1 | barrier | read T0' | MFMA T2
-    // All reads of iteration `it` are issued before its barrier, so the staging waves' protocol (which stage is free after
-    // which barrier, csrc header) is unchanged: they still see one barrier per iteration.
-    struct TapFrag {
-      bf16x8 a[MB][2], b[NB][2];
-    };
-    auto read_tap = [&](int it, int jx, TapFrag& f) {
-      const int c = it / 3, jy = it - 3 * c;
-      const unsigned char* A = Abase + (c & 1) * kAStage;
-      const unsigned char* B = Bbase + (BDMA ? it % 3 : (it & 1)) * kBStage;
-      const int dy = p.oy0 + jy * p.oys, dx = p.ox0 + jx * p.oxs;
+    for (int jx = 0; jx < 3; ++jx) {
+      const int dx = p.ox0 + jx * p.oxs;
+      bf16x8 fa[MB][3], fbv[NB][3];
 #pragma unroll
       for (int a = 0; a < MB; ++a) {
-        const int off = half_off(hb[a] + dy * kHP + dx, lh);
+        const int hr = hb[a] + dy * kHP + dx;
+        const int off = half_off(hr, lh);
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) f.a[a][pt] = *reinterpret_cast<const bf16x8*>(A + pt * kHSlots * kRB + off);
+        for (int pt = 0; pt < NP; ++pt) fa[a][pt] = *reinterpret_cast<const bf16x8*>(A + pt * kHSlots * kRB + off);
       }
 #pragma unroll
       for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) f.b[b][pt] = *reinterpret_cast<const bf16x8*>(B + (jx * PL + pt) * BN * kRB + fb[b]);
-    };
-    auto mma_tap = [&](const TapFrag& f) {
+        for (int pt = 0; pt < NP; ++pt)
+          fbv[b][pt] = *reinterpret_cast<const bf16x8*>(B + (jx * PL + pt) * BN * kRB + fb[b]);
 #pragma unroll
-      for (int t6 = 0; t6 < 3; ++t6)
+      for (int t6 = 0; t6 < X3Prod<NP>::N; ++t6)
 #pragma unroll
         for (int a = 0; a < MB; ++a)
 #pragma unroll
-          for (int b = 0; b < NB; ++b) acc[a][b] = mfma_np<2>(f.b[b][x3_pb(2, t6)], f.a[a][x3_pa(2, t6)], acc[a][b]);
-    };
-    // one iteration; on entry f0 holds (the reads of) its first tap, on exit f1 holds the next iteration's first tap
-    // reads of the next tap INTERLEAVED with the MFMAs of the current one (one ds_read behind each MFMA): issued as a block
-    // in front of them they cost the wave their own issue time with the matrix pipe idle (measured: the four-matrix-wave
-    // forms fell from 928 to 1196 us on 3x3x256 @128^2 that way)
-    constexpr int kReads = (MB + NB) * 2, kMfma = 3 * MB * NB;
-    auto overlap = [&]() {
-#pragma unroll
-      for (int i = 0; i < kReads; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read
-      }
-      if (kMfma > kReads) __builtin_amdgcn_sched_group_barrier(0x008, kMfma - kReads, 0);
-    };
-    auto iter = [&](int it, TapFrag& f0, TapFrag& f1, auto has_next) {
-      __builtin_amdgcn_sched_barrier(0);
-      read_tap(it, 1, f1);
-      mma_tap(f0);
-      overlap();
-      __builtin_amdgcn_sched_barrier(0);
-      read_tap(it, 2, f0);
-      mma_tap(f1);
-      overlap();
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
-      if constexpr (decltype(has_next)::value) {
-        read_tap(it + 1, 0, f1);
-        mma_tap(f0);
-        overlap();
-      } else {
-        mma_tap(f0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    TapFrag F0, F1;
-    read_tap(0, 0, F0);
-    int it = 0;
-    // (pairs of iterations: three taps per iteration swap the roles of the two register sets; the tail is peeled so that no
-    // read behind a barrier is conditional — a conditional one makes hipcc wait for the reads just issued)
-    for (; it + 2 < niter; it += 2) {
-      iter(it, F0, F1, std::true_type{});
-      iter(it + 1, F1, F0, std::true_type{});
+          for (int b = 0; b < NB; ++b)
+            acc[a][b] = mfma_np<NP>(fbv[b][x3_pb(NP, t6)], fa[a][x3_pa(NP, t6)], acc[a][b]);
     }
-    if (niter - it == 2) {
-      iter(it, F0, F1, std::true_type{});
-      iter(it + 1, F1, F0, std::false_type{});
-    } else {
-      iter(it, F0, F1, std::false_type{});
-    }
-  } else {
-  for (int it = 0; it < niter; ++it) {
-      const int c = it / 3, jy = it - 3 * c;
-      const unsigned char* A = Abase + (c & 1) * kAStage;
-      const unsigned char* B = Bbase + (BDMA ? it % 3 : (it & 1)) * kBStage;
-      const int dy = p.oy0 + jy * p.oys;
-  #pragma unroll
-      for (int jx = 0; jx < 3; ++jx) {
-        const int dx = p.ox0 + jx * p.oxs;
-        bf16x8 fa[MB][3], fbv[NB][3];
-  #pragma unroll
-        for (int a = 0; a < MB; ++a) {
-          const int hr = hb[a] + dy * kHP + dx;
-          const int off = half_off(hr, lh);
-  #pragma unroll
-          for (int pt = 0; pt < NP; ++pt) fa[a][pt] = *reinterpret_cast<const bf16x8*>(A + pt * kHSlots * kRB + off);
-        }
-  #pragma unroll
-        for (int b = 0; b < NB; ++b)
-  #pragma unroll
-          for (int pt = 0; pt < NP; ++pt)
-            fbv[b][pt] = *reinterpret_cast<const bf16x8*>(B + (jx * PL + pt) * BN * kRB + fb[b]);
-  #pragma unroll
-        for (int t6 = 0; t6 < X3Prod<NP>::N; ++t6)
-  #pragma unroll
-          for (int a = 0; a < MB; ++a)
-  #pragma unroll
-            for (int b = 0; b < NB; ++b)
-              acc[a][b] = mfma_np<NP>(fbv[b][x3_pb(NP, t6)], fa[a][x3_pa(NP, t6)], acc[a][b]);
-      }
-      __syncthreads();
-    }
-  
-}
+    __syncthreads();
+  }
 
   if constexpr (NP == 2) igemm_scale_acc<MB, NB>(acc, op_scale(act_absmax(p.a_scale)).s * op_scale(*p.w_scale).s);
   if (p.bn_part) {
@@ -566,12 +369,6 @@ bool conv_desc_uses_halo(const evk_conv_desc* d, int for_dgrad) {
   return conv3x3_halo_applies(a);
 }
 
-// ablation switches, read on every launch under EVK_TUNE only: 1 = no staging work, 2 = no matrix work
-static int tune_dbg() {
-  static const bool tune = getenv("EVK_TUNE") != nullptr;
-  return tune && getenv("EVK_HALO_DBG") ? atoi(getenv("EVK_HALO_DBG")) : 0;
-}
-
 template <int BN, int PH, int NPX, bool WDMA = false, int MW = 4>
 static int launch_halo_np(IGemmArgs& a, hipStream_t stream) {
   constexpr int NP = X3Mode<NPX>::NP;
@@ -587,8 +384,7 @@ static int launch_halo_np(IGemmArgs& a, hipStream_t stream) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   const long long nwg = (long long)a.tiles_m * a.tiles_n;
-  hipLaunchKernelGGL((conv3x3_halo_x3_kernel<BN, PH, NPX, WDMA, MW>), dim3((unsigned)nwg), dim3(256 + 64 * MW), lds, stream, a, tiles_y, tiles_x,
-                     tune_dbg());
+  hipLaunchKernelGGL((conv3x3_halo_x3_kernel<BN, PH, NPX, WDMA, MW>), dim3((unsigned)nwg), dim3(256 + 64 * MW), lds, stream, a, tiles_y, tiles_x);
   return check_launch("conv3x3_halo_x3");
 }
 
@@ -600,10 +396,8 @@ static int launch_halo(IGemmArgs& a, hipStream_t stream) {
   }
   if (a.planes == 1) return launch_halo_np<BN, PH, 1>(a, stream);
   if (a.planes == 2) {
-    // EVK_HALO_WDMA=0: the weight tiles through registers as in the other arithmetics (A/B switch)
-    static const bool wdma = !(getenv("EVK_HALO_WDMA") && atoi(getenv("EVK_HALO_WDMA")) == 0);
-    if (wdma) return a.a_packed ? launch_halo_np<BN, PH, 4, true>(a, stream) : launch_halo_np<BN, PH, 2, true>(a, stream);
-    return a.a_packed ? launch_halo_np<BN, PH, 4>(a, stream) : launch_halo_np<BN, PH, 2>(a, stream);
+    // (the weight tiles by DMA; through registers as in the other arithmetics: 452.4 vs 465.0 tiles/s)
+    return a.a_packed ? launch_halo_np<BN, PH, 4, true>(a, stream) : launch_halo_np<BN, PH, 2, true>(a, stream);
   }
   return launch_halo_np<BN, PH, 3>(a, stream);
 }
@@ -624,23 +418,19 @@ int launch_conv3x3_halo(IGemmArgs& a, hipStream_t stream) {
       if (!strcmp(f, "m128x16") && a.Cd > 64) return launch_halo<128, 16, 8>(a, stream);
     }
   }
-  // (EVK_X3_HALO_MIN128 / EVK_X3_HALO_MINTALL: workgroup counts from which the 128-wide tile / the 16-row patch is taken — A/B in
-  // the step, where the chip is shared with the side stream)
-  static const long long min128 = getenv("EVK_X3_HALO_MIN128") ? atoll(getenv("EVK_X3_HALO_MIN128")) : 256;
-  static const long long mintall = getenv("EVK_X3_HALO_MINTALL") ? atoll(getenv("EVK_X3_HALO_MINTALL")) : 256;
+  // workgroup counts from which the 128-wide tile / the 16-row patch is taken (swept in the step in round 5, where the chip is
+  // shared with the side stream: 128 / 384 / 768 all within 0.1 % of 256)
+  constexpr long long min128 = 256, mintall = 256;
   if (a.Cd <= 64 || (long long)a.N * ceil_div(a.Hm, 8) * ceil_div(a.Wm, kPW) * ceil_div(a.Cd, 128) < min128)
     return launch_halo<64, 8>(a, stream);   // small maps (16^2 .. 32^2): 64-wide tiles keep every CU busy
   // 16 x 16 patches (256 GEMM rows) halve the weight bytes per MFMA, the larger share of the staging traffic now;
   // taken when they still fill the chip.  With the weights fed by DMA (f16x2) the staging waves no longer hold the matrix
   // waves back, and eight matrix waves (two per SIMD) are 1-7 % ahead of four on every 128-wide shape
   // (tools/autotune_convs.py: 777 -> 763 us on 3x3x256 @128^2, 61 -> 57 on 3x3x128 @64^2, 59-62 -> 58 on 3x3x256 @32^2).
-  static const int tall = getenv("EVK_X3_HALO_TALL") ? atoi(getenv("EVK_X3_HALO_TALL")) : 1;
-  static const bool m8 = !(getenv("EVK_HALO_WDMA") && atoi(getenv("EVK_HALO_WDMA")) == 0) &&
-                         !(getenv("EVK_HALO_M8") && atoi(getenv("EVK_HALO_M8")) == 0);
-  const bool wide8 = m8 && a.planes == 2;
+  const bool wide8 = a.planes == 2;
   // (16-row patches unless they would add a mostly empty last patch row: H % 16 in 1..8 is served better by 8-row patches)
   const bool tall_fits = (a.Hm % 16) == 0 || (a.Hm % 16) > 8;
-  if (tall && tall_fits && (long long)a.N * ceil_div(a.Hm, 16) * ceil_div(a.Wm, kPW) * ceil_div(a.Cd, 128) >= mintall)
+  if (tall_fits && (long long)a.N * ceil_div(a.Hm, 16) * ceil_div(a.Wm, kPW) * ceil_div(a.Cd, 128) >= mintall)
     return wide8 ? launch_halo<128, 16, 8>(a, stream) : launch_halo<128, 16>(a, stream);
   return wide8 ? launch_halo<128, 8, 8>(a, stream) : launch_halo<128, 8>(a, stream);
 }

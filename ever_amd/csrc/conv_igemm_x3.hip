@@ -294,7 +294,6 @@ int launch_igemm_x3(IGemmArgs& a, hipStream_t stream) {
       if (!strcmp(f, "d64") && conv1x1_dma_applicable(a)) return launch_conv1x1_dma_forced(a, 64, stream);
       if (!strcmp(f, "e128") && conv1x1_dma_applicable(a)) return launch_conv1x1_dma_forced(a, 2128, stream);
       if (!strcmp(f, "e64") && conv1x1_dma_applicable(a)) return launch_conv1x1_dma_forced(a, 2064, stream);
-      if (!strcmp(f, "p128") && conv1x1_ps_applicable(a)) return launch_conv1x1_ps(a, stream);
       if (!strcmp(f, "q128") && conv1x1_ps2_applicable(a)) return launch_conv1x1_ps2(a, stream);
       if (!strcmp(f, "s128") && conv1x1_sp_applicable(a)) return launch_conv1x1_sp_forced(a, 128, stream);
       if (!strcmp(f, "s64") && conv1x1_sp_applicable(a)) return launch_conv1x1_sp_forced(a, 64, stream);
@@ -319,23 +318,14 @@ int launch_igemm_x3(IGemmArgs& a, hipStream_t stream) {
   auto tiles = [&](int bm) { return (long long)ceil_div(a.M, bm) * tn; };
   // single LDS stage (48 KB at 128x128 => 2-3 workgroups per CU, whose split / MFMA phases interleave)
   // measured faster than a double-buffered stage at 1 workgroup per CU: 180 vs 157 TFLOP/s on 3x3x256 @128^2
-  static const int nbuf = getenv("EVK_X3_NBUF") ? atoi(getenv("EVK_X3_NBUF")) : 1;
-  if (nbuf == 1) {
-    if (bn == 64) {
-      if (tiles(128) >= 256) return launch_cfg3<128, 64, 2, 2, 1>(a, stream);
-      return launch_cfg3<64, 64, 2, 2, 1>(a, stream);
-    }
-    if (tiles(128) >= 256) return launch_cfg3<128, 128, 2, 2, 1>(a, stream);
-    if (tiles(64) >= 256) return launch_cfg3<64, 128, 2, 2, 1>(a, stream);
-    // 16^2 maps (M = 4096 rows at batch 16): 64 x 64 tiles are the only ones that give every CU a workgroup
+  if (bn == 64) {
+    if (tiles(128) >= 256) return launch_cfg3<128, 64, 2, 2, 1>(a, stream);
     return launch_cfg3<64, 64, 2, 2, 1>(a, stream);
   }
-  if (bn == 64) {
-    if (tiles(128) >= 256) return launch_cfg3<128, 64, 2, 2, 2>(a, stream);
-    return launch_cfg3<64, 64, 2, 2, 2>(a, stream);
-  }
-  if (tiles(128) >= 256) return launch_cfg3<128, 128, 2, 2, 2>(a, stream);
-  return launch_cfg3<64, 128, 2, 2, 2>(a, stream);
+  if (tiles(128) >= 256) return launch_cfg3<128, 128, 2, 2, 1>(a, stream);
+  if (tiles(64) >= 256) return launch_cfg3<64, 128, 2, 2, 1>(a, stream);
+  // 16^2 maps (M = 4096 rows at batch 16): 64 x 64 tiles are the only ones that give every CU a workgroup
+  return launch_cfg3<64, 64, 2, 2, 1>(a, stream);
 }
 
 // Weight planes for the split kernel.  Forward (`classes == nullptr` form): row co, k = (ky, kx, ci) as in

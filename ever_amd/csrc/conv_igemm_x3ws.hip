@@ -281,12 +281,9 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws_kernel(const IGemmArgs p)
   if (p.out_amax) amax_commit(p.out_amax, amax_l.m);   // once per wave, over all the tiles of this workgroup
 }
 
-// EVK_X3_WS_PERSIST: 1 (default) persistent workgroups, and the wave-specialised form also for short reductions;
-// 0 = one tile per workgroup, short reductions on the single-role kernel
-static int ws_persist() {
-  static const int v = getenv("EVK_X3_WS_PERSIST") ? atoi(getenv("EVK_X3_WS_PERSIST")) : 1;
-  return v;
-}
+// persistent workgroups, and the wave-specialised form also for short reductions (one tile per workgroup with the short
+// reductions on the single-role kernel: 3-9 % behind on the K <= 512 layers with Cd >= 128)
+static constexpr int ws_persist() { return 1; }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int NP>
 static int launch_ws_np(IGemmArgs& a, hipStream_t stream) {
@@ -361,8 +358,7 @@ int launch_igemm_x3ws(IGemmArgs& a, hipStream_t stream) {
     return 1;
   // 128x256 tiles where the output is wide enough: the activation split (VALU) and the L2 -> CU bytes per MFMA
   // drop by half / a fifth
-  static const int wide = getenv("EVK_X3_WIDE") ? atoi(getenv("EVK_X3_WIDE")) : 1;
-  if (wide && a.Cd >= 256 && (long long)ceil_div(a.M, 128) * ceil_div(a.Cd, 256) >= 256)
+  if (a.Cd >= 256 && (long long)ceil_div(a.M, 128) * ceil_div(a.Cd, 256) >= 256)
     return launch_ws<128, 256, 2, 2, 2>(a, stream);
   if (bn == 128) return launch_ws<128, 128, 2, 2, 2>(a, stream);
   return launch_ws<128, 64, 2, 2, 2>(a, stream);

@@ -279,17 +279,20 @@ WGradPlan plan_wgrad(const evk_conv_desc* d, int x3, int planes, int tr, int sha
   pl.bm = d->Cout <= 64 ? 64 : 128;
   pl.bn = Ktot <= 64 ? 64 : 128;
   // wide wave-specialised tile (128 x 256, one 8-wave workgroup per CU) when both dimensions are there
-  // (under EVK_TUNE=1 the three knobs are re-read on every call: tools/autotune_wgrad.py)
+  // (planner constants; ONLY under EVK_TUNE=1 — the survey tool tools/autotune_wgrad.py — are they read from the environment,
+  // on every call, and clamped to values the plan below can divide by)
   static const bool tune = getenv("EVK_TUNE") != nullptr;
-  auto knob = [&](const char* name, int cached) { const char* v = tune ? getenv(name) : nullptr; return (v && *v) ? atoi(v) : cached; };
-  static const int ws_mode0 = getenv("EVK_WG_WS") ? atoi(getenv("EVK_WG_WS")) : 1;
-  const int ws_mode = knob("EVK_WG_WS", ws_mode0);
+  auto knob = [&](const char* name, int dflt, int lo) {
+    const char* v = tune ? getenv(name) : nullptr;
+    const int k = (v && *v) ? atoi(v) : dflt;
+    return k < lo ? lo : k;
+  };
+  const int ws_mode = knob("EVK_WG_WS", 1, 0);
   // (its gathers are raw buffer loads: 32-bit byte offsets, so both tensors must stay below 2 GiB)
   const bool fits32 = (long long)d->N * d->H * d->W * d->Cin * 4 < 0x7fffffffLL &&
                       (long long)d->N * d->Ho * d->Wo * d->Cout * 4 < 0x7fffffffLL;
-  // (Cout below 128 leaves rows of the 128-row tile empty; EVK_WG_WS_MINCOUT: from which width the wide tile still wins)
-  static const int ws_min0 = getenv("EVK_WG_WS_MINCOUT") ? atoi(getenv("EVK_WG_WS_MINCOUT")) : 128;
-  const int ws_min = knob("EVK_WG_WS_MINCOUT", ws_min0);
+  // (Cout below 128 leaves rows of the 128-row tile empty: 96 / 64 measured level on C5)
+  const int ws_min = knob("EVK_WG_WS_MINCOUT", 128, 1);
   pl.ws = (x3 && ws_mode && d->Cout >= ws_min && Ktot >= 256 && fits32) ? 1 : 0;
   if (tr) { pl.ws = 1; pl.bm = 128; }
   if (pl.ws) pl.bn = 256;
@@ -299,9 +302,7 @@ WGradPlan plan_wgrad(const evk_conv_desc* d, int x3, int planes, int tr, int sha
   // Split the pixel reduction so that the grid fills WHOLE rounds of the machine: slots = 256 CUs x
   // resident workgroups per CU (LDS-limited: 64 KB tiles -> 2, 48 KB -> 3, 32 KB -> 4).  A grid of
   // 2.04 rounds costs 3 (measured: 1044 workgroups on 512 slots ran at 63 % MFMA utilisation).
-  static const int rounds0 = getenv("EVK_WG_ROUNDS") ? atoi(getenv("EVK_WG_ROUNDS")) : 1;
-  static const int min_chunk0 = getenv("EVK_WG_MINCHUNK") ? atoi(getenv("EVK_WG_MINCHUNK")) : 256;
-  const int rounds = knob("EVK_WG_ROUNDS", rounds0), min_chunk = knob("EVK_WG_MINCHUNK", min_chunk0);
+  const int rounds = knob("EVK_WG_ROUNDS", 1, 1), min_chunk = knob("EVK_WG_MINCHUNK", 256, 32);
   const int lds_kb = 2 * BKP * (pl.bm + pl.bn) * 4 / 1024;
   // split kernel: single-buffered 3-plane bf16 stage (48 KB at 128x128), residency set by its VGPRs
   const int per_cu = pl.ws ? 1 : x3 ? (pl.bm + pl.bn >= 256 ? 3 : 4)
@@ -311,9 +312,8 @@ WGradPlan plan_wgrad(const evk_conv_desc* d, int x3, int planes, int tr, int sha
   // stay with the main stream's kernels instead of queueing behind it.  Round 5, three interleaved rounds per box, tiles/s:
   // 100 % 545.9 / 541.8 / 560.0, 75 % 564.7, 62 % 545.6, 56 % 544.6, 50 % 557.4 / 552.2 / 565.9 (+1.1 .. +2.1 %), 44 % 545.8,
   // 37 % 531.2, 25 % 469.7; the nine-tap planar kernel alone at 50 %: +1.1 %, the x3ws kernels alone: +0.3 %; the 128 x 128
-  // single-role tiles (3-4 workgroups per CU) do not care (EVK_WG_SHARED_FILL, percent; 100 = as if alone).
-  static const int shared_fill0 = getenv("EVK_WG_SHARED_FILL") ? atoi(getenv("EVK_WG_SHARED_FILL")) : 50;
-  const int fill = (shared && pl.ws) ? knob("EVK_WG_SHARED_FILL", shared_fill0) : 100;
+  // single-role tiles (3-4 workgroups per CU) do not care (percent; 100 = as if alone).
+  const int fill = (shared && pl.ws) ? knob("EVK_WG_SHARED_FILL", 50, 1) : 100;
   const int slots = 256 * per_cu * (fill > 0 && fill <= 100 ? fill : 100) / 100;
   int maxsplit = ceil_div(M, min_chunk);  // at least min_chunk pixels per split
   int sk = (rounds * slots) / tiles;      // floor: never spill into an extra, nearly empty round

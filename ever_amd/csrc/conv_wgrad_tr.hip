@@ -30,7 +30,12 @@
 #include "lds_dma.hpp"
 #include <stdlib.h>
 
+#ifndef EVK_WG_ABL
+#define EVK_WG_ABL 0   // timing ablations (tools/build_variant.sh -DEVK_WG_ABL=n; wrong results): 1 no loads, 2 no split / LDS writes,
+#endif                 // 4 no fragment reads / MFMAs, 8 no stores
 namespace evk {
+constexpr int kWgAbl = EVK_WG_ABL;
+
 
 namespace {
 
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(const WGradArgs p) {
 
   auto issue = [&](int kt) {
     const uint32_t S = lds0 + (uint32_t)((kt % NST) * G::kStage);
-    if (p.dbg & 1) return;
+    if (kWgAbl & 1) return;
     const int m0 = pbeg + kt * BKP;
     // the step's first pixel (wave-uniform).  NT = 9: the whole step lies in this image row; NT = 1: an octet does
     // (a step starts at a multiple of 32 pixels, Wo % 8 == 0 is the launcher's condition)
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(const WGradArgs p) {
     // the step, the other four between the k-halves, so that a SIMD's matrix pipe has one wave's MFMAs meanwhile
     if (kt + 2 < nk && wave < 4) issue(kt + 2);
     const uint32_t S = lds0 + (uint32_t)((kt % NST) * G::kStage);
-    if (!(p.dbg & 4)) {
+    if (!(kWgAbl & 4)) {
       // units u = (k-half, group of GS column blocks); the fragments of unit u + 1 are read before the MFMAs of unit u are
       // issued and nothing else moves across (sched_barrier): left alone, the scheduler hoists every read of the step to
       // its top (9 taps x 2 planes x 4 registers beside 144 accumulators: spills)
@@ -265,11 +270,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(const WGradArgs p) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if ((p.dbg & 4) && kt + 2 < nk && wave >= 4) issue(kt + 2);
+    if ((kWgAbl & 4) && kt + 2 < nk && wave >= 4) issue(kt + 2);
     if (kt + 2 < nk) wait_vmcnt<PER>(); else wait_vmcnt<0>();   // all but the newest step's: step kt + 1 has landed
     ring_barrier();
   }
-  if (p.dbg & 8) {
+  if (kWgAbl & 8) {
     if (acc[0][0] == 12345.f) p.out[0] = 0.f;
     return;
   }
@@ -312,8 +317,6 @@ static int launch_tr(const WGradArgs& b, hipStream_t stream) {
 
 int launch_wgrad_tr(const WGradArgs& a, int nine_tap, hipStream_t stream) {
   WGradArgs b = a;
-  static const int dbg = getenv("EVK_WG_DBG") ? atoi(getenv("EVK_WG_DBG")) : 0;
-  b.dbg = dbg;
   return nine_tap ? launch_tr<9>(b, stream) : launch_tr<1>(b, stream);
 }
 

@@ -12,7 +12,12 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef EVK_WG_ABL
+#define EVK_WG_ABL 0   // timing ablations (tools/build_variant.sh -DEVK_WG_ABL=n; wrong results): 1 no loads, 2 no split / LDS writes,
+#endif                 // 4 no fragment reads / MFMAs, 8 no stores
 namespace evk {
+constexpr int kWgAbl = EVK_WG_ABL;
+
 
 struct WGather {
   const float* src;
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
     auto load = [&](auto SET, int kt) {
       constexpr int s = decltype(SET)::value;
       const int pix0 = pbeg + kt * BKP;
-      if (p.dbg & 1) return;   // ablation: no global loads
+      if (kWgAbl & 1) return;   // ablation: no global loads
       if constexpr (kBuf) {
         gather8_buf<W8>(p, gb, rs_x, pix0 + bpg * 8, pend, rb[s]);
         gather8h_buf(rs_dy, p.Cout, a_coff, a_cvalid, pix0 + apg * 8, pend, ra[s]);
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
       constexpr int s = decltype(SET)::value;
       unsigned char* Ab = smem3 + stage * kStage;
       unsigned char* Bb = Ab + 3 * BM * kRowBytes;
-      if (p.dbg & 2) return;   // ablation: no split, no LDS writes
+      if (kWgAbl & 2) return;   // ablation: no split, no LDS writes
       if constexpr (kBuf) {
         split_store_buf<NP, 4, PKX>(rb[s], Bb, BN * kRowBytes, QB, bcq, bpg, x_inv);
         split_store_buf<NP, 2, PKD>(ra[s], Ab, BM * kRowBytes, QA2, acq, apg, dy_inv);
@@ -373,13 +378,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3ws_kernel(const WGradArgs p)
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned char* S = smem3 + (kt & 1) * kStage;
-    if (!(p.dbg & 4)) {      // ablation: no fragment reads / MFMAs
+    if (!(kWgAbl & 4)) {      // ablation: no fragment reads / MFMAs
       half_step(S, 0);
       half_step(S, 1);
     }
     __syncthreads();
   }
-  if (p.dbg & 8) {           // ablation: no stores
+  if (kWgAbl & 8) {           // ablation: no stores
     if (acc[0][0][0] == 12345.f) p.out[0] = 0.f;
     return;
   }
@@ -427,8 +432,6 @@ static int launch_wgrad_x3ws_t(const WGradArgs& b, hipStream_t stream) {
 
 int launch_wgrad_x3ws(const WGradArgs& a, hipStream_t stream) {
   WGradArgs b = a;
-  static const int dbg = getenv("EVK_WG_DBG") ? atoi(getenv("EVK_WG_DBG")) : 0;
-  b.dbg = dbg;
   const bool w8 = (a.Wo & 7) == 0;
   if (a.planes == 1) return w8 ? launch_wgrad_x3ws_t<1, true>(b, stream) : launch_wgrad_x3ws_t<1, false>(b, stream);
   if (a.planes == 2) {

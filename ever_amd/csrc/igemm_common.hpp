@@ -345,8 +345,6 @@ int launch_igemm_x3ws_forced(IGemmArgs& a, int bn, hipStream_t stream);
 int launch_conv1x1_dma(IGemmArgs& a, hipStream_t stream);  // 1 = not applicable (conv1x1_dma.hip)
 int launch_conv1x1_dma_forced(IGemmArgs& a, int bn, hipStream_t stream);
 bool conv1x1_dma_applicable(const IGemmArgs& a);
-int launch_conv1x1_ps(IGemmArgs& a, hipStream_t stream);   // persistent form with a store role (conv1x1_ps.hip)
-bool conv1x1_ps_applicable(const IGemmArgs& a);
 int launch_conv1x1_sp_forced(IGemmArgs& a, int bn, hipStream_t stream);   // software-pipelined, loader waves (conv1x1_sp.hip)
 bool conv1x1_sp_applicable(const IGemmArgs& a);
 int launch_conv1x1_ps2(IGemmArgs& a, hipStream_t stream);  // persistent, loader + compute + store waves (conv1x1_ps2.hip)

@@ -752,9 +752,8 @@ __global__ __launch_bounds__(256) void relation_bn_bwd_kernel(
 }
 
 static int relation_blocks(int HW) {
-  // pixels per workgroup and the cap on workgroups per image (EVK_REL_PPB / EVK_REL_MAXBLK, read once)
-  static const int ppb = getenv("EVK_REL_PPB") ? atoi(getenv("EVK_REL_PPB")) : 64;
-  static const int cap = getenv("EVK_REL_MAXBLK") ? atoi(getenv("EVK_REL_MAXBLK")) : 256;
+  // pixels per workgroup and the cap on workgroups per image (swept in the step in round 5: level)
+  constexpr int ppb = 64, cap = 256;
   int b = (HW + ppb - 1) / ppb;
   return b > cap ? cap : (b < 1 ? 1 : b);
 }

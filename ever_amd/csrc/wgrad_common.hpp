@@ -21,7 +21,7 @@ struct WGradArgs {
   const uint32_t* dy_scale;
   int x_packed, dy_packed;   // planes == 2: the operand holds packed (h | l << 16) words of value / s (x3_common.hpp)
   int planar;                // planes == 2: BOTH operands are planar fp16 pairs (conv_wgrad_tr.hip)
-  int dbg;  // EVK_WG_DBG ablation switches of the wave-specialised kernel (0 in production)
+  int reserved;  // (was: run-time ablation switches; they are compile-time now, EVK_WG_ABL)
 };
 
 constexpr int BKP = 32;  // pixels per step

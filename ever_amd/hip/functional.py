@@ -980,6 +980,11 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False,
             if side is not None and _WGRAD_BATCH > 1 and x3 and _f16x2():
                 pre = (absmax_bits(xk, st), absmax_bits(dyk, st), _is_packed(xk))
 
+            # the half-chip split-K plan is a property of the CONFIGURATION (side stream enabled + split on), not of the stream
+            # this launch ends up on (the probe that picks the side stream is a timing measurement, and a launch that
+            # fell back to the backward's stream used to take the other plan — other bits for the same model and switches)
+            shared = _WGRAD_SHARED if (_WGRAD_STREAM[0] and _WGRAD_SHARED_ON[0]) else 0
+
             def launch(st):
                 """the weight-gradient launches of this layer on stream `st` (torch's current stream when this runs)"""
                 ws = workspace(dev, ws_bytes)
@@ -1017,7 +1022,7 @@ def _conv_backward(cs, dy, need_dx, need_dw, need_db, accum=None, inplace=False,
                             _tmp.append(dp)
                     _C.call('evk_conv2d_wgrad_f16x2_ex', ctypes.byref(dk), xw_ptr, xbits.data_ptr(), dyw_ptr, dybits.data_ptr(),
                             dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes,
-                            (planar if planar else ((2 if x_pk else 0) | (4 if dy_pk_ else 0))) | (_WGRAD_SHARED if side is not None and _WGRAD_SHARED_ON[0] else 0), st)
+                            (planar if planar else ((2 if x_pk else 0) | (4 if dy_pk_ else 0))) | shared, st)
                 else:
                     _C.call(_entry('evk_conv2d_wgrad_x3') if x3 else 'evk_conv2d_wgrad', ctypes.byref(dk), xk.data_ptr(), dy_ptr,
                             dwk.data_ptr(), _ptr(dbk), ws.data_ptr(), ws_bytes, st)

@@ -15,7 +15,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize('env', [dict(EVK_C1_DMA='2'),                              # two-stage ring, 128-wide tiles (production form)
-                                 dict(EVK_C1_PS='2'),                               # persistent form with a store role (conv1x1_ps.hip) wherever it applies
                                  dict(EVK_C1_PS2='2'),                              # three-role persistent form (conv1x1_ps2.hip) wherever it applies
                                  dict(EVK_TUNE='1', EVK_X3_FORCE='s128'),           # software-pipelined form with loader waves (conv1x1_sp.hip), ring of four
                                  dict(EVK_TUNE='1', EVK_X3_FORCE='t64'),            # ... ring of three, 64-wide tiles

@@ -1,5 +1,5 @@
 """dev tool (GPU box): the LDS-DMA one-tap kernel (csrc/conv1x1_dma.hip) against the dispatch default on the FarSeg 1x1
-shapes, fp32 and packed activation operand, plus its ablations (EVK_C1_DMA_DBG: 1 no activation DMA, 2 no weight DMA,
+shapes, fp32 and packed activation operand, plus its ablations (-DEVK_C1_DMA_ABL, tools/build_variant.sh: 1 no activation DMA, 2 no weight DMA,
 4 no compute, 8 no stores).  usage: EVK_TUNE=1 python tools/ab_c1dma.py [ablate]"""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -52,34 +52,8 @@ SHAPES = [(128, 64, 256), (128, 256, 64), (128, 256, 256), (128, 256, 128), (64,
 
 
 def main():
-    ablate = len(sys.argv) > 1 and sys.argv[1] == 'ablate'
-    if ablate:
-        for (h, ci, co) in [(128, 256, 256)]:
-            for packed, force in ((0, 'e128'), (1, 'e128'), (0, 'p128'), (1, 'p128')):
-                fn, out, keep = problem(h, ci, co, packed, 0)
-                os.environ['EVK_X3_FORCE'] = force
-                row = []
-                for dbg in (0, 8, 11, 43, 43+64, 43+128, 43+192, 43+16, 43+16+192):
-                    os.environ['EVK_C1_DMA_DBG'] = str(dbg)
-                    row.append(f'dbg{dbg}={timeit(fn):.0f}')
-                os.environ['EVK_C1_DMA_DBG'] = '0'
-                print(f'{ci:4d}->{co:4d} @{h:3d}^2 packed={packed} {force}: ' + ' '.join(row), flush=True)
-        return
-    if len(sys.argv) > 1 and sys.argv[1] == 'khalf':
-        # timing probe (EVK_C1_DMA_DBG bit 16): every tile twice, each copy running one half of the K loop = what two
-        # co-resident workgroups per tile (a split of the reduction) would take per half
-        for (h, ci, co) in [(64, 512, 128), (64, 512, 256), (32, 256, 1024), (32, 1024, 256), (32, 1024, 512), (16, 512, 2048), (16, 2048, 512)]:
-            for packed in (0, 1):
-                fn, out, keep = problem(h, ci, co, packed, 0)
-                row = []
-                for force in ('e128', 'd128', 'e64'):
-                    os.environ['EVK_X3_FORCE'] = force
-                    for dbg in (0, 16):
-                        os.environ['EVK_C1_DMA_DBG'] = str(dbg)
-                        row.append(f'{force}/dbg{dbg}={timeit(fn):.1f}')
-                os.environ['EVK_C1_DMA_DBG'] = '0'
-                print(f'{ci:4d}->{co:4d} @{h:3d}^2 packed={packed}: ' + ' '.join(row), flush=True)
-        return
+    # (the kernel's ablations are compile-time since round 6: tools/build_variant.sh NAME conv1x1_dma.hip -DEVK_C1_DMA_ABL=n, then
+    # EVK_LIB=<that build> python tools/ab_c1dma.py)
     tot = {}
     for (h, ci, co) in SHAPES:
         for packed in (0, 1):
@@ -90,7 +64,7 @@ def main():
                 base = timeit(fn)
                 ref = out.clone()
                 res = {}
-                for cfg in ('d256', 'd128', 'd64', 'e128', 'e64', 'p128'):
+                for cfg in ('d256', 'd128', 'd64', 'e128', 'e64'):
                     os.environ['EVK_X3_FORCE'] = cfg
                     t = timeit(fn)
                     err = float((out - ref).abs().max() / ref.abs().max())

@@ -7,7 +7,7 @@ src = open(os.path.join(here, 'ab_c1dma.py')).read().replace('\nmain()\n', '\n')
 ns = {'__file__': os.path.join(here, 'ab_c1dma.py'), '__name__': 'ab'}
 exec(compile(src, ns['__file__'], 'exec'), ns)
 problem, timeit, B = ns['problem'], ns['timeit'], ns['B']
-forms = sys.argv[1].split(',') if len(sys.argv) > 1 else ['e128', 'd128', 'p128', 's128', 't128', 's64']
+forms = sys.argv[1].split(',') if len(sys.argv) > 1 else ['e128', 'd128', 'q128', 's128', 't128', 's64']
 quick = len(sys.argv) > 2 and sys.argv[2] == 'quick'
 tot = {}
 for (h, ci, co) in ns['SHAPES']:

@@ -1,7 +1,7 @@
 """dev tool (GPU box): the planar-operand weight gradient (csrc/conv_wgrad_tr.hip: DMA + transposing LDS reads) against
 the packed-operand wave-specialised kernel on the layer shapes of the FarSeg-R50 step: time, and the difference of the
 results (same operands, same scales, same split-K plan where both take the 128 x 256 tile).
-usage: [EVK_WG_DBG=bits] python tools/ab_wgrad_tr.py [quick]"""
+usage: [EVK_LIB=<variant built with -DEVK_WG_ABL=bits>] python tools/ab_wgrad_tr.py [quick]"""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ever_amd import _C
@@ -55,4 +55,4 @@ for (h, cin, cout, k, s) in SHAPES:
     tot_p += tp; tot_t += tt
     print(f'{k}x{k} s{s} {cin:4d}->{cout:4d} @{h:3d}: packed ws {tp:7.1f} us ({gf / tp * 1e3:6.1f} TF)   planar tr {tt:7.1f} us ({gf / tt * 1e3:6.1f} TF)'
           f'   x{tp / tt:4.2f}   max rel diff {err:.1e}   planar round trip {rt:.1e}', flush=True)
-print(f'EVK_WG_DBG={os.environ.get("EVK_WG_DBG", "0")}  sum: packed {tot_p:.0f} us, planar {tot_t:.0f} us')
+print(f'EVK_LIB={os.environ.get("EVK_LIB", "(default build)")}  sum: packed {tot_p:.0f} us, planar {tot_t:.0f} us')

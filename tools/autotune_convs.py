@@ -18,7 +18,7 @@ import ever_amd as er  # noqa: E402
 from ever_amd import _C  # noqa: E402
 
 FIELDS = [f[0] for f in _C.ConvDesc._fields_]
-GENERIC = ['c128x128', 'c64x128', 'c128x64', 'c64x64', 'w256', 'w128', 'w64', 'd256', 'd128', 'd64', 'e128', 'e64', 'p128', 'q128', 's128', 's64', 't128']
+GENERIC = ['c128x128', 'c64x128', 'c128x64', 'c64x64', 'w256', 'w128', 'w64', 'd256', 'd128', 'd64', 'e128', 'e64', 'q128', 's128', 's64', 't128']
 HALO = ['h64x8', 'm64x8', 'm64x16', 'h128x8', 'h128x16', 'm128x8', 'm128x16']
 B = int(os.environ.get('BATCH', 16))
 

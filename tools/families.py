@@ -7,8 +7,9 @@ A family is (key, label, substrings).  A kernel belongs to the FIRST family one 
 totals plus the rest add up to the capture's total."""
 
 # forward + data gradient convolution kernels (bench.py family `conv_igemm`)
-# every one-tap form starts with conv1x1_ (dma, ps, ps2, sp, smallm): ONE prefix, so that the next one cannot be forgotten
-CONV_IGEMM = ('conv_igemm', 'conv3x3_halo', '^conv1x1_')
+# every one-tap form starts with conv1x1_ (dma, ps2, sp, smallm): ONE prefix, so that the next one cannot be forgotten
+# ... and every 3x3 form with conv3x3_ (halo, wino)
+CONV_IGEMM = ('conv_igemm', '^conv3x3_', '^conv1x1_')
 CONV_WGRAD = ('conv_wgrad',)
 # what a weight-gradient C-ABI call launches besides its matrix kernel
 CONV_WGRAD_AUX = ('splitk_reduce', 'colsum_', 'pack_f16x2', 'pack_planar')
@@ -18,7 +19,7 @@ BN = ('bn_',)
 RESAMPLE_LOSS = ('^bilinear_', '^mean_loss', '^finalize_partials', '^bce_', '^dice_', '^ce_', '^focal_', '^prob_stats', '^ohem_', '^soft_ce_', '^sum_loss', '^nr_finalize')   # '^' = the bare name starts with it
 
 FAMILIES = (
-    ('conv_igemm', 'conv_igemm (forward + data gradient: conv3x3_halo_x3 / conv1x1_* (dma, ps, ps2, sp, smallm) / conv_igemm_x3ws / '
+    ('conv_igemm', 'conv_igemm (forward + data gradient: conv3x3_* (wino, halo) / conv1x1_* (dma, ps2, sp, smallm) / conv_igemm_x3ws / '
                    'conv_igemm_x3 / conv_igemm kernels)', CONV_IGEMM),
     ('conv_wgrad', 'conv_wgrad (conv_wgrad_x3ws / conv_wgrad_x3 / conv_wgrad_tr / conv_wgrad kernels)', CONV_WGRAD),
     ('conv_wgrad_aux', 'weight-gradient auxiliaries (splitk_reduce, colsum_*, pack_f16x2 / pack_planar): part of a '

@@ -1,5 +1,5 @@
 """dev tool (GPU box): launch ONE one-tap convolution form a few times (for rocprofv3 --pmc runs).
-usage: EVK_TUNE=1 EVK_X3_FORCE=p128 [EVK_C1_DMA_DBG=n] python tools/one_c1.py h cin cout packed stats [iters]"""
+usage: EVK_TUNE=1 EVK_X3_FORCE=q128 [EVK_LIB=<variant built with -DEVK_C1_DMA_ABL=n>] python tools/one_c1.py h cin cout packed stats [iters]"""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault('EVK_TUNE', '1')

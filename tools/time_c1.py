@@ -1,4 +1,4 @@
-"""dev tool (GPU box): time ONE one-tap convolution form.  usage: EVK_TUNE=1 EVK_X3_FORCE=p128 [EVK_LIB=...] python tools/time_c1.py h cin cout packed stats"""
+"""dev tool (GPU box): time ONE one-tap convolution form.  usage: EVK_TUNE=1 EVK_X3_FORCE=q128 [EVK_LIB=...] python tools/time_c1.py h cin cout packed stats"""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault('EVK_TUNE', '1')
