@@ -126,6 +126,8 @@ SIGNATURES = {
     'evk_maxpool3x3s2_bwd': (c_int, [P, P, P, c_i32, c_i32, c_i32, c_i32, P]),
     'evk_upsample_nearest2x_add_fwd': (c_int, [P, P, P, c_i32, c_i32, c_i32, c_i32, P, P]),
     'evk_upsample_nearest2x_bwd': (c_int, [P, P, c_i32, c_i32, c_i32, c_i32, P]),
+    'evk_subsample2_fwd': (c_int, [P, P, c_i32, c_i32, c_i32, c_i32, P]),
+    'evk_subsample2_bwd': (c_int, [P, P, c_i32, c_i32, c_i32, c_i32, P]),
     'evk_upsample_bilinear_fwd': (c_int, [P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, P]),
     'evk_upsample_bilinear_bwd': (c_int, [P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, P]),
     'evk_gap_fwd': (c_int, [P, P, c_i32, c_i32, c_i32, P]),

@@ -264,6 +264,30 @@ __global__ __launch_bounds__(256) void nearest2x_bwd_kernel(const float* __restr
   }
 }
 
+// F.max_pool2d(x, 1, 2, 0) — a window of ONE pixel, stride 2: y[n, yo, xo, :] = x[n, 2 yo, 2 xo, :] (reference fpn.py:118-120,
+// LastLevelMaxPool).  ADJ = the adjoint: dx is dy at the even pixels and zero elsewhere (one thread per 16 bytes of dx).
+template <bool ADJ>
+__global__ __launch_bounds__(256) void subsample2_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int H,
+                                                         int W, int C, int Ho, int Wo) {
+  const int c4 = C >> 2;
+  const size_t total = ADJ ? (size_t)N * H * W * c4 : (size_t)N * Ho * Wo * c4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cb = (int)(i % c4);
+    size_t pix = i / c4;
+    const int wd = ADJ ? W : Wo, hd = ADJ ? H : Ho;
+    const int x = (int)(pix % wd);
+    pix /= wd;
+    const int y = (int)(pix % hd);
+    const int n = (int)(pix / hd);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (!ADJ)
+      v = *reinterpret_cast<const f32x4*>(src + (((size_t)n * H + 2 * y) * W + 2 * x) * C + cb * 4);
+    else if (!(x & 1) && !(y & 1))
+      v = *reinterpret_cast<const f32x4*>(src + (((size_t)n * Ho + (y >> 1)) * Wo + (x >> 1)) * C + cb * 4);
+    *reinterpret_cast<f32x4*>(dst + i * 4) = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Bilinear, align_corners=True (nn.UpsamplingBilinear2d).  Index math follows aten's
 // upsample_bilinear2d: scale = (in-1)/(out-1) in float, src = scale*dst, i0 = (int)src,
@@ -905,6 +929,21 @@ extern "C" int evk_upsample_nearest2x_bwd(const float* dout, float* dtop, int32_
   hipLaunchKernelGGL(nearest2x_bwd_kernel, dim3(grid_for((size_t)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0,
                      (hipStream_t)stream, dout, dtop, N, H, W, C);
   return check_launch("nearest2x_bwd");
+}
+
+extern "C" int evk_subsample2_fwd(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+  EVK_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, EVK_E_INVALID, "subsample2_fwd: bad argument (C %% 4 == 0)");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  hipLaunchKernelGGL(subsample2_kernel<false>, dim3(grid_for((size_t)N * Ho * Wo * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y,
+                     N, H, W, C, Ho, Wo);
+  return check_launch("subsample2_fwd");
+}
+extern "C" int evk_subsample2_bwd(const float* dy, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+  EVK_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, EVK_E_INVALID, "subsample2_bwd: bad argument (C %% 4 == 0)");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  hipLaunchKernelGGL(subsample2_kernel<true>, dim3(grid_for((size_t)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy, dx,
+                     N, H, W, C, Ho, Wo);
+  return check_launch("subsample2_bwd");
 }
 
 static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }

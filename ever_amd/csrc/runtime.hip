@@ -13,7 +13,7 @@ void set_error(const char* fmt, ...) {
 }  // namespace evk
 
 extern "C" const char* evk_last_error(void) { return evk::g_err; }
-extern "C" int evk_abi_version(void) { return 20; }
+extern "C" int evk_abi_version(void) { return 21; }
 extern "C" const char* evk_build_arch(void) { return "gfx950"; }
 
 // Fork of one stream from another without a torch Event object per call (53 weight gradients per step fork the side

@@ -1872,6 +1872,35 @@ def upsample_nearest2x_add(top, lateral):
     return _Nearest2xAddFn.apply(top, lateral)
 
 
+class _Subsample2Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        n, c, h, w = x.shape
+        y = empty_nhwc(n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1, x.device)
+        _C.call('evk_subsample2_fwd', x.data_ptr(), y.data_ptr(), n, h, w, c, _stream())
+        _inherit_amax(y, x)                       # a selection of x's elements: its scale bounds them
+        ctx.shape = (n, c, h, w)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        n, c, h, w = ctx.shape
+        g = as_nhwc(g, 'subsample2.backward')
+        dx = empty_nhwc(n, c, h, w, g.device)
+        _C.call('evk_subsample2_bwd', g.data_ptr(), dx.data_ptr(), n, h, w, c, _stream())
+        return dx
+
+
+def max_pool1x1s2(x):
+    """F.max_pool2d(x, 1, 2, 0) (reference fpn.py:118-120, LastLevelMaxPool): every second pixel of every second row."""
+    _require_cuda(x, 'max_pool1x1s2')
+    x = as_nhwc(x, 'max_pool1x1s2')
+    if x.shape[1] % 4:
+        raise HipPathError('max_pool1x1s2: channels must be a multiple of 4')
+    return _Subsample2Fn.apply(x)
+
+
 class _BilinearFn(Function):
     @staticmethod
     def forward(ctx, x, ho, wo):
@@ -2213,10 +2242,8 @@ def bce_with_logits(y_pred, y_true, ignore_index=255, label_smoothing=0.0, pos_w
     """reference ever/module/loss.py:229-235 (reduction 'mean' | 'sum', optional pos_weight: a number or a one-element
     tensor — the heads on this path have one logit channel); label_smoothing > 0 gives
     label_smoothing_binary_cross_entropy (loss.py:222-226)."""
-    if reduction not in ('mean', 'sum'):
-        # 'none' returns one value per NON-IGNORED pixel (the reference compacts with masked_select first): a
-        # data-dependent shape, which a pre-allocated-output kernel cannot produce
-        raise NotImplementedError("binary_cross_entropy_with_logits: reduction must be 'mean' or 'sum' on the HIP path")
+    if reduction not in ('mean', 'sum', 'none'):
+        raise ValueError(f"binary_cross_entropy_with_logits: reduction '{reduction}'")
     if pos_weight is None:
         pw = 1.0
     elif isinstance(pos_weight, torch.Tensor):
@@ -2233,6 +2260,26 @@ def bce_with_logits(y_pred, y_true, ignore_index=255, label_smoothing=0.0, pos_w
     else:
         y_pred = y_pred.contiguous()
     labels = _labels(y_true, y_pred.numel(), 'bce')
+    if reduction == 'none':
+        # One value per NON-ignored pixel, in pixel order (the reference compacts logits and targets with masked_select first,
+        # loss.py:10-17,229-235): a data-dependent shape, so the compaction is a boolean index (one host round trip, as in the
+        # reference).  Per pixel BCE(z, t) = t * CE([0, z], 1) + (1 - t) * CE([0, z], 0): the two-class per-pixel cross entropy
+        # kernel on the logit pair (0, z), which is the same softplus arithmetic.
+        from . import functional_next as HN
+        z = y_pred.reshape(-1, 1, 1, 1)
+        z2 = as_nhwc(torch.cat([torch.zeros_like(z), z], dim=1), 'bce.none')
+        yl = labels.reshape(-1, 1, 1)
+        valid = yl != ignore_index
+        if not label_smoothing and pw == 1.0:
+            per = HN.cross_entropy_per_pixel(z2, yl, ignore_index)
+        else:
+            l1 = HN.cross_entropy_per_pixel(z2, torch.where(valid, torch.ones_like(yl), yl), ignore_index)
+            l0 = HN.cross_entropy_per_pixel(z2, torch.where(valid, torch.zeros_like(yl), yl), ignore_index)
+            t = yl.to(torch.float32)
+            if label_smoothing:
+                t = torch.where(yl == 0, t + label_smoothing, t - label_smoothing)
+            per = pw * t * l1 + (1.0 - t) * l0
+        return per.reshape(-1)[valid.reshape(-1)]
     return _BceFn.apply(y_pred, labels, int(ignore_index), float(label_smoothing), pw, 0 if reduction == 'mean' else 1)
 
 
@@ -2306,11 +2353,13 @@ class _CeFn(Function):
                 stats.data_ptr(), _stream())
         ctx.save_for_backward(logits, labels, stats)
         ctx.cfg = (ignore_index, eps)
-        return loss
+        count = stats[1:2].to(torch.float32).reshape(())     # valid pixels (for reduction='sum'); not differentiable
+        ctx.mark_non_differentiable(count)
+        return loss, count
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g):
+    def backward(ctx, g, _gcount=None):
         logits, labels, stats = ctx.saved_tensors
         ignore_index, eps = ctx.cfg
         n, c, h, w = logits.shape
@@ -2352,12 +2401,38 @@ def soft_cross_entropy(y_pred, target):
     return _SoftCeFn.apply(y_pred, target)
 
 
-def cross_entropy(y_pred, y_true, ignore_index=255, label_smoothing=0.0):
-    """F.cross_entropy(ignore_index=...) / label_smoothing_cross_entropy (reference loss.py:207-219)."""
+def cross_entropy(y_pred, y_true, ignore_index=255, label_smoothing=0.0, reduction='mean'):
+    """F.cross_entropy(ignore_index=...) / label_smoothing_cross_entropy (reference loss.py:207-219).
+    reduction 'sum' = the mean times the number of valid pixels, a device word of the same kernel (no host round trip; 0 when
+    every pixel is ignored, as the reference's sums over nothing).  'none': per pixel, 0 on ignored pixels — the reference's
+    own expression (a compacted 1-D term plus an uncompacted one, loss.py:213-219) is defined only where nothing is ignored,
+    and equals this there; built from the per-pixel cross entropy: -sum_c q_c log p_c with q = (1 - eps) onehot + eps / C,
+    the uniform part as the sum over the C constant-label cross entropies."""
     _require_cuda(y_pred, 'cross_entropy')
+    if reduction not in ('mean', 'sum', 'none'):
+        raise ValueError(f"cross_entropy: reduction '{reduction}'")
+    squeeze = y_pred.dim() == 2          # flat [M, C] logits with [M] targets (the form the reference's 'none' is defined on)
+    if squeeze:
+        y_pred = y_pred.reshape(y_pred.shape[0], y_pred.shape[1], 1, 1)
     y_pred = as_nhwc(y_pred, 'cross_entropy')
+    if reduction == 'none':
+        from . import functional_next as HN
+        n, c, h, w = y_pred.shape
+        yt = y_true.to(torch.int64).reshape(n, h, w)
+        out = HN.cross_entropy_per_pixel(y_pred, yt, ignore_index)
+        if label_smoothing:
+            valid = yt != ignore_index
+            uni = None
+            for k in range(c):
+                t = HN.cross_entropy_per_pixel(y_pred, torch.where(valid, torch.full_like(yt, k), yt), ignore_index)
+                uni = t if uni is None else uni + t
+            out = out * (1.0 - label_smoothing) + uni * (label_smoothing / c)
+        return out.reshape(y_true.shape)
     labels = _labels(y_true, y_pred.numel() // y_pred.shape[1], 'cross_entropy')
-    return _CeFn.apply(y_pred, labels, int(ignore_index), float(label_smoothing))
+    mean, count = _CeFn.apply(y_pred, labels, int(ignore_index), float(label_smoothing))
+    if reduction == 'mean':
+        return mean
+    return torch.where(count > 0, mean * count, torch.zeros_like(mean))
 
 
 # ------------------------------------------------------------------ SURVEY §8 f2 / f3 rows

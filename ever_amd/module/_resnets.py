@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from ..hip import functional as HF
 from .fold import _takes_epilogue_stats, _use_folded, conv_bn
-from .layers import AdaptiveAvgPool2d, BatchNorm2d, Conv2d, HipSequential, MaxPool2d, ReLU
+from .layers import AdaptiveAvgPool2d, BatchNorm2d, Conv2d, GroupNorm, HipSequential, MaxPool2d, ReLU
 
 __all__ = ['ResNet', 'BasicBlock', 'Bottleneck', 'resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152',
            'resnext50_32x4d', 'resnext101_32x4d', 'resnext101_32x8d', 'resnet50_v1c', 'resnet101_v1c']
@@ -25,9 +25,33 @@ def conv1x1(cin, cout, stride=1):
 
 
 def _norm(norm_layer):
+    """The factory `norm_layer(num_features)` of reference _resnets.py:72-75 / resnet.py:213-225 on the HIP layers:
+    BatchNorm2d (default), or any callable that builds an nn.GroupNorm (e.g. functools.partial(nn.GroupNorm, 32)) or a
+    BatchNorm2d — instances of the stock classes are retargeted to this package's; anything else has no kernel."""
     if norm_layer is None or norm_layer is nn.BatchNorm2d or norm_layer is BatchNorm2d:
         return BatchNorm2d
-    raise NotImplementedError(f'ever_amd ResNet: norm_layer {norm_layer} has no HIP kernel (BatchNorm2d only)')
+
+    def make(num_features):
+        m = norm_layer(num_features)
+        if isinstance(m, nn.GroupNorm):
+            m.__class__ = GroupNorm
+        elif isinstance(m, nn.BatchNorm2d) and not isinstance(m, nn.SyncBatchNorm):
+            m.__class__ = BatchNorm2d
+        elif not isinstance(m, nn.SyncBatchNorm):
+            raise NotImplementedError(f'ever_amd ResNet: norm layer {type(m).__name__} has no HIP kernel (BatchNorm2d, '
+                                      f'SyncBatchNorm and GroupNorm are implemented)')
+        return m
+    return make
+
+
+def _plain_norm(m):
+    """a norm without the BatchNorm-only fusions (statistics from the convolution epilogue, folded inference, ReLU bits):
+    the block runs layer by layer — convolution, norm (+ fused ReLU), add, ReLU"""
+    return not isinstance(m, BatchNorm2d)
+
+
+def _norm_act(norm, x, relu):
+    return norm(x, relu=relu) if isinstance(norm, GroupNorm) else (HF.relu(norm(x)) if relu else norm(x))
 
 
 def _inference(bn):
@@ -85,6 +109,10 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if _plain_norm(self.bn1):
+            shortcut = x if self.downsample is None else self.downsample(x)
+            out = _norm_act(self.bn1, self.conv1(x), True)
+            return HF.relu(HF.add(_norm_act(self.bn2, self.conv2(out), False), shortcut))
         if _inference(self.bn1):
             shortcut = x if self.downsample is None else conv_bn(self.downsample[0], self.downsample[1], x)
             out = conv_bn(self.conv1, self.bn1, x, relu=True)
@@ -114,6 +142,11 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if _plain_norm(self.bn1):
+            shortcut = x if self.downsample is None else self.downsample(x)
+            out = _norm_act(self.bn1, self.conv1(x), True)
+            out = _norm_act(self.bn2, self.conv2(out), True)
+            return HF.relu(HF.add(_norm_act(self.bn3, self.conv3(out), False), shortcut))
         if _inference(self.bn1):
             shortcut = x if self.downsample is None else conv_bn(self.downsample[0], self.downsample[1], x)
             out = conv_bn(self.conv1, self.bn1, x, relu=True)
@@ -193,6 +226,9 @@ class ResNet(nn.Module):
     def stem_forward(self, x):
         if self.deep_stem:
             return self.stem(x)
+        if _plain_norm(self.bn1):
+            h = HF.stem_conv7x7s2(x, self.conv1.weight) if HF.stem_conv_applicable(x, self.conv1) else self.conv1(x)
+            return _norm_act(self.bn1, h, True)
         if HF.stem_conv_applicable(x, self.conv1) and not _use_folded(self.conv1, self.bn1):
             # 7x7 / stride 2 on a 3- or 4-band image: space-to-depth form on the split-MFMA kernels (csrc/stem_s2d.hip)
             return self.bn1(HF.stem_conv7x7s2(x, self.conv1.weight, bn_stats=_takes_epilogue_stats(self.bn1)), relu=True)

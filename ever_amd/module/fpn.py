@@ -15,8 +15,8 @@ from ..hip import functional as HF
 from .layers import BatchNorm2d, Conv2d, Dropout, GELU, GroupNorm, HipSequential, ReLU, UpsamplingBilinear2d
 from .ops import Bf16compatible, ConvBlock
 
-__all__ = ['FPN', 'AssymetricDecoder', 'conv_with_kaiming_uniform', 'default_conv_block', 'conv_bn_block',
-           'conv_bn_relu_block']
+__all__ = ['FPN', 'AssymetricDecoder', 'LastLevelMaxPool', 'LastLevelP6P7', 'conv_with_kaiming_uniform',
+           'default_conv_block', 'conv_bn_block', 'conv_bn_relu_block']
 
 
 def init_conv(m):
@@ -41,9 +41,9 @@ conv_bn_relu_block = conv_with_kaiming_uniform(use_bn=True, use_relu=True)
 class FPN(nn.Module):
     def __init__(self, in_channels_list, out_channels, conv_block=default_conv_block, top_blocks=None):
         super().__init__()
-        if top_blocks is not None:
-            raise NotImplementedError('ever_amd FPN: top_blocks (P6/P7, LastLevelMaxPool) are not on the FarSeg '
-                                      'path and have no HIP kernel')
+        if top_blocks is not None and not isinstance(top_blocks, (LastLevelMaxPool, LastLevelP6P7)):
+            # (the reference's forward ignores any other module, fpn.py:109-114; saying so beats a silent no-op)
+            raise TypeError('ever_amd FPN: top_blocks must be a LastLevelMaxPool or a LastLevelP6P7 (ever_amd.module.fpn)')
         self.inner_blocks, self.layer_blocks = [], []
         for idx, cin in enumerate(in_channels_list, 1):
             inner, layer = f'fpn_inner{idx}', f'fpn_layer{idx}'
@@ -53,7 +53,7 @@ class FPN(nn.Module):
             self.add_module(layer, conv_block(out_channels, out_channels, 3, 1))
             self.inner_blocks.append(inner)
             self.layer_blocks.append(layer)
-        self.top_blocks = None
+        self.top_blocks = top_blocks
 
     def forward(self, x):
         """x: feature maps, highest resolution first -> tuple of FPN maps, highest resolution first."""
@@ -66,6 +66,11 @@ class FPN(nn.Module):
             last_inner = HF.upsample_nearest2x_add(top, lateral)  # lateral + nearest_x2(top), one pass
             out, top = self._output_conv(layer, last_inner, i + 1 < len(names))
             results.insert(0, out)
+        # reference fpn.py:109-114: extra, coarser levels appended behind the last (smallest-resolution) FPN output
+        if isinstance(self.top_blocks, LastLevelP6P7):
+            results.extend(self.top_blocks(x[-1], results[-1]))
+        elif isinstance(self.top_blocks, LastLevelMaxPool):
+            results.extend(self.top_blocks(results[-1]))
         return tuple(results)
 
     def _output_conv(self, layer, last_inner, has_finer_level):
@@ -84,6 +89,33 @@ class FPN(nn.Module):
         slot = HF.GradSlot()
         out = HF.conv2d(last_inner, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, grad_slot=slot)
         return out, (HF.slot_output(last_inner, slot) if slot.claimed else last_inner)
+
+
+class LastLevelMaxPool(nn.Module):
+    """reference fpn.py:118-120: `F.max_pool2d(x, 1, 2, 0)` of the coarsest FPN map — a one-pixel window at stride 2"""
+
+    def forward(self, x):
+        return [HF.max_pool1x1s2(x)]
+
+
+class LastLevelP6P7(nn.Module):
+    """reference fpn.py:123-141 (RetinaNet's P6, P7): two 3x3 / stride-2 convolutions with bias, a ReLU between them, fed by
+    P5 when the channel counts agree and by C5 otherwise; same parameter names (`p6.weight`, `p7.bias`, ...)"""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.p6 = Conv2d(in_channels, out_channels, 3, 2, 1)
+        self.p7 = Conv2d(out_channels, out_channels, 3, 2, 1)
+        for module in (self.p6, self.p7):
+            nn.init.kaiming_uniform_(module.weight, a=1)
+            nn.init.constant_(module.bias, 0)
+        self.use_P5 = in_channels == out_channels
+
+    def forward(self, c5, p5):
+        x = p5 if self.use_P5 else c5
+        p6 = self.p6(x)
+        p7 = self.p7(HF.relu(p6))
+        return [p6, p7]
 
 
 class AssymetricDecoder(nn.Module):

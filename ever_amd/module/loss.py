@@ -8,7 +8,8 @@ __all__ = ['binary_cross_entropy_with_logits', 'dice_loss_with_logits', 'cross_e
 
 
 def binary_cross_entropy_with_logits(output, target, reduction='mean', ignore_index=255, pos_weight=None):
-    """reference loss.py:229-235 (reduction 'mean' | 'sum'; 'none' has a data-dependent shape and raises)"""
+    """reference loss.py:229-235 (reduction 'mean' | 'sum' | 'none' — 'none': one loss per NON-ignored pixel, a 1-D tensor
+    in pixel order, as the reference's masked_select leaves it)"""
     return HF.bce_with_logits(output, target, ignore_index=ignore_index, pos_weight=pos_weight, reduction=reduction)
 
 
@@ -24,10 +25,8 @@ def cross_entropy(output, target, ignore_index=255):
 
 
 def label_smoothing_cross_entropy(output, target, eps=0.1, reduction='mean', ignore_index=-1):
-    """reference loss.py:207-219"""
-    if reduction != 'mean':
-        raise NotImplementedError('ever_amd label_smoothing_cross_entropy: only reduction="mean"')
-    return HF.cross_entropy(output, target, ignore_index=ignore_index, label_smoothing=eps)
+    """reference loss.py:207-219 (reduction 'mean' | 'sum' | 'none')"""
+    return HF.cross_entropy(output, target, ignore_index=ignore_index, label_smoothing=eps, reduction=reduction)
 
 
 def label_smoothing_binary_cross_entropy(output, target, eps=0.1, reduction='mean', ignore_index=255):

@@ -409,6 +409,12 @@ int evk_upsample_nearest2x_add_fwd(const float* top, const float* lateral, float
 int evk_upsample_nearest2x_bwd(const float* dout, float* dtop, int32_t N, int32_t H, int32_t W,
                                int32_t C, void* stream);
 
+/* F.max_pool2d(x, 1, 2, 0) of LastLevelMaxPool — fpn.py:118-120 (the FPN's optional `top_blocks`): a one-pixel window at
+ * stride 2, y[n,yo,xo,:] = x[n,2yo,2xo,:] with Ho = (H-1)/2+1; _bwd is its adjoint (dx = dy at the even pixels, 0 elsewhere;
+ * H, W are x's dims in both). */
+int evk_subsample2_fwd(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int evk_subsample2_bwd(const float* dy, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+
 /* nn.UpsamplingBilinear2d(scale_factor=s) == bilinear, align_corners=True — fpn.py:168,180.
  * x: [N,Hi,Wi,C] -> y: [N,Ho,Wo,C]; src = dst*(in-1)/(out-1). Backward is the gather-form adjoint. */
 int evk_upsample_bilinear_fwd(const float* x, float* y, int32_t N, int32_t Hi, int32_t Wi,

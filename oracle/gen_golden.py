@@ -473,6 +473,83 @@ def next_rows_kats(er):
     print('next-row KATs:', len(out), 'values,', len(arrays), 'arrays')
 
 
+def api_holes_kats(er):
+    """Round 6 (VERDICT r5 "missing" 3): the FPN's top blocks (reference fpn.py:109-141), the 'sum' / 'none' reductions of
+    label_smoothing_cross_entropy and binary_cross_entropy_with_logits (loss.py:207-235), ResNetEncoder with a GroupNorm
+    norm_layer (resnet.py:213-225).  Inputs / weights from oracle/portable.py, outputs of the reference."""
+    import functools
+    from oracle import portable
+    from ever.module import fpn as RF
+    from ever.module import loss as L
+    from ever.module.resnet import ResNetEncoder
+    arrays, out = {}, {}
+    chans, sizes = (16, 32, 64, 128), (32, 16, 8, 4)
+    for tag, top in (('maxpool', lambda: RF.LastLevelMaxPool()), ('p6p7_c5', lambda: RF.LastLevelP6P7(128, 32)),
+                     ('p6p7_p5', lambda: RF.LastLevelP6P7(32, 32))):
+        torch.manual_seed(0)
+        m = RF.FPN(chans, 32, top_blocks=top())
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in portable.fill_state_dict(m.state_dict()).items()})
+        xs = [torch.from_numpy(portable.normalish(f'fpn_top/x{i}', (2, c, s, s))).requires_grad_() for i, (c, s) in enumerate(zip(chans, sizes))]
+        outs = m(xs)
+        gouts = [torch.from_numpy(portable.normalish(f'fpn_top/{tag}/g{i}', tuple(o.shape))) for i, o in enumerate(outs)]
+        torch.autograd.backward(outs, gouts)
+        for i, o in enumerate(outs):
+            arrays[f'fpn_{tag}/out{i}'] = o.detach().numpy()
+        for i, x in enumerate(xs):
+            arrays[f'fpn_{tag}/dx{i}'] = x.grad.numpy()
+        for k, p_ in m.named_parameters():
+            arrays[f'fpn_{tag}/grad/{k}'] = p_.grad.numpy()
+    # --- label smoothing cross entropy
+    z = torch.from_numpy(portable.uniform('ls_ce', (2, 5, 12, 10), -3.0, 3.0)).requires_grad_()
+    y = torch.from_numpy(portable.integers('ls_ce_y', (2, 12, 10), 5).astype(np.int64))
+    y[1, 3:6, 2:9] = 255
+    for red in ('mean', 'sum'):
+        z.grad = None
+        v = L.label_smoothing_cross_entropy(z, y, eps=0.1, reduction=red, ignore_index=255)
+        v.backward()
+        out[f'ls_ce_{red}'] = float(v)
+        arrays[f'ls_ce_{red}_grad'] = z.grad.numpy().copy()
+    zf = torch.from_numpy(portable.uniform('ls_ce_flat', (40, 6), -3.0, 3.0)).requires_grad_()
+    yf = torch.from_numpy(portable.integers('ls_ce_flat_y', (40,), 6).astype(np.int64))
+    v = L.label_smoothing_cross_entropy(zf, yf, eps=0.2, reduction='none', ignore_index=255)   # (defined: nothing ignored)
+    gv = torch.from_numpy(portable.normalish('ls_ce_flat_g', tuple(v.shape)))
+    v.backward(gv)
+    arrays['ls_ce_none'] = v.detach().numpy()
+    arrays['ls_ce_none_grad'] = zf.grad.numpy().copy()
+    # --- binary cross entropy
+    zb = torch.from_numpy(portable.uniform('bce_none', (2, 1, 9, 11), -4.0, 4.0)).requires_grad_()
+    yb = torch.from_numpy((portable.uniform01('bce_none_y', 2 * 9 * 11) > 0.6).astype(np.int64).reshape(2, 9, 11))
+    yb[0, :3, 4:] = 255
+    for tag, fn in (('bce_none', lambda: L.binary_cross_entropy_with_logits(zb, yb.reshape(2, 1, 9, 11).float(), 'none', 255)),
+                    ('bce_none_pw', lambda: L.binary_cross_entropy_with_logits(zb, yb.reshape(2, 1, 9, 11).float(), 'none', 255,
+                                                                               pos_weight=torch.tensor(2.5))),
+                    ('lsbce_none', lambda: L.label_smoothing_binary_cross_entropy(zb, yb.reshape(2, 1, 9, 11).float(), 0.1, 'none', 255))):
+        zb.grad = None
+        v = fn()
+        gv = torch.from_numpy(portable.normalish(tag + '_g', tuple(v.shape)))
+        v.backward(gv)
+        arrays[tag] = v.detach().numpy()
+        arrays[tag + '_grad'] = zb.grad.numpy().copy()
+    # --- ResNet-18 encoder with GroupNorm(8, C)
+    torch.manual_seed(0)
+    enc = ResNetEncoder(dict(resnet_type='resnet18', in_channels=4, pretrained=False,
+                             norm_layer=functools.partial(torch.nn.GroupNorm, 8)))
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in portable.fill_state_dict(enc.state_dict()).items()})
+    enc.train()
+    x = torch.from_numpy(portable.normalish('gn_enc/x', (2, 4, 64, 64)))
+    feats = enc(x)
+    gouts = [torch.from_numpy(portable.normalish(f'gn_enc/g{i}', tuple(o.shape))) for i, o in enumerate(feats)]
+    torch.autograd.backward(feats, gouts)
+    for i, o in enumerate(feats):
+        arrays[f'gn_enc/out{i}'] = o.detach().numpy()
+    # (11 M parameters: digests — norm, sum, four samples, a +-1 projection per tensor — instead of the gradients themselves)
+    out['gn_enc_grad_digest'] = grad_digest([(k, p_) for k, p_ in enc.named_parameters() if p_.grad is not None])
+    with open(os.path.join(OUT, 'r6_api.json'), 'w') as f:
+        json.dump(out, f)
+    np.savez_compressed(os.path.join(OUT, 'r6_api.npz'), **arrays)
+    print('round-6 API KATs:', len(out), 'values,', len(arrays), 'arrays')
+
+
 def fsrel_v2_case(er):
     """FSRelationV2 (reference fs_relation.py:76-163) forward + backward with portable weights; Dropout2d is set to
     p = 0 so that the training-mode run is deterministic (the mask path is tested against its formula)."""
@@ -539,6 +616,9 @@ def main():
         next_rows_kats(er)
         fsrel_v2_case(er)
         return
+    if only == 'holes':
+        api_holes_kats(er)
+        return
     if only == 'bf16':
         for name in BF16_CASES:
             bf16_autocast_case(er, name)
@@ -546,6 +626,7 @@ def main():
     op_kats(er)
     block_vectors(er)
     next_rows_kats(er)
+    api_holes_kats(er)
     fsrel_v2_case(er)
     launcher_case(er)
     for a in E2E_CASES:

@@ -190,7 +190,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, f'declared in include/ever_hip.h but not exported: {missing}'
     assert sorted(_C.SIGNATURES) == declared, 'ctypes signature table out of sync with the header'
     lib = _C.load()
-    assert lib.evk_abi_version() == 20 and lib.evk_build_arch() == b'gfx950'
+    assert lib.evk_abi_version() == 21 and lib.evk_build_arch() == b'gfx950'
     # argument validation happens before any launch: safe without a GPU
     d = _C.ConvDesc(1, 8, 8, 3, 8, 8, 4, 1, 1, 1, 1, 0, 0, 1, 1)
     rc = lib.evk_conv2d_fwd(ctypes.byref(d), 1, 1, None, 1, 0, None)

@@ -18,7 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize('cfg', ['c2', 'c3'])
 def test_backward_linearity_with_a_pinned_kernel_plan(cuda, cfg):
-    env = dict(os.environ, EVK_X3_HALO_MIN_WG='0', EVK_CONV_MATH='f16x2')
+    # (EVK_WINO=2: the Winograd 3x3 kernel wherever its geometry allows, whatever the batch — its default rule counts workgroups)
+    env = dict(os.environ, EVK_X3_HALO_MIN_WG='0', EVK_WINO='2', EVK_CONV_MATH='f16x2')
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'linearity_check.py'), cfg], env=env,
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]

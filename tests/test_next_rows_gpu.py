@@ -371,8 +371,16 @@ def test_bce_pos_weight_and_reduction_match_reference_formula(cuda, pw, red):
     out.backward()
     assert abs(out.item() - ref.item()) <= 2e-6 * abs(ref.item())
     _close(zg.grad.cpu().numpy(), gr.numpy(), 1e-5)
-    with pytest.raises(NotImplementedError):
-        L.binary_cross_entropy_with_logits(zg, y.to(cuda), reduction='none')
+    # reduction='none' (round 6): one value per non-ignored pixel, in pixel order (tests/test_api_rows_gpu.py holds it against
+    # the imported reference's fixture)
+    none = L.binary_cross_entropy_with_logits(zg, y.to(cuda), reduction='none', pos_weight=None if pw is None else torch.tensor(pw))
+    refn = torch.nn.functional.binary_cross_entropy_with_logits(
+        z.double().reshape(-1)[valid], y.reshape(-1)[valid].double(), reduction='none',
+        pos_weight=None if pw is None else torch.tensor(pw, dtype=torch.float64))
+    assert none.shape == refn.shape
+    _close(none.detach().cpu().numpy(), refn.detach().numpy(), 2e-6)
+    with pytest.raises(ValueError):
+        L.binary_cross_entropy_with_logits(zg, y.to(cuda), reduction='median')
 
 
 def test_gelu_and_dropout_kernels(cuda):
