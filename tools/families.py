@@ -27,9 +27,9 @@ FAMILIES = (
     ('bn', 'BatchNorm (bn_* kernels; bench.py times C-ABI calls of 2-3 kernels each)', BN),
     ('resample_loss', 'bilinear resampling + pixel losses (bilinear_* / bce_* / dice_* / ce_* kernels and their finalisation)', RESAMPLE_LOSS),
     ('pointwise', 'other streaming kernels of the model (relation_* / nearest2x_* / gap_* / mean4 / ew / stem_s2d / maxpool / gn_* / concat / '
-                  'channel_scale / confusion)', ('^relation_', '^nearest2x_', '^gap_', '^mean4', '^ew_', '^stem_s2d_kernel', '^maxpool', '^gn_', '^concat2',
+                  'channel_scale / confusion / subsample2)', ('^relation_', '^nearest2x_', '^gap_', '^mean4', '^ew_', '^stem_s2d_kernel', '^maxpool', '^gn_', '^concat2',
                                                 '^split2', '^channel_scale', '^confusion', '^nchw_', '^nhwc_', '^bias_rows', '^pad_channels', '^unpad_channels',
-                                                '^relu_bits_apply', '^scale_store')),
+                                                '^relu_bits_apply', '^scale_store', '^subsample2')),
     ('operand_prep', 'operand preparation of the f16x2 arithmetic (absmax* scale words, split_weight* planes)',
      ('^absmax', '^split_weight', '^pack_dgrad_weight', '^stem_s2d_weight', '^group_weight')),
     ('optimizer', 'fused optimizer / gradient-bucket kernels (sgd_multi, sqnorm_multi, pack_multi, clip)', ('^sgd_', '^adam_', '^sqnorm_', '^pack_multi', '^clip_', '^unpack_multi', '^scale_multi')),
