@@ -206,7 +206,7 @@ _WGRAD_HOLD_BYTES = [0]
 # operand bytes held for pending weight gradients beyond which the backward joins the side stream in mid-pass:
 # EVK_WGRAD_HOLD_GB, default a quarter of the device's memory (a fixed 64 GB was the whole of a smaller part)
 _WGRAD_HOLD_CAP = [int(float(os.environ['EVK_WGRAD_HOLD_GB']) * 2 ** 30) if 'EVK_WGRAD_HOLD_GB' in os.environ else None]
-_WGRAD_MAIN = {}                 # device -> the stream the pending weight gradients forked from (joins go there)
+_WGRAD_MAIN = {}                 # device -> {stream id: stream} the weight gradients forked from (joins go to each)
 _cuda_get_stream = getattr(torch._C, '_cuda_getCurrentStream', None)
 _cuda_set_stream = getattr(torch._C, '_cuda_setStream', None)
 
@@ -247,9 +247,10 @@ def flush_wgrad_queue(dev=None):
 def _issue_wgrads(d, fns):
     side = _WGRAD_SIDE[d]
     main_id = _cuda_get_stream(d.index)
-    main = _WGRAD_MAIN.get(d)
-    if main is None or main.stream_id != main_id[0]:
-        main = _WGRAD_MAIN[d] = torch.cuda.current_stream(d)
+    mains = _WGRAD_MAIN.setdefault(d, {})    # every stream weight gradients forked from (the backward's, the head's branch stream)
+    main = mains.get(main_id[0])
+    if main is None:
+        main = mains[main_id[0]] = torch.cuda.current_stream(d)
     _C.call('evk_stream_fork', main.cuda_stream, side.cuda_stream)
     # torch's current stream by the raw setter (the Python context manager costs 20 us)
     _cuda_set_stream(stream_id=side.stream_id, device_index=side.device_index, device_type=side.device_type)
@@ -403,7 +404,7 @@ def _wgrad_side_stream(dev, weight, bias=None):
         wait_wgrad_stream()
     s = _WGRAD_SIDE.get(dev)
     if s is None:
-        s = _pick_side_stream(dev)
+        s = _pick_side_stream(dev, avoid=_HEAD_SIDE.get(dev) or None)
         if s is not None:
             _WGRAD_SIDE[dev] = s
     if not s:                   # no stream of this process overlaps with the backward's stream: stay on it
@@ -420,7 +421,7 @@ _SIDE_CANDIDATES = []
 _WGRAD_PRIO = int(os.environ.get('EVK_WGRAD_PRIO', '0'))
 
 
-def _pick_side_stream(dev):
+def _pick_side_stream(dev, avoid=None):
     """A stream whose kernels really run beside those of the current stream.  HIP multiplexes streams onto a few hardware
     queues, and which stream objects share one depends on how many streams the process made before (RCCL, a communication
     stream, torch's pools): with FlatGradDDP in the process the first stream made here sat on the backward's own queue —
@@ -437,6 +438,10 @@ def _pick_side_stream(dev):
         rc = _C.load().evk_streams_overlap(main, cand.cuda_stream, 150, ctypes.byref(took))
         if rc < 0:
             _C.check(rc, 'evk_streams_overlap')
+        if rc == 1 and avoid:    # (the other side stream of this process: the two must not share a hardware queue either)
+            rc = _C.load().evk_streams_overlap(avoid.cuda_stream, cand.cuda_stream, 150, ctypes.byref(took))
+            if rc < 0:
+                _C.check(rc, 'evk_streams_overlap')
         if rc == 1:
             return cand
         _SIDE_CANDIDATES.append(cand)
@@ -495,9 +500,10 @@ def wait_wgrad_stream():
                 continue
             cur = torch.cuda.current_stream(dev)
             cur.wait_stream(s)
-            main = _WGRAD_MAIN.get(dev)
-            if main is not None and main != cur:
-                main.wait_stream(s)
+            for main in _WGRAD_MAIN.get(dev, {}).values():
+                if main != cur:
+                    main.wait_stream(s)
+            _WGRAD_MAIN.pop(dev, None)       # (origins of THIS pass only: a capture stream must not be waited on later)
         _WGRAD_PASS['pending'] = False
         del _WGRAD_HOLD[:]
         _WGRAD_HOLD_BYTES[0] = 0
@@ -512,6 +518,101 @@ def wgrad_side_stream_of(dev):
 def _dist_initialized():
     import torch.distributed as dist
     return dist.is_available() and dist.is_initialized()
+
+
+# The head's pyramid levels on two streams.  Behind the FPN the four levels are independent until the
+# decoder's mean (reference fs_relation.py:56-73 relation per level, fpn.py:183-189 decoder branch per level): level 0 (the
+# 128^2 map of a 512^2 tile, three quarters of the head's work) stays on the caller's stream, levels 1.. run on a branch
+# stream forked behind the FPN and joined in front of the mean.  Their kernels fill a quarter to a half of the chip
+# (32^2 / 16^2 maps: 32..128 workgroups) and sit beside the 128^2 kernels instead of in front of them.  Autograd replays
+# each node on the stream its forward ran on, so the backward of those levels runs on the branch stream as well, its
+# tensors synchronised by the engine at the edges that cross streams (same values either way: no kernel changes its
+# launch plan with the stream it is on; tests/test_head_branch_gpu.py pins bit-identity of the two orders).
+# MEASURED, OFF BY DEFAULT (EVK_HEAD_BRANCH=1 turns it on; profiles/r06_experiments/ab_head_branch*.txt, head_branch_timeline.txt):
+# 556.3 -> 551.1 tiles/s with levels 1..3 aside, 567.1 -> 564.8 / 566.6 with levels 2..3 / level 3 only (EVK_HEAD_BRANCH_FROM).
+# Under rocprofv3 the forward has two kernels in flight for 0.86 of its 10.9 ms and is 0.07 ms shorter: the kernels that run
+# side by side take 0.73 ms longer than alone (the 64^2 level fills the chip by itself, the 128^2 kernels are bound by the
+# matrix pipe's power or by HBM, so sharing is a zero-sum split), and the backward is 0.65 ms LONGER (the engine's
+# cross-stream events leave 0.7 ms more of it with no kernel in flight, and the weight-gradient stream waits for whichever
+# of the two streams forked last).  The step is bound by resource-time, not by the dependency chain.
+_HEAD_BRANCH = [os.environ.get('EVK_HEAD_BRANCH', '0') == '1']
+_HEAD_FROM = int(os.environ.get('EVK_HEAD_BRANCH_FROM', '1'))     # first pyramid level that goes to the branch stream
+_HEAD_SIDE = {}                  # device -> stream, or False when no stream of the process runs beside the caller's
+
+
+def set_head_branch(on):
+    """runtime switch of the head's branch stream (returns the previous setting)"""
+    prev, _HEAD_BRANCH[0] = _HEAD_BRANCH[0], bool(on)
+    return prev
+
+
+class HeadBranches:
+    """One fork / join of the branch stream: `with br.level(i):` around the work of pyramid level i, `br.join()` in front of
+    the first consumer of all levels.  level(0) and every level of a session without a stream are no-ops."""
+
+    def __init__(self, dev, side):
+        self.dev, self.side = dev, side
+        self.main_id = None          # (stream_id, device_index, device_type) of the caller's stream while a level runs aside
+        self.main_raw = None
+        self.forked = False
+
+    class _Level:
+        def __init__(self, br, aside):
+            self.br, self.aside = br, aside
+
+        def __enter__(self):
+            br = self.br
+            if not self.aside:
+                return br
+            if not br.forked:
+                br.main_raw = _stream()
+                _C.call('evk_stream_fork', br.main_raw, br.side.cuda_stream)
+                weight_planes.alias_stream(br.side.cuda_stream, br.main_raw)
+                br.forked = True
+            br.main_id = _cuda_get_stream(br.dev.index)
+            s = br.side
+            _cuda_set_stream(stream_id=s.stream_id, device_index=s.device_index, device_type=s.device_type)
+            return br
+
+        def __exit__(self, *exc):
+            br = self.br
+            if self.aside and br.main_id is not None:
+                _cuda_set_stream(stream_id=br.main_id[0], device_index=br.main_id[1], device_type=br.main_id[2])
+                br.main_id = None
+            return False
+
+    def level(self, i):
+        return HeadBranches._Level(self, bool(self.side) and i >= _HEAD_FROM)
+
+    def join(self):
+        if self.forked:
+            _C.call('evk_stream_fork', self.side.cuda_stream, _stream())
+            self.forked = False
+
+
+def head_branches(t):
+    """a HeadBranches session for the head that consumes the CUDA tensor t, or None (switched off, no raw stream setters in
+    this torch build, observers installed, no second hardware queue)"""
+    if not _HEAD_BRANCH[0] or not t.is_cuda or _cuda_get_stream is None or _cuda_set_stream is None:
+        return None
+    if observers_active():
+        return None
+    dev = t.device
+    s = _HEAD_SIDE.get(dev)
+    if s is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None          # (under a stream capture nothing can be measured: plain order this time)
+        # the weight-gradient stream is picked HERE, from the caller's stream, when it has not been yet: the first weight
+        # gradient of a backward pass would otherwise pick it from inside a node that runs on the branch stream
+        if _WGRAD_STREAM[0] and _WGRAD_SIDE.get(dev) is None:
+            w = _pick_side_stream(dev)
+            if w is not None:
+                _WGRAD_SIDE[dev] = w
+        s = _pick_side_stream(dev, avoid=_WGRAD_SIDE.get(dev) or None)
+        if s is None:
+            return None
+        _HEAD_SIDE[dev] = s
+    return HeadBranches(dev, s) if s else None
 
 
 def _collectives_world():

@@ -130,9 +130,24 @@ def _layout(d, for_dgrad):
     return lay
 
 
+_alias = {}                      # raw stream -> the stream it forks from and joins again within a step
+
+
+def alias_stream(branch, origin):
+    """`branch` (raw handle) only ever runs work that is ordered behind `origin`'s by a fork — the head's branch stream
+    (functional.HeadBranches), forward and backward: planes produced on `origin` are valid there, and a request from it must
+    not re-split every registered weight under the kernels of `origin` that read them."""
+    if branch != origin:
+        _alias[branch] = _alias.get(origin, origin)
+
+
+def _canon(stream):
+    return _alias.get(stream, stream)
+
+
 def _valid(e, weight, stream):
     return (e.ptr == weight.data_ptr() and e.version == weight._version and e.epoch == _epoch
-            and e.stream == stream)
+            and e.stream == _canon(stream))
 
 
 def _build_table(device):
@@ -196,7 +211,7 @@ def _refresh_all(device, stream):
     stats['multi'] += 1
     for w, per in _by_weight.items():
         for e in per.values():
-            e.version, e.epoch, e.stream = w._version, _epoch, stream
+            e.version, e.epoch, e.stream = w._version, _epoch, _canon(stream)
 
 
 def planes_for(weight, w_dense, d, for_dgrad, stream, f16x2=False):
@@ -249,7 +264,7 @@ def planes_for(weight, w_dense, d, for_dgrad, stream, f16x2=False):
         else:
             _C.call('evk_conv2d_split_weight', ctypes.byref(d), e.ptr, for_dgrad, e.planes.data_ptr(), stream)
         stats['single'] += 1
-        e.version, e.epoch, e.stream = weight._version, _epoch, stream
+        e.version, e.epoch, e.stream = weight._version, _epoch, _canon(stream)
         per[sig] = e
         _table = None
         return result(e)

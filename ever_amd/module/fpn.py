@@ -163,9 +163,18 @@ class AssymetricDecoder(nn.Module):
                 Conv2d(out_channels, num_classes, kernel_size, padding=(kernel_size - 1) // 2),
                 Bf16compatible(UpsamplingBilinear2d(scale_factor=scale_factor)) if scale_factor > 1 else nn.Identity())
 
-    def features(self, feat_list):
-        """mean of the per-level decoder outputs, before the classifier (what ChangeStar's ChangeMixin consumes)"""
-        inner = [block(feat_list[i]) for i, block in enumerate(self.blocks)]
+    def features(self, feat_list, branches=None):
+        """mean of the per-level decoder outputs, before the classifier (what ChangeStar's ChangeMixin consumes).
+        branches: the calling head's HF.HeadBranches session — branches 1.. run on its stream, joined here in front of the mean"""
+        inner = []
+        for i, block in enumerate(self.blocks):
+            if branches is None:
+                inner.append(block(feat_list[i]))
+            else:
+                with branches.level(i):
+                    inner.append(block(feat_list[i]))
+        if branches is not None:
+            branches.join()
         if len(inner) == 4:
             return HF.mean4(*inner)
         out = inner[0]  # generic: running add then scale (same left-to-right association as python sum)
@@ -173,10 +182,10 @@ class AssymetricDecoder(nn.Module):
             out = HF.add(out, t)
         return _Scale.apply(out, 1.0 / len(inner))
 
-    def forward(self, feat_list):
+    def forward(self, feat_list, branches=None):
         if self.cls_cfg and self._classifier_commutes():
-            return self._forward_commuted(feat_list)
-        out = self.features(feat_list)
+            return self._forward_commuted(feat_list, branches)
+        out = self.features(feat_list, branches)
         if self.cls_cfg:
             out = self.classifier(self.dropout(out))
         return out
@@ -235,23 +244,32 @@ class AssymetricDecoder(nn.Module):
             bn._nbt_pending = getattr(bn, '_nbt_pending', 0) + 1
         return out
 
-    def _forward_commuted(self, feat_list):
+    def _commuted_branch(self, block, x, conv):
+        from .layers import run_sequence
+        subs = list(block)
+        for sub in subs[:-1]:
+            x = sub(x)
+        last = list(subs[-1])
+        up = last[-1]
+        has_up = not isinstance(up, nn.Identity)
+        z = self._bn_relu_classifier(last, x, conv)
+        if z is None:
+            x = run_sequence(last[:-1] if has_up else last, x)
+            z = conv(x)
+        return up(z) if has_up else z
+
+    def _forward_commuted(self, feat_list, branches=None):
         from .layers import run_sequence
         conv = self.classifier[0]
         zs = []
         for i, block in enumerate(self.blocks):
-            subs = list(block)
-            x = feat_list[i]
-            for sub in subs[:-1]:
-                x = sub(x)
-            last = list(subs[-1])
-            up = last[-1]
-            has_up = not isinstance(up, nn.Identity)
-            z = self._bn_relu_classifier(last, x, conv)
-            if z is None:
-                x = run_sequence(last[:-1] if has_up else last, x)
-                z = conv(x)
-            zs.append(up(z) if has_up else z)
+            if branches is None:
+                zs.append(self._commuted_branch(block, feat_list[i], conv))
+            else:
+                with branches.level(i):
+                    zs.append(self._commuted_branch(block, feat_list[i], conv))
+        if branches is not None:
+            branches.join()
         if len(zs) == 4:
             out = HF.mean4(*zs)
         else:

@@ -34,7 +34,26 @@ def _fusable_bn(seq):
     return not any(m._forward_hooks or m._forward_pre_hooks for m in (seq, seq[0], bn, seq[2]))
 
 
-def _relation_levels(content_encoders, feature_reencoders, scenes, features):
+class _NoBranches:
+    """stand-in for HF.HeadBranches when the levels run in plain order"""
+
+    def level(self, i):
+        return self
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+    def join(self):
+        pass
+
+
+_PLAIN = _NoBranches()
+
+
+def _relation_levels(content_encoders, feature_reencoders, scenes, features, branches=None):
     """[relation(scene_i, content_i(f_i), reencode_i(f_i))].  Training, plain BatchNorm: the two 1x1 convolutions of a level
     run as one fork node and BatchNorm + ReLU of both branches run INSIDE the relation kernels (HF.fs_relation_bn:
     the normalised maps are never written, the BatchNorm backward sums come out of the relation backward);
@@ -42,27 +61,25 @@ def _relation_levels(content_encoders, feature_reencoders, scenes, features):
     import os
     import torch
     fuse = (os.environ.get('EVK_RELATION_BN', '1') != '0' and torch.is_grad_enabled() and not HF.observers_active())
+    br = branches if branches is not None else _PLAIN     # (HF.HeadBranches: levels 1.. on the head's branch stream)
     outs = []
-    rest_c, rest_f, rest_s, rest_x, idx = [], [], [], [], []
     for i, (ce, fr, s, f) in enumerate(zip(content_encoders, feature_reencoders, scenes, features)):
-        out = None
-        if fuse and f.requires_grad and _fusable_bn(ce) and _fusable_bn(fr):
-            zc, zf = HF.conv2d_fork(f, ce[0], fr[0], bn_stats=(True, True))
-            out = HF.fs_relation_bn(s, zc, zf, ce[1], fr[1])
-            if out is None:     # the convolutions left no statistics records: finish the level layer by layer
-                from .layers import run_sequence
-                out = HF.fs_relation(s, run_sequence(list(ce)[1:], zc), run_sequence(list(fr)[1:], zf))
-            else:
-                for bn in (ce[1], fr[1]):
-                    if bn.track_running_stats and bn.num_batches_tracked is not None:
-                        bn._nbt_pending = getattr(bn, '_nbt_pending', 0) + 1
-        outs.append(out)
-        if out is None:
-            rest_c.append(ce); rest_f.append(fr); rest_s.append(s); rest_x.append(f); idx.append(i)
-    if idx:
-        contents, feats = _content_and_reencoded(rest_c, rest_f, rest_x)
-        for i, s, c, p in zip(idx, rest_s, contents, feats):
-            outs[i] = HF.fs_relation(s, c, p)
+        with br.level(i):
+            out = None
+            if fuse and f.requires_grad and _fusable_bn(ce) and _fusable_bn(fr):
+                zc, zf = HF.conv2d_fork(f, ce[0], fr[0], bn_stats=(True, True))
+                out = HF.fs_relation_bn(s, zc, zf, ce[1], fr[1])
+                if out is None:     # the convolutions left no statistics records: finish the level layer by layer
+                    from .layers import run_sequence
+                    out = HF.fs_relation(s, run_sequence(list(ce)[1:], zc), run_sequence(list(fr)[1:], zf))
+                else:
+                    for bn in (ce[1], fr[1]):
+                        if bn.track_running_stats and bn.num_batches_tracked is not None:
+                            bn._nbt_pending = getattr(bn, '_nbt_pending', 0) + 1
+            if out is None:
+                contents, feats = _content_and_reencoded([ce], [fr], [f])
+                out = HF.fs_relation(s, contents[0], feats[0])
+            outs.append(out)
     return outs
 
 
@@ -103,12 +120,14 @@ class FSRelation(nn.Module):
         self.feature_reencoders = nn.ModuleList([_conv_bn_relu(c, out_channels) for c in in_channels_list])
         self.normalizer = nn.Sigmoid()  # parameter-free; the sigmoid runs inside the relation kernel
 
-    def forward(self, scene_feature, features):
+    def forward(self, scene_feature, features, branches=None):
+        """branches: a HF.HeadBranches session of the calling head (levels 1.. then run on its branch stream and the CALLER
+        joins it in front of the first consumer of all levels); None = plain order on the current stream"""
         if self.scale_aware_proj:
             scenes = [enc(scene_feature) for enc in self.scene_encoder]
         else:
             scenes = [self.scene_encoder(scene_feature)] * len(features)
-        return _relation_levels(self.content_encoders, self.feature_reencoders, scenes, features)
+        return _relation_levels(self.content_encoders, self.feature_reencoders, scenes, features, branches)
 
 
 class FSRelationV2(nn.Module):
@@ -139,17 +158,20 @@ class FSRelationV2(nn.Module):
         self.feature_reencoders = nn.ModuleList([_conv_bn_relu(c, out_channels) for c in in_channels_list])
         self.normalizer = nn.Sigmoid()
 
-    def forward(self, scene_feature, features):
+    def forward(self, scene_feature, features, branches=None):
         from ..hip import functional_next as HN
         if self.scale_aware_proj:
             scenes = [enc(scene_feature) for enc in self.scene_encoder]
         else:
             scenes = [self.scene_encoder(scene_feature)] * len(features)
-        related = _relation_levels(self.content_encoders, self.feature_reencoders, scenes, features)
-        refined = [HN.concat_channels(rel, o) for rel, o in zip(related, features)]
-        if self.scale_aware_proj:
-            return [op(x) for op, x in zip(self.project, refined)]
-        return [self.project(x) for x in refined]
+        br = branches if branches is not None else _PLAIN
+        related = _relation_levels(self.content_encoders, self.feature_reencoders, scenes, features, branches)
+        projects = self.project if self.scale_aware_proj else [self.project] * len(related)
+        outs = []
+        for i, (rel, o, op) in enumerate(zip(related, features, projects)):
+            with br.level(i):
+                outs.append(op(HN.concat_channels(rel, o)))
+        return outs
 
 
 _RELATIONS = {'v1': FSRelation, 'v2': FSRelationV2}
@@ -169,17 +191,39 @@ class FarSegHead(ERModule):
         self.fs_relation = _RELATIONS[version](**self.config.fs_relation)
         self.fpn_decoder = AssymetricDecoder(**self.config.fpn_decoder)
 
-    def refined(self, feature_list):
+    def refined(self, feature_list, branches=None):
         fpn_feats = self.fpn(feature_list)
         scene = HF.global_avg_pool(feature_list[-1])  # GAP of c5 (encoder output), not of P5
-        return self.fs_relation(scene, fpn_feats)
+        if branches is None:
+            return self.fs_relation(scene, fpn_feats)
+        return self.fs_relation(scene, fpn_feats, branches=branches)
+
+    def _branches(self, feature_list):
+        """the pyramid levels behind the FPN on two streams (HF.HeadBranches), when nothing watches the modules in between"""
+        if type(self.fs_relation) not in (FSRelation, FSRelationV2) or type(self.fpn_decoder) is not AssymetricDecoder:
+            return None
+        if any(m._forward_hooks or m._forward_pre_hooks for m in (self.fs_relation, self.fpn_decoder)):
+            return None
+        return HF.head_branches(feature_list[-1])
 
     def forward(self, feature_list):
-        return self.fpn_decoder(self.refined(feature_list))
+        br = self._branches(feature_list)
+        if br is None:
+            return self.fpn_decoder(self.refined(feature_list))
+        try:
+            return self.fpn_decoder(self.refined(feature_list, br), branches=br)
+        finally:
+            br.join()       # (the decoder joins in front of its mean; this one only acts when an exception left the fork open)
 
     def features(self, feature_list):
         """decoder feature map before the classifier (stride out_feat_output_stride)"""
-        return self.fpn_decoder.features(self.refined(feature_list))
+        br = self._branches(feature_list)
+        if br is None:
+            return self.fpn_decoder.features(self.refined(feature_list))
+        try:
+            return self.fpn_decoder.features(self.refined(feature_list, br), branches=br)
+        finally:
+            br.join()
 
     def set_default_config(self):
         self.config.update(dict(
