@@ -95,14 +95,14 @@ class GraphedTrainStep:
         # A replayed graph serialises its two branches at every fork: with one fork of the weight-gradient
         # branch per layer the replay runs at the single-stream graph's speed (501.7 tiles/s where eager is 525.3); with one
         # per 32 layers it reaches the eager two-stream step (522.6).  EVK_WGRAD_BATCH, when set, is respected.
-        batch0 = HF._WGRAD_BATCH
+        batch0 = HF._WGRAD_BATCH[0]
         if 'EVK_WGRAD_BATCH' not in os.environ:
-            HF._WGRAD_BATCH = 32
+            HF._WGRAD_BATCH[0] = 32
         try:
             with torch.cuda.graph(self.graph, stream=self._stream):     # records the launches, executes nothing
                 out = self.step_fn(*static_data)
         finally:
-            HF._WGRAD_BATCH = batch0
+            HF._WGRAD_BATCH[0] = batch0
             torch.cuda.synchronize()
         HF._ZERO_POOL.clear()
         for m, n in zip(self._bns, pending):   # the host-side counters of the recording pass are not a step

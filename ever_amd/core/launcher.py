@@ -12,7 +12,7 @@ Differences, all outside the numerics:
     iteration (reference launcher.py:211 calls .item() per loss per step);
   * `mixed_precision` defaults to 'fp32' so `Trainer.build_launcher` works (reference defect,
     SURVEY §0.5); for models built from the HIP layers 'bf16' selects the plain-bf16 convolution arithmetic
-    (hip/functional.py: conv math 'bf16'), 'fp16' keeps the default fp16-MFMA arithmetic and adds the GradScaler protocol;
+    (hip/_base.py: conv math 'bf16'), 'fp16' keeps the default fp16-MFMA arithmetic and adds the GradScaler protocol;
     stock torch models keep the reference's autocast.
 """
 import os

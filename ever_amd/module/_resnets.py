@@ -62,7 +62,7 @@ def _inference(bn):
 
 def _fork(block, x):
     """(conv1(x), shortcut) — the block input feeds both; one autograd node so that the two input
-    gradients are summed inside the data-gradient kernel (hip/functional.py:_ConvForkFn)."""
+    gradients are summed inside the data-gradient kernel (hip/conv.py:_ConvForkFn)."""
     if block.downsample is None:
         return HF.conv2d_fork(x, block.conv1, bn_stats=(_takes_epilogue_stats(block.bn1), False))
     h, s = HF.conv2d_fork(x, block.conv1, block.downsample[0],
@@ -236,7 +236,7 @@ class ResNet(nn.Module):
 
     def stem_pool_forward(self, x):
         """maxpool(stem_forward(x)); BatchNorm + ReLU + max-pool as one pass each way where the 7x7 stem runs in its
-        space-to-depth form under a training-mode BatchNorm2d (hip/functional.py:batch_norm_relu_max_pool)."""
+        space-to-depth form under a training-mode BatchNorm2d (hip/norm.py:batch_norm_relu_max_pool)."""
         if (not self.deep_stem and type(self.maxpool) is MaxPool2d and _takes_epilogue_stats(self.bn1)
                 and HF.stem_conv_applicable(x, self.conv1) and not _use_folded(self.conv1, self.bn1)):
             return self.bn1.forward_relu_pool(HF.stem_conv7x7s2(x, self.conv1.weight, bn_stats=True))

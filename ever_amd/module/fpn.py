@@ -76,7 +76,7 @@ class FPN(nn.Module):
     def _output_conv(self, layer, last_inner, has_finer_level):
         """(P_k, the tensor to hand to the next finer level).  last_inner_k feeds its 3x3 output convolution AND, later in the
         forward, the top-down path of level k - 1; backward runs that later consumer first, so its gradient is parked in a
-        GradSlot and added inside the output convolution's data-gradient epilogue (hip/functional.py: GradSlot) instead of by
+        GradSlot and added inside the output convolution's data-gradient epilogue (hip/conv.py: GradSlot) instead of by
         autograd's own add pass over a 256-channel map — which also left a tensor without an operand scale behind, i.e. a
         stand-alone absmax pass in front of the two gradient kernels that read it."""
         block = getattr(self, layer)

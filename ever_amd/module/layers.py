@@ -29,7 +29,7 @@ class Conv2d(nn.Conv2d):
         self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
 
     def forward(self, x, relu=False, bn_stats=False):
-        """bn_stats: a training-mode BatchNorm consumes the result next (hip/functional.py:conv2d)"""
+        """bn_stats: a training-mode BatchNorm consumes the result next (hip/conv.py:conv2d)"""
         w = self.weight if self.groups == 1 else HF.grouped_dense_weight(self.weight, self.groups)
         y = HF.conv2d(x, w, self.bias, self.stride, self.padding, self.dilation, relu=relu, bn_stats=bn_stats)
         if self._forward_hooks and getattr(y, '_evk_bn_parts', None) is not None and len(y._evk_bn_parts) > 2:
@@ -66,10 +66,10 @@ class BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d with optional fused residual add and ReLU (one apply pass over HBM)."""
 
     def forward(self, x, residual=None, relu=False, conv_only=False, lazy_res=False):
-        """lazy_res: see hip/functional.py:batch_norm_act (residual blocks of this package only).
+        """lazy_res: see hip/norm.py:batch_norm_act (residual blocks of this package only).
         conv_only: the result is read by ONE convolution of this package (and that convolution's weight gradient) and
         by nothing else — under the f16x2 arithmetic the pass may then store it already split ("packed",
-        hip/functional.py:batch_norm_act); any other reader would see raw words."""
+        hip/norm.py:batch_norm_act); any other reader would see raw words."""
         if self.momentum is None:
             raise NotImplementedError('ever_amd BatchNorm2d: cumulative moving average (momentum=None) unsupported')
         training = self.training or (self.running_mean is None)
@@ -88,7 +88,7 @@ class BatchNorm2d(nn.BatchNorm2d):
 
     def forward_relu_pool(self, x):
         """max_pool3x3s2(relu(self(x))): the ResNet stem's tail; fused into one pass each way in training mode
-        (hip/functional.py:batch_norm_relu_max_pool)."""
+        (hip/norm.py:batch_norm_relu_max_pool)."""
         training = self.training or (self.running_mean is None)
         if not training or self.momentum is None:
             return HF.max_pool3x3s2(self.forward(x, relu=True))

@@ -116,7 +116,7 @@ class ResNetEncoder(ERModule):
         x = r.stem_pool_forward(x)
         wcp = self.config.with_cp
         # A stage output feeds the next stage AND (later) the caller.  With gradient slots the caller's gradient is
-        # added inside the next stage's first data-gradient launch (hip/functional.py:GradSlot) instead of by an
+        # added inside the next stage's first data-gradient launch (hip/conv.py:GradSlot) instead of by an
         # autograd add pass over the whole map; off under activation checkpointing (the fork nodes are rebuilt then).
         slots = HF.grad_slots_enabled() and not any(wcp) and torch.is_grad_enabled()
         outs = []

@@ -74,7 +74,7 @@ class FlatGradDDP(nn.Module):
         self._exposed = []
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
         if self._cuda:
-            for p in params:      # hip/functional.py: these hooks read the gradients through _flush below, which follows
+            for p in params:      # hip/streams.py: these hooks read the gradients through _flush below, which follows
                 p._evk_flat_ddp = True   # the weight-gradient side stream — the convolutions may use it
         self._sync_initial_state()
 
@@ -165,7 +165,7 @@ class FlatGradDDP(nn.Module):
             side = HF.wgrad_side_stream_of(self.device)
             main = torch.cuda.current_stream()
             if side is not None:
-                # weight gradients of this bucket may still be running on the side stream (hip/functional.py): the layout
+                # weight gradients of this bucket may still be running on the side stream (hip/streams.py): the layout
                 # copies and the pack follow them THERE — after everything the main stream has produced so far (BatchNorm
                 # / bias gradients, the pointer table) — instead of making the main stream wait.  The gradients stay
                 # alive in b._keep until _finalize, which runs after the join.

@@ -1,4 +1,4 @@
-"""The head's pyramid levels on two streams (hip/functional.py: HeadBranches, EVK_HEAD_BRANCH=1 — measured level to
+"""The head's pyramid levels on two streams (hip/streams.py: HeadBranches, EVK_HEAD_BRANCH=1 — measured level to
 -0.9 % on the step and therefore off by default; reference fs_relation.py:56-73,
 fpn.py:183-189 — the per-level relation and decoder branches are independent between the FPN and the decoder's mean).
 It must be invisible: losses, first-step gradients and trained weights bit for bit those of the plain order, for the FarSeg

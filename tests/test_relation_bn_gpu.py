@@ -1,4 +1,4 @@
-"""FS-Relation with BatchNorm + ReLU of its two branches inside the relation kernels (hip/functional.py:fs_relation_bn,
+"""FS-Relation with BatchNorm + ReLU of its two branches inside the relation kernels (hip/pointwise.py:fs_relation_bn,
 include/ever_hip.h: evk_relation_bn_*; reference fs_relation.py:39-53,61-71).  Same function as the layer-by-layer path
 (EVK_RELATION_BN=0): outputs, input / scene gradients, every parameter gradient and the BatchNorm running statistics agree
 to fp32 rounding (the partial sums are formed by other workgroups in another order); the layer-by-layer path is kept where

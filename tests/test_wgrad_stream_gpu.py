@@ -1,4 +1,4 @@
-"""Weight gradients on a second stream (hip/functional.py: _WGRAD_STREAM, default on): nothing in a backward pass depends
+"""Weight gradients on a second stream (hip/streams.py: _WGRAD_STREAM, default on): nothing in a backward pass depends
 on dw, so the MFMA-bound weight-gradient launches run beside the HBM-bound rest of the backward.  It must be invisible:
 gradients and trained weights equal to the one-stream run, shared weights / hooks / accumulated gradients / direct
 autograd.grad calls handled, the FlatGradDDP pack ordered behind the side stream."""
