@@ -157,6 +157,44 @@ def test_hip_modules_refuse_cpu_tensors():
         er.module.loss.binary_cross_entropy_with_logits(torch.randn(1, 1, 4, 4), torch.zeros(1, 4, 4).long())
 
 
+def test_functional_facade_reads_and_forwards_assignments():
+    """hip/functional.py is a facade over the family modules (_base, streams, conv, norm, pointwise, losses): every public
+    name and every `HF._X` switch callers use is visible on it, and ASSIGNING through it rebinds the name in each family
+    module that holds it — a flag defined in _base.py and imported by value into norm.py must change in both, or the tests
+    and tools that flip `HF._LAZY_RES` / `HF._rank_sum_hook` / `HF._cuda_set_stream` would flip nothing."""
+    from ever_amd.hip import functional as HF
+    from ever_amd.hip import _base, conv, losses, norm, pointwise, streams
+    assert all(hasattr(HF, n) for n in HF.__all__)
+    assert HF.conv2d is conv.conv2d and HF.relu is pointwise.relu and HF.batch_norm_act is norm.batch_norm_act
+    assert HF.bce_with_logits is losses.bce_with_logits and HF.wait_wgrad_stream is streams.wait_wgrad_stream
+    assert HF._WGRAD_STREAM is streams._WGRAD_STREAM and HF._ZERO_POOL is _base._ZERO_POOL        # containers: shared objects
+    prev = HF._LAZY_RES
+    try:
+        HF._LAZY_RES = not prev
+        assert _base._LAZY_RES is (not prev) and norm._LAZY_RES is (not prev) and HF._LAZY_RES is (not prev)
+    finally:
+        HF._LAZY_RES = prev
+    assert norm._LAZY_RES is prev
+    marker = object()
+    try:
+        HF._rank_sum_hook = marker
+        assert losses._rank_sum_hook is marker
+    finally:
+        HF._rank_sum_hook = None
+    saved = streams._cuda_set_stream
+    try:
+        HF._cuda_set_stream = None
+        assert streams._cuda_set_stream is None
+    finally:
+        HF._cuda_set_stream = saved
+    prev_math = HF.get_conv_math()
+    try:
+        HF.set_conv_math('f32')
+        assert _base.get_conv_math() == 'f32' and not conv._f16x2()
+    finally:
+        HF.set_conv_math(prev_math)
+
+
 def test_to_hip_retargets_a_stock_model():
     net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.ReLU(True),
                               torch.nn.MaxPool2d(3, 2, 1))
