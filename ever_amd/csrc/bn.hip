@@ -18,6 +18,13 @@ namespace evk {
 // Bits: 1 bn_apply, 2 bn_bwd_apply, 4 bn_bwd_partial.
 __device__ __forceinline__ unsigned bn_blk() { return gridDim.x - 1u - blockIdx.x; }
 
+// Channel group of a FINALISATION workgroup (round 6).  Consecutive channel groups read neighbouring 4-byte .. 32-byte pieces of
+// the same 64-byte lines of the partial records, and the hardware deals consecutive workgroups to the eight XCDs round-robin:
+// with group = blockIdx every line of the records was fetched by up to eight L2s (bn_parts_final_kernel<1, 256>: 53.8 MB of HBM
+// fetches for 6.3 MB of records, profiles/r06_experiments/traffic_by_kernel.txt).  xcd_remap hands the workgroups of ONE XCD
+// consecutive groups instead.  Which workgroup finalises a channel changes, what it computes does not: the same bits.
+__device__ __forceinline__ int bn_fin_group() { return xcd_remap((int)blockIdx.x, (int)gridDim.x); }
+
 // non-temporal loads of the stem's 268 MB map in its fused BatchNorm + pool passes (experiment: a plain read of more than 256 MB
 // behind a plain-store writer streams at 4.1 TB/s, with the hint at 6.8 — tools/probes/mall_direction.hip).
 // Bits: 1 backward reduce pass, 2 forward, 4 backward apply pass
@@ -149,7 +156,7 @@ __device__ __forceinline__ bool reduce_partials(const float* __restrict__ partia
                                                 double& q) {
   __shared__ double red[4][FC];
   const int tc = threadIdx.x % FC, tl = threadIdx.x / FC;
-  c = blockIdx.x * FC + tc;
+  c = bn_fin_group() * FC + tc;
   s = 0.0;
   q = 0.0;
   if (c < C) {
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
   if (pmax) {
     __shared__ float mred[4][FC];
     const int tc = threadIdx.x % FC, tl = threadIdx.x / FC;
-    const int cc = blockIdx.x * FC + tc;
+    const int cc = bn_fin_group() * FC + tc;
     if (cc < C) {
       const float* pm = pmax + cc;
       const size_t st = (size_t)2 * C;
@@ -567,7 +574,7 @@ __global__ __launch_bounds__(256) void bn_parts_final_kernel(const float* __rest
   // (Chan's pairwise formula telescoped; no division inside the loop, no order dependence beyond the fixed one below).
   __shared__ double red[4][FC];
   const int tc = threadIdx.x % FC, tl = threadIdx.x / FC;
-  const int c = blockIdx.x * FC + tc;
+  const int c = bn_fin_group() * FC + tc;
   double N = 0.0, A = 0.0, B = 0.0, piv = 0.0;
   if (c < C) {
     const size_t st = (size_t)3 * C;
