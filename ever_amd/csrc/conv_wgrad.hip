@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
   // 8 channels x 32 partial-lanes per workgroup, four loads in flight per lane (as the BatchNorm finalisation)
   __shared__ double red[32][8];
   const int tc = threadIdx.x & 7, tl = threadIdx.x >> 3;
-  const int c = blockIdx.x * 8 + tc;
+  const int c = xcd_remap((int)blockIdx.x, (int)gridDim.x) * 8 + tc;   // (neighbouring channel groups on ONE XCD: bn.hip, bn_fin_group)
   double s = 0.0;
   if (c < C) {
     int b = tl;
