@@ -38,7 +38,7 @@ extern "C" int evk_stream_fork(void* from, void* to) {
   ForkRing& r = g_fork[dev];
   if (!r.made) {
     for (int i = 0; i < kForkEvents; ++i)
-      if (hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming) != hipSuccess) {
+      if (hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
         evk::set_error("evk_stream_fork: hipEventCreateWithFlags failed");
         return 1;
       }
