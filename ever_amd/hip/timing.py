@@ -123,12 +123,16 @@ class KernelTimer:
         — a one-tap convolution with 64 reduction channels is bound by its bytes, not by the matrix pipe."""
         out = {}
         raw = _raw_events()
-        for fam, flops, nbytes, s, e, sc in self.records:
-            if isinstance(s, int):
-                sec = raw.elapsed_ms(s, e) * 1e-3
-                raw.release(s, e)
+        for i, (fam, flops, nbytes, s, e, sc) in enumerate(self.records):
+            if e is None:                    # resolved by an earlier call: s holds the seconds
+                sec = s
             else:
-                sec = s.elapsed_time(e) * 1e-3
+                if isinstance(s, int):
+                    sec = raw.elapsed_ms(s, e) * 1e-3
+                    raw.release(s, e)        # (the handles go back to the pool: a second summary() must not read them again)
+                else:
+                    sec = s.elapsed_time(e) * 1e-3
+                self.records[i] = (fam, flops, nbytes, sec, None, sc)
             bound = max(flops / peak_flops if peak_flops else 0.0, nbytes / peak_bytes if peak_bytes else 0.0)
             for key in ((fam,) if not sc else (fam, f'{sc}/{fam}')):
                 d = out.setdefault(key, dict(launches=0, flops=0.0, bytes=0.0, seconds=0.0, bound_seconds=0.0))
